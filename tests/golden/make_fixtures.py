@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the reference itself.
+
+Runs ONLY in the build container (needs /root/reference; the GPU box never has it).
+The reference's own glue (PeraNet.forward / training_step / predict_step label logic,
+AnomalyDetector, extract_patches, gt2label, dataset_generator primitives) is imported
+as-is; third-party packages that are missing here are replaced by throw-away
+``sys.modules`` stubs:
+
+  torchsummary                      -> no-op
+  pytorch_lightning.LightningModule -> nn.Module + no-op save_hyperparameters/log_dict
+  torchmetrics.functional.accuracy  -> argmax accuracy
+  torchvision.models.resnet18       -> oracle.resnet18 (restated from the public spec)
+  skimage / torchvision.transforms  -> empty shells (only names are imported)
+
+Outputs are data only (inputs are regenerated from seeds by oracle.weights):
+  forward.npz, train_step.npz, detector.npz, patches.npz, upsample.npz, cutpaste.npz, auroc.npz
+
+    python tests/golden/make_fixtures.py
+"""
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+from torch import nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF_SRC = "/root/reference/src"
+
+from oracle import weights as ow            # noqa: E402
+from oracle import scoring as osc           # noqa: E402
+from oracle import resnet18 as ores         # noqa: E402
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def install_stubs():
+    _stub("torchsummary", summary=lambda *a, **k: None)
+
+    class LightningModule(nn.Module):
+        current_epoch = 0
+
+        def save_hyperparameters(self, *a, **k):
+            pass
+
+        def log_dict(self, *a, **k):
+            pass
+
+    class _Any:
+        def __init__(self, *a, **k):
+            pass
+
+    pl = _stub("pytorch_lightning", LightningModule=LightningModule, LightningDataModule=_Any,
+               Trainer=_Any, Callback=_Any)
+    _stub("pytorch_lightning.callbacks", ModelCheckpoint=_Any, Callback=_Any)
+    pl.callbacks = sys.modules["pytorch_lightning.callbacks"]
+
+    def accuracy(y_hat, y):
+        return (y_hat.argmax(1) == y).float().mean()
+
+    tm = _stub("torchmetrics", JaccardIndex=_Any, PrecisionRecallCurve=_Any, F1Score=_Any)
+    tm.functional = _stub("torchmetrics.functional", accuracy=accuracy)
+
+    tv = _stub("torchvision")
+    tv.models = _stub("torchvision.models", resnet18=ores.resnet18, ResNet=ores.ResNet18)
+    tv.transforms = _stub("torchvision.transforms", ColorJitter=_Any, Compose=_Any)
+    tv.transforms.functional = _stub("torchvision.transforms.functional")
+
+    sk = _stub("skimage")
+    sk.morphology = _stub("skimage.morphology", square=None, label=None)
+    sk.feature = _stub("skimage.feature")
+    sk.segmentation = _stub("skimage.segmentation", slic=None)
+    sk.color = _stub("skimage.color")
+    sk.transform = _stub("skimage.transform", swirl=None)
+
+
+def t2n(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def main():
+    assert os.path.isdir(REF_SRC), "reference not present: fixtures can only be made in the build container"
+    install_stubs()
+    sys.path.insert(0, REF_SRC)
+    from self_supervised import models as rm                     # reference
+    from self_supervised import functional as rf
+    from self_supervised import converters as rc
+    from self_supervised import dataset_generator as rg
+
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    sd = ow.seeded_state_dict(0)
+
+    # ---------------- (i) extract_patches ----------------
+    a = torch.arange(2 * 3 * 48 * 40, dtype=torch.float32).reshape(2, 3, 48, 40)
+    p_small = rf.extract_patches(a, dim=32, stride=8)
+    big = torch.arange(3 * 256 * 256, dtype=torch.float32).reshape(1, 3, 256, 256)
+    p_big = rf.extract_patches(big, dim=32, stride=8)
+    sel = [0, 1, 28, 29, 420, 840]
+    np.savez_compressed(os.path.join(HERE, "patches.npz"),
+                        small=t2n(p_small).astype(np.int32),
+                        big_shape=np.array(p_big.shape), big_sel=np.array(sel),
+                        big_corners=np.stack([t2n(p_big[0, s, :, [0, 0, 31, 31], [0, 31, 0, 31]]) for s in sel]).astype(np.int32))
+
+    # ---------------- (ii) forward, eval ----------------
+    model = rm.PeraNet()
+    missing = model.load_state_dict(sd, strict=True)
+    model.eval()
+    out = {}
+    with torch.no_grad():
+        x_img = ow.synthetic_images(2, 256, seed=1234)
+        o = model(x_img)
+        out["img_logits"], out["img_emb"] = t2n(o["classifier"]), t2n(o["latent_space"])
+        x_c1 = ow.synthetic_images(8, 64, seed=77)
+        o = model(x_c1)
+        out["c1_logits"], out["c1_emb"] = t2n(o["classifier"]), t2n(o["latent_space"])
+        x_32 = ow.synthetic_images(4, 32, seed=78)          # nearest-upsample branch (h < 64)
+        o = model(x_32)
+        out["up_logits"], out["up_emb"] = t2n(o["classifier"]), t2n(o["latent_space"])
+        x_48 = ow.synthetic_images(2, 48, seed=79)          # non-integer nearest ratio 48 -> 64
+        o = model(x_48)
+        out["up48_logits"], out["up48_emb"] = t2n(o["classifier"]), t2n(o["latent_space"])
+        # patch level: one 256^2 image -> 841 patches
+        model.enable_patch_level_mode()
+        x_p = ow.synthetic_images(1, 256, seed=4321)
+        o = model(x_p)
+        assert (model.batch, model.num_patches) == (1, 841)
+        emb = t2n(o["latent_space"])
+        rows = np.array([0, 1, 2, 28, 29, 30, 57, 400, 420, 421, 811, 812, 838, 839, 840, 500])
+        out["patch_logits"] = t2n(o["classifier"])
+        out["patch_rows"] = rows
+        out["patch_emb_rows"] = emb[rows]
+        out["patch_emb_rowsum"] = emb.astype(np.float64).sum(1)
+        out["patch_emb_rownorm"] = np.sqrt((emb.astype(np.float64) ** 2).sum(1))
+        # small patch-level case kept in full: 64x48 image -> 5x3 = 15 patches
+        x_ps = ow.synthetic_images(2, 64, seed=99)[:, :, :, :48].contiguous()
+        o = model(x_ps)
+        out["psmall_logits"], out["psmall_emb"] = t2n(o["classifier"]), t2n(o["latent_space"])
+        out["psmall_bp"] = np.array([model.batch, model.num_patches])
+        model.disable_patch_level_mode()
+        # predict_step label logic (models.py:311-333) on a synthetic gt stack
+        gts = torch.zeros(3, 1, 8, 8); gts[1, 0, 2, 3] = 1.0
+        out["gt2label_bin"] = np.array(rc.gt2label(gts))
+        out["gt2label_multi"] = np.array(rc.gt2label(gts, negative=-1, positive=4))
+        out["multiclass2binary"] = t2n(rc.multiclass2binary(torch.tensor([0, 1, 2, 3, 0])))
+    np.savez_compressed(os.path.join(HERE, "forward.npz"), **out)
+    full_patch_emb = emb
+
+    # ---------------- (iii) training step (train-mode BN, autograd) ----------------
+    model = rm.PeraNet()
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    model.trainer = types.SimpleNamespace(max_epochs=10)
+    xb = ow.synthetic_images(8, 64, seed=55)
+    yb = ow.synthetic_labels(8, seed=56)
+    loss = model.training_step((xb, yb, None), 0)
+    loss.backward()
+    tr = {"loss": t2n(loss)}
+    names = ["feature_extractor.conv1.weight", "feature_extractor.bn1.weight", "feature_extractor.bn1.bias",
+             "feature_extractor.layer1.0.conv1.weight", "feature_extractor.layer2.0.downsample.0.weight",
+             "feature_extractor.layer2.0.downsample.1.weight",
+             "feature_extractor.layer3.1.conv2.weight", "feature_extractor.layer4.1.bn2.bias",
+             "feature_extractor.layer4.1.conv2.weight",
+             "concatenator.0.weight", "concatenator.1.weight", "latent_space.0.0.weight", "latent_space.2.1.bias",
+             "latent_space.3.weight", "latent_space.3.bias", "latent_space.4.weight", "classifier.weight",
+             "classifier.bias"]
+    params = dict(model.named_parameters())
+    tr["grad_names"] = np.array(names)
+    tr["grad_norms"] = np.array([params[n].grad.double().norm().item() for n in names])
+    tr["grad_classifier_weight"] = t2n(params["classifier.weight"].grad)
+    tr["grad_classifier_bias"] = t2n(params["classifier.bias"].grad)
+    tr["grad_bn1_bias"] = t2n(params["feature_extractor.bn1.bias"].grad)
+    tr["grad_conv1_slice"] = t2n(params["feature_extractor.conv1.weight"].grad[:4])
+    tr["grad_l4_conv2_slice"] = t2n(params["feature_extractor.layer4.1.conv2.weight"].grad[:2, :8])
+    bufs = dict(model.named_buffers())
+    tr["bn1_running_mean"] = t2n(bufs["feature_extractor.bn1.running_mean"])
+    tr["bn1_running_var"] = t2n(bufs["feature_extractor.bn1.running_var"])
+    tr["l4_bn2_running_var"] = t2n(bufs["feature_extractor.layer4.1.bn2.running_var"])
+    # one SGD step exactly as configure_optimizers builds it (models.py:336-341)
+    model.lr, model.num_epochs, model.stage = 0.03, 10, "projection_train"
+    (opt,), _ = model.configure_optimizers()
+    opt.step()
+    tr["post_step_classifier_weight"] = t2n(params["classifier.weight"])
+    tr["post_step_conv1_slice"] = t2n(params["feature_extractor.conv1.weight"][:4])
+    # second step to exercise the momentum buffer
+    opt.zero_grad()
+    loss2 = model.training_step((xb, yb, None), 1)
+    loss2.backward()
+    opt.step()
+    tr["loss2"] = t2n(loss2)
+    tr["post_step2_classifier_weight"] = t2n(params["classifier.weight"])
+    np.savez_compressed(os.path.join(HERE, "train_step.npz"), **tr)
+
+    # ---------------- (iv) AnomalyDetector ----------------
+    det = {}
+    bank_src = full_patch_emb                                 # 841 patch embeddings of one "good" image
+    model = rm.PeraNet(); model.load_state_dict(sd, strict=True); model.eval(); model.enable_patch_level_mode()
+    with torch.no_grad():
+        q = model(ow.synthetic_images(2, 256, seed=2468))["latent_space"]
+    np.random.seed(7)
+    d = rm.AnomalyDetector(patch_level=True, batch=2, num_patches=841)
+    d.fit(torch.from_numpy(bank_src))
+    det["threshold"] = np.float64(d.threshold)
+    det["bank_rows"] = np.int64(d.nbrs.n_samples_fit_)
+    det["scores"] = t2n(d.predict(q))
+    # split-free variant: bank given explicitly, the kernel-level contract
+    bank = ow.synthetic_bank(588, 512, seed=2)
+    qs = ow.synthetic_bank(300, 512, seed=3)
+    det["kernel_scores"] = t2n(osc.sklearn_knn_mean(bank.numpy(), qs.numpy(), 3))
+    # image-level (no reshape)
+    d2 = rm.AnomalyDetector()
+    np.random.seed(11)
+    d2.fit(bank)
+    det["img_threshold"] = np.float64(d2.threshold)
+    det["img_scores"] = t2n(d2.predict(qs[:17]))
+    np.savez_compressed(os.path.join(HERE, "detector.npz"), **det)
+
+    # ---------------- (v) upsample: restated third-party blur + torch bilinear ----------------
+    g = torch.Generator().manual_seed(5)
+    maps = torch.rand(3, 1, 29, 29, generator=g) - 0.2
+    onehot = torch.zeros(1, 1, 29, 29); onehot[0, 0, 0, 0] = 1; onehot[0, 0, 14, 20] = 2; onehot[0, 0, 28, 27] = -1
+    maps = torch.cat([maps, onehot])
+    np.savez_compressed(os.path.join(HERE, "upsample.npz"), maps=t2n(maps),
+                        kernel1d=t2n(osc.gaussian_kernel1d(7)),
+                        blurred=t2n(osc.gaussian_blur(maps, 7)),
+                        up256=t2n(osc.upsample(maps, 256)), up64=t2n(osc.upsample(maps, 64)))
+
+    # ---------------- (vi) cut-paste primitives under a fixed python RNG ----------------
+    from PIL import Image
+    cp = {}
+    base = (ow.synthetic_images(1, 256, seed=31, normalized=False)[0].permute(1, 2, 0) * 255).round().byte().numpy()
+    img = Image.fromarray(base, "RGB")
+    cp["base"] = base
+    random.seed(123)
+    patch = rg.generate_patch(img, area_ratio=(0.03, 0.07), aspect_ratio=((0.3, 0.5), (1, 3.3)))
+    cp["patch"] = np.array(patch)
+    random.seed(124)
+    mask = rg.rect2poly(patch, regular=False, sides=8)
+    cp["mask_rgba"] = np.array(mask)
+    coords = rg.check_valid_coordinates_by_container((256, 256), patch.size, current_coords=(250, 10),
+                                                      container_scaling_factor=1.75)
+    cp["coords"] = np.array(coords)
+    cp["pasted"] = np.array(rg.paste_patch(img, patch, coords, mask))
+    c = rg.Container((256, 256), 1.75)
+    cp["container"] = np.array([c.center, c.dim, c.left, c.top, c.right, c.bottom, c.width, c.height])
+    cp["color_sim"] = np.float64(rg.check_color_similarity(img.crop((0, 0, 40, 40)), patch))
+    random.seed(125)
+    avg = rg.generate_patch(img, area_ratio=(0.2, 0.5), colorized=True, color_type="average")
+    cp["avg_patch_size"] = np.array(avg.size)
+    cp["avg_patch_color"] = np.array(avg)[0, 0]
+    np.savez_compressed(os.path.join(HERE, "cutpaste.npz"), **cp)
+
+    # ---------------- (vii) AUROC through sklearn (metrics.py:49-56) ----------------
+    from sklearn.metrics import roc_curve, auc
+    g = torch.Generator().manual_seed(9)
+    labels = (torch.rand(4096, generator=g) > 0.8).int().numpy()
+    scores = (torch.rand(4096, generator=g) + 0.5 * torch.from_numpy(labels)).numpy().astype(np.float32)
+    fpr, tpr, _ = roc_curve(labels, scores)
+    np.savez_compressed(os.path.join(HERE, "auroc.npz"), labels=labels, scores=scores, auroc=np.float64(auc(fpr, tpr)))
+    print("fixtures written to", HERE)
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f"  {f:20s} {os.path.getsize(os.path.join(HERE, f)) / 1024:8.1f} KiB")
+
+
+if __name__ == "__main__":
+    main()
