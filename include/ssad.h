@@ -1,0 +1,87 @@
+/*
+ * ssad.h -- C ABI of libssad_hip.so, the MI355X (gfx950) kernels behind the
+ * self-supervised anomaly-detection hot path.
+ *
+ * The reference (gabry1998/Self-Supervised-Anomaly-Detection) is pure Python and has no
+ * FFI of its own: its numerics are PyTorch / torchvision / scikit-learn calls.  Each entry
+ * point below replaces one such call site (cited as path:line relative to the reference
+ * root).  Conventions:
+ *   - plain pointers + sizes, no torch types; every pointer is a DEVICE pointer unless
+ *     the name ends in _host;
+ *   - the caller owns every buffer (inputs, outputs, workspaces);
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it and the
+ *     library never synchronises;
+ *   - return 0 on success, non-zero on error; ssad_last_error() returns a message for
+ *     the calling thread.  Never aborts.
+ *   - activations are NHWC fp32 inside the library; conv weights are OHWI fp32
+ *     ([Cout][KH][KW][Cin]); images enter as NCHW fp32 exactly as the reference's
+ *     Dataset emits them (src/self_supervised/datasets.py:394).
+ */
+#ifndef SSAD_H
+#define SSAD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSAD_VERSION 100
+
+int ssad_version(void);
+const char* ssad_last_error(void);
+
+/* ---- weight repacking (checkpoint tensors keep the reference's OIHW shapes, SURVEY s.5) ---- */
+/* OIHW -> OHWI.  Linear weights [out][in] are already "OHWI" with KH=KW=1. */
+int ssad_repack_oihw_to_ohwi(const float* w_oihw, float* w_ohwi, int O, int I, int KH, int KW, void* stream);
+int ssad_repack_ohwi_to_oihw(const float* w_ohwi, float* w_oihw, int O, int I, int KH, int KW, void* stream);
+/* conv1 7x7 OIHW [64][3][7][7] -> MFMA K-order [168][64] (kx padded 7->8 with zeros). */
+int ssad_pack_stem_weight(const float* w_oihw, float* wk, void* stream);
+
+/* ---- forward kernels ---- */
+/* Replaces: extract_patches (src/self_supervised/functional.py:77-82) + reshape
+ * (src/self_supervised/models.py:212-214) + F.interpolate(x, 64, 'nearest') (models.py:217-219)
+ * + resnet conv1/bn1/relu (models.py:224; torchvision resnet18 stem), fused: the patch window and
+ * the nearest resize are applied in the loader, nothing is materialised.
+ *   img      : [B][3][H][W] NCHW fp32
+ *   patch_dim/patch_stride : sliding window (32, 8); patch_dim = 0 -> whole image is one sample
+ *   Hv, Wv   : size after the nearest resize (== window size when no resize happens)
+ *   wk       : ssad_pack_stem_weight output
+ *   scale/shift : per-channel affine applied to the conv output (eval-mode BN folded); NULL -> raw conv
+ *   out      : [Nsamp][Ho][Wo][64] NHWC, Ho = (Hv-1)/2+1.  Nsamp = B * patches per image.
+ */
+int ssad_stem_fwd(const float* img, int B, int H, int W, int patch_dim, int patch_stride, int Hv, int Wv,
+                  const float* wk, const float* scale, const float* shift, int relu, float* out, void* stream);
+
+/* Replaces nn.MaxPool2d(3, 2, 1) of the torchvision stem (models.py:224).  NHWC. */
+int ssad_maxpool3x3s2_fwd(const float* in, float* out, int64_t N, int H, int W, int C, void* stream);
+
+/* Replaces every nn.Conv2d(3x3 / 1x1, bias=False) + eval BatchNorm2d + residual add + ReLU of the
+ * BasicBlocks (models.py:224), and every nn.Linear (+BatchNorm1d, +ReLU) of concatenator /
+ * latent_space / classifier (models.py:247-249) with H=W=KH=KW=1.  Implicit GEMM on
+ * v_mfma_f32_32x32x2_f32: out[m][co] = act( (sum_k in[m,k] * w[co,k]) * scale[co] + shift[co] + residual[m][co] ).
+ * Requires Cin % 32 == 0.  scale/shift/residual may be NULL.
+ */
+int ssad_conv_igemm_fwd(const float* in, const float* w_ohwi, float* out, const float* scale, const float* shift,
+                        const float* residual, int relu, int64_t N, int H, int W, int Cin, int Cout, int KH, int KW,
+                        int stride, int pad, void* stream);
+
+/* Replaces F.adaptive_avg_pool2d(., (1,1)) + flatten + torch.cat (models.py:227-245):
+ * out[n*out_stride + out_offset + c] = mean over HW of in[n][hw][c]. */
+int ssad_gap_fwd(const float* in, float* out, int64_t N, int HW, int C, int out_stride, int out_offset, void* stream);
+
+/* ---- scoring ---- */
+/* Replaces sklearn NearestNeighbors(metric='cosine').kneighbors + torch.mean (models.py:352-370).
+ * l2norm: out[i] = x[i] / ||x[i]||.  knn3: given sim[Nq][Nb] = qn . bn, writes mean of the 3 smallest
+ * clip(1 - sim, 0, 2) per row. */
+int ssad_l2_normalize_rows(const float* x, float* out, int64_t N, int D, void* stream);
+int ssad_cosine_knn_mean(const float* sim, float* out, int64_t Nq, int Nb, int k, void* stream);
+
+/* Replaces tools.upsample (src/self_supervised/tools.py:394-399): relu(gaussian_blur(k, sigma=0.15k+0.35,
+ * reflect)) then bilinear (align_corners=False) to target x target.  maps [n][h][w] -> out [n][target][target]. */
+int ssad_blur_relu_bilinear(const float* maps, float* out, int n, int h, int w, int ksize, int target, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSAD_H */

@@ -1,0 +1,35 @@
+// Shared helpers for the gfx950 kernels (wave64, fp32 MFMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+void ssad_set_error(const char* fmt, ...);
+
+#define SSAD_CHECK_ARG(cond, msg)                                     \
+    do {                                                              \
+        if (!(cond)) {                                                \
+            ssad_set_error("%s: %s (%s)", __func__, msg, #cond);      \
+            return 2;                                                 \
+        }                                                             \
+    } while (0)
+
+#define SSAD_CHECK_LAUNCH()                                           \
+    do {                                                              \
+        hipError_t e_ = hipGetLastError();                            \
+        if (e_ != hipSuccess) {                                       \
+            ssad_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e_)); \
+            return 1;                                                 \
+        }                                                             \
+    } while (0)
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// v_mfma_f32_32x32x2_f32: lane l feeds A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];
+// D[row = (reg&3) + 8*(reg>>2) + 4*(l>>5)][col = l&31].  Exact f32 fma chain in k order.
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}

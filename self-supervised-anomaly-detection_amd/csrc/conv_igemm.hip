@@ -1,0 +1,212 @@
+// Implicit-GEMM convolution / linear layer on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+//   out[m][co] = act( (sum_k A[m][k] * Wt[co][k]) * scale[co] + shift[co] + residual[m][co] )
+//   m = (n, oy, ox) flattened NHWC output pixel, k = (ky, kx, ci) with ci fastest (OHWI weights).
+//
+// Replaces the nn.Conv2d/BatchNorm2d/ReLU/residual chains of the torchvision BasicBlocks and the
+// nn.Linear/BatchNorm1d/ReLU chains of the projection head that the reference runs through cuDNN /
+// MKLDNN (src/self_supervised/models.py:224, :247-249).
+//
+// Design (MI355X): 256-thread workgroups = 4 waves, one per SIMD; each wave owns TM x TN accumulator
+// tiles of 32x32 (f32x16 each).  A (gathered activations) and B (weights) K-slices of 32 floats are
+// staged global -> registers -> LDS with 144-byte rows (128 B + 16 B pad: conflict-free ds_read_b128
+// for the "row = lane&31" fragment pattern), double buffered, one barrier per K-step.  Each lane reads
+// 4 consecutive k per ds_read_b128; lane half h takes k = 8*kk + 4*h + e for the e-th MFMA of a chunk,
+// the same permutation for A and B, so the contraction is unchanged.  Zero padding is produced by
+// predicated loads (no padded copy of the activations exists anywhere).
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;    // floats per K-step
+constexpr int LDK = 36;   // LDS row stride in floats (144 B)
+
+struct ConvParams {
+    const float* in;
+    const float* wt;
+    float* out;
+    const float* scale;
+    const float* shift;
+    const float* residual;
+    int64_t M;          // N*Ho*Wo
+    int H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, relu;
+    int K;              // KH*KW*Cin
+};
+
+template <int BM, int BN, int TM, int TN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
+    constexpr int WN = BN / (32 * TN);
+    constexpr int AR = BM / 32;     // 16-byte chunks of A staged per thread per K-step
+    constexpr int BR = BN / 32;
+    constexpr int STAGE = (BM + BN) * LDK;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int sc = tid & 7, sr = tid >> 3;
+
+    // ---- per-thread staging rows (fixed across the K loop) ----
+    int64_t a_base[AR];
+    int a_iy[AR], a_ix[AR];
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        int64_t m = m0 + sr + 32 * i;
+        if (m < p.M) {
+            int64_t n = m / HoWo;
+            int rem = (int)(m - n * HoWo);
+            int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            a_base[i] = n * (int64_t)p.H * p.W * p.Cin + sc * 4;
+            a_iy[i] = oy * p.stride - p.pad;
+            a_ix[i] = ox * p.stride - p.pad;
+        } else {
+            a_base[i] = 0;
+            a_iy[i] = -(1 << 20);
+            a_ix[i] = -(1 << 20);
+        }
+    }
+    int64_t b_off[BR];
+    bool b_ok[BR];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+        int co = n0 + sr + 32 * i;
+        b_ok[i] = co < p.Cout;
+        b_off[i] = (int64_t)co * p.K + sc * 4;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int cpt = p.Cin / BK;               // K-steps per filter tap
+    const int nk = p.KH * p.KW * cpt;
+    f32x4 ra[AR], rb[BR];
+
+    int ld_ky = 0, ld_kx = 0, ld_cc = 0, ld_ks = 0;   // state of the next K-step to load
+    auto load_step = [&]() {
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            int y = a_iy[i] + ld_ky, x = a_ix[i] + ld_kx;
+            bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *(const f32x4*)(p.in + a_base[i] + ((int64_t)y * p.W + x) * p.Cin + ld_cc * BK);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (b_ok[i]) v = *(const f32x4*)(p.wt + b_off[i] + (int64_t)ld_ks * BK);
+            rb[i] = v;
+        }
+        ++ld_ks;
+        if (++ld_cc == cpt) {
+            ld_cc = 0;
+            if (++ld_kx == p.KW) { ld_kx = 0; ++ld_ky; }
+        }
+    };
+    auto store_step = [&](float* buf) {
+        float* As = buf;
+        float* Bs = buf + BM * LDK;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) *(f32x4*)(As + (sr + 32 * i) * LDK + sc * 4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BR; ++i) *(f32x4*)(Bs + (sr + 32 * i) * LDK + sc * 4) = rb[i];
+    };
+
+    load_step();
+    store_step(lds);
+    __syncthreads();
+
+    for (int ks = 0; ks < nk; ++ks) {
+        float* cur = lds + (ks & 1) * STAGE;
+        const bool more = ks + 1 < nk;
+        if (more) load_step();
+        const float* As = cur + (wm * 32 * TM + r) * LDK + h * 4;
+        const float* Bs = cur + BM * LDK + (wn * 32 * TN + r) * LDK + h * 4;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *(const f32x4*)(As + i * 32 * LDK + kk * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *(const f32x4*)(Bs + j * 32 * LDK + kk * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(a[i][e], b[j][e], acc[i][j]);
+        }
+        if (more) store_step(lds + ((ks + 1) & 1) * STAGE);
+        __syncthreads();
+    }
+
+    // ---- epilogue: affine (folded BN / bias), residual, ReLU; 128-B row segments per half-wave ----
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 32 + r;
+        if (col >= p.Cout) continue;
+        const float s = p.scale ? p.scale[col] : 1.f;
+        const float t = p.shift ? p.shift[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                int64_t row = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row < p.M) {
+                    int64_t o = row * p.Cout + col;
+                    float v = acc[i][j][e] * s + t;
+                    if (p.residual) v += p.residual[o];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    p.out[o] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int TM, int TN>
+int launch(const ConvParams& p, hipStream_t st) {
+    constexpr int lds_bytes = 2 * (BM + BN) * LDK * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_igemm_f32_kernel<BM, BN, TM, TN>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        attr_set = true;
+    }
+    dim3 grid((unsigned)cdiv64(p.M, BM), (unsigned)((p.Cout + BN - 1) / BN));
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, TM, TN>), grid, dim3(256), lds_bytes, st, p);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int ssad_conv_igemm_fwd(const float* in, const float* w_ohwi, float* out, const float* scale,
+                                   const float* shift, const float* residual, int relu, int64_t N, int H, int W,
+                                   int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream) {
+    SSAD_CHECK_ARG(in && w_ohwi && out, "null pointer");
+    SSAD_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "empty shape");
+    SSAD_CHECK_ARG(Cin % BK == 0, "Cin must be a multiple of 32");
+    SSAD_CHECK_ARG(KH > 0 && KW > 0 && stride > 0 && pad >= 0, "bad filter geometry");
+    ConvParams p;
+    p.in = in; p.wt = w_ohwi; p.out = out; p.scale = scale; p.shift = shift; p.residual = residual;
+    p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.relu = relu;
+    p.Ho = (H + 2 * pad - KH) / stride + 1;
+    p.Wo = (W + 2 * pad - KW) / stride + 1;
+    SSAD_CHECK_ARG(p.Ho > 0 && p.Wo > 0, "empty output");
+    p.M = N * p.Ho * p.Wo;
+    p.K = KH * KW * Cin;
+    SSAD_CHECK_ARG(cdiv64(p.M, 128) < (int64_t)2147483647, "M too large for one launch");
+    hipStream_t st = (hipStream_t)stream;
+    if (Cout <= 64) launch<128, 64, 1, 2>(p, st);
+    else launch<128, 128, 2, 2>(p, st);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}

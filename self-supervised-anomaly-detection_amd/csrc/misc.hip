@@ -1,0 +1,213 @@
+// HBM-bound helpers: weight repacking, global average pool, cosine 3-NN reduction, blur+ReLU+bilinear.
+#include "common.h"
+#include <stdarg.h>
+
+// ---------------------------------------------------------------------------------------------
+// error reporting
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void ssad_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* ssad_last_error(void) { return g_err; }
+extern "C" int ssad_version(void) { return 100; }
+
+namespace {
+
+// OIHW <-> OHWI (one thread per element; weights are tiny next to activations)
+__global__ void repack_kernel(const float* __restrict__ src, float* __restrict__ dst, int O, int I, int KH, int KW,
+                              int to_ohwi) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = (int64_t)O * I * KH * KW;
+    if (idx >= total) return;
+    // idx enumerates OHWI
+    int ci = (int)(idx % I);
+    int64_t t = idx / I;
+    int kx = (int)(t % KW); t /= KW;
+    int ky = (int)(t % KH);
+    int o = (int)(t / KH);
+    int64_t oihw = (((int64_t)o * I + ci) * KH + ky) * KW + kx;
+    if (to_ohwi) dst[idx] = src[oihw];
+    else dst[oihw] = src[idx];
+}
+
+// in [N][HW][C] -> out[n*stride + off + c] = sum/HW.  One thread per (n, c); lanes run over c (coalesced).
+__global__ void gap_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t N, int HW, int C,
+                           int out_stride, int out_offset) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    int c = (int)(i % C);
+    int64_t n = i / C;
+    const float* p = in + n * HW * C + c;
+    float s = 0.f;
+    for (int k = 0; k < HW; ++k) s += p[(int64_t)k * C];
+    out[n * out_stride + out_offset + c] = s / (float)HW;
+}
+
+// one wave per row
+__global__ void l2norm_rows_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t N, int D) {
+    int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= N) return;
+    int lane = threadIdx.x & 63;
+    const float* p = x + row * D;
+    float s = 0.f;
+    for (int k = lane; k < D; k += 64) s += p[k] * p[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    float nrm = sqrtf(s);
+    for (int k = lane; k < D; k += 64) out[row * D + k] = p[k] / nrm;
+}
+
+__device__ __forceinline__ void insert3(float v, float& a, float& b, float& c) {
+    // keeps a <= b <= c as the three smallest
+    if (v < c) {
+        if (v < b) {
+            c = b;
+            if (v < a) { b = a; a = v; } else b = v;
+        } else c = v;
+    }
+}
+
+// sim [Nq][Nb] -> mean of the k (<=3) smallest clip(1-sim,0,2).  One wave per row.
+__global__ void knn_mean_kernel(const float* __restrict__ sim, float* __restrict__ out, int64_t Nq, int Nb, int k) {
+    int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= Nq) return;
+    int lane = threadIdx.x & 63;
+    const float* p = sim + row * Nb;
+    float a = INFINITY, b = INFINITY, c = INFINITY;
+    for (int j = lane; j < Nb; j += 64) {
+        float d = 1.f - p[j];
+        d = fminf(fmaxf(d, 0.f), 2.f);
+        insert3(d, a, b, c);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float oa = __shfl_xor(a, o), ob = __shfl_xor(b, o), oc = __shfl_xor(c, o);
+        insert3(oa, a, b, c);
+        insert3(ob, a, b, c);
+        insert3(oc, a, b, c);
+    }
+    if (lane == 0) {
+        float s = a;
+        if (k > 1) s += b;
+        if (k > 2) s += c;
+        out[row] = s / (float)k;
+    }
+}
+
+// relu(gaussian_blur(reflect pad)) then bilinear(align_corners=False).  One workgroup per map.
+__global__ void blur_relu_bilinear_kernel(const float* __restrict__ maps, float* __restrict__ out, int h, int w, int ks,
+                                          int target) {
+    extern __shared__ float sm[];
+    float* src = sm;                 // h*w
+    float* blr = sm + h * w;         // h*w
+    float* k1 = blr + h * w;         // ks
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const float* m = maps + (int64_t)n * h * w;
+    for (int i = tid; i < h * w; i += blockDim.x) src[i] = m[i];
+    if (tid == 0) {
+        // torchvision: sigma = 0.15*k + 0.35; x = linspace(-(k-1)/2, (k-1)/2, k); pdf = exp(-0.5 (x/sigma)^2); k1 = pdf/sum
+        float sigma = 0.15f * (float)ks + 0.35f;
+        float half = (float)(ks - 1) * 0.5f, sum = 0.f;
+        for (int i = 0; i < ks; ++i) {
+            float x = -half + (float)i;
+            float v = expf(-0.5f * (x / sigma) * (x / sigma));
+            k1[i] = v;
+            sum += v;
+        }
+        for (int i = 0; i < ks; ++i) k1[i] /= sum;
+    }
+    __syncthreads();
+    const int pad = ks / 2;
+    for (int i = tid; i < h * w; i += blockDim.x) {
+        int y = i / w, x = i - y * w;
+        float acc = 0.f;
+        for (int dy = 0; dy < ks; ++dy) {
+            int yy = y + dy - pad;
+            yy = yy < 0 ? -yy : (yy >= h ? 2 * h - 2 - yy : yy);
+            for (int dx = 0; dx < ks; ++dx) {
+                int xx = x + dx - pad;
+                xx = xx < 0 ? -xx : (xx >= w ? 2 * w - 2 - xx : xx);
+                acc += src[yy * w + xx] * (k1[dy] * k1[dx]);
+            }
+        }
+        blr[i] = fmaxf(acc, 0.f);
+    }
+    __syncthreads();
+    const float shy = (float)h / (float)target, swx = (float)w / (float)target;
+    float* o = out + (int64_t)n * target * target;
+    for (int i = tid; i < target * target; i += blockDim.x) {
+        int y = i / target, x = i - y * target;
+        float sy = fmaxf(shy * ((float)y + 0.5f) - 0.5f, 0.f);
+        float sx = fmaxf(swx * ((float)x + 0.5f) - 0.5f, 0.f);
+        int y0 = (int)sy, x0 = (int)sx;
+        int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+        float ly = sy - (float)y0, lx = sx - (float)x0;
+        float hy = 1.f - ly, hx = 1.f - lx;
+        o[i] = hy * (hx * blr[y0 * w + x0] + lx * blr[y0 * w + x1]) + ly * (hx * blr[y1 * w + x0] + lx * blr[y1 * w + x1]);
+    }
+}
+
+}  // namespace
+
+static int repack(const float* src, float* dst, int O, int I, int KH, int KW, int to_ohwi, void* stream) {
+    int64_t total = (int64_t)O * I * KH * KW;
+    hipLaunchKernelGGL(repack_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, O, I,
+                       KH, KW, to_ohwi);
+    return 0;
+}
+
+extern "C" int ssad_repack_oihw_to_ohwi(const float* w_oihw, float* w_ohwi, int O, int I, int KH, int KW, void* stream) {
+    SSAD_CHECK_ARG(w_oihw && w_ohwi && O > 0 && I > 0 && KH > 0 && KW > 0, "bad argument");
+    repack(w_oihw, w_ohwi, O, I, KH, KW, 1, stream);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ssad_repack_ohwi_to_oihw(const float* w_ohwi, float* w_oihw, int O, int I, int KH, int KW, void* stream) {
+    SSAD_CHECK_ARG(w_oihw && w_ohwi && O > 0 && I > 0 && KH > 0 && KW > 0, "bad argument");
+    repack(w_ohwi, w_oihw, O, I, KH, KW, 0, stream);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ssad_gap_fwd(const float* in, float* out, int64_t N, int HW, int C, int out_stride, int out_offset,
+                            void* stream) {
+    SSAD_CHECK_ARG(in && out && N > 0 && HW > 0 && C > 0, "bad argument");
+    SSAD_CHECK_ARG(out_offset >= 0 && out_offset + C <= out_stride, "slice does not fit the output row");
+    hipLaunchKernelGGL(gap_kernel, dim3((unsigned)cdiv64(N * C, 256)), dim3(256), 0, (hipStream_t)stream, in, out, N, HW, C,
+                       out_stride, out_offset);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ssad_l2_normalize_rows(const float* x, float* out, int64_t N, int D, void* stream) {
+    SSAD_CHECK_ARG(x && out && N > 0 && D > 0, "bad argument");
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)cdiv64(N, 4)), dim3(256), 0, (hipStream_t)stream, x, out, N, D);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ssad_cosine_knn_mean(const float* sim, float* out, int64_t Nq, int Nb, int k, void* stream) {
+    SSAD_CHECK_ARG(sim && out && Nq > 0 && Nb > 0, "bad argument");
+    SSAD_CHECK_ARG(k >= 1 && k <= 3 && k <= Nb, "k must be 1..3 and <= bank rows");
+    hipLaunchKernelGGL(knn_mean_kernel, dim3((unsigned)cdiv64(Nq, 4)), dim3(256), 0, (hipStream_t)stream, sim, out, Nq, Nb, k);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ssad_blur_relu_bilinear(const float* maps, float* out, int n, int h, int w, int ksize, int target,
+                                       void* stream) {
+    SSAD_CHECK_ARG(maps && out && n > 0 && h > 0 && w > 0 && target > 0, "bad argument");
+    SSAD_CHECK_ARG(ksize >= 1 && (ksize & 1) && ksize / 2 < h && ksize / 2 < w, "kernel must be odd and reflect-pad must fit");
+    size_t lds = (size_t)(2 * h * w + ksize) * sizeof(float);
+    SSAD_CHECK_ARG(lds <= 64 * 1024, "map too large for the single-workgroup kernel");
+    hipLaunchKernelGGL(blur_relu_bilinear_kernel, dim3(n), dim3(256), lds, (hipStream_t)stream, maps, out, h, w, ksize, target);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}

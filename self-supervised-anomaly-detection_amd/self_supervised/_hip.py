@@ -1,0 +1,77 @@
+"""ctypes binding of libssad_hip.so (C ABI declared in include/ssad.h).
+
+The product path has no CPU fallback: if the shared object is missing or a tensor is not a
+contiguous fp32 ROCm tensor, these wrappers raise.  PyTorch is used only for device memory and
+streams (``data_ptr()``, ``torch.cuda.current_stream()``).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libssad_hip.so")
+
+_c_fp = ctypes.c_void_p
+_c_i = ctypes.c_int
+_c_l = ctypes.c_int64
+
+# name -> argtypes; mirrors include/ssad.h one to one (tests/test_capi_symbols.py checks the header too)
+SIGNATURES = {
+    "ssad_repack_oihw_to_ohwi": [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_repack_ohwi_to_oihw": [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_pack_stem_weight": [_c_fp, _c_fp, _c_fp],
+    "ssad_stem_fwd": [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_i, _c_fp, _c_fp],
+    "ssad_maxpool3x3s2_fwd": [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_conv_igemm_fwd": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
+                            _c_i, _c_i, _c_fp],
+    "ssad_gap_fwd": [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_l2_normalize_rows": [_c_fp, _c_fp, _c_l, _c_i, _c_fp],
+    "ssad_cosine_knn_mean": [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp],
+    "ssad_blur_relu_bilinear": [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
+}
+
+_lib = None
+
+
+class HipExtensionError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads the shared object once; raises HipExtensionError when it is absent (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipExtensionError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path.")
+        l = ctypes.CDLL(LIB_PATH)
+        l.ssad_version.restype = _c_i
+        l.ssad_last_error.restype = ctypes.c_char_p
+        for name, args in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.argtypes = args
+            fn.restype = _c_i
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise HipExtensionError(lib().ssad_last_error().decode())
+
+
+def ptr(t, allow_none=False):
+    if t is None:
+        if allow_none:
+            return None
+        raise HipExtensionError("null tensor")
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise HipExtensionError(
+            f"expected a contiguous fp32 ROCm tensor, got device={t.device} dtype={t.dtype} contiguous={t.is_contiguous()}")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream

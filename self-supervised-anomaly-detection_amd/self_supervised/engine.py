@@ -1,0 +1,126 @@
+"""Forward engine: runs PeraNet's trunk + head on the HIP kernels (NHWC, fp32 MFMA).
+
+Mirrors the op sequence of ``PeraNet.forward`` (src/self_supervised/models.py:210-253 of the
+reference): [patch window + nearest resize +] stem, max-pool, 8 BasicBlocks, global average pool of
+layer2/3/4 concatenated in that order, concatenator, latent MLP, classifier.  Eval-mode BatchNorm is
+folded to a per-channel scale/shift applied in the conv epilogue (alpha = gamma/sqrt(var+eps),
+beta' = beta - mean*alpha: the same two-constant form PyTorch's CPU kernel evaluates).
+"""
+import torch
+from torch import nn
+
+from . import ops
+
+BLOCKS = [("layer1", 64, 64, 1), ("layer2", 64, 128, 2), ("layer3", 128, 256, 2), ("layer4", 256, 512, 2)]
+
+
+class _Block(nn.Module):
+    """Parameter holder with torchvision BasicBlock names; never called."""
+
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+        self.stride = stride
+
+
+class ResNet18Params(nn.Module):
+    """Holds the trunk's parameters/buffers under torchvision's state_dict names (SURVEY s.5).
+    Weights are random (kaiming-normal fan_out, as torchvision initialises): the IMAGENET1K_V1
+    checkpoint the reference downloads (models.py:59) is loaded via load_state_dict where available."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        for name, cin, cout, stride in BLOCKS:
+            setattr(self, name, nn.Sequential(_Block(cin, cout, stride), _Block(cout, cout, 1)))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def forward(self, *a, **k):
+        raise RuntimeError("ResNet18Params only holds parameters; PeraNet.forward drives the HIP engine")
+
+
+def _fold_bn(bn, bias=None):
+    """eval BN -> (scale, shift); an optional preceding Linear bias is folded into the shift."""
+    with torch.no_grad():
+        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        shift = bn.bias - bn.running_mean * scale
+        if bias is not None:
+            shift = shift + bias * scale
+    return scale.contiguous(), shift.contiguous()
+
+
+class EvalPlan:
+    """Packed (OHWI / stem-order) weights and folded BN constants for one parameter version."""
+
+    def __init__(self, model):
+        fe = model.feature_extractor
+        self.version = param_version(model)
+        with torch.no_grad():
+            self.stem_w = ops.pack_stem_weight(fe.conv1.weight.contiguous())
+            self.stem_s, self.stem_t = _fold_bn(fe.bn1)
+            self.blocks = []
+            for name, _, _, _ in BLOCKS:
+                for blk in getattr(fe, name):
+                    d = {"stride": blk.stride,
+                         "w1": ops.repack_oihw_to_ohwi(blk.conv1.weight.contiguous()),
+                         "w2": ops.repack_oihw_to_ohwi(blk.conv2.weight.contiguous())}
+                    d["s1"], d["t1"] = _fold_bn(blk.bn1)
+                    d["s2"], d["t2"] = _fold_bn(blk.bn2)
+                    if blk.downsample is not None:
+                        d["wd"] = ops.repack_oihw_to_ohwi(blk.downsample[0].weight.contiguous())
+                        d["sd"], d["td"] = _fold_bn(blk.downsample[1])
+                    self.blocks.append((name, d))
+            self.head = []
+            lin, bn = model.concatenator[0], model.concatenator[1]
+            self.head.append((lin.weight.contiguous(), *_fold_bn(bn, lin.bias), False))
+            ls = list(model.latent_space)
+            for seq in ls[:-2]:
+                self.head.append((seq[0].weight.contiguous(), *_fold_bn(seq[1], seq[0].bias), True))
+            self.head.append((ls[-2].weight.contiguous(), *_fold_bn(ls[-1], ls[-2].bias), False))
+            self.cls_w = model.classifier.weight.contiguous()
+            self.cls_b = model.classifier.bias.contiguous()
+
+
+def param_version(model):
+    return tuple(t._version for t in list(model.parameters()) + list(model.buffers())) + (
+        next(model.parameters()).device,)
+
+
+def trunk_eval(plan, x, patch_dim, patch_stride, layer_outputs, pooled):
+    """x NCHW fp32 -> writes the GAP vectors of the requested stages into ``pooled`` [N][D]."""
+    a = ops.stem_fwd(x, plan.stem_w, plan.stem_s, plan.stem_t, True, patch_dim, patch_stride)
+    a = ops.maxpool3x3s2_fwd(a)
+    offs, off = {}, 0
+    for k in ("layer1", "layer2", "layer3"):
+        if k in layer_outputs:
+            offs[k] = off
+            off += {"layer1": 64, "layer2": 128, "layer3": 256}[k]
+    offs["layer4"] = off
+    for i, (name, d) in enumerate(plan.blocks):
+        s = d["stride"]
+        idt = a
+        if "wd" in d:
+            idt = ops.conv_fwd(a, d["wd"], d["sd"], d["td"], None, False, s, 0)
+        t = ops.conv_fwd(a, d["w1"], d["s1"], d["t1"], None, True, s, 1)
+        a = ops.conv_fwd(t, d["w2"], d["s2"], d["t2"], idt, True, 1, 1)
+        last_of_stage = (i % 2 == 1)
+        if last_of_stage and name in offs:
+            ops.gap_fwd(a, pooled, offs[name])
+    return pooled
+
+
+def head_eval(plan, pooled):
+    f = pooled
+    for w, s, t, relu in plan.head:
+        f = ops.linear_fwd(f, w, s, t, relu)
+    logits = ops.linear_fwd(f, plan.cls_w, None, plan.cls_b, False)
+    return logits, f

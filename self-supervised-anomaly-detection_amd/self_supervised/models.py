@@ -1,0 +1,274 @@
+"""PeraNet and AnomalyDetector with the reference's call surface, computed by HIP kernels.
+
+Drop-in for src/self_supervised/models.py of gabry1998/Self-Supervised-Anomaly-Detection:
+same constructor arguments, method names, return types and state_dict keys.  Numerics run in
+libssad_hip.so (see engine.py / ops.py); there is no CPU fallback -- inputs must live on the GPU.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+from torch import Tensor, nn
+
+from . import engine, ops
+from .constants import ModelOutputsContainer
+from .converters import gt2label, multiclass2binary
+from .functional import get_prediction_class
+
+try:                                    # optional: behave as a LightningModule when PL is installed
+    import pytorch_lightning as pl
+    _Base = pl.LightningModule
+except Exception:                       # PL is absent in the build image; trainer.py supplies the loop
+    pl = None
+
+    class _Base(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.current_epoch = 0
+            self.trainer = None
+            self.hparams = {}
+            self.logged = OrderedDict()
+
+        def save_hyperparameters(self, **kw):
+            self.hparams = dict(kw)
+
+        def log_dict(self, metrics, **kw):
+            for k, v in metrics.items():
+                self.logged.setdefault(k, []).append(float(v))
+
+
+class PeraNet(_Base):
+    """src/self_supervised/models.py:21-341."""
+
+    def __init__(self, learning_rate: float = 0.03, epochs: int = 30, layer_outputs: list = ['layer2', 'layer3'],
+                 latent_space_layers: int = 5, latent_space_layers_base_dim: int = 512, num_classes: int = 4,
+                 memory_bank_dim: int = 1000, stage='projection_train') -> None:
+        super().__init__()
+        if pl is not None:
+            self.save_hyperparameters()
+        else:
+            self.save_hyperparameters(learning_rate=learning_rate, epochs=epochs, layer_outputs=layer_outputs,
+                                      latent_space_layers=latent_space_layers,
+                                      latent_space_layers_base_dim=latent_space_layers_base_dim,
+                                      num_classes=num_classes, memory_bank_dim=memory_bank_dim, stage=stage)
+        self.backbone = 'resnet18'
+        self.layer_outputs = list(layer_outputs)
+        dim_in = 512 + sum({'layer1': 64, 'layer2': 128, 'layer3': 256}[k] for k in self.layer_outputs)
+        base = latent_space_layers_base_dim
+        self.feature_extractor = engine.ResNet18Params()
+        self.concatenator = nn.Sequential(nn.Linear(dim_in, base, bias=False), nn.BatchNorm1d(base))
+        # (latent_space_layers-1) entries: hidden [Linear(nb)+BN+ReLU] blocks then Linear(bias)+BN (models.py:65-88)
+        n_hidden = max(latent_space_layers - 1, 1) - 1
+        layers = [nn.Sequential(nn.Linear(base, base, bias=False), nn.BatchNorm1d(base), nn.ReLU(inplace=True))
+                  for _ in range(n_hidden)]
+        layers += [nn.Linear(base, 512, bias=True), nn.BatchNorm1d(512)]
+        self.latent_space = nn.Sequential(*layers)
+        self.classifier = nn.Linear(512, num_classes)
+
+        self.mvtec = False
+        self.patch_level = False
+        self.num_classes = num_classes
+        self.lr = learning_rate
+        self.num_epochs = epochs
+        self.stage = stage
+        self.memory_bank_dim = memory_bank_dim
+        self.memory_bank = torch.tensor([], device='cpu')
+        self.batch = None
+        self.num_patches = None
+        self.max_samples_per_pass = 16384      # patches pushed through the trunk per kernel sequence
+        self._plan = None
+        self._frozen = set()
+
+    # ---- mode switches (models.py:149-172) ----
+    def enable_patch_level_mode(self):
+        self.patch_level = True
+
+    def disable_patch_level_mode(self):
+        self.patch_level = False
+
+    def enable_mvtec_inference(self) -> None:
+        self.mvtec = True
+
+    def disable_mvtec_inference(self) -> None:
+        self.mvtec = False
+
+    def clear_memory_bank(self) -> None:
+        self.memory_bank = torch.tensor([])
+
+    def unfreeze_net(self, modules: list = ['backbone', 'latent_space']) -> None:
+        if 'backbone' in modules:
+            for p in self.feature_extractor.parameters():
+                p.requires_grad = True
+            self._frozen.discard('backbone')
+        if 'latent_space' in modules:
+            for m in (self.concatenator, self.latent_space):
+                for p in m.parameters():
+                    p.requires_grad = True
+            self._frozen.discard('latent_space')
+
+    def freeze_net(self, modules: list = ['backbone', 'latent_space']) -> None:
+        if 'backbone' in modules:
+            for p in self.feature_extractor.parameters():
+                p.requires_grad = False
+            self.feature_extractor.eval()
+            self._frozen.add('backbone')
+        if 'latent_space' in modules:
+            for m in (self.concatenator, self.latent_space):
+                for p in m.parameters():
+                    p.requires_grad = False
+                m.eval()
+            self._frozen.add('latent_space')
+
+    def unfreeze(self) -> None:          # LightningModule.unfreeze(), used at tools.py:282
+        for p in self.parameters():
+            p.requires_grad = True
+        self._frozen.clear()
+        self.train()
+
+    def on_save_checkpoint(self, checkpoint) -> None:
+        checkpoint['memory_bank'] = self.memory_bank.to('cpu')
+
+    def on_load_checkpoint(self, checkpoint) -> None:
+        self.memory_bank = checkpoint['memory_bank'] if 'memory_bank' in checkpoint else torch.tensor([])
+
+    # ---- forward (models.py:210-253) ----
+    def _eval_plan(self):
+        v = engine.param_version(self)
+        if self._plan is None or self._plan.version != v:
+            self._plan = engine.EvalPlan(self)
+        return self._plan
+
+    def forward(self, x: Tensor) -> dict:
+        if not x.is_cuda:
+            raise RuntimeError("PeraNet.forward runs on the MI355X HIP kernels only: move the batch to the GPU")
+        x = x.contiguous().float()
+        if self.training and torch.is_grad_enabled():
+            from . import training
+            return training.forward_train(self, x)
+        b, _, h, w = x.shape
+        pd, ps = (32, 8) if self.patch_level else (0, 0)
+        p = ops.stem_geometry(h, w, pd, ps)[0]
+        if self.patch_level:
+            self.batch, self.num_patches = b, p
+        plan = self._eval_plan()
+        dim_in = self.concatenator[0].in_features
+        pooled = torch.empty((b * p, dim_in), device=x.device, dtype=torch.float32)
+        per_pass = max(1, self.max_samples_per_pass // p)
+        for i0 in range(0, b, per_pass):
+            i1 = min(b, i0 + per_pass)
+            engine.trunk_eval(plan, x[i0:i1], pd, ps, self.layer_outputs, pooled[i0 * p:i1 * p])
+        logits, emb = engine.head_eval(plan, pooled)
+        return {'classifier': logits, 'latent_space': emb}
+
+    # ---- steps (models.py:256-333) ----
+    def training_step(self, batch, batch_idx) -> Tensor:
+        from . import training
+        return training.training_step(self, batch, batch_idx)
+
+    def on_train_epoch_end(self) -> None:
+        self.memory_bank = self.memory_bank[-self.memory_bank_dim:].clone()
+
+    def fill_memory_bank(self, embeds: Tensor, y: Tensor, y_hat: Tensor):
+        mask = (y == 0) & (y_hat == 0)
+        embeds = embeds[mask].detach().to('cpu')
+        self.memory_bank = torch.cat([self.memory_bank, embeds])[-self.memory_bank_dim:].clone()
+
+    def validation_step(self, batch, batch_idx) -> dict:
+        from . import training
+        x, y, _ = batch
+        with torch.no_grad():
+            was = self.training
+            self.eval()
+            out = self(x)
+            self.train(was)
+        loss, acc = training.cross_entropy_eval(out['classifier'], y)
+        metrics = {"val_accuracy": acc, "val_loss": loss}
+        self.log_dict(metrics, on_step=False, on_epoch=True, prog_bar=True)
+        return metrics
+
+    def predict_step(self, batch, batch_idx, dataloader_idx=0) -> ModelOutputsContainer:
+        outputs = ModelOutputsContainer()
+        x_prime, groundtruths, x = batch
+        if self.mvtec:
+            outputs.y_true_binary_labels = torch.tensor(gt2label(groundtruths))
+            outputs.y_true_multiclass_labels = torch.tensor(gt2label(groundtruths, negative=-1, positive=self.num_classes))
+            outputs.ground_truths = groundtruths
+        else:
+            outputs.y_true_binary_labels = multiclass2binary(groundtruths)
+            outputs.y_true_multiclass_labels = groundtruths
+        with torch.no_grad():
+            predictions = self(x_prime)
+        raw_predictions = predictions['classifier']
+        outputs.original_data = x
+        outputs.tensor_data = x_prime
+        outputs.raw_predictions = raw_predictions
+        outputs.embedding_vectors = predictions['latent_space']
+        outputs.y_hat = get_prediction_class(raw_predictions)
+        return outputs
+
+    def configure_optimizers(self):
+        from . import training
+        optimizer = training.FusedSGD(self, self.lr, momentum=0.9, weight_decay=0.0005)
+        scheduler = training.CosineWarmRestarts(optimizer, self.num_epochs)
+        if self.stage == 'fine_tune':
+            return [optimizer], [scheduler]
+        return [optimizer], []
+
+
+class AnomalyDetector:
+    """src/self_supervised/models.py:345-370: cosine 3-NN distance to a bank of normal embeddings.
+
+    ``fit`` keeps the reference's unseeded 70/30 split (quirk Q5: depends on the global numpy RNG);
+    the bank is L2-normalised once and kept on the GPU, ``predict`` = normalise + MFMA GEMM + top-3 mean."""
+
+    def __init__(self, patch_level: bool = False, batch: int = None, num_patches: int = None) -> None:
+        self.patch_level = patch_level
+        self.batch = batch
+        self.dim = int(np.sqrt(num_patches)) if num_patches else None
+        self.k = 3
+        self.bank = None
+        self.threshold = None
+
+    @staticmethod
+    def _dev(t):
+        t = torch.as_tensor(t, dtype=torch.float32)
+        if not t.is_cuda:
+            if not torch.cuda.is_available():
+                raise RuntimeError("AnomalyDetector needs the MI355X HIP kernels (no CPU fallback)")
+            t = t.cuda()
+        return t.contiguous()
+
+    def fit(self, embeddings: Tensor, split: bool = True) -> None:
+        emb = torch.as_tensor(embeddings)
+        n = emb.shape[0]
+        if split:
+            # sklearn.model_selection.train_test_split(test_size=0.3): n_test = ceil(0.3 n), one global-RNG permutation,
+            # test = first n_test indices of the permutation, train = the rest
+            n_test = int(np.ceil(0.3 * n))
+            perm = np.random.permutation(n)
+            val_idx, train_idx = perm[:n_test], perm[n_test:n_test + (n - n_test)]
+            train, val = emb[train_idx], emb[val_idx]
+        else:
+            train, val = emb, emb
+        self.k = 3
+        self.fit_bank(train)
+        scores = self._scores(self._dev(val))
+        self.threshold = torch.max(scores).item()
+
+    def fit_bank(self, bank: Tensor) -> None:
+        self.bank = ops.l2_normalize_rows(self._dev(bank))
+
+    def _scores(self, x):
+        qn = ops.l2_normalize_rows(x)
+        out = torch.empty(x.shape[0], device=x.device, dtype=torch.float32)
+        step = 1 << 18
+        for i in range(0, x.shape[0], step):
+            sim = ops.linear_fwd(qn[i:i + step], self.bank)
+            out[i:i + step] = ops.cosine_knn_mean(sim, self.k)
+        return out
+
+    def predict(self, x: Tensor) -> Tensor:
+        anomaly_scores = self._scores(self._dev(x))
+        if self.patch_level:
+            anomaly_scores = torch.reshape(anomaly_scores, (self.batch, 1, self.dim, self.dim))
+        return anomaly_scores

@@ -1,0 +1,218 @@
+"""GPU parity: every HIP kernel and the full scoring path against the CPU oracle / golden vectors.
+All calls go through the C ABI (self_supervised.ops -> libssad_hip.so)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu-marked tests need the MI355X"
+    from self_supervised import _hip
+    _hip.lib()
+    return torch.device("cuda:0")
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def assert_close(got, want, tol=1e-4):
+    """|got-want| <= tol * max(1, max|want|): fp32 tolerance of BASELINE.json (1e-4), scale-aware."""
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    assert got.shape == want.shape
+    scale = max(1.0, want.abs().max().item())
+    err = (got - want).abs().max().item()
+    assert err <= tol * scale, f"max err {err:.3e} > {tol} * {scale:.3e}"
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad, affine, residual, relu
+    (3, 16, 16, 64, 64, 3, 1, 1, True, True, True),
+    (2, 16, 16, 64, 128, 3, 2, 1, True, False, True),
+    (2, 16, 16, 64, 128, 1, 2, 0, True, False, False),
+    (5, 4, 4, 256, 256, 3, 1, 1, True, True, True),
+    (7, 2, 2, 512, 512, 3, 1, 1, False, False, False),
+    (1, 9, 7, 32, 96, 3, 1, 1, True, True, False),          # ragged M and Cout tails
+    (2, 5, 5, 128, 588, 1, 1, 0, False, False, False),      # bank-like Cout (not a multiple of 32)
+    (1, 1, 1, 64, 4, 1, 1, 0, True, False, False),          # classifier-like
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_igemm(dev, case):
+    from self_supervised import ops
+    n, h, w, cin, cout, k, s, p, affine, res, relu = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    want = F.conv2d(x, wt, None, s, p)
+    sc = sh = r = None
+    if affine:
+        sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+        want = want * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    if res:
+        r = torch.randn(want.shape, generator=g)
+        want = want + r
+    if relu:
+        want = want.relu()
+    w_ohwi = ops.repack_oihw_to_ohwi(wt.to(dev))
+    assert torch.equal(w_ohwi.cpu(), wt.permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(ops.repack_ohwi_to_oihw(w_ohwi).cpu(), wt)
+    got = ops.conv_fwd(nhwc(x).to(dev), w_ohwi, None if sc is None else sc.to(dev), None if sh is None else sh.to(dev),
+                       None if r is None else nhwc(r).to(dev), relu, s, p)
+    assert_close(nchw(got), want, 2e-5)
+
+
+def test_conv_identity_asymmetric(dev):
+    """A = I check with an asymmetric B (guards against a transposed C/D map)."""
+    from self_supervised import ops
+    cin = cout = 64
+    wt = torch.zeros(cout, cin, 1, 1)
+    wt[torch.arange(cout), torch.arange(cin)] = 1.0
+    x = torch.arange(4 * cin * 3 * 5, dtype=torch.float32).reshape(4, cin, 3, 5) / 7.0
+    got = ops.conv_fwd(nhwc(x).to(dev), ops.repack_oihw_to_ohwi(wt.to(dev)))
+    assert torch.equal(nchw(got).cpu(), x)
+
+
+@pytest.mark.parametrize("mode", ["image64", "image256", "patch", "up32", "up48", "odd"])
+def test_stem_and_pool(dev, mode, seeded_sd):
+    from self_supervised import ops
+    from oracle import weights as ow, scoring as osc
+    w = seeded_sd["feature_extractor.conv1.weight"]
+    g = torch.Generator().manual_seed(3)
+    sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    pd = ps = 0
+    if mode == "image64":
+        x = ow.synthetic_images(3, 64, seed=1); ref_in = x
+    elif mode == "image256":
+        x = ow.synthetic_images(1, 256, seed=2); ref_in = x
+    elif mode == "patch":
+        x = ow.synthetic_images(2, 64, seed=4)[:, :, :, :56].contiguous(); pd, ps = 32, 8
+        p = osc.extract_patches(x, 32, 8); ref_in = F.interpolate(p.reshape(-1, 3, 32, 32), 64, mode="nearest")
+    elif mode == "up32":
+        x = ow.synthetic_images(2, 32, seed=5); ref_in = F.interpolate(x, 64, mode="nearest")
+    elif mode == "up48":
+        x = ow.synthetic_images(2, 48, seed=6); ref_in = F.interpolate(x, 64, mode="nearest")
+    else:
+        x = ow.synthetic_images(2, 256, seed=7)[:, :, :101, :77].contiguous(); ref_in = x
+    want = (F.conv2d(ref_in, w, None, 2, 3) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).relu()
+    wk = ops.pack_stem_weight(w.to(dev))
+    got = ops.stem_fwd(x.to(dev), wk, sc.to(dev), sh.to(dev), True, pd, ps)
+    assert_close(nchw(got), want, 2e-5)
+    pooled = ops.maxpool3x3s2_fwd(got)
+    assert torch.equal(nchw(pooled).cpu(), F.max_pool2d(nchw(got).cpu(), 3, 2, 1))
+
+
+def test_gap(dev):
+    from self_supervised import ops
+    x = torch.randn(5, 8, 8, 128)
+    out = torch.zeros(5, 896, device=dev)
+    ops.gap_fwd(x.to(dev), out, 128)
+    assert_close(out[:, 128:256], x.mean(dim=(1, 2)), 1e-6)
+    assert out[:, :128].abs().max().item() == 0 and out[:, 256:].abs().max().item() == 0
+
+
+def _model(sd, dev, patch):
+    from self_supervised.models import PeraNet
+    m = PeraNet()
+    m.load_state_dict(sd, strict=True)
+    m.eval().to(dev)
+    if patch:
+        m.enable_patch_level_mode()
+    return m
+
+
+def test_forward_golden_image_level(dev, golden, seeded_sd):
+    from oracle import weights as ow
+    g = golden("forward")
+    m = _model(seeded_sd, dev, False)
+    with torch.no_grad():
+        for key, x in (("img", ow.synthetic_images(2, 256, seed=1234)), ("c1", ow.synthetic_images(8, 64, seed=77)),
+                       ("up", ow.synthetic_images(4, 32, seed=78)), ("up48", ow.synthetic_images(2, 48, seed=79))):
+            o = m(x.to(dev))
+            assert_close(o["latent_space"], torch.from_numpy(g[key + "_emb"]))
+            assert_close(o["classifier"], torch.from_numpy(g[key + "_logits"]))
+
+
+def test_forward_golden_patch_level(dev, golden, seeded_sd):
+    from oracle import weights as ow
+    g = golden("forward")
+    m = _model(seeded_sd, dev, True)
+    with torch.no_grad():
+        o = m(ow.synthetic_images(2, 64, seed=99)[:, :, :, :48].contiguous().to(dev))
+        assert [m.batch, m.num_patches] == list(g["psmall_bp"])
+        assert_close(o["latent_space"], torch.from_numpy(g["psmall_emb"]))
+        assert_close(o["classifier"], torch.from_numpy(g["psmall_logits"]))
+        o = m(ow.synthetic_images(1, 256, seed=4321).to(dev))
+        assert (m.batch, m.num_patches) == (1, 841)
+        emb = o["latent_space"].cpu()
+        assert_close(emb[torch.from_numpy(g["patch_rows"])], torch.from_numpy(g["patch_emb_rows"]))
+        assert_close(emb.double().sum(1), torch.from_numpy(g["patch_emb_rowsum"]), 1e-4)
+        assert_close(o["classifier"], torch.from_numpy(g["patch_logits"]))
+        # chunked trunk passes must not change anything
+        m.max_samples_per_pass = 841
+        o2 = m(torch.cat([ow.synthetic_images(1, 256, seed=4321)] * 3).to(dev))
+        assert torch.equal(o2["latent_space"][:841], o["latent_space"]) and torch.equal(o2["latent_space"][1682:], o["latent_space"])
+
+
+def test_knn_golden(dev, golden):
+    from self_supervised.models import AnomalyDetector
+    from oracle import weights as ow
+    g = golden("detector")
+    bank, qs = ow.synthetic_bank(588, 512, seed=2), ow.synthetic_bank(300, 512, seed=3)
+    d = AnomalyDetector()
+    d.fit_bank(bank)
+    got = d.predict(qs).cpu().numpy()
+    np.testing.assert_allclose(got, g["kernel_scores"], atol=2e-6)
+    np.random.seed(11)
+    d2 = AnomalyDetector()
+    d2.fit(bank)
+    np.testing.assert_allclose(d2.threshold, g["img_threshold"], atol=2e-6)
+    np.testing.assert_allclose(d2.predict(qs[:17]).cpu().numpy(), g["img_scores"], atol=2e-6)
+
+
+def test_scoring_path_golden(dev, golden, seeded_sd):
+    """Reference order of tools.inference: bank = embeddings of one good image, split, fit, predict, upsample."""
+    from self_supervised.models import AnomalyDetector
+    from self_supervised import tools
+    from oracle import weights as ow, scoring as osc
+    g = golden("detector")
+    m = _model(seeded_sd, dev, True)
+    with torch.no_grad():
+        bank_src = m(ow.synthetic_images(1, 256, seed=4321).to(dev))["latent_space"]
+        q = m(ow.synthetic_images(2, 256, seed=2468).to(dev))["latent_space"]
+    np.random.seed(7)
+    d = AnomalyDetector(patch_level=True, batch=2, num_patches=m.num_patches)
+    d.fit(bank_src.cpu())
+    assert d.bank.shape[0] == int(g["bank_rows"])
+    maps = d.predict(q)
+    assert tuple(maps.shape) == (2, 1, 29, 29)
+    np.testing.assert_allclose(maps.cpu().numpy(), g["scores"], atol=1e-4)
+    np.testing.assert_allclose(d.threshold, g["threshold"], atol=1e-4)
+    up = tools.upsample(maps, 256)
+    want = osc.upsample(torch.from_numpy(g["scores"]), 256)
+    assert_close(up, want, 1e-4)
+
+
+def test_upsample_golden(dev, golden):
+    from self_supervised import tools
+    g = golden("upsample")
+    maps = torch.from_numpy(g["maps"]).to(dev)
+    np.testing.assert_allclose(tools.upsample(maps, 256).cpu().numpy(), g["up256"], atol=2e-6)
+    np.testing.assert_allclose(tools.upsample(maps, 64).cpu().numpy(), g["up64"], atol=2e-6)
+
+
+def test_errors_are_python_exceptions(dev):
+    from self_supervised import ops, _hip
+    with pytest.raises(_hip.HipExtensionError):
+        ops.conv_fwd(torch.zeros(1, 2, 2, 3, device=dev), torch.zeros(8, 1, 1, 3, device=dev))   # Cin % 32
+    with pytest.raises(_hip.HipExtensionError):
+        ops.conv_fwd(torch.zeros(1, 2, 2, 32), torch.zeros(8, 1, 1, 32))                           # CPU tensors
