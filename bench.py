@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): train images/sec + anomaly-maps/sec, ResNet-18, 256x256, batch 256.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of 256 synthetic 256x256 images per GPU, inputs already
+resident in HBM: (a) one pretext training step (forward + backward + SGD update, + RCCL gradient all-reduce when
+N > 1) and (b) anomaly-map scoring of the same batch (841 sliding-window patches per image -> trunk -> 512-d
+embedding -> cosine 3-NN against a 588-row bank -> blur -> bilinear 256x256 map).  Both rates are reported;
+``value`` is the training rate (the first-named metric), ``anomaly_maps_per_sec`` the scoring rate.
+Weak scaling: every rank processes its own 256-image batch.  fp32 throughout (exact f32 MFMA).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "self-supervised-anomaly-detection_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch
+import torch.distributed as dist
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBPS = 8000.0
+
+
+def build_model(dev, seed=0):
+    from self_supervised.models import PeraNet
+    g = torch.Generator().manual_seed(seed)
+    m = PeraNet()
+    with torch.no_grad():        # random-init weights of the named architecture + non-trivial BN statistics
+        for mod in m.modules():
+            if isinstance(mod, (torch.nn.BatchNorm2d, torch.nn.BatchNorm1d)):
+                mod.running_mean.copy_(0.1 * torch.randn(mod.num_features, generator=g))
+                mod.running_var.copy_(0.5 + torch.rand(mod.num_features, generator=g))
+    return m.to(dev)
+
+
+def synth_images(n, size, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    u8 = torch.randint(0, 256, (n, 3, size, size), generator=g, dtype=torch.int32).float()
+    k = torch.ones(3, 1, 3, 3) / 9.0
+    u8 = torch.nn.functional.conv2d(torch.nn.functional.pad(u8, [1, 1, 1, 1], mode="replicate"), k, groups=3)
+    x = u8.round().clamp(0, 255) / 255.0
+    mean = torch.tensor((0.485, 0.456, 0.406)).view(1, 3, 1, 1)
+    std = torch.tensor((0.229, 0.224, 0.225)).view(1, 3, 1, 1)
+    return ((x - mean) / std).contiguous().to(dev)
+
+
+def score_batch(model, det, x, target=256):
+    from self_supervised import tools
+    with torch.no_grad():
+        emb = model(x)["latent_space"]
+        det.batch = x.shape[0]
+        maps = det.predict(emb)
+        return tools.upsample(maps, target, verbose=False)
+
+
+def host_cores():
+    """Threads the CPU baseline may use: the cgroup CPU quota when one is set (the GPU box gives a 1-GPU job a
+    16-CPU share of a 256-thread host), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return min(n, int(os.environ.get("SSAD_CPU_THREADS", "16")))
+
+
+def cpu_baseline(args):
+    """Oracle (torch-CPU fp32 restatement of the reference path) timed on the host cores: bounded sample."""
+    from oracle import weights as ow, scoring as osc
+    from oracle.peranet import OraclePeraNet, train_step, make_optimizer
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    sd = ow.seeded_state_dict(0)
+    m = OraclePeraNet(); m.load_state_dict(sd)
+    # training: batch 16 @ 256^2, fwd + bwd + SGD step
+    m.train()
+    opt, _ = make_optimizer(m, 0.03, 10, "projection_train")
+    xb, yb = ow.synthetic_images(16, 256, seed=1234), ow.synthetic_labels(16, seed=1235)
+    for it in range(3):
+        if it == 1:
+            t0 = time.perf_counter()
+        opt.zero_grad(); loss, _, _ = train_step(m, xb, yb); loss.backward(); opt.step()
+    t_train = (time.perf_counter() - t0) / 2
+    # scoring: 2 images -> 1682 patches -> kNN(588) -> blur -> bilinear
+    m.eval(); m.patch_level = True
+    bank = ow.synthetic_bank(588, 512, seed=2).numpy()
+    xs = ow.synthetic_images(2, 256, seed=4321)
+    with torch.no_grad():
+        for it in range(2):
+            t0 = time.perf_counter()
+            emb = m(xs)["latent_space"].numpy()
+            s, _, _ = osc.cosine_knn_mean(bank, emb, 3)
+            osc.upsample(torch.from_numpy(s).reshape(2, 1, 29, 29), 256)
+            t_score = time.perf_counter() - t0
+    return {"value": round(16 / t_train, 2), "unit": "images/sec", "cores": cores, "kind": "port",
+            "anomaly_maps_per_sec": round(2 / t_score, 3),
+            "sample": "oracle on torch-CPU fp32: 2 timed train steps of batch 16 @256x256 (fwd+bwd+SGD); "
+                      "scoring of 2 images (1682 patches, 588-row bank, blur+bilinear)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--phase", choices=["both", "train", "score"], default="both")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from self_supervised import ops
+    from self_supervised.models import AnomalyDetector
+
+    model = build_model(dev)
+    x = synth_images(args.batch, args.size, 1234 + rank, dev)
+    y = torch.randint(0, 4, (args.batch,), generator=torch.Generator().manual_seed(1235 + rank)).to(dev)
+    bank = torch.randn(588, 512, generator=torch.Generator().manual_seed(2)).to(dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        return dt
+
+    res = {}
+    prof = {}
+    if args.phase in ("both", "score"):
+        model.eval(); model.enable_patch_level_mode()
+        det = AnomalyDetector(patch_level=True, batch=args.batch, num_patches=841)
+        det.fit_bank(bank)
+        ops.PROFILE = None
+        for _ in range(args.warmup):
+            score_batch(model, det, x, args.size)
+        ops.PROFILE = []
+        dt = timed(lambda: score_batch(model, det, x, args.size), args.steps, 0)
+        prof["score"] = ops.drain_profile()
+        res["score_s"] = dt
+        model.disable_patch_level_mode()
+    if args.phase in ("both", "train"):
+        from self_supervised import training
+        model.train()
+        model.unfreeze()
+        trainer = training.DataParallelStep(model, lr=0.005, world_size=world)
+        ops.PROFILE = None
+        for _ in range(args.warmup):
+            trainer.step(x, y)
+        ops.PROFILE = []
+        dt = timed(lambda: trainer.step(x, y), args.steps, 0)
+        prof["train"] = ops.drain_profile()
+        res["train_s"] = dt
+    ops.PROFILE = None
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    out = {
+        "metric": "train images/sec + anomaly-maps/sec, ResNet-18 256x256 bs256",
+        "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"ResNet-18 {args.size}x{args.size} bs{args.batch} self-sup train + anomaly map, "
+                               f"{world}xMI355X, synthetic images (BASELINE configs[{1 if world == 1 else 2}])",
+                   "images_per_gpu": args.batch, "patches_per_image": 841, "bank_rows": 588,
+                   "parallelism": f"dp{world}"},
+    }
+    tot_s = 0.0
+    if "train_s" in res:
+        out["value"] = round(world * args.batch * args.steps / res["train_s"], 2)
+        out["train_ms_per_step"] = round(1e3 * res["train_s"] / args.steps, 3)
+        tot_s += res["train_s"]
+    if "score_s" in res:
+        out["anomaly_maps_per_sec"] = round(world * args.batch * args.steps / res["score_s"], 3)
+        out["score_ms_per_step"] = round(1e3 * res["score_s"] / args.steps, 3)
+        tot_s += res["score_s"]
+        if "value" not in out:
+            out["value"], out["unit"] = out["anomaly_maps_per_sec"], "anomaly-maps/sec"
+            out["metric"] = "anomaly-maps/sec, ResNet-18 256x256 bs256 (scoring phase only)"
+    out["ms_per_step"] = round(1e3 * tot_s / args.steps, 3)
+
+    # roofline of the dominant kernel (conv_igemm_f32: every 3x3 / 1x1 conv and linear layer), live HIP events
+    phase = "score" if "score" in prof else "train"
+    recs = [r for r in prof[phase] if r["kernel"].startswith("conv_igemm")]
+    if recs:
+        t = sum(r["ms"] for r in recs) * 1e-3
+        fl = sum(r["flops"] for r in recs)
+        allk = sum(r["ms"] for r in prof[phase]) * 1e-3
+        ach = fl / t / 1e12
+        out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                           "kernel": "conv_igemm_f32_kernel", "phase": phase, "launches": len(recs),
+                           "avg_launch_ms": round(1e3 * t / len(recs), 4),
+                           "alg_gflop_per_launch": round(fl / len(recs) / 1e9, 3),
+                           "alg_GBps": round(sum(r["bytes"] for r in recs) / t / 1e9, 1),
+                           "share_of_gpu_time": round(t / allk, 4)}
+        by = {}
+        for r in prof[phase]:
+            by.setdefault(r["kernel"], [0.0, 0]); by[r["kernel"]][0] += r["ms"]; by[r["kernel"]][1] += 1
+        out["kernel_ms"] = {k: [round(v[0] / args.steps, 3), v[1] // args.steps] for k, v in sorted(by.items())}
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(args)
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -81,6 +81,50 @@ int ssad_cosine_knn_mean(const float* sim, float* out, int64_t Nq, int Nb, int k
  * reflect)) then bilinear (align_corners=False) to target x target.  maps [n][h][w] -> out [n][target][target]. */
 int ssad_blur_relu_bilinear(const float* maps, float* out, int n, int h, int w, int ksize, int target, void* stream);
 
+/* ---- training step (forward in train mode, backward, update) ---- */
+/* Replaces autograd's conv2d/linear input-gradient (loss.backward() inside pl.Trainer.fit, tools.py:270,:303).
+ * w_flipT = ssad_flip_transpose_weight(w_ohwi).  dx = dgrad(dy) (+ residual).  Cout % 32 == 0. */
+int ssad_flip_transpose_weight(const float* w_ohwi, float* out, int O, int I, int KH, int KW, void* stream);
+int ssad_conv_igemm_dgrad(const float* dy, const float* w_flipT, float* dx, const float* residual, int64_t N, int Hy, int Wy,
+                          int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride, int pad, void* stream);
+/* Replaces autograd's conv2d/linear weight-gradient.  Two launches: partial tiles per pixel split into
+ * slab[splits][Cout][KH*KW*Cin], then a fixed-order sum written as OIHW (to_oihw=1, checkpoint layout) or OHWI. */
+int ssad_wgrad_splits(int64_t M, int Cin, int Cout, int KH, int KW);
+int ssad_conv_wgrad(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin, int Cout,
+                    int KH, int KW, int stride, int pad, void* stream);
+int ssad_wgrad_reduce(const float* slab, float* dw, int splits, int Cout, int Kpad, int KH, int KW, int Cin, int to_oihw,
+                      int accumulate, void* stream);
+/* Stem in training: im2col rows of 160 floats (147 taps + zero pad, nearest resize fused) so that conv1 forward and
+ * its weight gradient run on the generic MFMA kernels.  Replaces conv1 of torchvision resnet18 under autograd. */
+int ssad_stem_im2col(const float* img, float* col, int64_t B, int H, int W, int Hv, int Wv, void* stream);
+int ssad_pack_stem_weight_2d(const float* w_oihw, float* out, void* stream);
+/* Replaces nn.BatchNorm2d / nn.BatchNorm1d in training mode (models.py:65-95 + torchvision BasicBlock):
+ * batch statistics over R rows (biased variance for normalisation, unbiased for running_var, momentum),
+ * y = (z-mean)*invstd*gamma+beta (+residual)(ReLU), and the matching backward.  workspace: doubles, see
+ * ssad_colreduce_workspace. */
+int64_t ssad_colreduce_workspace(int64_t R, int C);
+int ssad_bn_stats(const float* z, int64_t R, int C, float eps, float momentum, float* mean, float* invstd,
+                  float* running_mean, float* running_var, double* workspace, void* stream);
+int ssad_bn_apply_fwd(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                      const float* residual, float* y, int64_t R, int C, int relu, void* stream);
+int ssad_bn_bwd_reduce(const float* dy, const float* yact, const float* z, const float* mean, const float* invstd,
+                       float* dbeta, float* dgamma, int64_t R, int C, double* workspace, void* stream);
+int ssad_bn_apply_bwd(const float* dy, const float* yact, const float* z, const float* mean, const float* invstd,
+                      const float* gamma, const float* dbeta, const float* dgamma, float* dz, float* dres, int64_t R, int C,
+                      int eval_mode, void* stream);
+/* Replaces the backward of nn.MaxPool2d(3,2,1) and of adaptive_avg_pool2d + cat (models.py:224-245). */
+int ssad_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int64_t N, int H, int W, int C, void* stream);
+int ssad_gap_bwd(const float* dpooled, float* dy, int64_t N, int HW, int C, int stride, int offset, int accumulate,
+                 void* stream);
+/* Replaces F.cross_entropy + torchmetrics accuracy (models.py:261-262) and their backward: loss_acc[0] = mean NLL,
+ * loss_acc[1] = accuracy, dlogits[b][0..ldd) = (softmax - onehot) * grad_scale (zero padded to ldd columns). */
+int ssad_softmax_ce(const float* logits, const int64_t* labels, int B, int C, float* loss_acc, float* dlogits, int ldd,
+                    float grad_scale, void* stream);
+/* Replaces torch.optim.SGD(lr, momentum=0.9, weight_decay=5e-4).step() (models.py:337) over a flat parameter arena:
+ * m = momentum*m + (g*grad_scale + weight_decay*p); p -= lr*m. */
+int ssad_sgd_step(float* p, const float* g, float* m, int64_t n, float lr, float momentum, float weight_decay,
+                  float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,8 @@ struct ConvParams {
     int64_t M;          // N*Ho*Wo
     int H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, relu;
     int K;              // KH*KW*Cin
+    int ts;             // 1: convolution.  >1: transposed gather (dgrad of a stride-ts conv): the tap reads
+                        // in[(oy - pad + ky) / ts] only where the numerator is a non-negative multiple of ts
 };
 
 template <int BM, int BN, int TM, int TN>
@@ -94,7 +96,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             int y = a_iy[i] + ld_ky, x = a_ix[i] + ld_kx;
-            bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+            bool ok = true;
+            if (p.ts > 1) {
+                ok = y >= 0 && x >= 0 && (y % p.ts) == 0 && (x % p.ts) == 0;
+                y /= p.ts;
+                x /= p.ts;
+            }
+            ok = ok && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (ok) v = *(const f32x4*)(p.in + a_base[i] + ((int64_t)y * p.W + x) * p.Cin + ld_cc * BK);
             ra[i] = v;
@@ -200,12 +208,40 @@ extern "C" int ssad_conv_igemm_fwd(const float* in, const float* w_ohwi, float* 
     p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.relu = relu;
     p.Ho = (H + 2 * pad - KH) / stride + 1;
     p.Wo = (W + 2 * pad - KW) / stride + 1;
+    p.ts = 1;
     SSAD_CHECK_ARG(p.Ho > 0 && p.Wo > 0, "empty output");
     p.M = N * p.Ho * p.Wo;
     p.K = KH * KW * Cin;
     SSAD_CHECK_ARG(cdiv64(p.M, 128) < (int64_t)2147483647, "M too large for one launch");
     hipStream_t st = (hipStream_t)stream;
     if (Cout <= 64) launch<128, 64, 1, 2>(p, st);
+    else launch<128, 128, 2, 2>(p, st);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+// dgrad: dx[n][iy][ix][ci] = sum_{ky,kx,co} dy[n][(iy+pad-ky)/s][(ix+pad-kx)/s][co] * w[co][ky][kx][ci] (+ residual).
+// w_flipT is ssad_flip_transpose_weight(w): [Cin][KH][KW][Cout] with both taps reversed, so the sum becomes the
+// same gather-GEMM with k = (ky', kx', co), numerator row = iy - (KH-1-pad) + ky'.
+extern "C" int ssad_conv_igemm_dgrad(const float* dy, const float* w_flipT, float* dx, const float* residual, int64_t N,
+                                     int Hy, int Wy, int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride,
+                                     int pad, void* stream) {
+    SSAD_CHECK_ARG(dy && w_flipT && dx, "null pointer");
+    SSAD_CHECK_ARG(N > 0 && Hy > 0 && Wy > 0 && Hx > 0 && Wx > 0 && Cin > 0 && Cout > 0, "empty shape");
+    SSAD_CHECK_ARG(Cout % BK == 0, "Cout (the contraction) must be a multiple of 32");
+    SSAD_CHECK_ARG(KH > 0 && KW > 0 && stride > 0 && pad >= 0 && pad < KH && pad < KW, "bad filter geometry");
+    SSAD_CHECK_ARG((Hx + 2 * pad - KH) / stride + 1 == Hy && (Wx + 2 * pad - KW) / stride + 1 == Wy, "dy/dx sizes disagree");
+    ConvParams p;
+    p.in = dy; p.wt = w_flipT; p.out = dx; p.scale = nullptr; p.shift = nullptr; p.residual = residual;
+    p.H = Hy; p.W = Wy; p.Cin = Cout; p.Cout = Cin; p.KH = KH; p.KW = KW; p.relu = 0;
+    p.stride = 1; p.pad = KH - 1 - pad; p.ts = stride;
+    SSAD_CHECK_ARG(KH == KW, "square filters only");
+    p.Ho = Hx; p.Wo = Wx;
+    p.M = N * Hx * Wx;
+    p.K = KH * KW * Cout;
+    SSAD_CHECK_ARG(cdiv64(p.M, 128) < (int64_t)2147483647, "M too large for one launch");
+    hipStream_t st = (hipStream_t)stream;
+    if (Cin <= 64) launch<128, 64, 1, 2>(p, st);
     else launch<128, 128, 2, 2>(p, st);
     SSAD_CHECK_LAUNCH();
     return 0;

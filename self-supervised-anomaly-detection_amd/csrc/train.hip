@@ -1,0 +1,461 @@
+// HBM-bound kernels of the training step: train-mode BatchNorm (forward statistics / apply, backward reduce /
+// apply), max-pool and global-average-pool backward, stem im2col, softmax cross-entropy, fused SGD, weight
+// flip-transpose for dgrad.
+//
+// Replaces the BatchNorm2d/1d, MaxPool2d, adaptive_avg_pool2d, F.cross_entropy autograd nodes and
+// torch.optim.SGD(momentum=0.9, weight_decay=5e-4) of the reference's training step
+// (src/self_supervised/models.py:256-277, :336-341).
+// Per-channel sums accumulate in fp64 and are combined in a fixed order (two-stage, no atomics), so batch
+// statistics and BN gradients are deterministic and free of E[x^2]-E[x]^2 cancellation.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// column reductions over [R][C] (C % 4 == 0): threads = TC channel quads x RL row lanes
+// ---------------------------------------------------------------------------------------------
+struct ColReduce {
+    int TC, RL;
+};
+static inline ColReduce col_geom(int C) {
+    int TC = C / 4;
+    if (TC > 256) TC = 256;
+    return {TC, 256 / TC};
+}
+
+// mode 0: s0 = sum z, s1 = sum z^2
+// mode 1: g = dy * (yact > 0 if yact) ; s0 = sum g ; s1 = sum g * (z - mean) * invstd   (z may be null -> s1 = 0)
+template <int MODE>
+__global__ void col_reduce_kernel(const float* __restrict__ a, const float* __restrict__ yact, const float* __restrict__ z,
+                                  const float* __restrict__ mean, const float* __restrict__ invstd,
+                                  double* __restrict__ partial, int64_t R, int C, int TC, int RL, int rows_per_block) {
+    __shared__ double sh[2][256][4];
+    const int tid = threadIdx.x;
+    const int tx = tid % TC, ty = tid / TC;
+    const int C4 = C / 4;
+    for (int cq = blockIdx.x * TC + tx; cq < C4 && ty < RL; cq += gridDim.x * TC) {
+        double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+        f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {1.f, 1.f, 1.f, 1.f};
+        if (MODE == 1 && z) { mu = ((const f32x4*)mean)[cq]; is = ((const f32x4*)invstd)[cq]; }
+        const int64_t rb = (int64_t)blockIdx.y * rows_per_block;
+        const int64_t re = rb + rows_per_block < R ? rb + rows_per_block : R;
+        for (int64_t row = rb + ty; row < re; row += RL) {
+            const int64_t o = row * C4 + cq;
+            f32x4 v = ((const f32x4*)a)[o];
+            if (MODE == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { s0[k] += (double)v[k]; s1[k] += (double)v[k] * (double)v[k]; }
+            } else {
+                if (yact) {
+                    f32x4 ya = ((const f32x4*)yact)[o];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = ya[k] > 0.f ? v[k] : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s0[k] += (double)v[k];
+                if (z) {
+                    f32x4 zz = ((const f32x4*)z)[o];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) s1[k] += (double)v[k] * (double)((zz[k] - mu[k]) * is[k]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { sh[0][tid][k] = s0[k]; sh[1][tid][k] = s1[k]; }
+    }
+    __syncthreads();
+    if (ty == 0) {
+        for (int cq = blockIdx.x * TC + tx; cq < C4; cq += gridDim.x * TC) {
+            double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+            for (int l = 0; l < RL; ++l)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { s0[k] += sh[0][l * TC + tx][k]; s1[k] += sh[1][l * TC + tx][k]; }
+            double* pp = partial + (int64_t)blockIdx.y * 2 * C;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { pp[cq * 4 + k] = s0[k]; pp[C + cq * 4 + k] = s1[k]; }
+        }
+    }
+}
+
+// BN forward statistics: mean, invstd (biased var), running stats (unbiased var, momentum)
+__global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, int nblk, int64_t R, int C, float eps,
+                                         float momentum, float* __restrict__ mean, float* __restrict__ invstd,
+                                         float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s0 = 0, s1 = 0;
+    for (int b = 0; b < nblk; ++b) { s0 += partial[(int64_t)b * 2 * C + c]; s1 += partial[(int64_t)b * 2 * C + C + c]; }
+    const double m = s0 / (double)R;
+    double var = s1 / (double)R - m * m;
+    if (var < 0) var = 0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblk, int C, float* __restrict__ dbeta,
+                                       float* __restrict__ dgamma) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s0 = 0, s1 = 0;
+    for (int b = 0; b < nblk; ++b) { s0 += partial[(int64_t)b * 2 * C + c]; s1 += partial[(int64_t)b * 2 * C + C + c]; }
+    if (dbeta) dbeta[c] = (float)s0;
+    if (dgamma) dgamma[c] = (float)s1;
+}
+
+// y = (z - mean) * invstd * gamma + beta (+ res) (relu)
+__global__ void bn_apply_fwd_kernel(const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ res, float* __restrict__ y, int64_t total4, int C4, int relu) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cq = (int)(i % C4);
+        const f32x4 mu = ((const f32x4*)mean)[cq], is = ((const f32x4*)invstd)[cq];
+        const f32x4 g = ((const f32x4*)gamma)[cq], b = ((const f32x4*)beta)[cq];
+        f32x4 v = ((const f32x4*)z)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (v[k] - mu[k]) * is[k] * g[k] + b[k];
+        if (res) {
+            const f32x4 rr = ((const f32x4*)res)[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] += rr[k];
+        }
+        if (relu) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        ((f32x4*)y)[i] = v;
+    }
+}
+
+// g = dy * (yact > 0); dz = gamma*invstd*(g - dbeta/R - xhat*dgamma/R)  [train]   or  g*gamma*invstd  [eval];
+// optionally dres = g (gradient of the identity branch of a residual block)
+__global__ void bn_apply_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ yact, const float* __restrict__ z,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ dbeta,
+                                    const float* __restrict__ dgamma, float* __restrict__ dz, float* __restrict__ dres,
+                                    int64_t total4, int C4, float invR, int eval_mode) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cq = (int)(i % C4);
+        const f32x4 mu = ((const f32x4*)mean)[cq], is = ((const f32x4*)invstd)[cq], ga = ((const f32x4*)gamma)[cq];
+        f32x4 g = ((const f32x4*)dy)[i];
+        if (yact) {
+            const f32x4 ya = ((const f32x4*)yact)[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g[k] = ya[k] > 0.f ? g[k] : 0.f;
+        }
+        if (dres) ((f32x4*)dres)[i] = g;
+        f32x4 o;
+        if (eval_mode) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = g[k] * ga[k] * is[k];
+        } else {
+            const f32x4 db = ((const f32x4*)dbeta)[cq], dg = ((const f32x4*)dgamma)[cq];
+            const f32x4 zz = ((const f32x4*)z)[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float xh = (zz[k] - mu[k]) * is[k];
+                o[k] = ga[k] * is[k] * (g[k] - db[k] * invR - xh * dg[k] * invR);
+            }
+        }
+        ((f32x4*)dz)[i] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pooling backward
+// ---------------------------------------------------------------------------------------------
+// dx[n][y][x][c] = sum over the (<= 4) 3x3/2 windows covering (y,x) whose FIRST maximum (row-major scan, as
+// PyTorch's max_pool2d picks it) is (y,x).  Gather form: deterministic, no atomics.
+__global__ void maxpool_bwd_kernel(const float* __restrict__ xin, const float* __restrict__ dy, float* __restrict__ dx,
+                                   int64_t total, int H, int W, int C, int Ho, int Wo) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    int64_t t = i / C;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H);
+    const int64_t n = t / H;
+    const float* xp = xin + n * H * W * C + c;
+    float acc = 0.f;
+    const int oy0 = y / 2, oy1 = (y + 1) / 2, ox0 = x / 2, ox1 = (x + 1) / 2;     // windows with 2*o-1 <= pos <= 2*o+1
+    for (int oy = oy0; oy <= oy1; ++oy) {
+        if (oy >= Ho) continue;
+        for (int ox = ox0; ox <= ox1; ++ox) {
+            if (ox >= Wo) continue;
+            float best = -INFINITY;
+            int by = -1, bx = -1;
+            for (int dyy = 0; dyy < 3; ++dyy) {
+                const int yy = 2 * oy - 1 + dyy;
+                if ((unsigned)yy >= (unsigned)H) continue;
+                for (int dxx = 0; dxx < 3; ++dxx) {
+                    const int xx = 2 * ox - 1 + dxx;
+                    if ((unsigned)xx >= (unsigned)W) continue;
+                    const float v = xp[((int64_t)yy * W + xx) * C];
+                    if (v > best || by < 0) { best = v; by = yy; bx = xx; }
+                }
+            }
+            if (by == y && bx == x) acc += dy[((n * Ho + oy) * Wo + ox) * C + c];
+        }
+    }
+    dx[i] = acc;
+}
+
+// dy[n][hw][c] (+)= dpooled[n*stride + off + c] / HW
+__global__ void gap_bwd_kernel(const float* __restrict__ dpooled, float* __restrict__ dy, int64_t total, int HW, int C,
+                               int stride, int off, int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const int64_t n = i / ((int64_t)HW * C);
+    const float g = dpooled[n * stride + off + c] / (float)HW;
+    dy[i] = accumulate ? dy[i] + g : g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stem im2col: Xcol[m][k], k = (ky*7 + kx)*3 + c for k < 147, zero for 147 <= k < 160; nearest resize fused
+// ---------------------------------------------------------------------------------------------
+__global__ void stem_im2col_kernel(const float* __restrict__ img, float* __restrict__ col, int64_t total, int H, int W,
+                                   int Hv, int Wv, int Ho, int Wo) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int k = (int)(i % 160);
+    int64_t m = i / 160;
+    const int ox = (int)(m % Wo); m /= Wo;
+    const int oy = (int)(m % Ho);
+    const int64_t n = m / Ho;
+    float v = 0.f;
+    if (k < 147) {
+        const int c = k % 3, tap = k / 3, ky = tap / 7, kx = tap % 7;
+        const int vy = 2 * oy - 3 + ky, vx = 2 * ox - 3 + kx;
+        if ((unsigned)vy < (unsigned)Hv && (unsigned)vx < (unsigned)Wv) {
+            const int sy = (vy * H) / Hv, sx = (vx * W) / Wv;
+            v = img[((n * 3 + c) * H + sy) * W + sx];
+        }
+    }
+    col[i] = v;
+}
+
+// OIHW [64][3][7][7] -> [64][160] rows in im2col k order (zero padded)
+__global__ void pack_stem_weight_2d_kernel(const float* __restrict__ w, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 64 * 160) return;
+    const int k = i % 160, co = i / 160;
+    float v = 0.f;
+    if (k < 147) {
+        const int c = k % 3, tap = k / 3, ky = tap / 7, kx = tap % 7;
+        v = w[((co * 3 + c) * 7 + ky) * 7 + kx];
+    }
+    out[i] = v;
+}
+
+// OHWI [O][KH][KW][I] -> [I][KH][KW][O] with both taps reversed (dgrad operand)
+__global__ void flip_transpose_kernel(const float* __restrict__ w, float* __restrict__ out, int O, int I, int KH, int KW) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)O * I * KH * KW) return;
+    const int o = (int)(idx % O);
+    int64_t t = idx / O;
+    const int kx = (int)(t % KW); t /= KW;
+    const int ky = (int)(t % KH);
+    const int i = (int)(t / KH);
+    out[idx] = w[(((int64_t)o * KH + (KH - 1 - ky)) * KW + (KW - 1 - kx)) * I + i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// softmax cross-entropy (mean over the batch) + accuracy + dlogits; one workgroup, fixed reduction order
+// ---------------------------------------------------------------------------------------------
+__global__ void softmax_ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, int B, int C,
+                                  float* __restrict__ loss_acc, float* __restrict__ dlogits, int ldd, float gscale) {
+    __shared__ double sl[256];
+    __shared__ int sc[256];
+    double l = 0;
+    int correct = 0;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const float* p = logits + (int64_t)b * C;
+        float mx = p[0];
+        int am = 0;
+        for (int c = 1; c < C; ++c)
+            if (p[c] > mx) { mx = p[c]; am = c; }
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += expf(p[c] - mx);
+        const float lse = logf(se) + mx;
+        const int y = (int)labels[b];
+        l += (double)(lse - p[y]);
+        correct += am == y;
+        if (dlogits) {
+            float* d = dlogits + (int64_t)b * ldd;
+            for (int c = 0; c < ldd; ++c) d[c] = c < C ? (expf(p[c] - lse) - (c == y ? 1.f : 0.f)) * gscale : 0.f;
+        }
+    }
+    sl[threadIdx.x] = l;
+    sc[threadIdx.x] = correct;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tl = 0;
+        int tc = 0;
+        for (int i = 0; i < blockDim.x; ++i) { tl += sl[i]; tc += sc[i]; }
+        loss_acc[0] = (float)(tl / B);
+        loss_acc[1] = (float)tc / (float)B;
+    }
+}
+
+// m = mu*m + (g*gscale + wd*p); p -= lr*m      (torch.optim.SGD, dampening 0, no nesterov; m starts at 0)
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, int64_t n, float lr,
+                           float mu, float wd, float gscale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float pv = p[i];
+        const float d = g[i] * gscale + wd * pv;
+        const float mv = mu * m[i] + d;
+        m[i] = mv;
+        p[i] = pv - lr * mv;
+    }
+}
+
+static inline unsigned ew_grid(int64_t n) {
+    int64_t b = cdiv64(n, 256);
+    return (unsigned)(b < 8192 ? (b < 1 ? 1 : b) : 8192);
+}
+
+}  // namespace
+
+// Number of doubles of workspace the column reductions need for R rows x C channels.
+extern "C" int64_t ssad_colreduce_workspace(int64_t R, int C) {
+    ColReduce g = col_geom(C);
+    int64_t nblk = cdiv64(R, (int64_t)g.RL * 64);
+    if (nblk > 1024) nblk = 1024;
+    if (nblk < 1) nblk = 1;
+    return nblk * 2 * C;
+}
+
+static int launch_col_reduce(int mode, const float* a, const float* yact, const float* z, const float* mean,
+                             const float* invstd, double* ws, int64_t R, int C, int* nblk_out, hipStream_t st) {
+    ColReduce g = col_geom(C);
+    int64_t nblk = cdiv64(R, (int64_t)g.RL * 64);
+    if (nblk > 1024) nblk = 1024;
+    if (nblk < 1) nblk = 1;
+    int rows_per_block = (int)cdiv64(R, nblk);
+    int gx = (C / 4 + g.TC - 1) / g.TC;
+    dim3 grid(gx, (unsigned)nblk);
+    if (mode == 0)
+        hipLaunchKernelGGL(col_reduce_kernel<0>, grid, dim3(256), 0, st, a, yact, z, mean, invstd, ws, R, C, g.TC, g.RL, rows_per_block);
+    else
+        hipLaunchKernelGGL(col_reduce_kernel<1>, grid, dim3(256), 0, st, a, yact, z, mean, invstd, ws, R, C, g.TC, g.RL, rows_per_block);
+    *nblk_out = (int)nblk;
+    return 0;
+}
+
+extern "C" int ssad_bn_stats(const float* z, int64_t R, int C, float eps, float momentum, float* mean, float* invstd,
+                             float* running_mean, float* running_var, double* workspace, void* stream) {
+    SSAD_CHECK_ARG(z && mean && invstd && workspace && R > 0 && C > 0 && C % 4 == 0, "bad argument");
+    int nblk;
+    launch_col_reduce(0, z, nullptr, nullptr, nullptr, nullptr, workspace, R, C, &nblk, (hipStream_t)stream);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace, nblk, R, C,
+                       eps, momentum, mean, invstd, running_mean, running_var);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ssad_bn_apply_fwd(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                 const float* residual, float* y, int64_t R, int C, int relu, void* stream) {
+    SSAD_CHECK_ARG(z && mean && invstd && gamma && beta && y && R > 0 && C > 0 && C % 4 == 0, "bad argument");
+    const int64_t total4 = R * (C / 4);
+    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, z, mean, invstd, gamma,
+                       beta, residual, y, total4, C / 4, relu);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+// dbeta/dgamma over rows of g = dy*(yact>0); with z == NULL only dbeta (= column sums: Linear bias gradient).
+extern "C" int ssad_bn_bwd_reduce(const float* dy, const float* yact, const float* z, const float* mean, const float* invstd,
+                                  float* dbeta, float* dgamma, int64_t R, int C, double* workspace, void* stream) {
+    SSAD_CHECK_ARG(dy && workspace && R > 0 && C > 0 && C % 4 == 0, "bad argument");
+    SSAD_CHECK_ARG(!z || (mean && invstd), "z needs mean/invstd");
+    int nblk;
+    launch_col_reduce(1, dy, yact, z, mean, invstd, workspace, R, C, &nblk, (hipStream_t)stream);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace, nblk, C, dbeta,
+                       z ? dgamma : nullptr);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ssad_bn_apply_bwd(const float* dy, const float* yact, const float* z, const float* mean, const float* invstd,
+                                 const float* gamma, const float* dbeta, const float* dgamma, float* dz, float* dres,
+                                 int64_t R, int C, int eval_mode, void* stream) {
+    SSAD_CHECK_ARG(dy && mean && invstd && gamma && dz && R > 0 && C > 0 && C % 4 == 0, "bad argument");
+    SSAD_CHECK_ARG(eval_mode || (z && dbeta && dgamma), "train-mode backward needs z, dbeta, dgamma");
+    const int64_t total4 = R * (C / 4);
+    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, dy, yact, z, mean, invstd,
+                       gamma, dbeta, dgamma, dz, dres, total4, C / 4, 1.f / (float)R, eval_mode);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ssad_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int64_t N, int H, int W, int C, void* stream) {
+    SSAD_CHECK_ARG(x && dy && dx && N > 0 && H > 0 && W > 0 && C > 0, "bad argument");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int64_t total = N * H * W * C;
+    SSAD_CHECK_ARG(cdiv64(total, 256) < (int64_t)2147483647, "too large");
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, total,
+                       H, W, C, Ho, Wo);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ssad_gap_bwd(const float* dpooled, float* dy, int64_t N, int HW, int C, int stride, int offset, int accumulate,
+                            void* stream) {
+    SSAD_CHECK_ARG(dpooled && dy && N > 0 && HW > 0 && C > 0 && offset >= 0 && offset + C <= stride, "bad argument");
+    const int64_t total = N * HW * C;
+    hipLaunchKernelGGL(gap_bwd_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, dpooled, dy, total,
+                       HW, C, stride, offset, accumulate);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ssad_stem_im2col(const float* img, float* col, int64_t B, int H, int W, int Hv, int Wv, void* stream) {
+    SSAD_CHECK_ARG(img && col && B > 0 && H > 0 && W > 0 && Hv > 0 && Wv > 0, "bad argument");
+    const int Ho = (Hv - 1) / 2 + 1, Wo = (Wv - 1) / 2 + 1;
+    const int64_t total = B * Ho * Wo * 160;
+    SSAD_CHECK_ARG(cdiv64(total, 256) < (int64_t)2147483647, "too large");
+    hipLaunchKernelGGL(stem_im2col_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, img, col, total,
+                       H, W, Hv, Wv, Ho, Wo);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ssad_pack_stem_weight_2d(const float* w_oihw, float* out, void* stream) {
+    SSAD_CHECK_ARG(w_oihw && out, "null pointer");
+    hipLaunchKernelGGL(pack_stem_weight_2d_kernel, dim3((64 * 160 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_oihw, out);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ssad_flip_transpose_weight(const float* w_ohwi, float* out, int O, int I, int KH, int KW, void* stream) {
+    SSAD_CHECK_ARG(w_ohwi && out && O > 0 && I > 0 && KH > 0 && KW > 0, "bad argument");
+    const int64_t total = (int64_t)O * I * KH * KW;
+    hipLaunchKernelGGL(flip_transpose_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, w_ohwi, out, O,
+                       I, KH, KW);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ssad_softmax_ce(const float* logits, const int64_t* labels, int B, int C, float* loss_acc, float* dlogits,
+                               int ldd, float grad_scale, void* stream) {
+    SSAD_CHECK_ARG(logits && labels && loss_acc && B > 0 && C > 0, "bad argument");
+    SSAD_CHECK_ARG(!dlogits || ldd >= C, "dlogits rows shorter than the class count");
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, labels, B, C, loss_acc, dlogits, ldd,
+                       grad_scale);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ssad_sgd_step(float* p, const float* g, float* m, int64_t n, float lr, float momentum, float weight_decay,
+                             float grad_scale, void* stream) {
+    SSAD_CHECK_ARG(p && g && m && n > 0, "bad argument");
+    hipLaunchKernelGGL(sgd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, n, lr, momentum, weight_decay,
+                       grad_scale);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,209 @@
+// Weight gradient of conv / linear layers on the fp32 matrix cores, split over pixel ranges.
+//
+//   dW[co][ky][kx][ci] = sum_m dY[m][co] * X[n(m)][oy(m)*s + ky - p][ox(m)*s + kx - p][ci]
+//
+// Replaces the wgrad half of autograd's conv2d / linear backward that the reference gets from
+// loss.backward() inside pl.Trainer.fit (src/self_supervised/tools.py:270, :303; models.py:256-277).
+//
+// MFMA formulation: D[co][ci] += A[co][m] * B[m][ci] with the contraction over output pixels m.  Both operands
+// are read from NHWC rows as they lie in HBM (dY row = Cout contiguous floats, X row = Cin contiguous floats),
+// staged [32 pixels][BT channels] in LDS; lane (r, h) of v_mfma_f32_32x32x2_f32 reads pixel 2*kk+h, channel r:
+// 32 consecutive floats per lane half, conflict-free ds_read_b32.  A workgroup owns one (tap, co-tile, ci-tile)
+// and one pixel range; partial tiles go to slab[split] and ssad_wgrad_reduce sums the splits in a fixed order
+// (deterministic, no float atomics), writing OIHW (checkpoint layout) or OHWI.
+#include "common.h"
+
+namespace {
+
+constexpr int PK = 32;   // pixels per staging step
+
+struct WgradParams {
+    const float* dy;
+    const float* x;
+    float* slab;
+    int64_t M, chunk;
+    int H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
+    int co_tiles, ci_tiles;
+};
+
+template <int BT>
+__global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(WgradParams p) {
+    constexpr int T = BT / 64;            // 32x32 tiles per wave per dim (waves 2x2)
+    constexpr int F4 = BT / 4;            // float4 per staged row
+    constexpr int RPP = 256 / F4;         // rows per pass
+    constexpr int NP = PK / RPP;          // passes
+    constexpr int STAGE = 2 * PK * BT;    // floats per stage (dY tile + X tile)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    int tile = blockIdx.x;
+    const int ci_t = tile % p.ci_tiles; tile /= p.ci_tiles;
+    const int co_t = tile % p.co_tiles;
+    const int tap = tile / p.co_tiles;
+    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+    const int co0 = co_t * BT, ci0 = ci_t * BT;
+    const int64_t m_begin = (int64_t)blockIdx.y * p.chunk;
+    const int64_t m_end = m_begin + p.chunk < p.M ? m_begin + p.chunk : p.M;
+    const int c4 = tid % F4, r0 = tid / F4;
+    const int HoWo = p.Ho * p.Wo;
+    const bool co_ok = co0 + c4 * 4 < p.Cout, ci_ok = ci0 + c4 * 4 < p.Cin;
+
+    f32x16 acc[T][T];
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    f32x4 ry[NP], rx[NP];
+    auto load_step = [&](int64_t mb) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int64_t m = mb + r0 + i * RPP;
+            f32x4 vy = {0.f, 0.f, 0.f, 0.f}, vx = {0.f, 0.f, 0.f, 0.f};
+            if (m < m_end) {
+                if (co_ok) vy = *(const f32x4*)(p.dy + m * p.Cout + co0 + c4 * 4);
+                const int64_t n = m / HoWo;
+                const int rem = (int)(m - n * HoWo);
+                const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                const int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
+                if (ci_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                    vx = *(const f32x4*)(p.x + ((n * p.H + iy) * p.W + ix) * p.Cin + ci0 + c4 * 4);
+            }
+            ry[i] = vy;
+            rx[i] = vx;
+        }
+    };
+    auto store_step = [&](float* buf) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            *(f32x4*)(buf + (r0 + i * RPP) * BT + c4 * 4) = ry[i];
+            *(f32x4*)(buf + PK * BT + (r0 + i * RPP) * BT + c4 * 4) = rx[i];
+        }
+    };
+
+    const int nsteps = (int)((m_end - m_begin + PK - 1) / PK);
+    if (nsteps > 0) {
+        load_step(m_begin);
+        store_step(lds);
+    }
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const float* cur = lds + (s & 1) * STAGE;
+        const bool more = s + 1 < nsteps;
+        if (more) load_step(m_begin + (int64_t)(s + 1) * PK);
+        const float* ya = cur + h * BT + wm * 32 * T + r;
+        const float* xb = cur + PK * BT + h * BT + wn * 32 * T + r;
+#pragma unroll
+        for (int kk = 0; kk < PK / 2; ++kk) {
+            float a[T], b[T];
+#pragma unroll
+            for (int i = 0; i < T; ++i) a[i] = ya[kk * 2 * BT + i * 32];
+#pragma unroll
+            for (int j = 0; j < T; ++j) b[j] = xb[kk * 2 * BT + j * 32];
+#pragma unroll
+            for (int i = 0; i < T; ++i)
+#pragma unroll
+                for (int j = 0; j < T; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+        }
+        if (more) store_step(lds + ((s + 1) & 1) * STAGE);
+        __syncthreads();
+    }
+
+    const int taps = p.KH * p.KW;
+    float* out = p.slab + (int64_t)blockIdx.y * p.Cout * taps * p.Cin;
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        const int ci = ci0 + (wn * T + j) * 32 + r;
+        if (ci >= p.Cin) continue;
+#pragma unroll
+        for (int i = 0; i < T; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co0 + (wm * T + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (co < p.Cout) out[((int64_t)co * taps + tap) * p.Cin + ci] = acc[i][j][e];
+            }
+    }
+}
+
+// out[...] = sum_s slab[s][co][k] for k < KH*KW*Cin_real; slab rows are Kpad floats long.
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int splits, int Cout, int Kpad,
+                                    int KH, int KW, int Cin, int to_oihw, int accumulate) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Kreal = KH * KW * Cin;
+    if (idx >= (int64_t)Cout * Kreal) return;
+    const int co = (int)(idx / Kreal), k = (int)(idx - (int64_t)co * Kreal);
+    const int64_t stride = (int64_t)Cout * Kpad;
+    const float* s = slab + (int64_t)co * Kpad + k;
+    float v = 0.f;
+    for (int i = 0; i < splits; ++i) v += s[i * stride];
+    int64_t o = idx;
+    if (to_oihw) {
+        const int tap = k / Cin, ci = k - tap * Cin;
+        o = ((int64_t)co * Cin + ci) * (KH * KW) + tap;
+    }
+    out[o] = accumulate ? out[o] + v : v;
+}
+
+}  // namespace
+
+// Number of pixel splits the kernel will use for a problem (the caller sizes the slab with it).
+extern "C" int ssad_wgrad_splits(int64_t M, int Cin, int Cout, int KH, int KW) {
+    const int BT = (Cin <= 64 && Cout <= 64) ? 64 : 128;
+    const int64_t tiles = (int64_t)KH * KW * ((Cout + BT - 1) / BT) * ((Cin + BT - 1) / BT);
+    int64_t splits = (1024 + tiles - 1) / tiles;
+    const int64_t max_splits = (M + 255) / 256;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    if (splits > 65535) splits = 65535;
+    return (int)splits;
+}
+
+extern "C" int ssad_conv_wgrad(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin,
+                               int Cout, int KH, int KW, int stride, int pad, void* stream) {
+    SSAD_CHECK_ARG(dy && x && slab, "null pointer");
+    SSAD_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0, "bad shape");
+    SSAD_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0, "channel counts must be multiples of 4");
+    SSAD_CHECK_ARG(splits >= 1 && splits <= 65535, "bad split count");
+    WgradParams p;
+    p.dy = dy; p.x = x; p.slab = slab;
+    p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
+    p.Ho = (H + 2 * pad - KH) / stride + 1;
+    p.Wo = (W + 2 * pad - KW) / stride + 1;
+    SSAD_CHECK_ARG(p.Ho > 0 && p.Wo > 0, "empty output");
+    p.M = N * p.Ho * p.Wo;
+    int64_t chunk = (p.M + splits - 1) / splits;
+    p.chunk = (chunk + PK - 1) / PK * PK;
+    const int BT = (Cin <= 64 && Cout <= 64) ? 64 : 128;
+    p.co_tiles = (Cout + BT - 1) / BT;
+    p.ci_tiles = (Cin + BT - 1) / BT;
+    dim3 grid((unsigned)(KH * KW * p.co_tiles * p.ci_tiles), (unsigned)splits);
+    hipStream_t st = (hipStream_t)stream;
+    if (BT == 64) {
+        hipLaunchKernelGGL(wgrad_f32_kernel<64>, grid, dim3(256), 2 * 2 * PK * 64 * 4, st, p);
+    } else {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)wgrad_f32_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      2 * 2 * PK * 128 * 4);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(wgrad_f32_kernel<128>, grid, dim3(256), 2 * 2 * PK * 128 * 4, st, p);
+    }
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ssad_wgrad_reduce(const float* slab, float* dw, int splits, int Cout, int Kpad, int KH, int KW, int Cin,
+                                 int to_oihw, int accumulate, void* stream) {
+    SSAD_CHECK_ARG(slab && dw && splits >= 1 && Cout > 0 && KH > 0 && KW > 0 && Cin > 0, "bad argument");
+    SSAD_CHECK_ARG(Kpad >= KH * KW * Cin, "slab rows shorter than the filter");
+    const int64_t total = (int64_t)Cout * KH * KW * Cin;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, slab, dw,
+                       splits, Cout, Kpad, KH, KW, Cin, to_oihw, accumulate);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libssad_hip.so")
 _c_fp = ctypes.c_void_p
 _c_i = ctypes.c_int
 _c_l = ctypes.c_int64
+_c_f = ctypes.c_float
 
 # name -> argtypes; mirrors include/ssad.h one to one (tests/test_capi_symbols.py checks the header too)
 SIGNATURES = {
@@ -29,7 +30,25 @@ SIGNATURES = {
     "ssad_l2_normalize_rows": [_c_fp, _c_fp, _c_l, _c_i, _c_fp],
     "ssad_cosine_knn_mean": [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp],
     "ssad_blur_relu_bilinear": [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_flip_transpose_weight": [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_conv_igemm_dgrad": [_c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
+                              _c_fp],
+    "ssad_wgrad_splits": [_c_l, _c_i, _c_i, _c_i, _c_i],
+    "ssad_conv_wgrad": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_wgrad_reduce": [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_stem_im2col": [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_pack_stem_weight_2d": [_c_fp, _c_fp, _c_fp],
+    "ssad_colreduce_workspace": [_c_l, _c_i],
+    "ssad_bn_stats": [_c_fp, _c_l, _c_i, _c_f, _c_f, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
+    "ssad_bn_apply_fwd": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp],
+    "ssad_bn_bwd_reduce": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_fp, _c_fp],
+    "ssad_bn_apply_bwd": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp],
+    "ssad_maxpool3x3s2_bwd": [_c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_gap_bwd": [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_softmax_ce": [_c_fp, _c_fp, _c_i, _c_i, _c_fp, _c_fp, _c_i, _c_f, _c_fp],
+    "ssad_sgd_step": [_c_fp, _c_fp, _c_fp, _c_l, _c_f, _c_f, _c_f, _c_f, _c_fp],
 }
+RESTYPES = {"ssad_colreduce_workspace": _c_l}
 
 _lib = None
 
@@ -52,7 +71,7 @@ def lib():
         for name, args in SIGNATURES.items():
             fn = getattr(l, name)
             fn.argtypes = args
-            fn.restype = _c_i
+            fn.restype = RESTYPES.get(name, _c_i)
         _lib = l
     return _lib
 
@@ -62,12 +81,12 @@ def check(rc):
         raise HipExtensionError(lib().ssad_last_error().decode())
 
 
-def ptr(t, allow_none=False):
+def ptr(t, allow_none=False, dtype=torch.float32):
     if t is None:
         if allow_none:
             return None
         raise HipExtensionError("null tensor")
-    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+    if not (t.is_cuda and t.dtype == dtype and t.is_contiguous()):
         raise HipExtensionError(
             f"expected a contiguous fp32 ROCm tensor, got device={t.device} dtype={t.dtype} contiguous={t.is_contiguous()}")
     return t.data_ptr()

@@ -4,8 +4,33 @@ import torch
 from . import _hip
 
 
+PROFILE = None      # bench.py sets this to a list: every launch is then bracketed by HIP events on its stream
+
+
 def _new(shape, like):
     return torch.empty(shape, device=like.device, dtype=torch.float32)
+
+
+def _run(kernel, flops, nbytes, rc_fn):
+    """Launch through the C ABI; when PROFILE is on, bracket the launch with events on the launch stream."""
+    if PROFILE is None:
+        _hip.check(rc_fn())
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _hip.check(rc_fn())
+    e1.record()
+    PROFILE.append((kernel, flops, nbytes, e0, e1))
+
+
+def drain_profile():
+    """-> [{kernel, flops, bytes, ms}] for every launch recorded since PROFILE was set."""
+    global PROFILE
+    recs = PROFILE or []
+    torch.cuda.synchronize()
+    out = [{"kernel": k, "flops": f, "bytes": b, "ms": e0.elapsed_time(e1)} for k, f, b, e0, e1 in recs]
+    PROFILE = [] if PROFILE is not None else None
+    return out
 
 
 def repack_oihw_to_ohwi(w):
@@ -46,16 +71,19 @@ def stem_fwd(img, wk, scale, shift, relu=True, patch_dim=0, patch_stride=0, out=
     p, hv, wv, ho, wo = stem_geometry(h, w, patch_dim, patch_stride)
     if out is None:
         out = _new((b * p, ho, wo, 64), img)
-    _hip.check(_hip.lib().ssad_stem_fwd(_hip.ptr(img), b, h, w, patch_dim, patch_stride, hv, wv, _hip.ptr(wk),
-                                        _hip.ptr(scale, True), _hip.ptr(shift, True), int(relu), _hip.ptr(out),
-                                        _hip.stream()))
+    n = b * p
+    _run("stem_conv7x7", 2.0 * n * ho * wo * 64 * 147, 4.0 * (b * 3 * h * w + n * ho * wo * 64),
+         lambda: _hip.lib().ssad_stem_fwd(_hip.ptr(img), b, h, w, patch_dim, patch_stride, hv, wv, _hip.ptr(wk),
+                                          _hip.ptr(scale, True), _hip.ptr(shift, True), int(relu), _hip.ptr(out),
+                                          _hip.stream()))
     return out
 
 
 def maxpool3x3s2_fwd(x):
     n, h, w, c = x.shape
     out = _new((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), x)
-    _hip.check(_hip.lib().ssad_maxpool3x3s2_fwd(_hip.ptr(x), _hip.ptr(out), n, h, w, c, _hip.stream()))
+    _run("maxpool3x3s2", 0.0, 4.0 * (x.numel() + out.numel()),
+         lambda: _hip.lib().ssad_maxpool3x3s2_fwd(_hip.ptr(x), _hip.ptr(out), n, h, w, c, _hip.stream()))
     return out
 
 
@@ -66,9 +94,11 @@ def conv_fwd(x, w_ohwi, scale=None, shift=None, residual=None, relu=False, strid
     assert cin == cin2
     ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
     out = _new((n, ho, wo, cout), x)
-    _hip.check(_hip.lib().ssad_conv_igemm_fwd(_hip.ptr(x), _hip.ptr(w_ohwi), _hip.ptr(out), _hip.ptr(scale, True),
-                                              _hip.ptr(shift, True), _hip.ptr(residual, True), int(relu), n, h, w, cin,
-                                              cout, kh, kw, stride, pad, _hip.stream()))
+    nb = 4.0 * (x.numel() + out.numel() * (2 if residual is not None else 1) + w_ohwi.numel())
+    _run("conv_igemm_f32", 2.0 * out.numel() * kh * kw * cin, nb,
+         lambda: _hip.lib().ssad_conv_igemm_fwd(_hip.ptr(x), _hip.ptr(w_ohwi), _hip.ptr(out), _hip.ptr(scale, True),
+                                                _hip.ptr(shift, True), _hip.ptr(residual, True), int(relu), n, h, w,
+                                                cin, cout, kh, kw, stride, pad, _hip.stream()))
     return out
 
 
@@ -77,32 +107,171 @@ def linear_fwd(x, w, scale=None, shift=None, relu=False):
     n, cin = x.shape
     cout = w.shape[0]
     out = _new((n, cout), x)
-    _hip.check(_hip.lib().ssad_conv_igemm_fwd(_hip.ptr(x), _hip.ptr(w), _hip.ptr(out), _hip.ptr(scale, True),
-                                              _hip.ptr(shift, True), None, int(relu), n, 1, 1, cin, cout, 1, 1, 1, 0,
-                                              _hip.stream()))
+    _run("conv_igemm_f32", 2.0 * n * cin * cout, 4.0 * (x.numel() + out.numel() + w.numel()),
+         lambda: _hip.lib().ssad_conv_igemm_fwd(_hip.ptr(x), _hip.ptr(w), _hip.ptr(out), _hip.ptr(scale, True),
+                                                _hip.ptr(shift, True), None, int(relu), n, 1, 1, cin, cout, 1, 1, 1, 0,
+                                                _hip.stream()))
     return out
 
 
 def gap_fwd(x, out, offset):
     n, h, w, c = x.shape
-    _hip.check(_hip.lib().ssad_gap_fwd(_hip.ptr(x), _hip.ptr(out), n, h * w, c, out.shape[1], offset, _hip.stream()))
+    _run("gap", 0.0, 4.0 * (x.numel() + n * c),
+         lambda: _hip.lib().ssad_gap_fwd(_hip.ptr(x), _hip.ptr(out), n, h * w, c, out.shape[1], offset, _hip.stream()))
     return out
 
 
 def l2_normalize_rows(x):
     out = torch.empty_like(x)
-    _hip.check(_hip.lib().ssad_l2_normalize_rows(_hip.ptr(x), _hip.ptr(out), x.shape[0], x.shape[1], _hip.stream()))
+    _run("l2norm_rows", 0.0, 8.0 * x.numel(),
+         lambda: _hip.lib().ssad_l2_normalize_rows(_hip.ptr(x), _hip.ptr(out), x.shape[0], x.shape[1], _hip.stream()))
     return out
 
 
 def cosine_knn_mean(sim, k=3):
     out = _new((sim.shape[0],), sim)
-    _hip.check(_hip.lib().ssad_cosine_knn_mean(_hip.ptr(sim), _hip.ptr(out), sim.shape[0], sim.shape[1], k, _hip.stream()))
+    _run("knn_mean", 0.0, 4.0 * sim.numel(),
+         lambda: _hip.lib().ssad_cosine_knn_mean(_hip.ptr(sim), _hip.ptr(out), sim.shape[0], sim.shape[1], k, _hip.stream()))
     return out
 
 
 def blur_relu_bilinear(maps, ksize=7, target=256):
     n, c, h, w = maps.shape
     out = _new((n, c, target, target), maps)
-    _hip.check(_hip.lib().ssad_blur_relu_bilinear(_hip.ptr(maps), _hip.ptr(out), n * c, h, w, ksize, target, _hip.stream()))
+    _run("blur_relu_bilinear", 0.0, 4.0 * (maps.numel() + out.numel()),
+         lambda: _hip.lib().ssad_blur_relu_bilinear(_hip.ptr(maps), _hip.ptr(out), n * c, h, w, ksize, target, _hip.stream()))
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# training kernels
+# ---------------------------------------------------------------------------------------------
+def flip_transpose_weight(w_ohwi):
+    o, kh, kw, i = w_ohwi.shape
+    out = _new((i, kh, kw, o), w_ohwi)
+    _hip.check(_hip.lib().ssad_flip_transpose_weight(_hip.ptr(w_ohwi), _hip.ptr(out), o, i, kh, kw, _hip.stream()))
+    return out
+
+
+def conv_dgrad(dy, w_flipT, x_shape, stride, pad, residual=None):
+    """dy NHWC [N][Hy][Wy][Cout]; w_flipT [Cin][KH][KW][Cout] -> dx NHWC of x_shape (+ residual)."""
+    n, hy, wy, cout = dy.shape
+    cin, kh, kw, _ = w_flipT.shape
+    dx = _new(tuple(x_shape), dy)
+    _run("conv_igemm_f32", 2.0 * dx.numel() * kh * kw * cout / (stride * stride),
+         4.0 * (dy.numel() + dx.numel() * (2 if residual is not None else 1) + w_flipT.numel()),
+         lambda: _hip.lib().ssad_conv_igemm_dgrad(_hip.ptr(dy), _hip.ptr(w_flipT), _hip.ptr(dx), _hip.ptr(residual, True),
+                                                  n, hy, wy, cout, x_shape[1], x_shape[2], cin, kh, kw, stride, pad,
+                                                  _hip.stream()))
+    return dx
+
+
+def conv_wgrad(dy, x, dw_out, kh, kw, stride, pad, kreal=None, to_oihw=False, accumulate=False):
+    """dy NHWC [N][Ho][Wo][Cout], x NHWC [N][H][W][Cin] -> dw_out (flat, Cout*KH*KW*Cin_real floats).
+    kreal = (KH, KW, Cin) of the real filter when x rows are padded im2col rows (stem)."""
+    n, h, w, cin = x.shape
+    cout = dy.shape[-1]
+    m = dy.numel() // cout
+    splits = _hip.lib().ssad_wgrad_splits(m, cin, cout, kh, kw)
+    slab = _new((splits, cout, kh * kw * cin), dy)
+    _run("wgrad_f32", 2.0 * m * cout * kh * kw * cin, 4.0 * (dy.numel() * kh * kw + x.numel() * kh * kw + slab.numel()),
+         lambda: _hip.lib().ssad_conv_wgrad(_hip.ptr(dy), _hip.ptr(x), _hip.ptr(slab), splits, n, h, w, cin, cout, kh, kw,
+                                            stride, pad, _hip.stream()))
+    rkh, rkw, rcin = kreal if kreal else (kh, kw, cin)
+    _run("wgrad_reduce", 0.0, 4.0 * slab.numel(),
+         lambda: _hip.lib().ssad_wgrad_reduce(_hip.ptr(slab), _hip.ptr(dw_out), splits, cout, kh * kw * cin, rkh, rkw, rcin,
+                                              int(to_oihw), int(accumulate), _hip.stream()))
+    return dw_out
+
+
+def stem_im2col(img, hv, wv):
+    b, c, h, w = img.shape
+    ho, wo = (hv - 1) // 2 + 1, (wv - 1) // 2 + 1
+    col = _new((b, ho, wo, 160), img)
+    _run("stem_im2col", 0.0, 4.0 * (img.numel() + col.numel()),
+         lambda: _hip.lib().ssad_stem_im2col(_hip.ptr(img), _hip.ptr(col), b, h, w, hv, wv, _hip.stream()))
+    return col
+
+
+def pack_stem_weight_2d(w_oihw):
+    out = _new((64, 1, 1, 160), w_oihw)
+    _hip.check(_hip.lib().ssad_pack_stem_weight_2d(_hip.ptr(w_oihw), _hip.ptr(out), _hip.stream()))
+    return out
+
+
+def _colreduce_ws(r, c, like):
+    n = _hip.lib().ssad_colreduce_workspace(r, c)
+    return torch.empty(n, device=like.device, dtype=torch.float64)
+
+
+def bn_stats(z, c, eps, momentum, running_mean, running_var):
+    r = z.numel() // c
+    mean, invstd = _new((c,), z), _new((c,), z)
+    ws = _colreduce_ws(r, c, z)
+    _run("bn_stats", 0.0, 4.0 * z.numel(),
+         lambda: _hip.lib().ssad_bn_stats(_hip.ptr(z), r, c, eps, momentum, _hip.ptr(mean), _hip.ptr(invstd),
+                                          _hip.ptr(running_mean, True), _hip.ptr(running_var, True), ws.data_ptr(),
+                                          _hip.stream()))
+    return mean, invstd
+
+
+def bn_apply_fwd(z, mean, invstd, gamma, beta, residual, relu):
+    c = mean.numel()
+    y = torch.empty_like(z)
+    _run("bn_apply_fwd", 0.0, 4.0 * z.numel() * (3 if residual is not None else 2),
+         lambda: _hip.lib().ssad_bn_apply_fwd(_hip.ptr(z), _hip.ptr(mean), _hip.ptr(invstd), _hip.ptr(gamma), _hip.ptr(beta),
+                                              _hip.ptr(residual, True), _hip.ptr(y), z.numel() // c, c, int(relu),
+                                              _hip.stream()))
+    return y
+
+
+def bn_bwd_reduce(dy, yact, z, mean, invstd, dbeta, dgamma, c):
+    r = dy.numel() // c
+    ws = _colreduce_ws(r, c, dy)
+    _run("bn_bwd_reduce", 0.0, 4.0 * dy.numel() * (1 + (yact is not None) + (z is not None)),
+         lambda: _hip.lib().ssad_bn_bwd_reduce(_hip.ptr(dy), _hip.ptr(yact, True), _hip.ptr(z, True), _hip.ptr(mean, True),
+                                               _hip.ptr(invstd, True), _hip.ptr(dbeta, True), _hip.ptr(dgamma, True), r, c,
+                                               ws.data_ptr(), _hip.stream()))
+
+
+def bn_apply_bwd(dy, yact, z, mean, invstd, gamma, dbeta, dgamma, want_dres, eval_mode=False):
+    c = mean.numel()
+    dz = torch.empty_like(dy)
+    dres = torch.empty_like(dy) if want_dres else None
+    _run("bn_apply_bwd", 0.0, 4.0 * dy.numel() * (3 + (yact is not None) + want_dres),
+         lambda: _hip.lib().ssad_bn_apply_bwd(_hip.ptr(dy), _hip.ptr(yact, True), _hip.ptr(z, True), _hip.ptr(mean),
+                                              _hip.ptr(invstd), _hip.ptr(gamma), _hip.ptr(dbeta, True), _hip.ptr(dgamma, True),
+                                              _hip.ptr(dz), _hip.ptr(dres, True), dy.numel() // c, c, int(eval_mode),
+                                              _hip.stream()))
+    return dz, dres
+
+
+def maxpool3x3s2_bwd(x, dy):
+    n, h, w, c = x.shape
+    dx = torch.empty_like(x)
+    _run("maxpool_bwd", 0.0, 4.0 * (2 * x.numel() + dy.numel()),
+         lambda: _hip.lib().ssad_maxpool3x3s2_bwd(_hip.ptr(x), _hip.ptr(dy), _hip.ptr(dx), n, h, w, c, _hip.stream()))
+    return dx
+
+
+def gap_bwd(dpooled, dy, offset, accumulate):
+    n, h, w, c = dy.shape
+    _run("gap_bwd", 0.0, 4.0 * dy.numel() * (2 if accumulate else 1),
+         lambda: _hip.lib().ssad_gap_bwd(_hip.ptr(dpooled), _hip.ptr(dy), n, h * w, c, dpooled.shape[1], offset,
+                                         int(accumulate), _hip.stream()))
+    return dy
+
+
+def softmax_ce(logits, labels, dlogits=None, grad_scale=1.0):
+    b, c = logits.shape
+    out = _new((2,), logits)
+    ldd = dlogits.shape[1] if dlogits is not None else 0
+    _hip.check(_hip.lib().ssad_softmax_ce(_hip.ptr(logits), _hip.ptr(labels, dtype=torch.int64), b, c, _hip.ptr(out),
+                                          _hip.ptr(dlogits, True), ldd, grad_scale, _hip.stream()))
+    return out
+
+
+def sgd_step(p, g, m, lr, momentum, weight_decay, grad_scale=1.0):
+    _run("sgd", 0.0, 20.0 * p.numel(),
+         lambda: _hip.lib().ssad_sgd_step(_hip.ptr(p), _hip.ptr(g), _hip.ptr(m), p.numel(), lr, momentum, weight_decay,
+                                          grad_scale, _hip.stream()))

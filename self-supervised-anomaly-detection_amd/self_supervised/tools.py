@@ -8,9 +8,10 @@ from torch import Tensor
 from . import ops
 
 
-def upsample(anomaly_maps: Tensor, target_size: int = 256):
+def upsample(anomaly_maps: Tensor, target_size: int = 256, verbose: bool = True):
     """tools.py:394-399: relu(gaussian_blur(k=7)) then bilinear to target_size, one fused kernel."""
-    print('>>> upsampling')
+    if verbose:
+        print('>>> upsampling')
     m = torch.as_tensor(anomaly_maps, dtype=torch.float32)
     if not m.is_cuda:
         if not torch.cuda.is_available():

@@ -1,0 +1,494 @@
+"""Training step on the HIP kernels: train-mode forward, hand-written backward, fused SGD, RCCL data parallel.
+
+Restates ``PeraNet.training_step`` + ``configure_optimizers`` (src/self_supervised/models.py:256-277, :336-341
+of the reference) and what ``pl.Trainer.fit`` does around them (autograd backward, optimizer step;
+tools.py:260-303).  The reference is single-GPU; the data-parallel layer (one process per GPU, gradients
+all-reduced with RCCL over xGMI in buckets that overlap the rest of backward) is new.
+
+Memory layout: all parameters live in ONE flat fp32 arena ordered by backward completion (classifier first,
+conv1 last); gradients and momentum are parallel arenas.  Conv weights are stored OHWI inside the arena and
+exposed to PyTorch as OIHW-shaped (channels_last-strided) views, so ``state_dict()`` keeps the reference's
+names and shapes while the kernels read them without repacking.  Bucketed all-reduce = contiguous arena
+ranges; SGD = one launch per trainable range.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from . import engine, ops
+
+BN_TYPES = (nn.BatchNorm1d, nn.BatchNorm2d)
+
+
+# ---------------------------------------------------------------------------------------------
+# parameter arena
+# ---------------------------------------------------------------------------------------------
+def _backward_order(model):
+    """Parameters in the order their gradients become final during backward."""
+    out = []
+    out += [model.classifier.weight, model.classifier.bias]
+    ls = list(model.latent_space)
+    out += [ls[-1].weight, ls[-1].bias, ls[-2].weight, ls[-2].bias]
+    for seq in reversed(ls[:-2]):
+        out += [seq[1].weight, seq[1].bias, seq[0].weight]
+    out += [model.concatenator[1].weight, model.concatenator[1].bias, model.concatenator[0].weight]
+    head_count = len(out)
+    fe = model.feature_extractor
+    for name, _, _, _ in reversed(engine.BLOCKS):
+        for blk in reversed(list(getattr(fe, name))):
+            out += [blk.bn2.weight, blk.bn2.bias, blk.conv2.weight, blk.bn1.weight, blk.bn1.bias, blk.conv1.weight]
+            if blk.downsample is not None:
+                out += [blk.downsample[1].weight, blk.downsample[1].bias, blk.downsample[0].weight]
+    out += [fe.bn1.weight, fe.bn1.bias, fe.conv1.weight]
+    assert len(out) == len(list(model.parameters())), "parameter walk does not cover the model"
+    return out, head_count
+
+
+class ParamArena:
+    def __init__(self, model):
+        params, head_count = _backward_order(model)
+        dev = params[0].device
+        total = sum(p.numel() for p in params)
+        self.p = torch.empty(total, device=dev, dtype=torch.float32)
+        self.g = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.m = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.params, self.offset = params, {}
+        off = 0
+        with torch.no_grad():
+            for i, p in enumerate(params):
+                n = p.numel()
+                self.offset[id(p)] = (off, n)
+                if p.dim() == 4:
+                    o, c, kh, kw = p.shape
+                    phys = self.p[off:off + n].view(o, kh, kw, c)
+                    phys.copy_(p.detach().permute(0, 2, 3, 1))
+                    p.data = phys.permute(0, 3, 1, 2)
+                    p.grad = self.g[off:off + n].view(o, kh, kw, c).permute(0, 3, 1, 2)
+                else:
+                    flat = self.p[off:off + n].view(p.shape)
+                    flat.copy_(p.detach())
+                    p.data = flat
+                    p.grad = self.g[off:off + n].view(p.shape)
+                off += n
+                if i + 1 == head_count:
+                    self.head_end = off
+        self.total = total
+
+    def valid_for(self, model):
+        p = self.params[0]
+        return p.data_ptr() == self.p.data_ptr() and p.device == self.p.device
+
+    def w(self, p):
+        """Kernel view of a parameter: OHWI for 4-D weights, as-is otherwise."""
+        off, n = self.offset[id(p)]
+        if p.dim() == 4:
+            o, c, kh, kw = p.shape
+            return self.p[off:off + n].view(o, kh, kw, c)
+        return self.p[off:off + n].view(p.shape)
+
+    def grad(self, p):
+        off, n = self.offset[id(p)]
+        return self.g[off:off + n]
+
+    def sync_grads(self):
+        """Compatibility path (PyTorch Lightning / set_to_none): make the arena hold whatever ``p.grad`` holds."""
+        for p in self.params:
+            off, n = self.offset[id(p)]
+            if p.grad is None or not p.requires_grad:
+                continue
+            view = self.g[off:off + n]
+            if p.grad.data_ptr() != view.data_ptr():
+                src = p.grad.permute(0, 2, 3, 1) if p.dim() == 4 else p.grad
+                view.view(src.shape).copy_(src)
+                p.grad = view.view(src.shape).permute(0, 3, 1, 2) if p.dim() == 4 else view.view(p.shape)
+
+    def trainable_ranges(self):
+        """Merged [start, end) arena ranges whose parameters require grad (frozen ones are never touched)."""
+        ranges = []
+        for p in self.params:
+            if not p.requires_grad:
+                continue
+            off, n = self.offset[id(p)]
+            if ranges and ranges[-1][1] == off:
+                ranges[-1][1] = off + n
+            else:
+                ranges.append([off, off + n])
+        return [tuple(r) for r in ranges]
+
+
+# ---------------------------------------------------------------------------------------------
+# layers with saved state
+# ---------------------------------------------------------------------------------------------
+class _Affine:
+    """conv/linear (+bias) followed by BatchNorm (train or eval statistics), optional residual and ReLU."""
+
+    def __init__(self, eng, lin, bn, stride=1, pad=0, relu=False, stem=False):
+        self.eng, self.lin, self.bn, self.stride, self.pad, self.relu, self.stem = eng, lin, bn, stride, pad, relu, stem
+        self.is_conv = isinstance(lin, nn.Conv2d)
+
+    def weight(self):
+        a = self.eng.arena
+        if self.stem:
+            return ops.pack_stem_weight_2d(self.lin.weight.detach().contiguous())
+        w = a.w(self.lin.weight)
+        return w if self.is_conv else w.view(w.shape[0], 1, 1, w.shape[1])
+
+    def fwd(self, x, residual=None):
+        """x NHWC (4-D).  Returns y NHWC."""
+        a, bn = self.eng.arena, self.bn
+        w = self.weight()
+        self.x, self.res_used = x, residual is not None
+        bias = getattr(self.lin, "bias", None)
+        if bn is None:
+            y = ops.conv_fwd(x, w, None, a.w(bias) if bias is not None else None, None, self.relu, self.stride, self.pad)
+            self.z = self.y = None
+            return y
+        c = bn.num_features
+        if bn.training:
+            z = ops.conv_fwd(x, w, None, a.w(bias) if bias is not None else None, None, False, self.stride, self.pad)
+            mom = 0.1 if bn.momentum is None else bn.momentum
+            self.mean, self.invstd = ops.bn_stats(z, c, bn.eps, mom, bn.running_mean, bn.running_var)
+            with torch.no_grad():
+                bn.num_batches_tracked += 1
+            y = ops.bn_apply_fwd(z, self.mean, self.invstd, a.w(bn.weight), a.w(bn.bias), residual, self.relu)
+            self.z = z
+        else:
+            with torch.no_grad():
+                self.invstd = torch.rsqrt(bn.running_var + bn.eps)
+                self.mean = bn.running_mean
+                scale = (bn.weight * self.invstd).contiguous()
+                shift = bn.bias - bn.running_mean * scale
+                if bias is not None:
+                    shift = shift + bias * scale
+            y = ops.conv_fwd(x, w, scale, shift.contiguous(), residual, self.relu, self.stride, self.pad)
+            self.z = None
+        self.y = y if self.relu else None
+        return y
+
+    def bwd(self, dy, need_dx=True, dx_residual=None, want_dres=False):
+        """dy NHWC grad of the output.  Returns (dx or None, dres or None)."""
+        a, bn = self.eng.arena, self.bn
+        dres = None
+        bias = getattr(self.lin, "bias", None)
+        if bn is None:
+            dz = dy
+        else:
+            c = bn.num_features
+            train_stats = self.z is not None
+            wg, bg = bn.weight.requires_grad, bn.bias.requires_grad
+            if train_stats or wg or bg:
+                dbeta = a.grad(bn.bias) if bg else torch.empty(c, device=dy.device)
+                dgamma = a.grad(bn.weight) if wg else torch.empty(c, device=dy.device)
+                zsrc = self.z if train_stats else None
+                if zsrc is None and wg:
+                    raise NotImplementedError("BatchNorm weight gradient with eval-mode statistics")
+                ops.bn_bwd_reduce(dy, self.y, zsrc, self.mean, self.invstd, dbeta, dgamma, c)
+            else:
+                dbeta = dgamma = None
+            dz, dres = ops.bn_apply_bwd(dy, self.y, self.z, self.mean, self.invstd, a.w(bn.weight), dbeta, dgamma,
+                                        want_dres, eval_mode=not train_stats)
+        cout = dz.shape[-1]
+        if bias is not None and bias.requires_grad:
+            ops.bn_bwd_reduce(dz, None, None, None, None, a.grad(bias), None, cout)
+        if self.lin.weight.requires_grad:
+            if self.stem:
+                ops.conv_wgrad(dz, self.x, a.grad(self.lin.weight), 1, 1, 1, 0, kreal=(7, 7, 3))
+            elif self.is_conv:
+                k = self.lin.kernel_size[0]
+                ops.conv_wgrad(dz, self.x, a.grad(self.lin.weight), k, k, self.stride, self.pad)
+            else:
+                ops.conv_wgrad(dz, self.x, a.grad(self.lin.weight), 1, 1, 1, 0)
+        dx = None
+        if need_dx:
+            w = self.weight()
+            dzz, wt = dz, w
+            if cout % 32:                       # classifier: pad the contraction to a multiple of 32 with zeros
+                padc = (cout + 31) // 32 * 32
+                dzz = torch.zeros(dz.shape[:-1] + (padc,), device=dz.device)
+                dzz[..., :cout] = dz
+                wt = torch.zeros((padc,) + tuple(w.shape[1:]), device=dz.device)
+                wt[:cout] = w
+            dx = ops.conv_dgrad(dzz, ops.flip_transpose_weight(wt), self.x.shape, self.stride, self.pad, dx_residual)
+        self.x = self.z = self.y = None
+        return dx, dres
+
+
+class TrainEngine:
+    """Owns the arenas and the per-step tape for one PeraNet."""
+
+    def __init__(self, model):
+        self.model = model
+        self.arena = ParamArena(model)
+        fe = model.feature_extractor
+        self.stem = _Affine(self, fe.conv1, fe.bn1, 1, 0, True, stem=True)   # 1x1 over im2col rows
+        self.blocks = []
+        for name, _, _, _ in engine.BLOCKS:
+            for blk in getattr(fe, name):
+                d = {"name": name,
+                     "c1": _Affine(self, blk.conv1, blk.bn1, blk.stride, 1, True),
+                     "c2": _Affine(self, blk.conv2, blk.bn2, 1, 1, True),
+                     "ds": None}
+                if blk.downsample is not None:
+                    d["ds"] = _Affine(self, blk.downsample[0], blk.downsample[1], blk.stride, 0, False)
+                self.blocks.append(d)
+        self.head = [_Affine(self, model.concatenator[0], model.concatenator[1])]
+        ls = list(model.latent_space)
+        for seq in ls[:-2]:
+            self.head.append(_Affine(self, seq[0], seq[1], relu=True))
+        self.head.append(_Affine(self, ls[-2], ls[-1]))
+        self.cls = _Affine(self, model.classifier, None)
+        self.gap_off, off = {}, 0
+        for k in ("layer1", "layer2", "layer3"):
+            if k in model.layer_outputs:
+                self.gap_off[k] = off
+                off += {"layer1": 64, "layer2": 128, "layer3": 256}[k]
+        self.gap_off["layer4"] = off
+        self.pooled_dim = off + 512
+        self.bucket_hooks = None      # set by DataParallelStep: callable(range_end) after each finished arena prefix
+
+    # ---- forward (models.py:210-253, train mode) ----
+    def forward(self, x):
+        m = self.model
+        b, _, h, w = x.shape
+        _, hv, wv, ho, wo = ops.stem_geometry(h, w, 0, 0)
+        self.trunk_grad = any(p.requires_grad for p in m.feature_extractor.parameters())
+        col = ops.stem_im2col(x, hv, wv)
+        a0 = self.stem.fwd(col)
+        if not self.trunk_grad:
+            self.stem.x = None
+        self.a0 = a0
+        a = ops.maxpool3x3s2_fwd(a0)
+        pooled = torch.empty((b, self.pooled_dim), device=x.device, dtype=torch.float32)
+        self.stage_shapes = {}
+        for i, d in enumerate(self.blocks):
+            idt = a
+            if d["ds"] is not None:
+                idt = d["ds"].fwd(a)
+            t = d["c1"].fwd(a)
+            a = d["c2"].fwd(t, residual=idt)
+            if i % 2 == 1 and d["name"] in self.gap_off:
+                ops.gap_fwd(a, pooled, self.gap_off[d["name"]])
+                self.stage_shapes[d["name"]] = a.shape
+        self.last_shape = a.shape
+        if not self.trunk_grad:
+            self._drop_trunk_tape()
+        f = pooled.view(b, 1, 1, -1)
+        for layer in self.head:
+            f = layer.fwd(f)
+        logits = self.cls.fwd(f)
+        self.batch = b
+        return logits.view(b, -1), f.view(b, -1)
+
+    # ---- backward ----
+    def backward(self, dlogits):
+        """dlogits [B][num_classes] -> fills the gradient arena."""
+        b = self.batch
+        notify = self.bucket_hooks or (lambda end: None)
+        a = self.arena
+        head_dx = self.trunk_grad or any(p.requires_grad for l in self.head for p in l.lin.parameters())
+        d, _ = self.cls.bwd(dlogits.view(b, 1, 1, -1), need_dx=head_dx)
+        for i, layer in enumerate(reversed(self.head)):
+            last = i == len(self.head) - 1
+            if d is None:
+                break
+            d, _ = layer.bwd(d, need_dx=(self.trunk_grad if last else True))
+        notify(a.head_end)
+        if not self.trunk_grad:
+            self._drop_tape()
+            return
+        dpooled = d.view(b, -1).contiguous()
+        dy = torch.empty(self.last_shape, device=dpooled.device, dtype=torch.float32)
+        ops.gap_bwd(dpooled, dy, self.gap_off["layer4"], accumulate=False)
+        for i in range(len(self.blocks) - 1, -1, -1):
+            blk = self.blocks[i]
+            dz2_dx, dres = blk["c2"].bwd(dy, need_dx=True, want_dres=True)
+            if blk["ds"] is not None:
+                dx_id, _ = blk["ds"].bwd(dres, need_dx=True)
+            else:
+                dx_id = dres
+            dy, _ = blk["c1"].bwd(dz2_dx, need_dx=True, dx_residual=dx_id)
+            if i % 2 == 0 and i > 0:
+                prev = self.blocks[i - 1]["name"]
+                if prev in self.gap_off:
+                    ops.gap_bwd(dpooled, dy, self.gap_off[prev], accumulate=True)
+            if i % 2 == 0:
+                notify(a.offset[id(blk["c1"].lin.weight)][0] + blk["c1"].lin.weight.numel()
+                       if blk["ds"] is None else
+                       a.offset[id(blk["ds"].lin.weight)][0] + blk["ds"].lin.weight.numel())
+        da0 = ops.maxpool3x3s2_bwd(self.a0, dy)
+        self.stem.bwd(da0, need_dx=False)
+        notify(a.total)
+        self._drop_tape()
+
+    def _drop_trunk_tape(self):
+        self.a0 = None
+        for d in self.blocks:
+            for k in ("c1", "c2", "ds"):
+                if d[k] is not None:
+                    d[k].x = d[k].z = d[k].y = None
+        self.stem.x = self.stem.z = self.stem.y = None
+
+    def _drop_tape(self):
+        self._drop_trunk_tape()
+        for l in self.head + [self.cls]:
+            l.x = l.z = l.y = None
+
+
+def get_engine(model):
+    eng = getattr(model, "_train_engine", None)
+    if eng is None or not eng.arena.valid_for(model):
+        eng = TrainEngine(model)
+        model._train_engine = eng
+        model._plan = None
+    return eng
+
+
+# ---------------------------------------------------------------------------------------------
+# module-level API used by models.PeraNet
+# ---------------------------------------------------------------------------------------------
+def forward_train(model, x):
+    eng = get_engine(model)
+    logits, emb = eng.forward(x)
+    return {"classifier": logits, "latent_space": emb}
+
+
+def cross_entropy_eval(logits, y):
+    la = ops.softmax_ce(logits.contiguous(), y.to(logits.device).contiguous())
+    return la[0], la[1]
+
+
+class _HipLoss(torch.autograd.Function):
+    """Lets ``loss.backward()`` (PyTorch Lightning, plain torch optimisers) drive the HIP backward pass:
+    the parameters are declared as inputs, their gradients are read back from the arena."""
+
+    @staticmethod
+    def forward(ctx, model, loss, dlogits, *params):
+        ctx.model, ctx.dlogits, ctx.params = model, dlogits, params
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        eng = get_engine(ctx.model)
+        eng.backward(ctx.dlogits * gout)
+        grads = tuple(p.grad.clone() if p.requires_grad else None for p in ctx.params)
+        eng.arena.g.zero_()          # autograd now accumulates the returned gradients into p.grad (= arena views)
+        return (None, None, None) + grads
+
+
+def training_step(model, batch, batch_idx):
+    """models.py:256-277."""
+    x, y, _ = batch
+    eng = get_engine(model)
+    x = x.contiguous().float()
+    y = y.to(x.device)
+    model.train() if not model.training else None
+    logits, embeds = eng.forward(x)
+    dlogits = torch.empty_like(logits)
+    la = ops.softmax_ce(logits, y.contiguous(), dlogits, 1.0 / x.shape[0])
+    loss, acc = la[0], la[1]
+    model.log_dict({"train_accuracy": acc, "train_loss": loss}, on_step=False, on_epoch=True, prog_bar=True)
+    max_epochs = getattr(getattr(model, "trainer", None), "max_epochs", None)
+    if max_epochs is not None and model.current_epoch > int(max_epochs / 2):
+        y_hat = torch.max(logits, 1).indices
+        mask = (y == 0) & (y_hat == 0)
+        model.memory_bank = torch.cat([model.memory_bank, embeds[mask].detach().to('cpu')])
+    if torch.is_grad_enabled():
+        params = [p for p in model.parameters()]
+        return _HipLoss.apply(model, loss, dlogits, *params)
+    return loss
+
+
+# ---------------------------------------------------------------------------------------------
+# optimiser / scheduler / data-parallel step
+# ---------------------------------------------------------------------------------------------
+class FusedSGD:
+    """torch.optim.SGD(params, lr, momentum, weight_decay) semantics over the flat arena (models.py:337)."""
+
+    def __init__(self, model, lr, momentum=0.9, weight_decay=0.0005):
+        self.model, self.momentum, self.weight_decay = model, momentum, weight_decay
+        self.param_groups = [{"lr": lr, "initial_lr": lr, "momentum": momentum, "weight_decay": weight_decay}]
+        self.grad_scale = 1.0
+
+    def zero_grad(self, set_to_none=False):
+        pass        # every gradient range is overwritten (never accumulated) by backward
+
+    def step(self, closure=None):
+        if closure is not None:
+            closure()
+        a = get_engine(self.model).arena
+        a.sync_grads()
+        lr = self.param_groups[0]["lr"]
+        for s, e in a.trainable_ranges():
+            ops.sgd_step(a.p[s:e], a.g[s:e], a.m[s:e], lr, self.momentum, self.weight_decay, self.grad_scale)
+
+    def state_dict(self):
+        return {"param_groups": self.param_groups, "momentum": get_engine(self.model).arena.m.cpu()}
+
+    def load_state_dict(self, sd):
+        self.param_groups = sd["param_groups"]
+        get_engine(self.model).arena.m.copy_(sd["momentum"])
+
+
+class CosineWarmRestarts:
+    """CosineAnnealingWarmRestarts(optimizer, T_0) stepped once per epoch (models.py:338)."""
+
+    def __init__(self, optimizer, T_0, eta_min=0.0):
+        self.opt, self.T_0, self.eta_min, self.epoch = optimizer, T_0, eta_min, 0
+        self.base = optimizer.param_groups[0]["lr"]
+
+    def step(self):
+        self.epoch += 1
+        t = self.epoch % self.T_0
+        self.opt.param_groups[0]["lr"] = self.eta_min + (self.base - self.eta_min) * (1 + math.cos(math.pi * t / self.T_0)) / 2
+
+    def get_last_lr(self):
+        return [self.opt.param_groups[0]["lr"]]
+
+
+class DataParallelStep:
+    """forward + loss + backward + (bucketed RCCL all-reduce overlapped with backward) + SGD for one rank.
+
+    Buckets are the arena prefixes that become final after the head, after each ResNet stage's first block, and
+    after the stem; each is all-reduced (sum) as soon as it is final, on RCCL's stream, while the compute stream
+    continues with the next stage.  The 1/world factor is applied inside the SGD kernel."""
+
+    def __init__(self, model, lr, momentum=0.9, weight_decay=0.0005, world_size=None, process_group=None):
+        self.model = model
+        self.eng = get_engine(model)
+        self.opt = FusedSGD(model, lr, momentum, weight_decay)
+        self.pg = process_group
+        self.world = world_size if world_size is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
+        self.opt.grad_scale = 1.0 / self.world
+        self._works, self._done = [], 0
+        self.min_bucket = 1 << 20          # floats: merge tiny ranges into >= 4 MB messages
+
+    def _notify(self, end):
+        a = self.eng.arena
+        ranges = [(s, e) for s, e in a.trainable_ranges()]
+        final = end == a.total or (not self.eng.trunk_grad and end == a.head_end)
+        if end - self._done < self.min_bucket and not final:
+            return
+        for s, e in ranges:
+            lo, hi = max(s, self._done), min(e, end)
+            if hi > lo:
+                self._works.append(dist.all_reduce(a.g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        self._done = end
+
+    def step(self, x, y):
+        eng = self.eng
+        eng.bucket_hooks = self._notify if self.world > 1 else None
+        self._works, self._done = [], 0
+        logits, emb = eng.forward(x)
+        dlogits = torch.empty_like(logits)
+        la = ops.softmax_ce(logits, y, dlogits, 1.0 / x.shape[0])
+        eng.backward(dlogits)
+        for w in self._works:
+            w.wait()
+        a = eng.arena
+        for s, e in a.trainable_ranges():
+            ops.sgd_step(a.p[s:e], a.g[s:e], a.m[s:e], self.opt.param_groups[0]["lr"], self.opt.momentum,
+                         self.opt.weight_decay, self.opt.grad_scale)
+        self.last_logits, self.last_embeddings = logits, emb
+        return la

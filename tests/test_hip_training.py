@@ -1,0 +1,196 @@
+"""GPU parity of the training step: HIP forward(train)/backward/SGD against torch-CPU autograd on the oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def rel_err(got, want, floor=1e-12):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    return (got - want).abs().max().item() / max(want.abs().max().item(), floor)
+
+
+def grad_floor(ref):
+    """Gradients that are analytically zero (a BN bias feeding another train-mode BN) are rounding noise on both
+    sides: compare every tensor against max(|its own reference|, 1e-4 * the largest gradient in the model)."""
+    return 1e-4 * max(p.grad.abs().max().item() for p in ref.parameters() if p.grad is not None)
+
+
+def _pair(sd, dev):
+    from self_supervised.models import PeraNet
+    from oracle.peranet import OraclePeraNet
+    ref = OraclePeraNet(); ref.load_state_dict(sd); ref.train()
+    m = PeraNet(); m.load_state_dict(sd); m.to(dev).train()
+    return ref, m
+
+
+def test_wgrad_dgrad_kernels(dev):
+    from self_supervised import ops
+    for (n, h, w, cin, cout, k, s, p) in [(3, 8, 8, 64, 64, 3, 1, 1), (2, 9, 9, 64, 128, 3, 2, 1), (2, 8, 8, 64, 128, 1, 2, 0),
+                                           (5, 2, 2, 128, 256, 3, 1, 1), (300, 1, 1, 896, 512, 1, 1, 0)]:
+        g = torch.Generator().manual_seed(n * 7 + k)
+        x = torch.randn(n, cin, h, w, generator=g, requires_grad=True)
+        wt = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).requires_grad_()
+        y = F.conv2d(x, wt, None, s, p)
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy)
+        xd, dyd = x.detach().permute(0, 2, 3, 1).contiguous().to(dev), dy.permute(0, 2, 3, 1).contiguous().to(dev)
+        w_ohwi = ops.repack_oihw_to_ohwi(wt.detach().to(dev))
+        dx = ops.conv_dgrad(dyd, ops.flip_transpose_weight(w_ohwi), xd.shape, s, p)
+        assert rel_err(dx.permute(0, 3, 1, 2), x.grad) < 2e-5
+        dw = torch.empty(cout * k * k * cin, device=dev)
+        ops.conv_wgrad(dyd, xd, dw, k, k, s, p)
+        assert rel_err(dw.view(cout, k, k, cin).permute(0, 3, 1, 2), wt.grad) < 2e-5
+        dw2 = torch.empty(cout * k * k * cin, device=dev)
+        ops.conv_wgrad(dyd, xd, dw2, k, k, s, p, to_oihw=True)
+        assert torch.equal(dw2.view(cout, cin, k, k), dw.view(cout, k, k, cin).permute(0, 3, 1, 2))
+
+
+def test_bn_pool_kernels(dev):
+    from self_supervised import ops
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(6, 64, 10, 10, generator=g) * 2 + 0.5).requires_grad_()
+    bn = torch.nn.BatchNorm2d(64)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(64, generator=g) + 0.5); bn.bias.copy_(torch.randn(64, generator=g))
+    res = torch.randn(6, 64, 10, 10, generator=g)
+    y = F.relu(bn(x) + res)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    nh = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().to(dev)
+    rm, rv = torch.zeros(64, device=dev), torch.ones(64, device=dev)
+    mean, invstd = ops.bn_stats(nh(x), 64, bn.eps, 0.1, rm, rv)
+    assert rel_err(rm, bn.running_mean) < 1e-5 and rel_err(rv, bn.running_var) < 1e-5
+    yy = ops.bn_apply_fwd(nh(x), mean, invstd, bn.weight.detach().to(dev), bn.bias.detach().to(dev), nh(res), True)
+    assert rel_err(yy, nh(y)) < 1e-5
+    db, dg = torch.empty(64, device=dev), torch.empty(64, device=dev)
+    ops.bn_bwd_reduce(nh(dy), yy, nh(x), mean, invstd, db, dg, 64)
+    assert rel_err(db, bn.bias.grad) < 1e-5 and rel_err(dg, bn.weight.grad) < 1e-5
+    dz, dres = ops.bn_apply_bwd(nh(dy), yy, nh(x), mean, invstd, bn.weight.detach().to(dev), db, dg, True)
+    assert rel_err(dz, nh(x.grad)) < 2e-5
+    # max-pool backward incl. ties (relu zeros) and gap backward
+    a = F.relu(torch.randn(3, 64, 9, 11, generator=g)).requires_grad_()
+    p = F.max_pool2d(a, 3, 2, 1)
+    dp = torch.randn(p.shape, generator=g)
+    p.backward(dp)
+    da = ops.maxpool3x3s2_bwd(nh(a), nh(dp))
+    assert torch.equal(da.cpu(), nh(a.grad).cpu())
+
+
+def test_training_step_matches_autograd(dev, golden, seeded_sd):
+    from self_supervised import training
+    from oracle import weights as ow
+    from oracle.peranet import train_step, make_optimizer
+    g = golden("train_step")
+    ref, m = _pair(seeded_sd, dev)
+    x, y = ow.synthetic_images(8, 64, seed=55), ow.synthetic_labels(8, seed=56)
+    loss_ref, acc_ref, out_ref = train_step(ref, x, y)
+    loss_ref.backward()
+    m.unfreeze()
+    step = training.DataParallelStep(m, lr=0.03, world_size=1)
+    eng = step.eng
+    logits, emb = eng.forward(x.to(dev))
+    assert rel_err(logits, out_ref["classifier"]) < 1e-4 and rel_err(emb, out_ref["latent_space"]) < 1e-4
+    dlogits = torch.empty_like(logits)
+    from self_supervised import ops
+    la = ops.softmax_ce(logits, y.to(dev), dlogits, 1.0 / 8)
+    np.testing.assert_allclose(la[0].item(), float(g["loss"]), rtol=1e-5)
+    np.testing.assert_allclose(la[1].item(), acc_ref.item(), rtol=1e-6)
+    eng.backward(dlogits)
+    ref_params = dict(ref.named_parameters())
+    worst = 0.0
+    for name, p in m.named_parameters():
+        e = rel_err(p.grad, ref_params[name].grad, grad_floor(ref))
+        worst = max(worst, e)
+        assert e < 1e-3, f"{name}: grad rel err {e:.3e}"
+    for n, want in zip(g["grad_names"], g["grad_norms"]):
+        got = dict(m.named_parameters())[str(n)].grad.double().norm().item()
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-6)   # analytically-zero grads are rounding noise
+    # fp64 truth: the HIP gradients must be as close to it as torch-CPU fp32 autograd is (same rounding class)
+    import copy
+    ref64 = copy.deepcopy(ref).double()
+    ref64.zero_grad()
+    l64, _, _ = train_step(ref64, x.double(), y)
+    l64.backward()
+    p64 = dict(ref64.named_parameters())
+    floor = grad_floor(ref)
+    ratios = []
+    for name, p in m.named_parameters():
+        t = p64[name].grad
+        e_hip = (p.grad.detach().cpu().double() - t).abs().max().item()
+        e_t32 = (ref_params[name].grad.double() - t).abs().max().item()
+        ratios.append((e_hip / max(e_t32, 1e-3 * floor), name))
+        assert e_hip <= 6 * e_t32 + 1e-2 * floor, f"{name}: |hip-f64|={e_hip:.3e} vs |torch32-f64|={e_t32:.3e}"
+    print("worst (|hip-f64| / |torch32-f64|):", max(ratios))
+    bufs = dict(m.named_buffers())
+    np.testing.assert_allclose(bufs["feature_extractor.bn1.running_var"].cpu().numpy(), g["bn1_running_var"], rtol=1e-5)
+    np.testing.assert_allclose(bufs["feature_extractor.layer4.1.bn2.running_var"].cpu().numpy(), g["l4_bn2_running_var"], rtol=1e-4)
+    print("worst grad rel err", worst)
+
+
+def test_two_sgd_steps_match_reference(dev, golden, seeded_sd):
+    from self_supervised import training
+    from oracle import weights as ow
+    g = golden("train_step")
+    _, m = _pair(seeded_sd, dev)
+    m.unfreeze()
+    step = training.DataParallelStep(m, lr=0.03, world_size=1)
+    x, y = ow.synthetic_images(8, 64, seed=55).to(dev), ow.synthetic_labels(8, seed=56).to(dev)
+    la = step.step(x, y)
+    sd = m.state_dict()
+    np.testing.assert_allclose(sd["classifier.weight"].cpu().numpy(), g["post_step_classifier_weight"], rtol=1e-4, atol=1e-6)
+    # conv1 is the deepest gradient (fp32 noise of 20 layers of batch-8 BN backward): lr * 1e-3 * |g|max ~ 1e-5
+    np.testing.assert_allclose(sd["feature_extractor.conv1.weight"][:4].cpu().numpy(), g["post_step_conv1_slice"], rtol=1e-4, atol=2e-5)
+    la2 = step.step(x, y)
+    np.testing.assert_allclose(la2[0].item(), float(g["loss2"]), rtol=1e-3)
+    np.testing.assert_allclose(m.state_dict()["classifier.weight"].cpu().numpy(), g["post_step2_classifier_weight"], rtol=1e-3, atol=5e-5)
+
+
+def test_frozen_backbone_stage(dev, seeded_sd):
+    """Stage 1 of tools.training: backbone frozen, only the head gets gradients / updates."""
+    from self_supervised import training
+    from oracle import weights as ow
+    from oracle.peranet import train_step
+    ref, m = _pair(seeded_sd, dev)
+    m.freeze_net(['backbone']); m.train()          # PL calls model.train() at fit start (quirk Q6)
+    for p in ref.feature_extractor.parameters():
+        p.requires_grad = False
+    x, y = ow.synthetic_images(8, 64, seed=55), ow.synthetic_labels(8, seed=56)
+    loss_ref, _, _ = train_step(ref, x, y)
+    loss_ref.backward()
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    step = training.DataParallelStep(m, lr=0.03, world_size=1)
+    la = step.step(x.to(dev), y.to(dev))
+    np.testing.assert_allclose(la[0].item(), loss_ref.item(), rtol=1e-5)
+    ref_params = dict(ref.named_parameters())
+    for name, p in m.named_parameters():
+        if name.startswith("feature_extractor"):
+            assert torch.equal(p.detach(), before[name]), name
+        else:
+            assert rel_err(p.grad, ref_params[name].grad, grad_floor(ref)) < 1e-3, name
+
+
+def test_autograd_bridge(dev, seeded_sd):
+    """loss.backward() on the tensor returned by training_step fills p.grad (PyTorch-Lightning-style use)."""
+    from oracle import weights as ow
+    from oracle.peranet import train_step
+    ref, m = _pair(seeded_sd, dev)
+    m.unfreeze()
+    x, y = ow.synthetic_images(8, 64, seed=55), ow.synthetic_labels(8, seed=56)
+    loss_ref, _, _ = train_step(ref, x, y)
+    loss_ref.backward()
+    loss = m.training_step((x.to(dev), y.to(dev), None), 0)
+    loss.backward()
+    ref_params = dict(ref.named_parameters())
+    for name, p in m.named_parameters():
+        assert rel_err(p.grad, ref_params[name].grad, grad_floor(ref)) < 1e-3, name
+    (opt,), _ = m.configure_optimizers()
+    opt.step()
