@@ -215,6 +215,15 @@ class PeraNet(_Base):
         return [optimizer], []
 
 
+def split_indices(n, test_size=0.3):
+    """Index form of sklearn.model_selection.train_test_split(test_size=..., random_state=None, shuffle=True):
+    n_test = ceil(test_size*n); one permutation from the global numpy RNG; test = its first n_test entries,
+    train = the rest (quirk Q5: unseeded in the reference)."""
+    n_test = int(np.ceil(test_size * n))
+    perm = np.random.permutation(n)
+    return perm[n_test:], perm[:n_test]
+
+
 class AnomalyDetector:
     """src/self_supervised/models.py:345-370: cosine 3-NN distance to a bank of normal embeddings.
 
@@ -242,11 +251,7 @@ class AnomalyDetector:
         emb = torch.as_tensor(embeddings)
         n = emb.shape[0]
         if split:
-            # sklearn.model_selection.train_test_split(test_size=0.3): n_test = ceil(0.3 n), one global-RNG permutation,
-            # test = first n_test indices of the permutation, train = the rest
-            n_test = int(np.ceil(0.3 * n))
-            perm = np.random.permutation(n)
-            val_idx, train_idx = perm[:n_test], perm[n_test:n_test + (n - n_test)]
+            train_idx, val_idx = split_indices(n, 0.3)
             train, val = emb[train_idx], emb[val_idx]
         else:
             train, val = emb, emb

@@ -447,46 +447,70 @@ class CosineWarmRestarts:
         return [self.opt.param_groups[0]["lr"]]
 
 
+class GradBucketer:
+    """Bucketed, overlapped gradient all-reduce over contiguous ranges of a flat gradient arena.
+
+    ``notify(end)`` is called by backward whenever the arena prefix [0, end) has become final.  Trainable ranges
+    inside the not-yet-reduced part of that prefix are all-reduced (sum, async) once at least ``min_bucket``
+    floats are pending, or when ``final`` is set.  Pure torch.distributed: works over RCCL on GPUs and over gloo
+    on CPU tensors (tests/test_distributed_gloo.py)."""
+
+    def __init__(self, grad_arena, ranges, process_group=None, min_bucket=1 << 20):
+        self.g, self.ranges, self.pg, self.min_bucket = grad_arena, list(ranges), process_group, min_bucket
+        self.works, self.done, self.launched = [], 0, []
+
+    def reset(self, ranges=None):
+        if ranges is not None:
+            self.ranges = list(ranges)
+        self.works, self.done, self.launched = [], 0, []
+
+    def notify(self, end, final=False):
+        if end <= self.done or (end - self.done < self.min_bucket and not final):
+            return
+        for s, e in self.ranges:
+            lo, hi = max(s, self.done), min(e, end)
+            if hi > lo:
+                self.works.append(dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                self.launched.append((lo, hi))
+        self.done = end
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+
 class DataParallelStep:
     """forward + loss + backward + (bucketed RCCL all-reduce overlapped with backward) + SGD for one rank.
 
     Buckets are the arena prefixes that become final after the head, after each ResNet stage's first block, and
     after the stem; each is all-reduced (sum) as soon as it is final, on RCCL's stream, while the compute stream
-    continues with the next stage.  The 1/world factor is applied inside the SGD kernel."""
+    continues with the next stage.  The 1/world factor is applied inside the SGD kernel.  BatchNorm statistics
+    stay per rank (the reference has no SyncBN; DDP-default semantics)."""
 
     def __init__(self, model, lr, momentum=0.9, weight_decay=0.0005, world_size=None, process_group=None):
         self.model = model
         self.eng = get_engine(model)
         self.opt = FusedSGD(model, lr, momentum, weight_decay)
-        self.pg = process_group
         self.world = world_size if world_size is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
         self.opt.grad_scale = 1.0 / self.world
-        self._works, self._done = [], 0
-        self.min_bucket = 1 << 20          # floats: merge tiny ranges into >= 4 MB messages
+        self.bucketer = GradBucketer(self.eng.arena.g, self.eng.arena.trainable_ranges(), process_group)
 
     def _notify(self, end):
         a = self.eng.arena
-        ranges = [(s, e) for s, e in a.trainable_ranges()]
         final = end == a.total or (not self.eng.trunk_grad and end == a.head_end)
-        if end - self._done < self.min_bucket and not final:
-            return
-        for s, e in ranges:
-            lo, hi = max(s, self._done), min(e, end)
-            if hi > lo:
-                self._works.append(dist.all_reduce(a.g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
-        self._done = end
+        self.bucketer.notify(end, final)
 
     def step(self, x, y):
         eng = self.eng
+        a = eng.arena
         eng.bucket_hooks = self._notify if self.world > 1 else None
-        self._works, self._done = [], 0
+        self.bucketer.reset(a.trainable_ranges())
         logits, emb = eng.forward(x)
         dlogits = torch.empty_like(logits)
         la = ops.softmax_ce(logits, y, dlogits, 1.0 / x.shape[0])
         eng.backward(dlogits)
-        for w in self._works:
-            w.wait()
-        a = eng.arena
+        self.bucketer.wait()
         for s, e in a.trainable_ranges():
             ops.sgd_step(a.p[s:e], a.g[s:e], a.m[s:e], self.opt.param_groups[0]["lr"], self.opt.momentum,
                          self.opt.weight_decay, self.opt.grad_scale)
