@@ -233,10 +233,13 @@ def main():
                            "alg_gflop_per_launch": round(fl / len(recs) / 1e9, 3),
                            "alg_GBps": round(sum(r["bytes"] for r in recs) / t / 1e9, 1),
                            "share_of_gpu_time": round(t / allk, 4)}
-        by = {}
-        for r in prof[phase]:
-            by.setdefault(r["kernel"], [0.0, 0]); by[r["kernel"]][0] += r["ms"]; by[r["kernel"]][1] += 1
-        out["kernel_ms"] = {k: [round(v[0] / args.steps, 3), v[1] // args.steps] for k, v in sorted(by.items())}
+        out["kernel_ms"] = {}
+        for ph in prof:
+            by = {}
+            for r in prof[ph]:
+                e = by.setdefault(r["kernel"], [0.0, 0, 0.0]); e[0] += r["ms"]; e[1] += 1; e[2] += r["flops"]
+            out["kernel_ms"][ph] = {k: [round(v[0] / args.steps, 3), v[1] // args.steps,
+                                        round(v[2] / max(v[0], 1e-9) / 1e9, 1)] for k, v in sorted(by.items())}
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args)
     print(json.dumps(out))

@@ -49,12 +49,14 @@ int ssad_pack_stem_weight(const float* w_oihw, float* wk, void* stream);
  *   wk       : ssad_pack_stem_weight output
  *   scale/shift : per-channel affine applied to the conv output (eval-mode BN folded); NULL -> raw conv
  *   out      : [Nsamp][Ho][Wo][64] NHWC, Ho = (Hv-1)/2+1.  Nsamp = B * patches per image.
+ *   hwnc     : 1 -> write the position-major layout [Ho][Wo][Nsamp][64] (patch-scoring trunk, see
+ *              ssad_conv_igemm_fwd_hwnc); the same flag selects the layout in ssad_maxpool3x3s2_fwd / ssad_gap_fwd.
  */
 int ssad_stem_fwd(const float* img, int B, int H, int W, int patch_dim, int patch_stride, int Hv, int Wv,
-                  const float* wk, const float* scale, const float* shift, int relu, float* out, void* stream);
+                  const float* wk, const float* scale, const float* shift, int relu, int hwnc, float* out, void* stream);
 
-/* Replaces nn.MaxPool2d(3, 2, 1) of the torchvision stem (models.py:224).  NHWC. */
-int ssad_maxpool3x3s2_fwd(const float* in, float* out, int64_t N, int H, int W, int C, void* stream);
+/* Replaces nn.MaxPool2d(3, 2, 1) of the torchvision stem (models.py:224).  NHWC, or [H][W][N][C] when hwnc. */
+int ssad_maxpool3x3s2_fwd(const float* in, float* out, int64_t N, int H, int W, int C, int hwnc, void* stream);
 
 /* Replaces every nn.Conv2d(3x3 / 1x1, bias=False) + eval BatchNorm2d + residual add + ReLU of the
  * BasicBlocks (models.py:224), and every nn.Linear (+BatchNorm1d, +ReLU) of concatenator /
@@ -66,9 +68,18 @@ int ssad_conv_igemm_fwd(const float* in, const float* w_ohwi, float* out, const 
                         const float* residual, int relu, int64_t N, int H, int W, int Cin, int Cout, int KH, int KW,
                         int stride, int pad, void* stream);
 
+/* Same contraction with every activation tensor (in, out, residual) stored position-major, [H][W][N][C]: the layout
+ * of the patch-scoring trunk (thousands of patches with 16x16 .. 2x2 maps).  A workgroup's 128 rows are 128 patches
+ * at one output position: contiguous in HBM for every filter tap, and taps that fall into the zero padding are
+ * skipped as whole K-steps (exact: only x*0 products are dropped). */
+int ssad_conv_igemm_fwd_hwnc(const float* in, const float* w_ohwi, float* out, const float* scale, const float* shift,
+                             const float* residual, int relu, int64_t N, int H, int W, int Cin, int Cout, int KH, int KW,
+                             int stride, int pad, void* stream);
+
 /* Replaces F.adaptive_avg_pool2d(., (1,1)) + flatten + torch.cat (models.py:227-245):
  * out[n*out_stride + out_offset + c] = mean over HW of in[n][hw][c]. */
-int ssad_gap_fwd(const float* in, float* out, int64_t N, int HW, int C, int out_stride, int out_offset, void* stream);
+int ssad_gap_fwd(const float* in, float* out, int64_t N, int HW, int C, int out_stride, int out_offset, int hwnc,
+                 void* stream);
 
 /* ---- scoring ---- */
 /* Replaces sklearn NearestNeighbors(metric='cosine').kneighbors + torch.mean (models.py:352-370).

@@ -33,6 +33,12 @@ struct ConvParams {
     int K;              // KH*KW*Cin
     int ts;             // 1: convolution.  >1: transposed gather (dgrad of a stride-ts conv): the tap reads
                         // in[(oy - pad + ky) / ts] only where the numerator is a non-negative multiple of ts
+    int posmajor;       // 1: a workgroup's rows are BM different samples at ONE output position, so the set of
+                        // in-bounds filter taps is workgroup-uniform and out-of-bounds taps (zero padding) are
+                        // skipped as whole K-steps.  Exact: the skipped products are all x*0.
+    int64_t N;          // samples (posmajor row bound)
+    int hwnc;           // activations (in, out, residual) laid out [H][W][N][C] instead of [N][H][W][C]: with
+                        // posmajor rows a workgroup then reads/writes 128 CONSECUTIVE rows of C floats per tap
 };
 
 template <int BM, int BN, int TM, int TN>
@@ -46,18 +52,52 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
     const int sc = tid & 7, sr = tid >> 3;
+    const int HoWo = p.Ho * p.Wo;
+    const int ntaps = p.KH * p.KW;
+
+    // ---- row geometry.  normal: row = flattened (n, oy, ox).  posmajor: row = sample, position from blockIdx ----
+    int64_t m0;                 // normal: first flattened row; posmajor: first sample
+    int pos = 0;
+    unsigned long long tapmask = ntaps >= 64 ? ~0ull : ((1ull << ntaps) - 1);
+    if (p.posmajor) {
+        // Engine-aware mapping.  Workgroups are dealt round-robin to the 8 XCDs and, inside an XCD, to its 4 shader
+        // engines: stream = block % 32 is served by one (XCD, SE) pair for the whole launch (measured: with
+        // pos = block % HoWo the heavy interior positions pin to the same engines and tap skipping buys nothing).
+        // Positions differ in work (corner 4 taps .. interior 9), so every stream sweeps ALL positions of its own
+        // sample groups (nb = 32*q + stream): equal work per engine, and a sample group's maps stay in one XCD's L2.
+        const int stream = blockIdx.x & 31;
+        const int64_t j = blockIdx.x >> 5;
+        const int64_t q = j / HoWo;
+        pos = (int)(j - q * HoWo);
+        const int64_t nb = q * 32 + stream;
+        m0 = nb * BM;
+        if (m0 >= p.N) return;
+        const int oy = pos / p.Wo, ox = pos - oy * p.Wo;
+        tapmask = 0;
+        for (int t = 0; t < ntaps; ++t) {
+            const int ky = t / p.KW, kx = t - ky * p.KW;
+            const int y = oy * p.stride - p.pad + ky, x = ox * p.stride - p.pad + kx;
+            if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) tapmask |= 1ull << t;
+        }
+    } else {
+        m0 = (int64_t)blockIdx.x * BM;
+    }
 
     // ---- per-thread staging rows (fixed across the K loop) ----
     int64_t a_base[AR];
     int a_iy[AR], a_ix[AR];
-    const int HoWo = p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
         int64_t m = m0 + sr + 32 * i;
-        if (m < p.M) {
+        if (p.posmajor) {
+            const int oy = pos / p.Wo, ox = pos - oy * p.Wo;
+            const bool ok = m < p.N;
+            a_base[i] = (ok ? m : 0) * (p.hwnc ? (int64_t)p.Cin : (int64_t)p.H * p.W * p.Cin) + sc * 4;
+            a_iy[i] = ok ? oy * p.stride - p.pad : -(1 << 20);
+            a_ix[i] = ok ? ox * p.stride - p.pad : -(1 << 20);
+        } else if (m < p.M) {
             int64_t n = m / HoWo;
             int rem = (int)(m - n * HoWo);
             int oy = rem / p.Wo, ox = rem - oy * p.Wo;
@@ -87,12 +127,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    const int64_t in_sp = p.hwnc ? p.N * p.Cin : (int64_t)p.Cin;      // floats between neighbouring pixels
     const int cpt = p.Cin / BK;               // K-steps per filter tap
-    const int nk = p.KH * p.KW * cpt;
+    const int nk = __builtin_popcountll(tapmask) * cpt;
     f32x4 ra[AR], rb[BR];
 
-    int ld_ky = 0, ld_kx = 0, ld_cc = 0, ld_ks = 0;   // state of the next K-step to load
+    // state of the next K-step to load: current tap (lowest set bit of ld_mask) and channel chunk
+    unsigned long long ld_mask = tapmask;
+    int ld_tap = tapmask ? __builtin_ctzll(tapmask) : 0;
+    int ld_ky = ld_tap / p.KW, ld_kx = ld_tap - ld_ky * p.KW, ld_cc = 0;
     auto load_step = [&]() {
+        const int ld_ks = ld_tap * cpt + ld_cc;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             int y = a_iy[i] + ld_ky, x = a_ix[i] + ld_kx;
@@ -104,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
             }
             ok = ok && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *(const f32x4*)(p.in + a_base[i] + ((int64_t)y * p.W + x) * p.Cin + ld_cc * BK);
+            if (ok) v = *(const f32x4*)(p.in + a_base[i] + ((int64_t)y * p.W + x) * in_sp + ld_cc * BK);
             ra[i] = v;
         }
 #pragma unroll
@@ -113,10 +158,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
             if (b_ok[i]) v = *(const f32x4*)(p.wt + b_off[i] + (int64_t)ld_ks * BK);
             rb[i] = v;
         }
-        ++ld_ks;
         if (++ld_cc == cpt) {
             ld_cc = 0;
-            if (++ld_kx == p.KW) { ld_kx = 0; ++ld_ky; }
+            ld_mask &= ld_mask - 1;
+            ld_tap = ld_mask ? __builtin_ctzll(ld_mask) : 0;
+            ld_ky = ld_tap / p.KW;
+            ld_kx = ld_tap - ld_ky * p.KW;
         }
     };
     auto store_step = [&](float* buf) {
@@ -128,8 +175,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
         for (int i = 0; i < BR; ++i) *(f32x4*)(Bs + (sr + 32 * i) * LDK + sc * 4) = rb[i];
     };
 
-    load_step();
-    store_step(lds);
+    if (nk > 0) {
+        load_step();
+        store_step(lds);
+    }
     __syncthreads();
 
     for (int ks = 0; ks < nk; ++ks) {
@@ -168,7 +217,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 int64_t row = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row < p.M) {
+                bool row_ok = row < p.M;
+                if (p.posmajor) {
+                    row_ok = row < p.N;
+                    row = p.hwnc ? (int64_t)pos * p.N + row : row * HoWo + pos;
+                }
+                if (row_ok) {
                     int64_t o = row * p.Cout + col;
                     float v = acc[i][j][e] * s + t;
                     if (p.residual) v += p.residual[o];
@@ -189,16 +243,17 @@ int launch(const ConvParams& p, hipStream_t st) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         attr_set = true;
     }
-    dim3 grid((unsigned)cdiv64(p.M, BM), (unsigned)((p.Cout + BN - 1) / BN));
+    const int64_t gx = p.posmajor ? cdiv64(cdiv64(p.N, BM), 32) * 32 * p.Ho * p.Wo : cdiv64(p.M, BM);
+    dim3 grid((unsigned)gx, (unsigned)((p.Cout + BN - 1) / BN));
     hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, TM, TN>), grid, dim3(256), lds_bytes, st, p);
     return 0;
 }
 
 }  // namespace
 
-extern "C" int ssad_conv_igemm_fwd(const float* in, const float* w_ohwi, float* out, const float* scale,
+static int conv_fwd_impl(const float* in, const float* w_ohwi, float* out, const float* scale,
                                    const float* shift, const float* residual, int relu, int64_t N, int H, int W,
-                                   int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream) {
+                                   int Cin, int Cout, int KH, int KW, int stride, int pad, int hwnc, void* stream) {
     SSAD_CHECK_ARG(in && w_ohwi && out, "null pointer");
     SSAD_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "empty shape");
     SSAD_CHECK_ARG(Cin % BK == 0, "Cin must be a multiple of 32");
@@ -210,14 +265,35 @@ extern "C" int ssad_conv_igemm_fwd(const float* in, const float* w_ohwi, float* 
     p.Wo = (W + 2 * pad - KW) / stride + 1;
     p.ts = 1;
     SSAD_CHECK_ARG(p.Ho > 0 && p.Wo > 0, "empty output");
+    SSAD_CHECK_ARG(KH * KW <= 64, "at most 64 filter taps");
     p.M = N * p.Ho * p.Wo;
+    p.N = N;
     p.K = KH * KW * Cin;
-    SSAD_CHECK_ARG(cdiv64(p.M, 128) < (int64_t)2147483647, "M too large for one launch");
+    // position-major rows pay off when padding is a visible share of the taps (small maps, many samples)
+    p.posmajor = (hwnc || (pad > 0 && N >= 128 && p.Ho * p.Wo <= 4)) ? 1 : 0;
+    p.hwnc = hwnc;
+    SSAD_CHECK_ARG(cdiv64(p.M, 128) + 32 * p.Ho * p.Wo < (int64_t)2147483647, "M too large for one launch");
     hipStream_t st = (hipStream_t)stream;
     if (Cout <= 64) launch<128, 64, 1, 2>(p, st);
     else launch<128, 128, 2, 2>(p, st);
     SSAD_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int ssad_conv_igemm_fwd(const float* in, const float* w_ohwi, float* out, const float* scale,
+                                   const float* shift, const float* residual, int relu, int64_t N, int H, int W,
+                                   int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream) {
+    return conv_fwd_impl(in, w_ohwi, out, scale, shift, residual, relu, N, H, W, Cin, Cout, KH, KW, stride, pad, 0, stream);
+}
+
+// Same contraction with every activation tensor (in, out, residual) stored position-major, [H][W][N][C].
+// This is the layout of the patch-scoring trunk: N = thousands of 64x64 patches whose maps are 16x16 .. 2x2,
+// so a workgroup's 128 rows (128 patches at one output position) are contiguous in HBM for every tap and taps
+// that fall into the zero padding are skipped as whole K-steps.
+extern "C" int ssad_conv_igemm_fwd_hwnc(const float* in, const float* w_ohwi, float* out, const float* scale,
+                                        const float* shift, const float* residual, int relu, int64_t N, int H, int W,
+                                        int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream) {
+    return conv_fwd_impl(in, w_ohwi, out, scale, shift, residual, relu, N, H, W, Cin, Cout, KH, KW, stride, pad, 1, stream);
 }
 
 // dgrad: dx[n][iy][ix][ci] = sum_{ky,kx,co} dy[n][(iy+pad-ky)/s][(ix+pad-kx)/s][co] * w[co][ky][kx][ci] (+ residual).
@@ -234,8 +310,8 @@ extern "C" int ssad_conv_igemm_dgrad(const float* dy, const float* w_flipT, floa
     ConvParams p;
     p.in = dy; p.wt = w_flipT; p.out = dx; p.scale = nullptr; p.shift = nullptr; p.residual = residual;
     p.H = Hy; p.W = Wy; p.Cin = Cout; p.Cout = Cin; p.KH = KH; p.KW = KW; p.relu = 0;
-    p.stride = 1; p.pad = KH - 1 - pad; p.ts = stride;
-    SSAD_CHECK_ARG(KH == KW, "square filters only");
+    p.stride = 1; p.pad = KH - 1 - pad; p.ts = stride; p.posmajor = 0; p.N = N; p.hwnc = 0;
+    SSAD_CHECK_ARG(KH == KW && KH * KW <= 64, "square filters with at most 64 taps only");
     p.Ho = Hx; p.Wo = Wx;
     p.M = N * Hx * Wx;
     p.K = KH * KW * Cout;

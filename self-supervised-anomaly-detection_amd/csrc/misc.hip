@@ -38,14 +38,15 @@ __global__ void repack_kernel(const float* __restrict__ src, float* __restrict__
 
 // in [N][HW][C] -> out[n*stride + off + c] = sum/HW.  One thread per (n, c); lanes run over c (coalesced).
 __global__ void gap_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t N, int HW, int C,
-                           int out_stride, int out_offset) {
+                           int out_stride, int out_offset, int hwnc) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N * C) return;
     int c = (int)(i % C);
     int64_t n = i / C;
-    const float* p = in + n * HW * C + c;
+    const float* p = hwnc ? in + n * C + c : in + n * HW * C + c;
+    const int64_t step = hwnc ? N * C : (int64_t)C;
     float s = 0.f;
-    for (int k = 0; k < HW; ++k) s += p[(int64_t)k * C];
+    for (int k = 0; k < HW; ++k) s += p[k * step];
     out[n * out_stride + out_offset + c] = s / (float)HW;
 }
 
@@ -177,11 +178,11 @@ extern "C" int ssad_repack_ohwi_to_oihw(const float* w_ohwi, float* w_oihw, int 
 }
 
 extern "C" int ssad_gap_fwd(const float* in, float* out, int64_t N, int HW, int C, int out_stride, int out_offset,
-                            void* stream) {
+                            int hwnc, void* stream) {
     SSAD_CHECK_ARG(in && out && N > 0 && HW > 0 && C > 0, "bad argument");
     SSAD_CHECK_ARG(out_offset >= 0 && out_offset + C <= out_stride, "slice does not fit the output row");
     hipLaunchKernelGGL(gap_kernel, dim3((unsigned)cdiv64(N * C, 256)), dim3(256), 0, (hipStream_t)stream, in, out, N, HW, C,
-                       out_stride, out_offset);
+                       out_stride, out_offset, hwnc);
     SSAD_CHECK_LAUNCH();
     return 0;
 }

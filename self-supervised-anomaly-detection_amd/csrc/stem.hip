@@ -31,6 +31,8 @@ struct StemParams {
     int ph, pw;           // window size in source pixels
     int tiles_y, tiles_x;
     int64_t total_tiles;
+    int64_t Nsamp;
+    int hwnc;             // write [Ho][Wo][Nsamp][64] instead of [Nsamp][Ho][Wo][64]
 };
 
 __global__ __launch_bounds__(256, 2) void stem_conv7x7_kernel(StemParams p) {
@@ -117,7 +119,8 @@ __global__ __launch_bounds__(256, 2) void stem_conv7x7_kernel(StemParams p) {
                     if (ox < p.Wo) {
                         float v = acc[i][j][e] * sc[j] + sh[j];
                         if (p.relu) v = fmaxf(v, 0.f);
-                        p.out[((n * p.Ho + oy) * p.Wo + ox) * 64 + j * 32 + r] = v;
+                        const int64_t pix = p.hwnc ? ((int64_t)oy * p.Wo + ox) * p.Nsamp + n : (n * p.Ho + oy) * p.Wo + ox;
+                        p.out[pix * 64 + j * 32 + r] = v;
                     }
                 }
             }
@@ -137,15 +140,24 @@ __global__ void pack_stem_weight_kernel(const float* __restrict__ w, float* __re
 
 // NHWC 3x3 stride-2 pad-1 max-pool, 4 channels per thread.
 __global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t total4, int H, int W,
-                                    int C4, int Ho, int Wo) {
+                                    int C4, int Ho, int Wo, int64_t N, int hwnc) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total4) return;
     int c4 = (int)(i % C4);
     int64_t pix = i / C4;
-    int ox = (int)(pix % Wo);
-    int64_t t = pix / Wo;
-    int oy = (int)(t % Ho);
-    int64_t n = t / Ho;
+    int ox, oy;
+    int64_t n;
+    if (hwnc) {                       // i enumerates [Ho][Wo][N][C4]
+        n = pix % N;
+        int64_t t = pix / N;
+        ox = (int)(t % Wo);
+        oy = (int)(t / Wo);
+    } else {
+        ox = (int)(pix % Wo);
+        int64_t t = pix / Wo;
+        oy = (int)(t % Ho);
+        n = t / Ho;
+    }
     f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
@@ -155,7 +167,8 @@ __global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restr
         for (int dx = 0; dx < 3; ++dx) {
             int x = ox * 2 - 1 + dx;
             if ((unsigned)x >= (unsigned)W) continue;
-            f32x4 v = ((const f32x4*)in)[((n * H + y) * W + x) * C4 + c4];
+            const int64_t ip = hwnc ? ((int64_t)y * W + x) * N + n : (n * H + y) * W + x;
+            f32x4 v = ((const f32x4*)in)[ip * C4 + c4];
             m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
         }
     }
@@ -172,7 +185,7 @@ extern "C" int ssad_pack_stem_weight(const float* w_oihw, float* wk, void* strea
 }
 
 extern "C" int ssad_stem_fwd(const float* img, int B, int H, int W, int patch_dim, int patch_stride, int Hv, int Wv,
-                             const float* wk, const float* scale, const float* shift, int relu, float* out,
+                             const float* wk, const float* scale, const float* shift, int relu, int hwnc, float* out,
                              void* stream) {
     SSAD_CHECK_ARG(img && wk && out, "null pointer");
     SSAD_CHECK_ARG(B > 0 && H > 0 && W > 0 && Hv > 0 && Wv > 0, "empty shape");
@@ -191,7 +204,9 @@ extern "C" int ssad_stem_fwd(const float* img, int B, int H, int W, int patch_di
     p.Wo = (Wv - 1) / 2 + 1;
     p.tiles_y = (p.Ho + TOH - 1) / TOH;
     p.tiles_x = (p.Wo + TOW - 1) / TOW;
-    p.total_tiles = (int64_t)B * p.prow * p.pcol * p.tiles_y * p.tiles_x;
+    p.Nsamp = (int64_t)B * p.prow * p.pcol;
+    p.hwnc = hwnc;
+    p.total_tiles = p.Nsamp * p.tiles_y * p.tiles_x;
     constexpr int lds_bytes = (W_TILE + IN_TILE) * 4;
     static bool attr_set = false;
     if (!attr_set) {
@@ -204,14 +219,14 @@ extern "C" int ssad_stem_fwd(const float* img, int B, int H, int W, int patch_di
     return 0;
 }
 
-extern "C" int ssad_maxpool3x3s2_fwd(const float* in, float* out, int64_t N, int H, int W, int C, void* stream) {
+extern "C" int ssad_maxpool3x3s2_fwd(const float* in, float* out, int64_t N, int H, int W, int C, int hwnc, void* stream) {
     SSAD_CHECK_ARG(in && out, "null pointer");
     SSAD_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "bad shape (C % 4)");
     int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     int64_t total4 = N * Ho * Wo * (C / 4);
     SSAD_CHECK_ARG(cdiv64(total4, 256) < (int64_t)2147483647, "too large");
     hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((unsigned)cdiv64(total4, 256)), dim3(256), 0, (hipStream_t)stream, in, out,
-                       total4, H, W, C / 4, Ho, Wo);
+                       total4, H, W, C / 4, Ho, Wo, N, hwnc);
     SSAD_CHECK_LAUNCH();
     return 0;
 }

@@ -22,11 +22,13 @@ SIGNATURES = {
     "ssad_repack_oihw_to_ohwi": [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp],
     "ssad_repack_ohwi_to_oihw": [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp],
     "ssad_pack_stem_weight": [_c_fp, _c_fp, _c_fp],
-    "ssad_stem_fwd": [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_i, _c_fp, _c_fp],
-    "ssad_maxpool3x3s2_fwd": [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_stem_fwd": [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_fp, _c_fp],
+    "ssad_maxpool3x3s2_fwd": [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_fp],
     "ssad_conv_igemm_fwd": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
                             _c_i, _c_i, _c_fp],
-    "ssad_gap_fwd": [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_conv_igemm_fwd_hwnc": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
+                                 _c_i, _c_i, _c_fp],
+    "ssad_gap_fwd": [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
     "ssad_l2_normalize_rows": [_c_fp, _c_fp, _c_l, _c_i, _c_fp],
     "ssad_cosine_knn_mean": [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp],
     "ssad_blur_relu_bilinear": [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],

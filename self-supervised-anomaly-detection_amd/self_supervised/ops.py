@@ -65,25 +65,44 @@ def stem_geometry(H, W, patch_dim, patch_stride):
     return p, hv, wv, (hv - 1) // 2 + 1, (wv - 1) // 2 + 1
 
 
-def stem_fwd(img, wk, scale, shift, relu=True, patch_dim=0, patch_stride=0, out=None):
+def stem_fwd(img, wk, scale, shift, relu=True, patch_dim=0, patch_stride=0, hwnc=False):
+    """-> [N][Ho][Wo][64], or the position-major [Ho][Wo][N][64] when hwnc."""
     b, c, h, w = img.shape
     assert c == 3
     p, hv, wv, ho, wo = stem_geometry(h, w, patch_dim, patch_stride)
-    if out is None:
-        out = _new((b * p, ho, wo, 64), img)
     n = b * p
+    out = _new((ho, wo, n, 64) if hwnc else (n, ho, wo, 64), img)
     _run("stem_conv7x7", 2.0 * n * ho * wo * 64 * 147, 4.0 * (b * 3 * h * w + n * ho * wo * 64),
          lambda: _hip.lib().ssad_stem_fwd(_hip.ptr(img), b, h, w, patch_dim, patch_stride, hv, wv, _hip.ptr(wk),
-                                          _hip.ptr(scale, True), _hip.ptr(shift, True), int(relu), _hip.ptr(out),
-                                          _hip.stream()))
+                                          _hip.ptr(scale, True), _hip.ptr(shift, True), int(relu), int(hwnc),
+                                          _hip.ptr(out), _hip.stream()))
     return out
 
 
-def maxpool3x3s2_fwd(x):
-    n, h, w, c = x.shape
-    out = _new((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), x)
+def maxpool3x3s2_fwd(x, hwnc=False):
+    if hwnc:
+        h, w, n, c = x.shape
+        out = _new(((h - 1) // 2 + 1, (w - 1) // 2 + 1, n, c), x)
+    else:
+        n, h, w, c = x.shape
+        out = _new((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), x)
     _run("maxpool3x3s2", 0.0, 4.0 * (x.numel() + out.numel()),
-         lambda: _hip.lib().ssad_maxpool3x3s2_fwd(_hip.ptr(x), _hip.ptr(out), n, h, w, c, _hip.stream()))
+         lambda: _hip.lib().ssad_maxpool3x3s2_fwd(_hip.ptr(x), _hip.ptr(out), n, h, w, c, int(hwnc), _hip.stream()))
+    return out
+
+
+def conv_fwd_hwnc(x, w_ohwi, scale=None, shift=None, residual=None, relu=False, stride=1, pad=0):
+    """Position-major activations: x [H][W][N][Cin] -> [Ho][Wo][N][Cout] (patch-scoring trunk layout)."""
+    h, w, n, cin = x.shape
+    cout, kh, kw, cin2 = w_ohwi.shape
+    assert cin == cin2
+    ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+    out = _new((ho, wo, n, cout), x)
+    nb = 4.0 * (x.numel() + out.numel() * (2 if residual is not None else 1) + w_ohwi.numel())
+    _run("conv_igemm_f32", 2.0 * out.numel() * kh * kw * cin, nb,
+         lambda: _hip.lib().ssad_conv_igemm_fwd_hwnc(_hip.ptr(x), _hip.ptr(w_ohwi), _hip.ptr(out), _hip.ptr(scale, True),
+                                                     _hip.ptr(shift, True), _hip.ptr(residual, True), int(relu), n, h, w,
+                                                     cin, cout, kh, kw, stride, pad, _hip.stream()))
     return out
 
 
@@ -114,10 +133,14 @@ def linear_fwd(x, w, scale=None, shift=None, relu=False):
     return out
 
 
-def gap_fwd(x, out, offset):
-    n, h, w, c = x.shape
+def gap_fwd(x, out, offset, hwnc=False):
+    if hwnc:
+        h, w, n, c = x.shape
+    else:
+        n, h, w, c = x.shape
     _run("gap", 0.0, 4.0 * (x.numel() + n * c),
-         lambda: _hip.lib().ssad_gap_fwd(_hip.ptr(x), _hip.ptr(out), n, h * w, c, out.shape[1], offset, _hip.stream()))
+         lambda: _hip.lib().ssad_gap_fwd(_hip.ptr(x), _hip.ptr(out), n, h * w, c, out.shape[1], offset, int(hwnc),
+                                         _hip.stream()))
     return out
 
 

@@ -43,6 +43,10 @@ CONV_CASES = [
     (1, 9, 7, 32, 96, 3, 1, 1, True, True, False),          # ragged M and Cout tails
     (2, 5, 5, 128, 588, 1, 1, 0, False, False, False),      # bank-like Cout (not a multiple of 32)
     (1, 1, 1, 64, 4, 1, 1, 0, True, False, False),          # classifier-like
+    (130, 4, 4, 64, 64, 3, 1, 1, True, True, True),          # >= 128 samples on a small map: position-major rows,
+    (200, 2, 2, 64, 128, 3, 1, 1, True, False, True),        #   zero-padding taps skipped as whole K-steps
+    (150, 8, 8, 32, 96, 3, 2, 1, False, True, False),
+    (129, 1, 1, 32, 64, 3, 1, 1, True, False, False),        # 1x1 map: only the centre tap survives
 ]
 
 
@@ -69,6 +73,25 @@ def test_conv_igemm(dev, case):
     got = ops.conv_fwd(nhwc(x).to(dev), w_ohwi, None if sc is None else sc.to(dev), None if sh is None else sh.to(dev),
                        None if r is None else nhwc(r).to(dev), relu, s, p)
     assert_close(nchw(got), want, 2e-5)
+
+
+@pytest.mark.parametrize("case", [(130, 4, 4, 64, 64, 3, 1, 1), (200, 2, 2, 64, 128, 3, 1, 1), (150, 8, 8, 32, 96, 3, 2, 1),
+                                  (70, 16, 16, 32, 64, 3, 1, 1), (300, 8, 8, 64, 128, 1, 2, 0), (129, 1, 1, 32, 64, 3, 1, 1)])
+def test_conv_igemm_hwnc(dev, case):
+    """Position-major layout [H][W][N][C] with padding taps skipped: same numbers as conv2d."""
+    from self_supervised import ops
+    n, h, w, cin, cout, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    want = F.conv2d(x, wt, None, s, p) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    r = torch.randn(want.shape, generator=g)
+    want = (want + r).relu()
+    hwnc = lambda t: t.permute(2, 3, 0, 1).contiguous()            # NCHW -> HWNC
+    got = ops.conv_fwd_hwnc(hwnc(x).to(dev), ops.repack_oihw_to_ohwi(wt.to(dev)), sc.to(dev), sh.to(dev), hwnc(r).to(dev),
+                            True, s, p)
+    assert_close(got.permute(2, 3, 0, 1), want, 2e-5)
 
 
 def test_conv_identity_asymmetric(dev):
