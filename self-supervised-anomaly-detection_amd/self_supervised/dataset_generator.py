@@ -1,0 +1,180 @@
+"""Cut-paste primitives on PIL images (host side of the synthetic-defect generator).
+
+Mirrors src/self_supervised/dataset_generator.py:15-275 of the reference: same function names, arguments and --
+because results are compared against vectors produced by the reference under a fixed ``random.seed`` -- the same
+order of draws from Python's ``random``.  The batched GPU version of the pixel work (polygon rasterise, masked
+paste, rotated scars, poly-lines, jitter, normalise) is csrc/augment.hip, driven by augment.py.
+"""
+import random
+from typing import Tuple
+
+import numpy as np
+from PIL import Image, ImageDraw
+from scipy import ndimage
+
+
+class Container:
+    """Centred square region defects are clamped into (dataset_generator.py:15-24)."""
+
+    def __init__(self, imsize: tuple, scaling_factor: float) -> None:
+        half = int(imsize[0] / 2)
+        reach = half / scaling_factor
+        self.center = half
+        self.dim = int(imsize[0] / scaling_factor)
+        self.left = self.top = int(half - reach)
+        self.right = self.bottom = int(half + reach)
+        self.width = self.right - self.left
+        self.height = self.bottom - self.top
+
+
+# ---- object mask: Canny -> dilate -> close -> fill -> erode -> largest component (dataset_generator.py:27-39) ----
+def _canny(gray, sigma, low, high):
+    """Canny edge map (restated, third-party: the reference calls skimage.feature.canny, not installed here):
+    Gaussian smoothing, Sobel gradients, non-maximum suppression along the quantised gradient direction,
+    hysteresis with absolute thresholds."""
+    g = ndimage.gaussian_filter(gray.astype(np.float64), sigma, mode="nearest")
+    gx = ndimage.sobel(g, axis=1, mode="nearest")
+    gy = ndimage.sobel(g, axis=0, mode="nearest")
+    mag = np.hypot(gx, gy)
+    ang = (np.rad2deg(np.arctan2(gy, gx)) + 180.0) % 180.0
+    q = (np.floor((ang + 22.5) / 45.0).astype(int)) % 4            # 0: E-W, 1: NE-SW, 2: N-S, 3: NW-SE
+    pad = np.pad(mag, 1, mode="constant")
+    h, w = mag.shape
+    offs = {0: ((0, 1), (0, -1)), 1: ((-1, 1), (1, -1)), 2: ((1, 0), (-1, 0)), 3: ((1, 1), (-1, -1))}
+    keep = np.zeros_like(mag, dtype=bool)
+    for k, ((dy1, dx1), (dy2, dx2)) in offs.items():
+        n1 = pad[1 + dy1:1 + dy1 + h, 1 + dx1:1 + dx1 + w]
+        n2 = pad[1 + dy2:1 + dy2 + h, 1 + dx2:1 + dx2 + w]
+        keep |= (q == k) & (mag >= n1) & (mag >= n2)
+    strong = keep & (mag >= high)
+    weak = keep & (mag >= low)
+    lab, n = ndimage.label(weak, structure=np.ones((3, 3), int))
+    if n == 0:
+        return np.zeros_like(weak)
+    good = np.unique(lab[strong])
+    return np.isin(lab, good[good > 0])
+
+
+def obj_mask(image: Image.Image) -> Image.Image:
+    gray = np.array(image.convert('L'))
+    edges = _canny(gray, sigma=1.5, low=5, high=15)
+    sq3, sq4 = np.ones((3, 3), int), np.ones((4, 4), int)
+    m = ndimage.binary_dilation(edges, sq3)
+    m = ndimage.binary_closing(m, sq3)
+    m = ndimage.binary_fill_holes(m, sq3)
+    m = ndimage.binary_erosion(m, sq4)
+    lab, n = ndimage.label(m)
+    if n == 0:
+        return Image.fromarray(m).convert('RGB')
+    sizes = np.bincount(lab.ravel(), weights=m.ravel().astype(np.float64))
+    return Image.fromarray(lab == int(np.argmax(sizes))).convert('RGB')
+
+
+# ---- polygon mask (dataset_generator.py:42-101) ----
+def _side_points(side: int, w: int, h: int):
+    """One or two points on a side of the w x h rectangle, drawn in the reference's order."""
+    two = random.randint(1, 2) == 2
+    hw, hh = int(w / 2), int(h / 2)
+    if side == 0:      # left, walking upwards
+        return [(0, random.randint(hh + 1, h)), (0, random.randint(1, hh))] if two else [(0, random.randint(1, h))]
+    if side == 1:      # top, walking right
+        return [(random.randint(1, hw), 0), (random.randint(hw + 1, w), 0)] if two else [(random.randint(1, w), 0)]
+    if side == 2:      # right, walking down
+        return [(w, random.randint(1, hh)), (w, random.randint(hh + 1, h))] if two else [(w, random.randint(1, h))]
+    return [(random.randint(hw + 1, w), h), (random.randint(1, hw), h)] if two else [(random.randint(1, w), h)]
+
+
+def polygon_points(size: Tuple[int, int], sides=4):
+    """Vertex list of the irregular polygon inscribed in a ``size`` rectangle (4 or up to 8 vertices)."""
+    w, h = size
+    if sides == 4:
+        return [(0, random.randint(1, h)), (random.randint(1, w), 0), (w, random.randint(1, h)), (random.randint(1, w), h)]
+    pts = []
+    for side in range(4):
+        pts += _side_points(side, w, h)
+    return pts
+
+
+def rect2poly(patch: Image.Image, regular: bool = False, sides: list = 4):
+    """RGBA mask (white polygon on transparent) of the patch's size."""
+    w, h = patch.size
+    mask = Image.new('RGBA', patch.size, color=(0, 0, 0, 0))
+    draw = ImageDraw.Draw(mask)
+    if regular:
+        draw.regular_polygon(bounding_circle=((int(w / 2), int(h / 2)), int(min(w, h) / 2)),
+                             n_sides=random.choice(sides), fill='white')
+    else:
+        draw.polygon(polygon_points((w, h), sides), fill='white')
+    return mask
+
+
+# ---- placement (dataset_generator.py:104-144) ----
+def check_valid_coordinates_by_container(imsize: tuple, patchsize: tuple, current_coords: tuple = None,
+                                         container_scaling_factor: int = 1):
+    """Top-left paste corner for a patch centred at ``current_coords`` (random centre when None), pulled back
+    inside the container on each side in the order right, bottom, left, top."""
+    pw, ph = patchsize
+    box = Container(imsize, scaling_factor=container_scaling_factor)
+    if current_coords is None:
+        cx, cy = random.randint(box.left, box.right), random.randint(box.top, box.bottom)
+    else:
+        cx, cy = current_coords[0], current_coords[1]
+    left, top = cx - int(pw / 2), cy - int(ph / 2)
+    right, bottom = cx + int(pw / 2), cy + int(ph / 2)
+    if right > box.right:
+        left = box.right - pw
+    if bottom > box.bottom:
+        top = box.bottom - ph
+    if left < box.left:
+        left = box.left
+    if top < box.top:
+        top = box.top
+    return (left, top)
+
+
+def check_color_similarity(patch: Image.Image, defect: Image.Image) -> float:
+    """Cosine similarity of the two mean RGB colours (dataset_generator.py:147-159)."""
+    a = np.array(patch).mean(axis=(0, 1))[:3] / 255.0
+    b = np.array(defect).mean(axis=(0, 1))[:3] / 255.0
+    return float(np.dot(a, b) / (np.linalg.norm(a) * np.linalg.norm(b)))
+
+
+# ---- patch sampling (dataset_generator.py:164-210) ----
+def sample_patch_box(imsize: Tuple[int, int], area_ratio, aspect_ratio):
+    """(left, top, w, h) of the random rectangle: area ~ U(area_ratio) * image area, aspect from one of two ranges."""
+    iw, ih = imsize
+    area = random.uniform(area_ratio[0], area_ratio[1]) * (iw * ih)
+    aspect = random.choice([random.uniform(*aspect_ratio[0]), random.uniform(*aspect_ratio[1])])
+    pw, ph = max(int(np.sqrt(area * aspect)), 2), max(int(np.sqrt(area / aspect)), 2)
+    left, top = random.randint(0, max(iw - pw, 1)), random.randint(0, max(ih - ph, 1))
+    return left, top, pw, ph
+
+
+def generate_patch(image: Image.Image, area_ratio: tuple = (0.02, 0.15), aspect_ratio: tuple = ((0.3, 1), (1, 3.3)),
+                   augs=None, colorized: bool = False, color_type: str = 'random') -> Image.Image:
+    left, top, pw, ph = sample_patch_box(image.size, area_ratio, aspect_ratio)
+    box = (left, top, left + pw, top + ph)
+    if not colorized:
+        return image.crop(box)
+    if color_type == 'random':
+        rgb = (random.randint(0, 255), random.randint(0, 255), random.randint(0, 255))
+    elif color_type == 'sample':
+        rgb = random.choice(['black', 'white', 'silver', 'gray'])
+    else:                                                  # 'average'
+        mean = np.array(image.crop(box)).mean(axis=(0, 1))
+        rgb = (int(mean[0]), int(mean[1]), int(mean[2]))
+    return Image.new('RGB', (pw, ph), color=rgb)
+
+
+def get_random_coordinate(xy_coords) -> Tuple[int, int]:
+    if len(xy_coords) == 0:
+        return None
+    if len(xy_coords) < 2:
+        return xy_coords[0]
+    return xy_coords[random.randint(0, len(xy_coords) - 1)]
+
+
+def paste_patch(image: Image.Image, patch: Image.Image, coords: tuple, mask: Image.Image = None):
+    out = image.copy()
+    out.paste(patch, (coords[0], coords[1]), mask=mask)
+    return out

@@ -1,0 +1,104 @@
+"""Evaluation metrics (mirrors src/self_supervised/metrics.py:49-228): ROC/AUC through scikit-learn as the
+reference does, F1 at a threshold, and the MVTec per-region-overlap (PRO) curve with its clipped trapezoid area.
+CPU side: these report parity (AUROC within 1e-4), they are not on the accelerated path (SURVEY s.8 f-1)."""
+from bisect import bisect
+
+import numpy as np
+import torch
+from scipy import ndimage
+
+
+def _np(a):
+    return a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+
+
+def compute_roc(labels, scores):
+    from sklearn.metrics import roc_curve
+    fpr, tpr, thr = roc_curve(_np(labels), _np(scores))
+    return np.array(fpr), np.array(tpr), np.array(thr)
+
+
+def compute_auc(false_positive_rate, true_positive_rate):
+    from sklearn.metrics import auc
+    return auc(false_positive_rate, true_positive_rate)
+
+
+def compute_f1(targets, predictions, threshold) -> float:
+    """Binary F1 of (predictions >= threshold) against targets > 0."""
+    t = _np(targets).ravel() > 0
+    p = _np(predictions).ravel() >= float(threshold)
+    tp = float(np.sum(p & t))
+    denom = 2 * tp + float(np.sum(p & ~t)) + float(np.sum(~p & t))
+    return 2 * tp / denom if denom else 0.0
+
+
+def best_f1_threshold(scores, targets):
+    """Threshold maximising F1 over the precision-recall curve (tools.py:141-146 of the reference)."""
+    from sklearn.metrics import precision_recall_curve
+    precision, recall, thr = precision_recall_curve(_np(targets).ravel() > 0, _np(scores).ravel())
+    f1 = (2 * precision * recall) / (precision + recall + 1e-10)
+    return float(thr[min(int(np.argmax(f1)), len(thr) - 1)])
+
+
+def compute_iou(scores, targets, threshold) -> float:
+    """Mean IoU over the two classes {normal, anomalous} of (scores >= threshold)."""
+    t = _np(targets).ravel() > 0
+    p = _np(scores).ravel() >= float(threshold)
+    ious = []
+    for cls in (False, True):
+        inter = float(np.sum((p == cls) & (t == cls)))
+        union = float(np.sum((p == cls) | (t == cls)))
+        if union:
+            ious.append(inter / union)
+    return float(np.mean(ious)) if ious else 0.0
+
+
+def compute_pro(anomaly_maps, ground_truth_maps):
+    """MVTec PRO curve: sweep the threshold down over all pixels; FPR over defect-free pixels, PRO = mean over
+    connected ground-truth regions of the covered fraction.  Returns (fprs, pros) from (0,0) to (1,1)."""
+    maps = np.asarray(anomaly_maps, dtype=np.float64)
+    gts = np.asarray(ground_truth_maps)
+    assert maps.size < np.iinfo(np.uint32).max, 'Potential overflow when using np.cumsum(), consider using np.uint64.'
+    fp_w = np.zeros(maps.shape, dtype=np.float64)
+    pro_w = np.zeros(maps.shape, dtype=np.float64)
+    n_regions = 0
+    eight = np.ones((3, 3), dtype=int)
+    for i, gt in enumerate(gts):
+        lab, n = ndimage.label(gt, eight)
+        n_regions += n
+        fp_w[i][lab == 0] = 1.0
+        if n:
+            sizes = np.bincount(lab.ravel())[1:]
+            inv = np.concatenate([[0.0], 1.0 / sizes])
+            pro_w[i] = inv[lab]
+    n_ok = fp_w.sum()
+    order = np.argsort(maps.ravel(), kind="stable")[::-1]
+    s = maps.ravel()[order]
+    fprs = (np.cumsum(fp_w.ravel()[order]) / max(n_ok, 1)).astype(np.float32)
+    pros = np.cumsum(pro_w.ravel()[order]) / max(n_regions, 1)
+    keep = np.append(np.diff(s) != 0, True)            # one point per distinct threshold: the last of each run
+    fprs, pros = np.clip(fprs[keep], None, 1.0), np.clip(pros[keep], None, 1.0)
+    return np.concatenate(([0.0], fprs, [1.0])), np.concatenate(([0.0], pros, [1.0]))
+
+
+def trapezoid(x, y, x_max: float = None) -> float:
+    """Trapezoid rule on sorted x with an optional upper limit (y interpolated at x_max)."""
+    x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
+    ok = np.isfinite(x) & np.isfinite(y)
+    if not ok.all():
+        print("WARNING: Not all x and y values passed to trapezoid(...) are finite. Will continue with only the finite values.")
+    x, y = x[ok], y[ok]
+    extra = 0.0
+    if x_max is not None:
+        if x_max not in x:
+            i = bisect(x, x_max)
+            assert 0 < i < len(x)
+            y_at = y[i - 1] + (y[i] - y[i - 1]) * (x_max - x[i - 1]) / (x[i] - x[i - 1])
+            extra = 0.5 * (y_at + y[i - 1]) * (x_max - x[i - 1])
+        sel = x <= x_max
+        x, y = x[sel], y[sel]
+    return float(np.sum(0.5 * (y[1:] + y[:-1]) * (x[1:] - x[:-1])) + extra)
+
+
+def compute_aupro(all_fprs, all_pros, integration_limit: float) -> float:
+    return trapezoid(all_fprs, all_pros, x_max=integration_limit) / integration_limit

@@ -125,6 +125,18 @@ class PeraNet(_Base):
         self._frozen.clear()
         self.train()
 
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, map_location='cpu', **overrides):
+        """LightningModule.load_from_checkpoint: rebuild from ``hyper_parameters`` (+ overrides, tools.py:277-281),
+        load ``state_dict``, restore the memory bank.  Callable on the class or on an instance (quirk Q8)."""
+        ck = torch.load(checkpoint_path, map_location=map_location, weights_only=False)
+        hp = dict(ck.get('hyper_parameters', {}))
+        hp.update(overrides)
+        model = cls(**hp)
+        model.load_state_dict(ck['state_dict'], strict=True)
+        model.on_load_checkpoint(ck)
+        return model
+
     def on_save_checkpoint(self, checkpoint) -> None:
         checkpoint['memory_bank'] = self.memory_bank.to('cpu')
 

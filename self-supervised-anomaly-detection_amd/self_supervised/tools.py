@@ -1,11 +1,171 @@
-"""Pipelines with the reference's signatures (src/self_supervised/tools.py:204-399).
+"""Pipelines with the reference's signatures (src/self_supervised/tools.py:52-146, :204-399).
 
-``upsample`` is the HIP blur+ReLU+bilinear kernel.  ``training`` / ``inference`` drive the built-in
-fit/predict loop of trainer.py (PyTorch Lightning is not required)."""
+``training`` = the two-stage schedule (head only, then the whole net), ``inference`` = predict + cosine 3-NN
+scoring, ``upsample`` = the fused blur+ReLU+bilinear HIP kernel, ``Evaluator`` = AUROC / F1 / AUPRO / IoU.
+They drive trainer.Trainer (PyTorch Lightning is not required).  Plots (the reference's ``vis.*`` calls) are out of
+scope: the histories / curves are returned or written as JSON instead."""
+import json
+import os
+import random
+import shutil
+
+import numpy as np
 import torch
 from torch import Tensor
 
+from . import metrics as mtr
 from . import ops
+from .constants import METRICS, EvaluationOutputContainer, ModelOutputsContainer
+from .datasets import MVTecDatamodule, PretextTaskDatamodule
+from .models import AnomalyDetector, PeraNet
+from .trainer import MetricTracker, ModelCheckpoint, Trainer
+
+
+class Evaluator:
+    """tools.py:52-146: scores an inference output; pixel level when ``patch_level`` (maps vs ground truths)."""
+
+    def __init__(self, evaluation_metrics: list = []) -> None:
+        self.evaluation_metrics = np.array(evaluation_metrics)
+        self.scores = EvaluationOutputContainer()
+        self.curves = {}
+
+    def evaluate(self, output_container: ModelOutputsContainer, subject: str, outputs_dir: str, patch_level: bool = False):
+        print('>>> start evaluation')
+        if self.evaluation_metrics.size == 0:
+            print('No metrics selected')
+        bad = [m for m in self.evaluation_metrics if m not in METRICS()]
+        if bad:
+            raise ValueError(f"Wrong metric(s): {bad}; correct metrics list: {METRICS()}")
+        targets, scores = output_container.y_true_binary_labels, output_container.anomaly_maps
+        if patch_level:
+            targets = torch.flatten(output_container.ground_truths, 0, -1)
+            scores = torch.flatten(scores, 0, -1)
+        targets, scores = targets.detach().cpu(), scores.detach().cpu()
+        for m in self.evaluation_metrics:
+            if m != 'auroc' and ((m == 'f1-score') == patch_level):
+                raise ValueError(f"'{m}' not a valid metric for '{'patch' if patch_level else 'image'}-level' mode")
+        threshold = self._get_threshold(scores, targets)
+        if 'auroc' in self.evaluation_metrics:
+            print(' pixel auroc' if patch_level else '>>> image auroc')
+            fpr, tpr, _ = mtr.compute_roc(targets, scores)
+            self.scores.auroc = mtr.compute_auc(fpr, tpr)
+            self.curves['roc'] = (fpr, tpr)
+        if 'f1-score' in self.evaluation_metrics:
+            self.scores.f1_score = mtr.compute_f1(targets, scores, threshold)
+        if 'aupro' in self.evaluation_metrics:
+            fprs, pros = mtr.compute_pro(np.array(output_container.anomaly_maps.cpu().squeeze(1)),
+                                         np.array(output_container.ground_truths.cpu().squeeze(1)))
+            self.scores.aupro = mtr.compute_aupro(fprs, pros, 0.3)
+            self.curves['pro'] = (fprs, pros)
+        if 'iou' in self.evaluation_metrics:
+            self.scores.iou = mtr.compute_iou(scores, targets, threshold)
+        if outputs_dir:
+            os.makedirs(outputs_dir, exist_ok=True)
+            with open(os.path.join(outputs_dir, subject + ('_pixel' if patch_level else '_image') + '_scores.json'), 'w') as f:
+                json.dump({k: (None if v is None else float(v)) for k, v in vars(self.scores).items()}, f)
+
+    def _get_threshold(self, scores: Tensor, targets: Tensor):
+        return mtr.best_f1_threshold(scores, targets)
+
+
+def _seed_everything(seed):
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed_all(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+    os.environ['PYTHONHASHSEED'] = str(seed)
+
+
+def training(dataset_dir: str, outputs_dir: str, subject: str, imsize: tuple = (256, 256), patch_localization: bool = False,
+             patchsize: int = 32, seed: int = 0, batch_size: int = 96, projection_training_params: tuple = (10, 0.03),
+             fine_tune_params: tuple = (30, 0.005), trainer_kwargs: dict = None) -> dict:
+    """tools.py:204-306.  Returns the two metric histories (the reference plots them)."""
+    print('>>> initializing training')
+    checkpoint_name = 'best_model.ckpt'
+    proj_epochs, proj_lr = projection_training_params
+    fine_tune_epochs, fine_tune_lr = fine_tune_params
+    os.makedirs(outputs_dir, exist_ok=True)
+    if os.path.exists(outputs_dir + 'logs/'):
+        shutil.rmtree(outputs_dir + 'logs/')
+    print('>>> setting seeds')
+    _seed_everything(seed)
+    print('>>> preparing datamodule')
+    datamodule = PretextTaskDatamodule(subject, dataset_dir, imsize=imsize, batch_size=batch_size, seed=seed,
+                                       patch_localization=patch_localization, patch_size=patchsize)
+    datamodule.setup()
+    tk = dict(trainer_kwargs or {})
+    print('>>> preparing model')
+    pretext_model = PeraNet(learning_rate=proj_lr, epochs=proj_epochs)
+    pretext_model.freeze_net(['backbone'])
+    cb = MetricTracker()
+    trainer = Trainer(default_root_dir=outputs_dir + 'logs/', callbacks=[cb], precision=16, benchmark=True,
+                      accelerator='auto', devices=1, max_epochs=proj_epochs, check_val_every_n_epoch=1, **tk)
+    print('>>> training projection head')
+    trainer.fit(pretext_model, datamodule=datamodule)
+    history = {'projection_train': cb.log_metrics}
+    pretext_model.clear_memory_bank()
+    trainer.save_checkpoint(outputs_dir + checkpoint_name, weights_only=True)
+
+    print('>>> setting up the model (fine tune whole net)')
+    pretext_model = PeraNet.load_from_checkpoint(outputs_dir + checkpoint_name, learning_rate=fine_tune_lr,
+                                                 epochs=fine_tune_epochs, stage='fine_tune')
+    pretext_model.unfreeze()
+    mc = ModelCheckpoint(dirpath=outputs_dir + 'logs/', filename='best_model_so_far', save_top_k=1, monitor="val_loss",
+                         mode='min', every_n_epochs=5)
+    cb = MetricTracker()
+    trainer = Trainer(default_root_dir=outputs_dir + 'logs/', callbacks=[cb, mc], precision=16, benchmark=True,
+                      accelerator='auto', devices=1, max_epochs=fine_tune_epochs, check_val_every_n_epoch=1, **tk)
+    print('>>> Fine tuning')
+    trainer.fit(pretext_model, datamodule=datamodule)
+    trainer.save_checkpoint(outputs_dir + checkpoint_name)
+    history['fine_tune'] = cb.log_metrics
+    with open(outputs_dir + 'history.json', 'w') as f:
+        json.dump(history, f)
+    return history
+
+
+def inference(model_input_dir: str, dataset_dir: str, subject: str, mvtec_inference: bool = True,
+              patch_localization: bool = False) -> ModelOutputsContainer:
+    """tools.py:310-390."""
+    print('>>> initializing inference')
+    print('>>> preparing model')
+    model = PeraNet.load_from_checkpoint(model_input_dir)
+    model.eval()
+    if patch_localization:
+        model.enable_patch_level_mode()
+    tester = Trainer(accelerator='auto', devices=1)
+    print('>>> preparing datamodule')
+    if mvtec_inference:
+        model.enable_mvtec_inference()
+        datamodule = MVTecDatamodule(dataset_dir, batch_size=1)
+    else:
+        datamodule = PretextTaskDatamodule(subject=subject, root_dir=dataset_dir, min_dataset_length=500, batch_size=1)
+    print('>>> doing prediction')
+    predictions = tester.predict(model, datamodule=datamodule)
+    output = ModelOutputsContainer()
+    output.from_list(predictions)
+    print('>>> anomaly detection phase')
+    if patch_localization:
+        detector = AnomalyDetector(patch_level=True, batch=len(predictions), num_patches=model.num_patches)
+    else:
+        detector = AnomalyDetector()
+    if model.memory_bank.shape[0] > 1000:            # quirk Q3: the bank is capped at 1000 rows, so this never holds
+        normality = model.memory_bank
+    else:
+        print(' not enough data in memory bank, sampling new data trom train set')
+        if mvtec_inference:
+            normality_datamodule = MVTecDatamodule(dataset_dir, batch_size=1)
+        else:
+            normality_datamodule = PretextTaskDatamodule(subject=subject, root_dir=dataset_dir, batch_size=1)
+        normality_datamodule.setup()
+        output_normality = tester.predict(model, dataloaders=normality_datamodule.train_dataloader())[0]
+        output_normality.to_cpu()
+        normality = output_normality.embedding_vectors
+    output.to_cpu()
+    detector.fit(normality)
+    print(' computing anomaly scores')
+    output.anomaly_maps = detector.predict(output.embedding_vectors).cpu()
+    return output
 
 
 def upsample(anomaly_maps: Tensor, target_size: int = 256, verbose: bool = True):

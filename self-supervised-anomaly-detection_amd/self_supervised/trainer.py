@@ -1,0 +1,156 @@
+"""Minimal fit / predict loop honouring the hooks the reference relies on from pytorch_lightning.Trainer
+(src/self_supervised/tools.py:260-304, :327-347): ``model.train()`` at fit start (quirk Q6), ``training_step`` per
+batch, ``on_train_epoch_end``, ``validation_step``, per-epoch scheduler step, callbacks with ``logged_metrics``,
+``save_checkpoint`` (with ``on_save_checkpoint``), ``predict`` returning the list of ``predict_step`` outputs.
+
+One process per GPU: when ``torch.distributed`` is initialised the train set is sharded with a DistributedSampler
+and gradients are all-reduced by training.DataParallelStep (RCCL); the reference itself is single-device."""
+import os
+
+import torch
+import torch.distributed as dist
+from torch.utils.data import DataLoader
+from torch.utils.data.distributed import DistributedSampler
+
+from . import training
+
+
+class Callback:
+    def on_train_epoch_end(self, trainer, pl_module):
+        pass
+
+
+class MetricTracker(Callback):
+    """Per-epoch accuracy / loss history (mirrors src/self_supervised/custom_callbacks.py:5-24)."""
+
+    def __init__(self):
+        self.log_metrics = {'train': {'accuracy': [], 'loss': []}, 'val': {'accuracy': [], 'loss': []}}
+
+    def on_train_epoch_end(self, trainer, pl_module):
+        logs = trainer.logged_metrics
+        for split in ('train', 'val'):
+            for k in ('accuracy', 'loss'):
+                if f'{split}_{k}' in logs:
+                    self.log_metrics[split][k].append(float(logs[f'{split}_{k}']))
+
+
+class ModelCheckpoint(Callback):
+    """save_top_k=1 on a monitored metric, checked every ``every_n_epochs`` (tools.py:284-290)."""
+
+    def __init__(self, dirpath, filename='best', save_top_k=1, monitor='val_loss', mode='min', every_n_epochs=1):
+        self.dirpath, self.filename, self.monitor, self.mode, self.every = dirpath, filename, monitor, mode, every_n_epochs
+        self.best, self.best_model_path = None, None
+
+    def on_train_epoch_end(self, trainer, pl_module):
+        if (trainer.current_epoch + 1) % self.every or self.monitor not in trainer.logged_metrics or trainer.global_rank:
+            return
+        v = float(trainer.logged_metrics[self.monitor])
+        better = self.best is None or (v < self.best if self.mode == 'min' else v > self.best)
+        if better:
+            self.best = v
+            os.makedirs(self.dirpath, exist_ok=True)
+            self.best_model_path = os.path.join(self.dirpath, self.filename + '.ckpt')
+            trainer.save_checkpoint(self.best_model_path)
+
+
+def _to_device(batch, dev):
+    return tuple(b.to(dev, non_blocking=True) if torch.is_tensor(b) else b for b in batch)
+
+
+class Trainer:
+    def __init__(self, default_root_dir=None, callbacks=None, precision=32, benchmark=False, accelerator='auto',
+                 devices=1, max_epochs=1, check_val_every_n_epoch=1, limit_train_batches=None, limit_val_batches=None,
+                 enable_progress=False):
+        self.default_root_dir, self.callbacks, self.max_epochs = default_root_dir, list(callbacks or []), max_epochs
+        self.precision = precision          # accepted for signature parity; this build computes in fp32 (exact f32 MFMA)
+        self.check_val_every_n_epoch = check_val_every_n_epoch
+        self.limit_train_batches, self.limit_val_batches = limit_train_batches, limit_val_batches
+        self.logged_metrics, self.current_epoch, self.global_step, self.model = {}, 0, 0, None
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.global_rank = dist.get_rank() if dist.is_initialized() else 0
+        if not torch.cuda.is_available():
+            raise RuntimeError("Trainer drives the MI355X HIP kernels: no GPU visible (there is no CPU fallback)")
+        self.device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+
+    def _shard(self, loader, epoch):
+        if self.world == 1:
+            return loader
+        sampler = DistributedSampler(loader.dataset, num_replicas=self.world, rank=self.global_rank, shuffle=True)
+        sampler.set_epoch(epoch)
+        return DataLoader(loader.dataset, batch_size=loader.batch_size, sampler=sampler, drop_last=True,
+                          num_workers=loader.num_workers)
+
+    def fit(self, model, datamodule=None, train_dataloaders=None, val_dataloaders=None):
+        self.model = model
+        model.trainer = self
+        model.to(self.device)
+        if datamodule is not None:
+            if not hasattr(datamodule, 'train_dataset'):
+                datamodule.setup('fit')
+            train_dataloaders = train_dataloaders or datamodule.train_dataloader()
+            val_dataloaders = val_dataloaders or datamodule.val_dataloader()
+        model.train()                                   # PL puts the whole module in train mode at fit start
+        (opt,), scheds = model.configure_optimizers()
+        step = training.DataParallelStep(model, lr=opt.param_groups[0]['lr'], momentum=opt.momentum,
+                                         weight_decay=opt.weight_decay, world_size=self.world)
+        step.opt = opt
+        opt.grad_scale = 1.0 / self.world
+        for epoch in range(self.max_epochs):
+            self.current_epoch = model.current_epoch = epoch
+            model.train()
+            sums = torch.zeros(3, device=self.device)
+            for i, batch in enumerate(self._shard(train_dataloaders, epoch)):
+                if self.limit_train_batches is not None and i >= self.limit_train_batches:
+                    break
+                x, y, _ = _to_device(batch, self.device)
+                la = step.step(x.contiguous().float(), y.contiguous())
+                sums += torch.stack([la[0], la[1], torch.ones_like(la[0])])
+                if epoch > int(self.max_epochs / 2):    # memory bank of well-classified normal samples (models.py:270-275)
+                    y_hat = torch.max(step.last_logits, 1).indices
+                    mask = (y == 0) & (y_hat == 0)
+                    model.memory_bank = torch.cat([model.memory_bank, step.last_embeddings[mask].detach().to('cpu')])
+                self.global_step += 1
+            model.on_train_epoch_end()
+            if self.world > 1:
+                dist.all_reduce(sums)
+            n = max(float(sums[2]), 1.0)
+            self.logged_metrics['train_loss'], self.logged_metrics['train_accuracy'] = sums[0] / n, sums[1] / n
+            if val_dataloaders is not None and (epoch + 1) % self.check_val_every_n_epoch == 0:
+                vs = torch.zeros(3, device=self.device)
+                for i, batch in enumerate(val_dataloaders):
+                    if self.limit_val_batches is not None and i >= self.limit_val_batches:
+                        break
+                    m = model.validation_step(_to_device(batch, self.device), i)
+                    vs += torch.stack([m['val_loss'], m['val_accuracy'], torch.ones_like(m['val_loss'])])
+                n = max(float(vs[2]), 1.0)
+                self.logged_metrics['val_loss'], self.logged_metrics['val_accuracy'] = vs[0] / n, vs[1] / n
+            for cb in self.callbacks:
+                cb.on_train_epoch_end(self, model)
+            for s in scheds:
+                s.step()
+        model.eval()
+
+    def predict(self, model, datamodule=None, dataloaders=None):
+        self.model = model
+        model.trainer = self
+        model.to(self.device).eval()
+        if dataloaders is None:
+            if not hasattr(datamodule, 'test_dataset'):
+                datamodule.setup('predict')
+            dataloaders = datamodule.predict_dataloader()
+        outs = []
+        with torch.no_grad():
+            for i, batch in enumerate(dataloaders):
+                outs.append(model.predict_step(_to_device(batch, self.device), i))
+        return outs
+
+    def save_checkpoint(self, path, weights_only=False):
+        if self.global_rank:
+            return
+        m = self.model
+        ck = {'epoch': self.current_epoch, 'global_step': self.global_step, 'pytorch-lightning_version': '1.9.0',
+              'state_dict': {k: v.detach().to('cpu').contiguous().clone() for k, v in m.state_dict().items()},
+              'hyper_parameters': dict(m.hparams)}
+        m.on_save_checkpoint(ck)
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        torch.save(ck, path)

@@ -1,0 +1,100 @@
+"""CPU tests of the host-side data path: cut-paste primitives against vectors from the reference, datasets on a
+synthetic MVTec-shaped tree, metrics."""
+import random
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from fake_mvtec import make_tree
+
+
+def test_cutpaste_primitives_match_reference(golden):
+    from self_supervised import dataset_generator as dg
+    g = golden("cutpaste")
+    img = Image.fromarray(g["base"], "RGB")
+    random.seed(123)
+    patch = dg.generate_patch(img, area_ratio=(0.03, 0.07), aspect_ratio=((0.3, 0.5), (1, 3.3)))
+    assert np.array_equal(np.array(patch), g["patch"])
+    random.seed(124)
+    mask = dg.rect2poly(patch, regular=False, sides=8)
+    assert np.array_equal(np.array(mask), g["mask_rgba"])
+    coords = dg.check_valid_coordinates_by_container((256, 256), patch.size, current_coords=(250, 10), container_scaling_factor=1.75)
+    assert tuple(coords) == tuple(g["coords"])
+    assert np.array_equal(np.array(dg.paste_patch(img, patch, coords, mask)), g["pasted"])
+    c = dg.Container((256, 256), 1.75)
+    assert [c.center, c.dim, c.left, c.top, c.right, c.bottom, c.width, c.height] == list(g["container"])
+    assert abs(dg.check_color_similarity(img.crop((0, 0, 40, 40)), patch) - float(g["color_sim"])) < 1e-9
+    random.seed(125)
+    avg = dg.generate_patch(img, area_ratio=(0.2, 0.5), colorized=True, color_type="average")
+    assert list(avg.size) == list(g["avg_patch_size"]) and list(np.array(avg)[0, 0]) == list(g["avg_patch_color"])
+
+
+def test_obj_mask_finds_the_object():
+    from self_supervised.dataset_generator import obj_mask
+    yy, xx = np.mgrid[0:128, 0:128]
+    disk = ((yy - 64) ** 2 + (xx - 60) ** 2) < 40 ** 2
+    img = np.where(disk[..., None], 180, 20).astype(np.uint8) * np.ones((1, 1, 3), np.uint8)
+    m = np.array(obj_mask(Image.fromarray(img)).convert('1'))
+    inter, union = (m & disk).sum(), (m | disk).sum()
+    assert inter / union > 0.9
+
+
+def test_datasets_on_synthetic_tree(tmp_path):
+    from self_supervised import datasets as ds
+    root = make_tree(str(tmp_path / "data"))
+    random.seed(0); np.random.seed(0); torch.manual_seed(0)
+    dm = ds.PretextTaskDatamodule("bottle", root + "bottle/", imsize=(96, 96), batch_size=4, min_dataset_length=12, seed=0)
+    dm.setup()
+    assert len(dm.train_dataset) >= 12 and len(dm.val_dataset) >= 12
+    # quirk Q1: the train set is built from the validation split (2 of 10 files, duplicated)
+    assert len(set(dm.train_dataset.images_filenames)) == 2 and len(set(dm.val_dataset.images_filenames)) == 8
+    labels = []
+    for i in range(12):
+        x, y, orig = dm.train_dataset[i]
+        assert tuple(x.shape) == (3, 96, 96) and x.dtype == torch.float32 and tuple(orig.shape) == (3, 96, 96)
+        assert 0 <= y <= 3 and 0.0 <= float(orig.min()) and float(orig.max()) <= 1.0
+        labels.append(y)
+    assert len(set(labels)) >= 3
+    pl = ds.PretextTaskDatamodule("carpet", root + "carpet/", imsize=(96, 96), batch_size=4, min_dataset_length=8,
+                                  patch_localization=True, patch_size=32)
+    pl.setup()
+    x, y, orig = pl.train_dataset[0]
+    assert tuple(x.shape) == (3, 32, 32) and tuple(orig.shape) == (3, 96, 96)
+    mv = ds.MVTecDatamodule(root + "bottle/", imsize=(96, 96), batch_size=1)
+    mv.setup()
+    assert len(mv.test_dataset) == 6
+    gts = [mv.test_dataset[i][1] for i in range(6)]
+    assert tuple(gts[0].shape) == (1, 96, 96) and sum(float(g.sum()) > 0 for g in gts) == 3
+    xb, gb, ob = next(iter(torch.utils.data.DataLoader(mv.test_dataset, batch_size=2)))
+    assert tuple(xb.shape) == (2, 3, 96, 96)
+
+
+def test_metrics(golden):
+    from self_supervised import metrics as m
+    g = golden("auroc")
+    fpr, tpr, _ = m.compute_roc(torch.from_numpy(g["labels"]), torch.from_numpy(g["scores"]))
+    assert abs(m.compute_auc(fpr, tpr) - float(g["auroc"])) < 1e-12
+    # PRO on a case small enough for a brute-force statement
+    rng = np.random.RandomState(3)
+    maps = rng.rand(2, 12, 12)
+    gts = np.zeros((2, 12, 12), int); gts[0, 2:5, 2:6] = 1; gts[0, 8:10, 8:11] = 1; gts[1, 5:7, 1:4] = 1
+    fprs, pros = m.compute_pro(maps, gts)
+    ok = gts == 0
+    regions = [(0, slice(2, 5), slice(2, 6)), (0, slice(8, 10), slice(8, 11)), (1, slice(5, 7), slice(1, 4))]
+    for t in np.sort(np.unique(maps))[::-1][::7]:
+        pred = maps >= t
+        fpr_t = (pred & ok).sum() / ok.sum()
+        pro_t = np.mean([pred[i, ys, xs].mean() for i, ys, xs in regions])
+        j = int(pred.sum())                       # scores are distinct: point j = after the j best pixels
+        assert abs(fprs[j] - fpr_t) < 1e-6 and abs(pros[j] - pro_t) < 1e-9
+    assert fprs[0] == 0 and pros[-1] == 1
+    x = np.array([0, 0.1, 0.2, 0.5, 1.0]); y = np.array([0, 0.5, 0.6, 0.8, 1.0])
+    assert abs(m.trapezoid(x, y) - np.trapz(y, x)) < 1e-12
+    assert abs(m.trapezoid(x, y, x_max=0.3) - (0.025 + 0.055 + 0.5 * (0.6 + 0.6 + 0.2 / 3) * 0.1)) < 1e-12
+    assert 0 < m.compute_aupro(fprs, pros, 0.3) <= 1
+    s = torch.tensor([0.1, 0.4, 0.35, 0.8]); t = torch.tensor([0, 0, 1, 1])
+    thr = m.best_f1_threshold(s, t)
+    assert abs(thr - 0.35) < 1e-6 and abs(m.compute_f1(t, s, thr) - 0.8) < 1e-9
+    assert abs(m.compute_iou(s, t, 0.5) - np.mean([2 / 3, 1 / 2])) < 1e-9

@@ -1,0 +1,67 @@
+"""GPU end-to-end: tools.training (two stages) -> checkpoint -> tools.inference (patch level) -> upsample -> Evaluator,
+on a synthetic MVTec-shaped tree; plus predict_step / validation_step against the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fake_mvtec import make_tree
+
+pytestmark = pytest.mark.gpu
+
+
+def test_training_inference_evaluation_roundtrip(tmp_path):
+    from self_supervised import tools, datasets
+    datasets._DataModule.num_workers = 0
+    root = make_tree(str(tmp_path / "data"), n_train=12, n_test_good=2, n_test_bad=2, size=96)
+    out = str(tmp_path / "out") + "/"
+    hist = tools.training(root + "bottle/", out, "bottle", imsize=(64, 64), batch_size=4, seed=0,
+                          projection_training_params=(2, 0.03), fine_tune_params=(2, 0.005),
+                          trainer_kwargs={"limit_train_batches": 3, "limit_val_batches": 2})
+    assert os.path.exists(out + "best_model.ckpt")
+    for stage in ("projection_train", "fine_tune"):
+        assert len(hist[stage]["train"]["loss"]) == 2 and np.isfinite(hist[stage]["train"]["loss"]).all()
+        assert len(hist[stage]["val"]["accuracy"]) == 2
+    ck = torch.load(out + "best_model.ckpt", map_location="cpu", weights_only=False)
+    assert len(ck["state_dict"]) == 153 and ck["hyper_parameters"]["stage"] == "fine_tune" and "memory_bank" in ck
+    assert tuple(ck["state_dict"]["feature_extractor.conv1.weight"].shape) == (64, 3, 7, 7)
+    assert ck["state_dict"]["feature_extractor.conv1.weight"].is_contiguous()
+    np.random.seed(0)
+    res = tools.inference(out + "best_model.ckpt", root + "bottle/", "bottle", mvtec_inference=True, patch_localization=True)
+    assert tuple(res.anomaly_maps.shape) == (4, 1, 29, 29) and tuple(res.embedding_vectors.shape) == (4 * 841, 512)
+    assert res.y_true_binary_labels.tolist().count(1) == 2
+    up = tools.upsample(res.anomaly_maps, 256)
+    assert tuple(up.shape) == (4, 1, 256, 256) and float(up.min()) >= 0
+    res.anomaly_maps = up.cpu()
+    ev = tools.Evaluator(evaluation_metrics=['auroc', 'aupro', 'iou'])
+    ev.evaluate(res, "bottle", out, patch_level=True)
+    assert 0.0 <= ev.scores.auroc <= 1.0 and 0.0 <= ev.scores.aupro <= 1.0 and 0.0 <= ev.scores.iou <= 1.0
+    with pytest.raises(ValueError):
+        tools.Evaluator(['f1-score']).evaluate(res, "bottle", None, patch_level=True)
+
+
+def test_predict_and_validation_steps(seeded_sd):
+    from self_supervised.models import PeraNet
+    from oracle import weights as ow
+    from oracle.peranet import OraclePeraNet
+    dev = torch.device("cuda:0")
+    m = PeraNet(); m.load_state_dict(seeded_sd); m.to(dev).eval()
+    ref = OraclePeraNet(); ref.load_state_dict(seeded_sd); ref.eval()
+    x = ow.synthetic_images(3, 64, seed=8)
+    gts = torch.zeros(3, 1, 64, 64); gts[2, 0, 5, 5] = 1
+    m.enable_mvtec_inference()
+    out = m.predict_step((x.to(dev), gts.to(dev), x.to(dev)), 0)
+    with torch.no_grad():
+        ro = ref(x)
+    assert out.y_true_binary_labels.tolist() == [0, 0, 1] and out.y_true_multiclass_labels.tolist() == [-1, -1, 4]
+    assert torch.equal(out.y_hat.cpu(), ro["classifier"].argmax(1))
+    assert (out.embedding_vectors.cpu() - ro["latent_space"]).abs().max() < 1e-4 * max(1.0, ro["latent_space"].abs().max().item())
+    m.disable_mvtec_inference()
+    out2 = m.predict_step((x.to(dev), torch.tensor([0, 2, 3]), x.to(dev)), 0)
+    assert out2.y_true_binary_labels.tolist() == [0, 1, 1]
+    y = ow.synthetic_labels(3, seed=9)
+    m.train()
+    v = m.validation_step((x.to(dev), y.to(dev), None), 0)
+    want = torch.nn.functional.cross_entropy(ro["classifier"], y)
+    assert abs(v["val_loss"].item() - want.item()) < 1e-4 and m.training
