@@ -136,6 +136,44 @@ int ssad_softmax_ce(const float* logits, const int64_t* labels, int B, int C, fl
 int ssad_sgd_step(float* p, const float* g, float* m, int64_t n, float lr, float momentum, float weight_decay,
                   float grad_scale, void* stream);
 
+/* ---- synthetic-defect augmentation (batched, GPU resident) ---- */
+/* One record per sample, drawn on the host in the reference's order (datasets.py:209-394): the GPU does the pixels.
+ * All fields are 32-bit; the Python side mirrors this layout with a numpy structured dtype (augment.py) and checks
+ * ssad_aug_params_size(). */
+typedef struct ssad_aug_params {
+    int32_t label;                          /* 0 good, 1 polygon patch, 2 scars, 3 poly-line */
+    int32_t crop_left, crop_top;            /* output window origin inside the (affine) source image */
+    float   aff[6];                         /* inverse affine output->input {a,b,c,d,e,f}: x' = a x + b y + c, y' = d x + e y + f */
+    int32_t cut_index, cut_left, cut_top;   /* cutting image: index into `cuts` (-1 = the sample's own image) + crop origin */
+    int32_t patch_src_left, patch_src_top, patch_w, patch_h, patch_dst_left, patch_dst_top, patch_flat;
+    float   patch_rgb[3];
+    float   patch_bright[2];                /* two successive ImageEnhance.Brightness factors (1,1 = none) */
+    int32_t poly_n;
+    float   poly_xy[16];                    /* up to 8 vertices in patch coordinates */
+    int32_t scar_src_left, scar_src_top, scar_w, scar_h, scar_flat;
+    float   scar_rgb[3];
+    float   scar_bright[2];
+    float   scar_cos, scar_sin;             /* inverse rotation */
+    int32_t scar_rw, scar_rh, scar_n;       /* rotated (expanded) size, number of pasted copies (<= 5) */
+    int32_t scar_dst[10];                   /* left, top per copy */
+    int32_t line_n;                         /* poly-line points (<= 32) */
+    float   line_xy[64];
+    float   line_rgb[3];
+    float   line_width;
+    int32_t jit_order[3];                   /* permutation of {0 brightness, 1 contrast, 2 saturation} */
+    float   jit_factor[3];                  /* indexed by op */
+} ssad_aug_params;
+
+int ssad_aug_params_size(void);
+/* Replaces the PIL pixel work of PretextTaskDataset.__getitem__ (src/self_supervised/datasets.py:209-394;
+ * dataset_generator.py:42-101, :268-275) for a whole batch: imgs [B][H][W][3] uint8 (and cuts [NC][H][W][3]) ->
+ * out [B][3][h][w] fp32 normalised with mean3/std3 (host pointers).  work: B*h*w*3 bytes, gray_mean: B floats. */
+int ssad_cutpaste_augment(const uint8_t* imgs, const uint8_t* cuts, const ssad_aug_params* params, uint8_t* work,
+                          float* gray_mean, float* out, int B, int H, int W, int h, int w, const float* mean3_host,
+                          const float* std3_host, void* stream);
+/* transforms.ToTensor() on a uint8 HWC batch: -> [B][3][H][W] fp32 in [0,1] (the Dataset's third output). */
+int ssad_u8hwc_to_f32chw(const uint8_t* img, float* out, int B, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

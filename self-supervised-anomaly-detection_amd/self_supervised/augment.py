@@ -1,0 +1,195 @@
+"""GPU-resident synthetic-defect pipeline: host-side parameter sampling + one HIP launch sequence per batch.
+
+``sample_defect`` restates the sampling of ``PretextTaskDataset.__getitem__`` (src/self_supervised/datasets.py:
+209-394 of the reference): label, optional affine / crop, defect source (crop 70 % / average colour 15 % / random
+colour 15 %), polygon vertices, container clamp, scar angle and copies, poly-line points, jitter -- using the same
+helpers (dataset_generator) and the same distributions.  It only produces numbers; ``GpuCutPaste.__call__`` sends
+one record per sample to csrc/augment.hip, which does every per-pixel operation for the whole batch.
+"""
+import ctypes
+import math
+import random
+
+import numpy as np
+import torch
+from scipy.signal import savgol_filter
+
+from . import _hip, constants
+from .dataset_generator import (check_valid_coordinates_by_container, get_random_coordinate, polygon_points,
+                                sample_patch_box)
+from .datasets import CPP, IMAGENET_MEAN, IMAGENET_STD
+
+AUG_DTYPE = np.dtype([
+    ("label", "<i4"), ("crop_left", "<i4"), ("crop_top", "<i4"), ("aff", "<f4", 6),
+    ("cut_index", "<i4"), ("cut_left", "<i4"), ("cut_top", "<i4"),
+    ("patch_src_left", "<i4"), ("patch_src_top", "<i4"), ("patch_w", "<i4"), ("patch_h", "<i4"),
+    ("patch_dst_left", "<i4"), ("patch_dst_top", "<i4"), ("patch_flat", "<i4"),
+    ("patch_rgb", "<f4", 3), ("patch_bright", "<f4", 2), ("poly_n", "<i4"), ("poly_xy", "<f4", 16),
+    ("scar_src_left", "<i4"), ("scar_src_top", "<i4"), ("scar_w", "<i4"), ("scar_h", "<i4"), ("scar_flat", "<i4"),
+    ("scar_rgb", "<f4", 3), ("scar_bright", "<f4", 2), ("scar_cos", "<f4"), ("scar_sin", "<f4"),
+    ("scar_rw", "<i4"), ("scar_rh", "<i4"), ("scar_n", "<i4"), ("scar_dst", "<i4", 10),
+    ("line_n", "<i4"), ("line_xy", "<f4", 64), ("line_rgb", "<f4", 3), ("line_width", "<f4"),
+    ("jit_order", "<i4", 3), ("jit_factor", "<f4", 3)])
+
+_NAMED = {"black": (0, 0, 0), "white": (255, 255, 255), "silver": (192, 192, 192), "gray": (128, 128, 128)}
+
+
+def _mean_rgb(img_u8, box):
+    l, t, w, h = box
+    return img_u8[t:t + h, l:l + w].reshape(-1, 3).mean(axis=0)
+
+
+def _cos(a, b):
+    a, b = np.asarray(a, float) / 255.0, np.asarray(b, float) / 255.0
+    return float(np.dot(a, b) / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-12))
+
+
+def _source(rec, prefix, cut_u8, area_ratio, aspect_ratio):
+    """crop / average colour / random colour choice + box, as generate_patch draws them."""
+    t = np.random.choice([0, 1, 2], p=[0.7, 0.15, 0.15])
+    l, tp, w, h = sample_patch_box((cut_u8.shape[1], cut_u8.shape[0]), area_ratio, aspect_ratio)
+    rec[prefix + "_src_left"], rec[prefix + "_src_top"], rec[prefix + "_w"], rec[prefix + "_h"] = l, tp, w, h
+    mean = _mean_rgb(cut_u8, (l, tp, w, h))
+    if t == 2:
+        rgb = (random.randint(0, 255), random.randint(0, 255), random.randint(0, 255))
+    elif t == 1:
+        rgb = tuple(int(c) for c in mean)
+    else:
+        rgb = None
+    rec[prefix + "_flat"] = int(rgb is not None)
+    if rgb is not None:
+        rec[prefix + "_rgb"] = rgb
+        mean = np.asarray(rgb, float)
+    return w, h, mean
+
+
+def _decorrelate(rec, prefix, x_mean, src_mean):
+    rec[prefix + "_bright"] = (1.0, 1.0)
+    if _cos(x_mean, src_mean) > 0.99:
+        low, high = np.random.uniform(0.75, 0.9), np.random.uniform(1.1, 1.15)
+        rec[prefix + "_bright"] = (random.choice([low, high]), random.choice([low, high]))
+
+
+def sample_defect(subject, img_u8, seg_mask, cuts_u8=None, patch_localization=False, patch_size=64):
+    """One ssad_aug_params record (numpy void) for an H x W uint8 image and its boolean object mask."""
+    H, W = img_u8.shape[:2]
+    rec = np.zeros((), AUG_DTYPE)
+    rec["aff"] = (1, 0, 0, 0, 1, 0)
+    rec["cut_index"] = -1
+    y = random.randint(0, 3)
+    if not patch_localization and subject not in constants.NON_FIXED_OBJECTS():
+        ang = math.radians(float(torch.empty(1).uniform_(-3, 3)))
+        sc = float(torch.empty(1).uniform_(1.05, 1.1))
+        ca, sa, cx, cy = math.cos(ang) / sc, math.sin(ang) / sc, W * 0.5, H * 0.5
+        rec["aff"] = (ca, sa, cx - ca * cx - sa * cy, -sa, ca, cy + sa * cx - ca * cy)
+    cut_u8 = img_u8
+    if subject in constants.TEXTURES() and cuts_u8 is not None and len(cuts_u8):
+        ci = random.randrange(len(cuts_u8))
+        rec["cut_index"], cut_u8 = ci, cuts_u8[ci]
+    h, w, k_patch, k_scar = H, W, 1.75, 2
+    seg = seg_mask
+    if patch_localization:
+        ps = patch_size
+        left, top = random.randint(0, W - ps), random.randint(0, H - ps)
+        rec["crop_left"], rec["crop_top"] = left, top
+        seg = seg_mask[top:top + ps, left:left + ps]
+        ct, cl = int(torch.randint(0, H - ps + 1, (1,))), int(torch.randint(0, W - ps + 1, (1,)))
+        rec["cut_left"], rec["cut_top"] = cl, ct
+        cut_u8 = cut_u8[ct:ct + ps, cl:cl + ps]
+        h = w = ps
+        k_patch = k_scar = 1
+        if seg.sum() < int((ps * ps) / 2):
+            y = 0
+    x_mean = img_u8[rec["crop_top"]:rec["crop_top"] + h, rec["crop_left"]:rec["crop_left"] + w].reshape(-1, 3).mean(axis=0)
+    area_p = CPP.rectangle_area_ratio_patch if patch_localization else CPP.rectangle_area_ratio
+    area_s = CPP.scar_area_ratio_patch if patch_localization else CPP.scar_area_ratio
+    if y > 0:
+        coords_map = np.flip(np.column_stack(np.where(seg)), axis=1)
+        if len(coords_map) == 0:
+            y = 0
+    if y == 1:
+        centre = get_random_coordinate(coords_map)
+        pw, ph, mean = _source(rec, "patch", cut_u8, area_p, CPP.rectangle_aspect_ratio)
+        _decorrelate(rec, "patch", x_mean, mean)
+        at = check_valid_coordinates_by_container((w, h), (pw, ph), current_coords=centre, container_scaling_factor=k_patch)
+        rec["patch_dst_left"], rec["patch_dst_top"] = at
+        pts = polygon_points((pw, ph), sides=8)
+        rec["poly_n"] = len(pts)
+        rec["poly_xy"][:2 * len(pts)] = np.asarray(pts, np.float32).ravel()
+    elif y == 2:
+        sw, sh, mean = _source(rec, "scar", cut_u8, area_s, CPP.scar_aspect_ratio)
+        _decorrelate(rec, "scar", x_mean, mean)
+        copies, angle = random.randint(2, 5), random.randint(-45, 45)
+        a = math.radians(angle)
+        c, s = math.cos(a), math.sin(a)
+        rw = int(math.ceil(abs(sw * c) + abs(sh * s)))
+        rh = int(math.ceil(abs(sw * s) + abs(sh * c)))
+        rec["scar_cos"], rec["scar_sin"], rec["scar_rw"], rec["scar_rh"], rec["scar_n"] = c, s, rw, rh, copies
+        for k in range(copies):
+            centre = get_random_coordinate(coords_map)
+            at = check_valid_coordinates_by_container((w, h), (rw, rh), current_coords=centre, container_scaling_factor=k_scar)
+            rec["scar_dst"][2 * k:2 * k + 2] = at
+    elif y == 3:
+        side = random.choice(['left', 'top'])
+        n = 30 if patch_localization else 60
+        pts, c = [], 0
+        for i in range(n):
+            idx = random.randint(c, int(len(coords_map) * (i / n)))
+            pts.append(tuple(coords_map[idx]))
+            c = idx
+        rgb = _NAMED[random.choice(['black', 'white', 'silver'])]
+        if side == 'left':
+            pts.sort(key=lambda t: t[0])
+        pts = savgol_filter(pts, 10, 2, axis=0)
+        if not patch_localization:
+            pts = np.array_split(pts, 10)[random.randint(0, 9)]
+        pts = np.asarray(pts, np.float32)[:32]
+        rec["line_n"] = len(pts)
+        rec["line_xy"][:2 * len(pts)] = pts.ravel()
+        rec["line_rgb"], rec["line_width"] = rgb, (1.0 if patch_localization else 3.0)
+    rec["label"] = y
+    order, f = CPP.jitter_transforms.sample()
+    rec["jit_order"], rec["jit_factor"] = order, f
+    return rec, (h, w)
+
+
+class GpuCutPaste:
+    """Batch augmenter: images stay on the GPU as uint8 HWC; returns (x fp32 NCHW normalised, y int64, original fp32)."""
+
+    def __init__(self, subject, images_u8, seg_masks, cuts_u8=None, patch_localization=False, patch_size=64, device="cuda"):
+        assert _hip.lib().ssad_aug_params_size() == AUG_DTYPE.itemsize, "ssad_aug_params layout drifted from augment.py"
+        self.subject, self.patch_localization, self.patch_size = subject, patch_localization, patch_size
+        self.images_cpu = np.ascontiguousarray(images_u8, dtype=np.uint8)
+        self.cuts_cpu = None if cuts_u8 is None else np.ascontiguousarray(cuts_u8, dtype=np.uint8)
+        self.masks = np.asarray(seg_masks, dtype=bool)
+        if self.masks.ndim == 2:
+            self.masks = np.broadcast_to(self.masks, self.images_cpu.shape[:3])
+        self.device = torch.device(device)
+        self.images = torch.from_numpy(self.images_cpu).to(self.device)
+        self.cuts = None if self.cuts_cpu is None else torch.from_numpy(self.cuts_cpu).to(self.device)
+        self._mean = (ctypes.c_float * 3)(*IMAGENET_MEAN)
+        self._std = (ctypes.c_float * 3)(*IMAGENET_STD)
+
+    def __call__(self, indices):
+        idx = np.asarray(indices, dtype=np.int64)
+        recs, hw = [], None
+        for i in idx:
+            r, hw = sample_defect(self.subject, self.images_cpu[i], self.masks[i], self.cuts_cpu, self.patch_localization,
+                                  self.patch_size)
+            recs.append(r)
+        recs = np.stack(recs)
+        b, (h, w) = len(idx), hw
+        _, H, W, _ = self.images.shape
+        params = torch.from_numpy(recs.view(np.uint8).reshape(b, -1)).to(self.device)
+        batch = self.images[torch.from_numpy(idx).to(self.device)].contiguous()
+        work = torch.empty((b, h, w, 3), dtype=torch.uint8, device=self.device)
+        gmean = torch.empty(b, dtype=torch.float32, device=self.device)
+        out = torch.empty((b, 3, h, w), dtype=torch.float32, device=self.device)
+        orig = torch.empty((b, 3, H, W), dtype=torch.float32, device=self.device)
+        lib = _hip.lib()
+        _hip.check(lib.ssad_cutpaste_augment(batch.data_ptr(), None if self.cuts is None else self.cuts.data_ptr(),
+                                             params.data_ptr(), work.data_ptr(), gmean.data_ptr(), out.data_ptr(), b, H, W, h, w,
+                                             self._mean, self._std, _hip.stream()))
+        _hip.check(lib.ssad_u8hwc_to_f32chw(batch.data_ptr(), orig.data_ptr(), b, H, W, _hip.stream()))
+        y = torch.from_numpy(recs["label"].astype(np.int64)).to(self.device)
+        return out, y, orig
