@@ -1,25 +1,32 @@
 // Implicit-GEMM convolution / linear layer on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
 //
 //   out[m][co] = act( (sum_k A[m][k] * Wt[co][k]) * scale[co] + shift[co] + residual[m][co] )
-//   m = (n, oy, ox) flattened NHWC output pixel, k = (ky, kx, ci) with ci fastest (OHWI weights).
+//   m = output pixel, k = (ky, kx, ci) with ci fastest (OHWI weights).
 //
 // Replaces the nn.Conv2d/BatchNorm2d/ReLU/residual chains of the torchvision BasicBlocks and the
 // nn.Linear/BatchNorm1d/ReLU chains of the projection head that the reference runs through cuDNN /
-// MKLDNN (src/self_supervised/models.py:224, :247-249).
+// MKLDNN (src/self_supervised/models.py:224, :247-249); in transposed-gather mode (ssad_conv_igemm_dgrad)
+// the input gradient of those layers under loss.backward() (src/self_supervised/tools.py:270, :303).
 //
-// Design (MI355X): 256-thread workgroups = 4 waves, one per SIMD; each wave owns TM x TN accumulator
-// tiles of 32x32 (f32x16 each).  A (gathered activations) and B (weights) K-slices of 32 floats are
-// staged global -> registers -> LDS with 144-byte rows (128 B + 16 B pad: conflict-free ds_read_b128
-// for the "row = lane&31" fragment pattern), double buffered, one barrier per K-step.  Each lane reads
-// 4 consecutive k per ds_read_b128; lane half h takes k = 8*kk + 4*h + e for the e-th MFMA of a chunk,
-// the same permutation for A and B, so the contraction is unchanged.  Zero padding is produced by
-// predicated loads (no padded copy of the activations exists anywhere).
+// Design (MI355X): 256-thread workgroups = 4 waves, one per SIMD; each wave owns TM x TN accumulator tiles of 32x32
+// (f32x16 each).  A (gathered activations) and B (weights) K-slices of 32 floats are staged global -> registers ->
+// LDS with 144-byte rows (128 B + 16 B pad: conflict-free ds_read_b128 for the "row = lane&31" fragment pattern),
+// double buffered, one barrier per K-step.  Each lane reads 4 consecutive k per ds_read_b128; lane half h takes
+// k = 8*kk + 4*h + e for the e-th MFMA of a chunk, the same permutation for A and B, so the contraction is unchanged.
+//
+// The K-loop carries no integer division and no branch: every staged row has a precomputed base pointer and a
+// bitmask of in-bounds filter taps; a tap's offset is a wave-uniform scalar; out-of-bounds (zero padding / tail)
+// rows load from a zero page instead of branching around the load.  The epilogue goes through LDS so that every
+// thread stores (and reads the residual as) 16-byte pieces of contiguous output rows, with all residual loads in
+// flight at once.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int BK = 32;    // floats per K-step
-constexpr int LDK = 36;   // LDS row stride in floats (144 B)
+constexpr int KALIGN = 32;   // Cin granularity every instantiation accepts
+
+__device__ __attribute__((aligned(16))) float g_zero_page[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 struct ConvParams {
     const float* in;
@@ -29,39 +36,46 @@ struct ConvParams {
     const float* shift;
     const float* residual;
     int64_t M;          // N*Ho*Wo
+    int64_t N;          // samples
     int H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, relu;
     int K;              // KH*KW*Cin
-    int ts;             // 1: convolution.  >1: transposed gather (dgrad of a stride-ts conv): the tap reads
-                        // in[(oy - pad + ky) / ts] only where the numerator is a non-negative multiple of ts
-    int posmajor;       // 1: a workgroup's rows are BM different samples at ONE output position, so the set of
-                        // in-bounds filter taps is workgroup-uniform and out-of-bounds taps (zero padding) are
-                        // skipped as whole K-steps.  Exact: the skipped products are all x*0.
-    int64_t N;          // samples (posmajor row bound)
-    int hwnc;           // activations (in, out, residual) laid out [H][W][N][C] instead of [N][H][W][C]: with
-                        // posmajor rows a workgroup then reads/writes 128 CONSECUTIVE rows of C floats per tap
+    int hwnc;           // activations (in, out, residual) laid out [H][W][N][C] instead of [N][H][W][C]
 };
 
-template <int BM, int BN, int TM, int TN>
+// TS   : 1 = convolution; 2 = transposed gather (dgrad of a stride-2 conv): tap (ky,kx) reads in[(oy-pad+ky)/2]
+//        only where the numerator is a non-negative even number.
+// POS  : a workgroup's rows are BM different samples at ONE output position, so the set of in-bounds taps is
+//        workgroup-uniform and taps in the zero padding are skipped as whole K-steps (exact: only x*0 is dropped).
+// BK   : floats per K-step (32: 144-byte LDS rows; 16: 80-byte rows -- both conflict-free for ds_read_b128).
+template <int BM, int BN, int TM, int TN, int BK, int TS, bool POS>
 __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
+    constexpr int LDK = BK + 4;     // LDS row stride in floats
+    constexpr int CPR = BK / 4;     // 16-byte chunks per staged row
+    constexpr int RPP = 256 / CPR;  // rows staged per pass
     constexpr int WN = BN / (32 * TN);
-    constexpr int AR = BM / 32;     // 16-byte chunks of A staged per thread per K-step
-    constexpr int BR = BN / 32;
+    constexpr int AR = BM / RPP;    // 16-byte chunks of A staged per thread per K-step
+    constexpr int BR = BN / RPP;
+    static_assert(AR >= 1 && BR >= 1, "tile too small for the staging pattern");
     constexpr int STAGE = (BM + BN) * LDK;
+    constexpr int LDC = BN + 4;     // epilogue tile row stride (floats)
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     const int n0 = blockIdx.y * BN;
-    const int sc = tid & 7, sr = tid >> 3;
+    const int sc = tid % CPR, sr = tid / CPR;
     const int HoWo = p.Ho * p.Wo;
     const int ntaps = p.KH * p.KW;
+    const int64_t in_sp = p.hwnc ? p.N * p.Cin : (int64_t)p.Cin;                       // floats between pixels
+    const int64_t in_sn = p.hwnc ? (int64_t)p.Cin : (int64_t)p.H * p.W * p.Cin;        // floats between samples
+    const float* zero = g_zero_page;
 
-    // ---- row geometry.  normal: row = flattened (n, oy, ox).  posmajor: row = sample, position from blockIdx ----
-    int64_t m0;                 // normal: first flattened row; posmajor: first sample
+    // ---- row geometry ----
+    int64_t m0;                 // first flattened row (normal) / first sample (POS)
     int pos = 0;
-    unsigned long long tapmask = ntaps >= 64 ? ~0ull : ((1ull << ntaps) - 1);
-    if (p.posmajor) {
+    unsigned tapmask = ntaps >= 32 ? ~0u : ((1u << ntaps) - 1);     // taps this workgroup iterates over
+    if (POS) {
         // Engine-aware mapping.  Workgroups are dealt round-robin to the 8 XCDs and, inside an XCD, to its 4 shader
         // engines: stream = block % 32 is served by one (XCD, SE) pair for the whole launch (measured: with
         // pos = block % HoWo the heavy interior positions pin to the same engines and tap skipping buys nothing).
@@ -71,52 +85,69 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
         const int64_t j = blockIdx.x >> 5;
         const int64_t q = j / HoWo;
         pos = (int)(j - q * HoWo);
-        const int64_t nb = q * 32 + stream;
-        m0 = nb * BM;
+        m0 = (q * 32 + stream) * BM;
         if (m0 >= p.N) return;
         const int oy = pos / p.Wo, ox = pos - oy * p.Wo;
         tapmask = 0;
-        for (int t = 0; t < ntaps; ++t) {
-            const int ky = t / p.KW, kx = t - ky * p.KW;
-            const int y = oy * p.stride - p.pad + ky, x = ox * p.stride - p.pad + kx;
-            if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) tapmask |= 1ull << t;
-        }
+        for (int ky = 0, t = 0; ky < p.KH; ++ky)
+            for (int kx = 0; kx < p.KW; ++kx, ++t) {
+                const int y = oy * p.stride - p.pad + ky, x = ox * p.stride - p.pad + kx;
+                if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) tapmask |= 1u << t;
+            }
     } else {
         m0 = (int64_t)blockIdx.x * BM;
     }
 
-    // ---- per-thread staging rows (fixed across the K loop) ----
-    int64_t a_base[AR];
-    int a_iy[AR], a_ix[AR];
+    // ---- per-thread staging rows (fixed across the K loop): base pointer at tap (0,0) + in-bounds tap mask ----
+    const float* a_ptr[AR];
+    unsigned a_mask[AR];
+    int a_iy[AR], a_ix[AR];                 // only live in the TS == 2 instantiation
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-        int64_t m = m0 + sr + 32 * i;
-        if (p.posmajor) {
-            const int oy = pos / p.Wo, ox = pos - oy * p.Wo;
-            const bool ok = m < p.N;
-            a_base[i] = (ok ? m : 0) * (p.hwnc ? (int64_t)p.Cin : (int64_t)p.H * p.W * p.Cin) + sc * 4;
-            a_iy[i] = ok ? oy * p.stride - p.pad : -(1 << 20);
-            a_ix[i] = ok ? ox * p.stride - p.pad : -(1 << 20);
-        } else if (m < p.M) {
-            int64_t n = m / HoWo;
-            int rem = (int)(m - n * HoWo);
-            int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-            a_base[i] = n * (int64_t)p.H * p.W * p.Cin + sc * 4;
-            a_iy[i] = oy * p.stride - p.pad;
-            a_ix[i] = ox * p.stride - p.pad;
+        const int64_t m = m0 + sr + RPP * i;
+        int64_t n;
+        int oy, ox;
+        bool ok;
+        if (POS) {
+            ok = m < p.N;
+            n = ok ? m : 0;
+            oy = pos / p.Wo;
+            ox = pos - oy * p.Wo;
         } else {
-            a_base[i] = 0;
-            a_iy[i] = -(1 << 20);
-            a_ix[i] = -(1 << 20);
+            ok = m < p.M;
+            const int64_t mm = ok ? m : 0;
+            n = mm / HoWo;
+            const int rem = (int)(mm - n * HoWo);
+            oy = rem / p.Wo;
+            ox = rem - oy * p.Wo;
         }
+        const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+        a_iy[i] = iy0;
+        a_ix[i] = ix0;
+        unsigned mk = 0;
+        if (POS) {
+            mk = ok ? tapmask : 0u;          // every row of the workgroup sits at the same position
+        } else if (ok) {
+            for (int ky = 0, t = 0; ky < p.KH; ++ky)
+                for (int kx = 0; kx < p.KW; ++kx, ++t) {
+                    int y = iy0 + ky, x = ix0 + kx;
+                    bool v = true;
+                    if (TS > 1) {
+                        v = y >= 0 && x >= 0 && (y % TS) == 0 && (x % TS) == 0;
+                        y /= TS;
+                        x /= TS;
+                    }
+                    if (v && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) mk |= 1u << t;
+                }
+        }
+        a_mask[i] = mk;
+        a_ptr[i] = TS > 1 ? p.in + n * in_sn + sc * 4 : p.in + n * in_sn + ((int64_t)iy0 * p.W + ix0) * in_sp + sc * 4;
     }
-    int64_t b_off[BR];
-    bool b_ok[BR];
+    const float* b_ptr[BR];
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
-        int co = n0 + sr + 32 * i;
-        b_ok[i] = co < p.Cout;
-        b_off[i] = (int64_t)co * p.K + sc * 4;
+        const int co = n0 + sr + RPP * i;
+        b_ptr[i] = co < p.Cout ? p.wt + (int64_t)co * p.K + sc * 4 : nullptr;
     }
 
     f32x16 acc[TM][TN];
@@ -127,41 +158,30 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int64_t in_sp = p.hwnc ? p.N * p.Cin : (int64_t)p.Cin;      // floats between neighbouring pixels
     const int cpt = p.Cin / BK;               // K-steps per filter tap
-    const int nk = __builtin_popcountll(tapmask) * cpt;
+    const int nk = __builtin_popcount(tapmask) * cpt;
     f32x4 ra[AR], rb[BR];
 
-    // state of the next K-step to load: current tap (lowest set bit of ld_mask) and channel chunk
-    unsigned long long ld_mask = tapmask;
-    int ld_tap = tapmask ? __builtin_ctzll(tapmask) : 0;
+    // state of the next K-step to load: current tap (lowest set bit of ld_mask) and channel chunk -- all scalar
+    unsigned ld_mask = tapmask;
+    int ld_tap = tapmask ? __builtin_ctz(tapmask) : 0;
     int ld_ky = ld_tap / p.KW, ld_kx = ld_tap - ld_ky * p.KW, ld_cc = 0;
     auto load_step = [&]() {
-        const int ld_ks = ld_tap * cpt + ld_cc;
+        const int64_t koff = TS > 1 ? (int64_t)ld_cc * BK : ((int64_t)ld_ky * p.W + ld_kx) * in_sp + ld_cc * BK;
+        const int woff = (ld_tap * cpt + ld_cc) * BK;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            int y = a_iy[i] + ld_ky, x = a_ix[i] + ld_kx;
-            bool ok = true;
-            if (p.ts > 1) {
-                ok = y >= 0 && x >= 0 && (y % p.ts) == 0 && (x % p.ts) == 0;
-                y /= p.ts;
-                x /= p.ts;
-            }
-            ok = ok && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *(const f32x4*)(p.in + a_base[i] + ((int64_t)y * p.W + x) * in_sp + ld_cc * BK);
-            ra[i] = v;
+            const bool ok = (a_mask[i] >> ld_tap) & 1u;
+            const float* src = a_ptr[i] + koff;
+            if (TS > 1) src += ((int64_t)((a_iy[i] + ld_ky) / TS) * p.W + (a_ix[i] + ld_kx) / TS) * in_sp;
+            ra[i] = *(const f32x4*)(ok ? src : zero);
         }
 #pragma unroll
-        for (int i = 0; i < BR; ++i) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (b_ok[i]) v = *(const f32x4*)(p.wt + b_off[i] + (int64_t)ld_ks * BK);
-            rb[i] = v;
-        }
+        for (int i = 0; i < BR; ++i) rb[i] = *(const f32x4*)(b_ptr[i] ? b_ptr[i] + woff : zero);
         if (++ld_cc == cpt) {
             ld_cc = 0;
             ld_mask &= ld_mask - 1;
-            ld_tap = ld_mask ? __builtin_ctzll(ld_mask) : 0;
+            ld_tap = ld_mask ? __builtin_ctz(ld_mask) : 0;
             ld_ky = ld_tap / p.KW;
             ld_kx = ld_tap - ld_ky * p.KW;
         }
@@ -170,9 +190,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
         float* As = buf;
         float* Bs = buf + BM * LDK;
 #pragma unroll
-        for (int i = 0; i < AR; ++i) *(f32x4*)(As + (sr + 32 * i) * LDK + sc * 4) = ra[i];
+        for (int i = 0; i < AR; ++i) *(f32x4*)(As + (sr + RPP * i) * LDK + sc * 4) = ra[i];
 #pragma unroll
-        for (int i = 0; i < BR; ++i) *(f32x4*)(Bs + (sr + 32 * i) * LDK + sc * 4) = rb[i];
+        for (int i = 0; i < BR; ++i) *(f32x4*)(Bs + (sr + RPP * i) * LDK + sc * 4) = rb[i];
     };
 
     if (nk > 0) {
@@ -205,80 +225,123 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: affine (folded BN / bias), residual, ReLU; 128-B row segments per half-wave ----
+    // ---- epilogue: accumulators -> LDS tile [BM/TM][BN+4] -> 16-byte pieces of contiguous output rows; one pass per
+    // accumulator row-tile so the tile never needs more LDS than the K-loop stages ----
+    float* C = lds;
+    constexpr int EM = BM / TM;                // rows per epilogue pass: wave wm contributes rows [wm*32, wm*32+32)
+    constexpr int C4 = BN / 4;                 // 16-byte pieces per tile row
+    constexpr int RP = 256 / C4;               // tile rows covered per sweep
+    constexpr int NPASS = EM / RP;
+    const int c4 = tid % C4, rr = tid / C4;
+    const int col = n0 + c4 * 4;
+    const bool aligned = (p.Cout & 3) == 0;    // otherwise rows are not 16-byte aligned (odd-sized k-NN bank): element-wise
+    const bool col_ok = col < p.Cout;
+    f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
+    if (aligned && col_ok && p.scale) s4 = *(const f32x4*)(p.scale + col);
+    if (aligned && col_ok && p.shift) t4 = *(const f32x4*)(p.shift + col);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + (wn * TN + j) * 32 + r;
-        if (col >= p.Cout) continue;
-        const float s = p.scale ? p.scale[col] : 1.f;
-        const float t = p.shift ? p.shift[col] : 0.f;
+    for (int i = 0; i < TM; ++i) {
+        if (i) __syncthreads();
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                int64_t row = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                bool row_ok = row < p.M;
-                if (p.posmajor) {
-                    row_ok = row < p.N;
-                    row = p.hwnc ? (int64_t)pos * p.N + row : row * HoWo + pos;
+            for (int e = 0; e < 16; ++e)
+                C[(wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + (wn * TN + j) * 32 + r] = acc[i][j][e];
+        __syncthreads();
+        int64_t o[NPASS];
+        f32x4 res[NPASS];
+#pragma unroll
+        for (int q = 0; q < NPASS; ++q) {
+            const int lr = rr + q * RP;                                      // row inside the pass tile
+            int64_t row = m0 + ((lr >> 5) * TM + i) * 32 + (lr & 31);        // lr>>5 = the wave-row that produced it
+            bool ok = col_ok;
+            if (POS) {
+                ok = ok && row < p.N;
+                row = p.hwnc ? (int64_t)pos * p.N + row : row * HoWo + pos;
+            } else {
+                ok = ok && row < p.M;
+            }
+            o[q] = ok ? row * p.Cout + col : -1;
+            res[q] = *(const f32x4*)((aligned && ok && p.residual) ? p.residual + o[q] : zero);
+        }
+#pragma unroll
+        for (int q = 0; q < NPASS; ++q) {
+            f32x4 v = *(const f32x4*)(C + (rr + q * RP) * LDC + c4 * 4);
+            if (aligned) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float x = v[k] * s4[k] + t4[k] + res[q][k];
+                    v[k] = p.relu ? fmaxf(x, 0.f) : x;
                 }
-                if (row_ok) {
-                    int64_t o = row * p.Cout + col;
-                    float v = acc[i][j][e] * s + t;
-                    if (p.residual) v += p.residual[o];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    p.out[o] = v;
+                if (o[q] >= 0) *(f32x4*)(p.out + o[q]) = v;
+            } else if (o[q] >= 0) {
+                for (int k = 0; k < 4 && col + k < p.Cout; ++k) {
+                    float x = v[k] * (p.scale ? p.scale[col + k] : 1.f) + (p.shift ? p.shift[col + k] : 0.f);
+                    if (p.residual) x += p.residual[o[q] + k];
+                    p.out[o[q] + k] = p.relu ? fmaxf(x, 0.f) : x;
                 }
             }
         }
     }
 }
 
-template <int BM, int BN, int TM, int TN>
+template <int BM, int BN, int TM, int TN, int BK, int TS, bool POS>
 int launch(const ConvParams& p, hipStream_t st) {
-    constexpr int lds_bytes = 2 * (BM + BN) * LDK * 4;
+    constexpr int stage_bytes = 2 * (BM + BN) * (BK + 4) * 4;
+    constexpr int epi_bytes = (BM / TM) * (BN + 4) * 4;
+    constexpr int lds_bytes = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_f32_kernel<BM, BN, TM, TN>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_f32_kernel<BM, BN, TM, TN, BK, TS, POS>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         attr_set = true;
     }
-    const int64_t gx = p.posmajor ? cdiv64(cdiv64(p.N, BM), 32) * 32 * p.Ho * p.Wo : cdiv64(p.M, BM);
+    const int64_t gx = POS ? cdiv64(cdiv64(p.N, BM), 32) * 32 * p.Ho * p.Wo : cdiv64(p.M, BM);
     dim3 grid((unsigned)gx, (unsigned)((p.Cout + BN - 1) / BN));
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, TM, TN>), grid, dim3(256), lds_bytes, st, p);
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, TM, TN, BK, TS, POS>), grid, dim3(256), lds_bytes, st, p);
     return 0;
 }
 
-}  // namespace
+template <int TS, bool POS>
+void dispatch(const ConvParams& p, hipStream_t st) {
+    static const int variant = getenv("SSAD_CONV64_VARIANT") ? atoi(getenv("SSAD_CONV64_VARIANT")) : 1;
+    if (p.Cout <= 64) {
+        if (variant == 1) launch<256, 64, 2, 2, 16, TS, POS>(p, st);
+        else launch<128, 64, 1, 2, 32, TS, POS>(p, st);
+    } else {
+        launch<128, 128, 2, 2, 32, TS, POS>(p, st);
+    }
+}
 
-static int conv_fwd_impl(const float* in, const float* w_ohwi, float* out, const float* scale,
-                                   const float* shift, const float* residual, int relu, int64_t N, int H, int W,
-                                   int Cin, int Cout, int KH, int KW, int stride, int pad, int hwnc, void* stream) {
+int conv_fwd_impl(const float* in, const float* w_ohwi, float* out, const float* scale, const float* shift,
+                  const float* residual, int relu, int64_t N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                  int pad, int hwnc, void* stream) {
     SSAD_CHECK_ARG(in && w_ohwi && out, "null pointer");
     SSAD_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "empty shape");
-    SSAD_CHECK_ARG(Cin % BK == 0, "Cin must be a multiple of 32");
-    SSAD_CHECK_ARG(KH > 0 && KW > 0 && stride > 0 && pad >= 0, "bad filter geometry");
+    SSAD_CHECK_ARG(Cin % KALIGN == 0, "Cin must be a multiple of 32");
+    SSAD_CHECK_ARG(KH > 0 && KW > 0 && stride > 0 && pad >= 0 && KH * KW <= 32, "bad filter geometry (<= 32 taps)");
     ConvParams p;
     p.in = in; p.wt = w_ohwi; p.out = out; p.scale = scale; p.shift = shift; p.residual = residual;
     p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.relu = relu;
     p.Ho = (H + 2 * pad - KH) / stride + 1;
     p.Wo = (W + 2 * pad - KW) / stride + 1;
-    p.ts = 1;
     SSAD_CHECK_ARG(p.Ho > 0 && p.Wo > 0, "empty output");
-    SSAD_CHECK_ARG(KH * KW <= 64, "at most 64 filter taps");
     p.M = N * p.Ho * p.Wo;
     p.N = N;
     p.K = KH * KW * Cin;
-    // position-major rows pay off when padding is a visible share of the taps (small maps, many samples)
-    p.posmajor = (hwnc || (pad > 0 && N >= 128 && p.Ho * p.Wo <= 4)) ? 1 : 0;
     p.hwnc = hwnc;
+    // position-major rows pay off when padding is a visible share of the taps (small maps, many samples); in the
+    // [H][W][N][C] layout they are also what makes a workgroup's rows contiguous
+    const bool posmajor = hwnc || (pad > 0 && N >= 128 && p.Ho * p.Wo <= 4);
     SSAD_CHECK_ARG(cdiv64(p.M, 128) + 32 * p.Ho * p.Wo < (int64_t)2147483647, "M too large for one launch");
     hipStream_t st = (hipStream_t)stream;
-    if (Cout <= 64) launch<128, 64, 1, 2>(p, st);
-    else launch<128, 128, 2, 2>(p, st);
+    if (posmajor) dispatch<1, true>(p, st);
+    else dispatch<1, false>(p, st);
     SSAD_CHECK_LAUNCH();
     return 0;
 }
+
+}  // namespace
 
 extern "C" int ssad_conv_igemm_fwd(const float* in, const float* w_ohwi, float* out, const float* scale,
                                    const float* shift, const float* residual, int relu, int64_t N, int H, int W,
@@ -304,21 +367,22 @@ extern "C" int ssad_conv_igemm_dgrad(const float* dy, const float* w_flipT, floa
                                      int pad, void* stream) {
     SSAD_CHECK_ARG(dy && w_flipT && dx, "null pointer");
     SSAD_CHECK_ARG(N > 0 && Hy > 0 && Wy > 0 && Hx > 0 && Wx > 0 && Cin > 0 && Cout > 0, "empty shape");
-    SSAD_CHECK_ARG(Cout % BK == 0, "Cout (the contraction) must be a multiple of 32");
-    SSAD_CHECK_ARG(KH > 0 && KW > 0 && stride > 0 && pad >= 0 && pad < KH && pad < KW, "bad filter geometry");
+    SSAD_CHECK_ARG(Cout % KALIGN == 0, "Cout (the contraction) must be a multiple of 32");
+    SSAD_CHECK_ARG(KH > 0 && KW > 0 && pad >= 0 && pad < KH && pad < KW, "bad filter geometry");
+    SSAD_CHECK_ARG(stride == 1 || stride == 2, "stride 1 or 2");
     SSAD_CHECK_ARG((Hx + 2 * pad - KH) / stride + 1 == Hy && (Wx + 2 * pad - KW) / stride + 1 == Wy, "dy/dx sizes disagree");
+    SSAD_CHECK_ARG(KH == KW && KH * KW <= 32, "square filters with at most 32 taps only");
     ConvParams p;
     p.in = dy; p.wt = w_flipT; p.out = dx; p.scale = nullptr; p.shift = nullptr; p.residual = residual;
     p.H = Hy; p.W = Wy; p.Cin = Cout; p.Cout = Cin; p.KH = KH; p.KW = KW; p.relu = 0;
-    p.stride = 1; p.pad = KH - 1 - pad; p.ts = stride; p.posmajor = 0; p.N = N; p.hwnc = 0;
-    SSAD_CHECK_ARG(KH == KW && KH * KW <= 64, "square filters with at most 64 taps only");
+    p.stride = 1; p.pad = KH - 1 - pad; p.N = N; p.hwnc = 0;
     p.Ho = Hx; p.Wo = Wx;
     p.M = N * Hx * Wx;
     p.K = KH * KW * Cout;
     SSAD_CHECK_ARG(cdiv64(p.M, 128) < (int64_t)2147483647, "M too large for one launch");
     hipStream_t st = (hipStream_t)stream;
-    if (Cin <= 64) launch<128, 64, 1, 2>(p, st);
-    else launch<128, 128, 2, 2>(p, st);
+    if (stride == 1) dispatch<1, false>(p, st);
+    else dispatch<2, false>(p, st);
     SSAD_CHECK_LAUNCH();
     return 0;
 }

@@ -47,6 +47,8 @@ CONV_CASES = [
     (200, 2, 2, 64, 128, 3, 1, 1, True, False, True),        #   zero-padding taps skipped as whole K-steps
     (150, 8, 8, 32, 96, 3, 2, 1, False, True, False),
     (129, 1, 1, 32, 64, 3, 1, 1, True, False, False),        # 1x1 map: only the centre tap survives
+    (3, 5, 5, 64, 411, 1, 1, 0, True, True, True),           # Cout not a multiple of 4 (odd-sized k-NN bank)
+    (140, 2, 2, 32, 70, 3, 1, 1, True, False, True),
 ]
 
 
