@@ -55,6 +55,14 @@ int ssad_pack_stem_weight(const float* w_oihw, float* wk, void* stream);
 int ssad_stem_fwd(const float* img, int B, int H, int W, int patch_dim, int patch_stride, int Hv, int Wv,
                   const float* wk, const float* scale, const float* shift, int relu, int hwnc, float* out, void* stream);
 
+/* Patch-scoring specialisation of the stem (32x32 windows, exact 2x nearest upsample): the same call sites as
+ * ssad_stem_fwd + ssad_maxpool3x3s2_fwd fused into one kernel.  conv7x7/2 over the upsampled window is evaluated as
+ * the equivalent 4x4 stride-1 conv over the 32x32 source with pre-summed weights (wf = ssad_pack_stem_weight_folded),
+ * BN+ReLU+max-pool are applied in LDS; out = [Nsamp][16][16][64] (or [16][16][Nsamp][64] when hwnc). */
+int ssad_pack_stem_weight_folded(const float* w_oihw, float* wf, void* stream);
+int ssad_stem_patch_pool_fwd(const float* img, int B, int H, int W, int patch_stride, const float* wf, const float* scale,
+                             const float* shift, int hwnc, float* out, void* stream);
+
 /* Replaces nn.MaxPool2d(3, 2, 1) of the torchvision stem (models.py:224).  NHWC, or [H][W][N][C] when hwnc. */
 int ssad_maxpool3x3s2_fwd(const float* in, float* out, int64_t N, int H, int W, int C, int hwnc, void* stream);
 

@@ -128,6 +128,133 @@ __global__ __launch_bounds__(256, 2) void stem_conv7x7_kernel(StemParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Patch-scoring stem: 32x32 window, exact 2x nearest upsample, conv7x7/2 + affine + ReLU + max-pool 3x3/2, fused.
+//
+// nearest-2x followed by a stride-2 7x7 conv touches each SOURCE pixel through a fixed group of taps:
+//   ky -> source row oy-2+a with a = 0:{0} 1:{1,2} 2:{3,4} 3:{5,6}   (same for kx -> b), and a virtual row is in
+// the zero padding exactly when its source row is outside [0,32).  So
+//   out[oy][ox][co] = sum_{a,b<4,c} src[oy-2+a][ox-2+b][c] * Wf[co][a][b][c],  Wf = group sums of W   (K 147 -> 48)
+// -- the same real number as the reference's sum, rounded differently (1 ulp-level).  The 32x32x64 conv map goes
+// through an LDS ring of 9 rows (32 channels at a time), is pooled there and only the 16x16x64 result is stored.
+// ---------------------------------------------------------------------------------------------
+constexpr int SP_SW = 40, SP_SH = 36;                 // source tile: rows -2..33, cols -2..37 (zero halo)
+constexpr int SP_SRC = SP_SH * SP_SW * 3;             // 4320 floats
+constexpr int SP_WF = 24 * 2 * 64;                    // folded weights [a*2+q][c][h][co] = 3072 floats
+constexpr int SP_CB = 9 * 32 * 32;                    // conv-row ring [slot][ox][32 ch] = 9216 floats
+
+struct StemPatchParams {
+    const float* img;
+    const float* wf;
+    const float* scale;
+    const float* shift;
+    float* out;
+    int B, H, W, ps, prow, pcol, hwnc;
+    int64_t Nsamp;
+};
+
+__global__ __launch_bounds__(256, 2) void stem_patch_fused_kernel(StemPatchParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wl = lds;
+    float* src = lds + SP_WF;
+    float* cb = src + SP_SRC;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    for (int i = tid; i < SP_WF / 4; i += 256) ((f32x4*)wl)[i] = ((const f32x4*)p.wf)[i];
+    const int P = p.prow * p.pcol;
+    const int64_t plane = (int64_t)p.H * p.W;
+
+    for (int64_t n = blockIdx.x; n < p.Nsamp; n += gridDim.x) {
+        const int b = (int)(n / P);
+        const int pi = (int)(n - (int64_t)b * P);
+        const int y0 = (pi / p.pcol) * p.ps, x0 = (pi % p.pcol) * p.ps;
+        const float* im = p.img + (int64_t)b * 3 * plane;
+        __syncthreads();                                    // previous patch fully consumed
+        for (int i = tid; i < SP_SH * SP_SW; i += 256) {
+            const int ty = i / SP_SW, tx = i - ty * SP_SW;
+            const int sy = ty - 2, sx = tx - 2;
+            float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+            if ((unsigned)sy < 32u && (unsigned)sx < 32u) {
+                const float* s = im + (int64_t)(y0 + sy) * p.W + x0 + sx;
+                v0 = s[0]; v1 = s[plane]; v2 = s[2 * plane];
+            }
+            float* d = src + i * 3;
+            d[0] = v0; d[1] = v1; d[2] = v2;
+        }
+        for (int pass = 0; pass < 2; ++pass) {
+            const float sc = p.scale ? p.scale[pass * 32 + r] : 1.f;
+            const float sh = p.shift ? p.shift[pass * 32 + r] : 0.f;
+            for (int i = tid; i < 32 * 32; i += 256) cb[i] = 0.f;      // ring slot 0 = conv row -1 (below every ReLU output)
+            __syncthreads();
+            for (int t = 0; t < 4; ++t) {
+                f32x16 acc0, acc1;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+                const int oy = 8 * t + 2 * wave;
+                const float* a0 = src + ((oy + 0) * SP_SW + r + h) * 3;
+                const float* a1 = src + ((oy + 1) * SP_SW + r + h) * 3;
+                const float* bw = wl + h * 64 + pass * 32 + r;
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const int ko = (a * SP_SW + 2 * q) * 3 + c;
+                            const float w = bw[((a * 2 + q) * 3 + c) * 128];
+                            acc0 = mfma32(a0[ko], w, acc0);
+                            acc1 = mfma32(a1[ko], w, acc1);
+                        }
+                float* c0 = cb + ((1 + 2 * wave) * 32) * 32 + r;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int ox = (e & 3) + 8 * (e >> 2) + 4 * h;
+                    c0[ox * 32] = fmaxf(acc0[e] * sc + sh, 0.f);
+                    c0[(32 + ox) * 32] = fmaxf(acc1[e] * sc + sh, 0.f);
+                }
+                __syncthreads();
+                // pool: pooled rows 4t .. 4t+3 from ring slots 2j .. 2j+2; 512 float4 items
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int item = tid + 256 * k;
+                    const int c4 = item & 7, px = (item >> 3) & 15, j = item >> 7;
+                    f32x4 m = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                        for (int dx = -1; dx < 2; ++dx) {
+                            const int cx = 2 * px + dx;
+                            if (cx < 0) continue;
+                            const f32x4 v = *(const f32x4*)(cb + ((2 * j + dy) * 32 + cx) * 32 + c4 * 4);
+                            m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+                        }
+                    const int py = 4 * t + j;
+                    const int64_t pix = p.hwnc ? ((int64_t)py * 16 + px) * p.Nsamp + n : (n * 16 + py) * 16 + px;
+                    *(f32x4*)(p.out + pix * 64 + pass * 32 + c4 * 4) = m;
+                }
+                __syncthreads();
+                ((f32x4*)cb)[tid] = ((const f32x4*)(cb + 8 * 32 * 32))[tid];      // slot 8 -> slot 0 for the next tile
+                __syncthreads();
+            }
+        }
+    }
+}
+
+// OIHW [64][3][7][7] -> folded [ (a*2+q)*3 + c ][h][co], b = 2q+h, a/b tap groups {0},{1,2},{3,4},{5,6}
+__global__ void pack_stem_weight_folded_kernel(const float* __restrict__ w, float* __restrict__ wf) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= SP_WF) return;
+    const int co = i & 63, hh = (i >> 6) & 1, s = i >> 7;
+    const int c = s % 3, q = (s / 3) & 1, a = s / 6;
+    const int b = 2 * q + hh;
+    const int ky0 = a == 0 ? 0 : 2 * a - 1, ky1 = a == 0 ? 0 : 2 * a;
+    const int kx0 = b == 0 ? 0 : 2 * b - 1, kx1 = b == 0 ? 0 : 2 * b;
+    float acc = 0.f;
+    for (int ky = ky0; ky <= ky1; ++ky)
+        for (int kx = kx0; kx <= kx1; ++kx) acc += w[((co * 3 + c) * 7 + ky) * 7 + kx];
+    wf[i] = acc;
+}
+
 __global__ void pack_stem_weight_kernel(const float* __restrict__ w, float* __restrict__ wk) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;     // over 168*64
     if (i >= 168 * 64) return;
@@ -215,6 +342,35 @@ extern "C" int ssad_stem_fwd(const float* img, int B, int H, int W, int patch_di
     }
     int64_t grid = p.total_tiles < 4096 ? p.total_tiles : 4096;   // 2 resident per CU x 256 CUs x 8 rounds
     hipLaunchKernelGGL(stem_conv7x7_kernel, dim3((unsigned)grid), dim3(256), lds_bytes, (hipStream_t)stream, p);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ssad_pack_stem_weight_folded(const float* w_oihw, float* wf, void* stream) {
+    SSAD_CHECK_ARG(w_oihw && wf, "null pointer");
+    hipLaunchKernelGGL(pack_stem_weight_folded_kernel, dim3((SP_WF + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_oihw, wf);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ssad_stem_patch_pool_fwd(const float* img, int B, int H, int W, int patch_stride, const float* wf,
+                                        const float* scale, const float* shift, int hwnc, float* out, void* stream) {
+    SSAD_CHECK_ARG(img && wf && out, "null pointer");
+    SSAD_CHECK_ARG(B > 0 && H >= 32 && W >= 32 && patch_stride > 0, "bad shape (32x32 windows)");
+    StemPatchParams p;
+    p.img = img; p.wf = wf; p.scale = scale; p.shift = shift; p.out = out;
+    p.B = B; p.H = H; p.W = W; p.ps = patch_stride; p.hwnc = hwnc;
+    p.prow = (H - 32) / patch_stride + 1;
+    p.pcol = (W - 32) / patch_stride + 1;
+    p.Nsamp = (int64_t)B * p.prow * p.pcol;
+    constexpr int lds_bytes = (SP_WF + SP_SRC + SP_CB) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)stem_patch_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        attr_set = true;
+    }
+    const int64_t grid = p.Nsamp < 2048 ? p.Nsamp : 2048;
+    hipLaunchKernelGGL(stem_patch_fused_kernel, dim3((unsigned)grid), dim3(256), lds_bytes, (hipStream_t)stream, p);
     SSAD_CHECK_LAUNCH();
     return 0;
 }

@@ -66,6 +66,7 @@ class EvalPlan:
         self.version = param_version(model)
         with torch.no_grad():
             self.stem_w = ops.pack_stem_weight(fe.conv1.weight.contiguous())
+            self.stem_wf = ops.pack_stem_weight_folded(fe.conv1.weight.contiguous())
             self.stem_s, self.stem_t = _fold_bn(fe.bn1)
             self.blocks = []
             for name, _, _, _ in BLOCKS:
@@ -105,8 +106,13 @@ def trunk_eval(plan, x, patch_dim, patch_stride, layer_outputs, pooled):
     p, hv, wv, _, _ = ops.stem_geometry(h, w, patch_dim, patch_stride)
     hwnc = b * p >= 128 and hv * wv <= 64 * 64
     conv = ops.conv_fwd_hwnc if hwnc else ops.conv_fwd
-    a = ops.stem_fwd(x, plan.stem_w, plan.stem_s, plan.stem_t, True, patch_dim, patch_stride, hwnc)
-    a = ops.maxpool3x3s2_fwd(a, hwnc)
+    win = (patch_dim, patch_dim) if patch_dim else (h, w)
+    if win == (32, 32):
+        # exact 2x nearest upsample: folded 4x4 conv + BN + ReLU + max-pool fused, the conv map never reaches HBM
+        a = ops.stem_patch_pool_fwd(x, plan.stem_wf, plan.stem_s, plan.stem_t, patch_stride if patch_dim else 1, hwnc)
+    else:
+        a = ops.stem_fwd(x, plan.stem_w, plan.stem_s, plan.stem_t, True, patch_dim, patch_stride, hwnc)
+        a = ops.maxpool3x3s2_fwd(a, hwnc)
     offs, off = {}, 0
     for k in ("layer1", "layer2", "layer3"):
         if k in layer_outputs:

@@ -79,6 +79,25 @@ def stem_fwd(img, wk, scale, shift, relu=True, patch_dim=0, patch_stride=0, hwnc
     return out
 
 
+def pack_stem_weight_folded(w):
+    assert tuple(w.shape) == (64, 3, 7, 7)
+    out = _new((24, 2, 64), w)
+    _hip.check(_hip.lib().ssad_pack_stem_weight_folded(_hip.ptr(w), _hip.ptr(out), _hip.stream()))
+    return out
+
+
+def stem_patch_pool_fwd(img, wf, scale, shift, patch_stride=8, hwnc=False):
+    """32x32 windows (stride patch_stride) of img [B][3][H][W] -> pooled stem output [N][16][16][64] / [16][16][N][64]:
+    window + 2x nearest upsample + conv7x7/2 + affine + ReLU + max-pool in one kernel."""
+    b, c, h, w = img.shape
+    n = b * ((h - 32) // patch_stride + 1) * ((w - 32) // patch_stride + 1)
+    out = _new((16, 16, n, 64) if hwnc else (n, 16, 16, 64), img)
+    _run("stem_patch_pool", 2.0 * n * 32 * 32 * 64 * 147, 4.0 * (img.numel() + out.numel()),
+         lambda: _hip.lib().ssad_stem_patch_pool_fwd(_hip.ptr(img), b, h, w, patch_stride, _hip.ptr(wf), _hip.ptr(scale, True),
+                                                     _hip.ptr(shift, True), int(hwnc), _hip.ptr(out), _hip.stream()))
+    return out
+
+
 def maxpool3x3s2_fwd(x, hwnc=False):
     if hwnc:
         h, w, n, c = x.shape

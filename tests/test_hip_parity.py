@@ -136,6 +136,29 @@ def test_stem_and_pool(dev, mode, seeded_sd):
     assert torch.equal(nchw(pooled).cpu(), F.max_pool2d(nchw(got).cpu(), 3, 2, 1))
 
 
+@pytest.mark.parametrize("hwnc", [False, True])
+def test_fused_patch_stem(dev, seeded_sd, hwnc):
+    """Folded 4x4 conv + affine + ReLU + max-pool == upsample, conv7x7/2, affine, ReLU, max_pool2d."""
+    from self_supervised import ops
+    from oracle import weights as ow, scoring as osc
+    w = seeded_sd["feature_extractor.conv1.weight"]
+    g = torch.Generator().manual_seed(4)
+    sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    x = ow.synthetic_images(2, 64, seed=11)[:, :, :, :56].contiguous()
+    p = osc.extract_patches(x, 32, 8).reshape(-1, 3, 32, 32)
+    want = F.max_pool2d((F.conv2d(F.interpolate(p, 64, mode="nearest"), w, None, 2, 3) * sc.view(1, -1, 1, 1)
+                         + sh.view(1, -1, 1, 1)).relu(), 3, 2, 1)
+    got = ops.stem_patch_pool_fwd(x.to(dev), ops.pack_stem_weight_folded(w.to(dev)), sc.to(dev), sh.to(dev), 8, hwnc)
+    got = got.permute(2, 3, 0, 1) if hwnc else got.permute(0, 3, 1, 2)
+    assert_close(got, want, 2e-5)
+    # image-level 32x32 inputs take the same kernel (one window per image)
+    xi = ow.synthetic_images(3, 32, seed=12)
+    want = F.max_pool2d((F.conv2d(F.interpolate(xi, 64, mode="nearest"), w, None, 2, 3) * sc.view(1, -1, 1, 1)
+                         + sh.view(1, -1, 1, 1)).relu(), 3, 2, 1)
+    got = ops.stem_patch_pool_fwd(xi.to(dev), ops.pack_stem_weight_folded(w.to(dev)), sc.to(dev), sh.to(dev), 1, False)
+    assert_close(got.permute(0, 3, 1, 2), want, 2e-5)
+
+
 def test_gap(dev):
     from self_supervised import ops
     x = torch.randn(5, 8, 8, 128)
