@@ -39,24 +39,35 @@ __global__ void col_reduce_kernel(const float* __restrict__ a, const float* __re
         if (MODE == 1 && z) { mu = ((const f32x4*)mean)[cq]; is = ((const f32x4*)invstd)[cq]; }
         const int64_t rb = (int64_t)blockIdx.y * rows_per_block;
         const int64_t re = rb + rows_per_block < R ? rb + rows_per_block : R;
-        for (int64_t row = rb + ty; row < re; row += RL) {
-            const int64_t o = row * C4 + cq;
-            f32x4 v = ((const f32x4*)a)[o];
-            if (MODE == 0) {
+        // 4 rows per iteration: all loads of an iteration are issued before any is consumed (latency-bound otherwise)
+        constexpr int U = 4;
+        for (int64_t row = rb + ty; row < re; row += (int64_t)U * RL) {
+            f32x4 v[U], ya[U], zz[U];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { s0[k] += (double)v[k]; s1[k] += (double)v[k] * (double)v[k]; }
-            } else {
-                if (yact) {
-                    f32x4 ya = ((const f32x4*)yact)[o];
+            for (int u = 0; u < U; ++u) {
+                const int64_t rw = row + (int64_t)u * RL;
+                const int64_t o = (rw < re ? rw : rb + ty) * C4 + cq;       // clamp: tail rows re-read a valid row ...
+                v[u] = ((const f32x4*)a)[o];
+                if (MODE == 1 && yact) ya[u] = ((const f32x4*)yact)[o];
+                if (MODE == 1 && z) zz[u] = ((const f32x4*)z)[o];
+            }
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = ya[k] > 0.f ? v[k] : 0.f;
-                }
+            for (int u = 0; u < U; ++u) {
+                if (row + (int64_t)u * RL >= re) continue;                  // ... and are dropped here
+                if (MODE == 0) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) s0[k] += (double)v[k];
-                if (z) {
-                    f32x4 zz = ((const f32x4*)z)[o];
+                    for (int k = 0; k < 4; ++k) { s0[k] += (double)v[u][k]; s1[k] += (double)v[u][k] * (double)v[u][k]; }
+                } else {
+                    if (yact) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) s1[k] += (double)v[k] * (double)((zz[k] - mu[k]) * is[k]);
+                        for (int k = 0; k < 4; ++k) v[u][k] = ya[u][k] > 0.f ? v[u][k] : 0.f;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) s0[k] += (double)v[u][k];
+                    if (z) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) s1[k] += (double)v[u][k] * (double)((zz[u][k] - mu[k]) * is[k]);
+                    }
                 }
             }
         }
@@ -77,14 +88,33 @@ __global__ void col_reduce_kernel(const float* __restrict__ a, const float* __re
     }
 }
 
-// BN forward statistics: mean, invstd (biased var), running stats (unbiased var, momentum)
+// Sum of the per-block partials of one channel: one wave per channel, lane l adds partials l, l+64, ... in order and
+// the 64 lane sums are combined by a fixed xor-butterfly (deterministic; every lane ends with the total).
+__device__ __forceinline__ void channel_totals(const double* __restrict__ partial, int nblk, int C, int c, double& s0, double& s1) {
+    const int lane = threadIdx.x & 63;
+    double a = 0, b = 0;
+    for (int k = lane; k < nblk; k += 64) {
+        a += partial[(int64_t)k * 2 * C + c];
+        b += partial[(int64_t)k * 2 * C + C + c];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o);
+        b += __shfl_xor(b, o);
+    }
+    s0 = a;
+    s1 = b;
+}
+
+// BN forward statistics: mean, invstd (biased var), running stats (unbiased var, momentum).  4 waves = 4 channels / block
 __global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, int nblk, int64_t R, int C, float eps,
                                          float momentum, float* __restrict__ mean, float* __restrict__ invstd,
                                          float* __restrict__ running_mean, float* __restrict__ running_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
-    double s0 = 0, s1 = 0;
-    for (int b = 0; b < nblk; ++b) { s0 += partial[(int64_t)b * 2 * C + c]; s1 += partial[(int64_t)b * 2 * C + C + c]; }
+    double s0, s1;
+    channel_totals(partial, nblk, C, c, s0, s1);
+    if ((threadIdx.x & 63) != 0) return;
     const double m = s0 / (double)R;
     double var = s1 / (double)R - m * m;
     if (var < 0) var = 0;
@@ -99,10 +129,11 @@ __global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, int
 
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblk, int C, float* __restrict__ dbeta,
                                        float* __restrict__ dgamma) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
-    double s0 = 0, s1 = 0;
-    for (int b = 0; b < nblk; ++b) { s0 += partial[(int64_t)b * 2 * C + c]; s1 += partial[(int64_t)b * 2 * C + C + c]; }
+    double s0, s1;
+    channel_totals(partial, nblk, C, c, s0, s1);
+    if ((threadIdx.x & 63) != 0) return;
     if (dbeta) dbeta[c] = (float)s0;
     if (dgamma) dgamma[c] = (float)s1;
 }
@@ -171,37 +202,45 @@ __global__ void bn_apply_bwd_kernel(const float* __restrict__ dy, const float* _
 // dx[n][y][x][c] = sum over the (<= 4) 3x3/2 windows covering (y,x) whose FIRST maximum (row-major scan, as
 // PyTorch's max_pool2d picks it) is (y,x).  Gather form: deterministic, no atomics.
 __global__ void maxpool_bwd_kernel(const float* __restrict__ xin, const float* __restrict__ dy, float* __restrict__ dx,
-                                   int64_t total, int H, int W, int C, int Ho, int Wo) {
+                                   int64_t total4, int H, int W, int C4, int Ho, int Wo) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int c = (int)(i % C);
-    int64_t t = i / C;
+    if (i >= total4) return;
+    const int c4 = (int)(i % C4);
+    int64_t t = i / C4;
     const int x = (int)(t % W); t /= W;
     const int y = (int)(t % H);
     const int64_t n = t / H;
-    const float* xp = xin + n * H * W * C + c;
-    float acc = 0.f;
+    const f32x4* xp = (const f32x4*)xin + n * H * W * C4 + c4;
+    const f32x4 self = xp[((int64_t)y * W + x) * C4];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int oy0 = y / 2, oy1 = (y + 1) / 2, ox0 = x / 2, ox1 = (x + 1) / 2;     // windows with 2*o-1 <= pos <= 2*o+1
     for (int oy = oy0; oy <= oy1; ++oy) {
         if (oy >= Ho) continue;
         for (int ox = ox0; ox <= ox1; ++ox) {
             if (ox >= Wo) continue;
-            float best = -INFINITY;
-            int by = -1, bx = -1;
+            // (y,x) is the window's FIRST maximum (PyTorch's tie rule) iff every earlier position (row-major) is
+            // strictly smaller and every later one is not larger
+            bool win[4] = {true, true, true, true};
+#pragma unroll
             for (int dyy = 0; dyy < 3; ++dyy) {
                 const int yy = 2 * oy - 1 + dyy;
                 if ((unsigned)yy >= (unsigned)H) continue;
+#pragma unroll
                 for (int dxx = 0; dxx < 3; ++dxx) {
                     const int xx = 2 * ox - 1 + dxx;
-                    if ((unsigned)xx >= (unsigned)W) continue;
-                    const float v = xp[((int64_t)yy * W + xx) * C];
-                    if (v > best || by < 0) { best = v; by = yy; bx = xx; }
+                    if ((unsigned)xx >= (unsigned)W || (yy == y && xx == x)) continue;
+                    const f32x4 v = xp[((int64_t)yy * W + xx) * C4];
+                    const bool earlier = yy < y || (yy == y && xx < x);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) win[k] = win[k] && (earlier ? v[k] < self[k] : v[k] <= self[k]);
                 }
             }
-            if (by == y && bx == x) acc += dy[((n * Ho + oy) * Wo + ox) * C + c];
+            const f32x4 g = ((const f32x4*)dy)[((n * Ho + oy) * Wo + ox) * C4 + c4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] += win[k] ? g[k] : 0.f;
         }
     }
-    dx[i] = acc;
+    ((f32x4*)dx)[i] = acc;
 }
 
 // dy[n][hw][c] (+)= dpooled[n*stride + off + c] / HW
@@ -218,25 +257,29 @@ __global__ void gap_bwd_kernel(const float* __restrict__ dpooled, float* __restr
 // ---------------------------------------------------------------------------------------------
 // stem im2col: Xcol[m][k], k = (ky*7 + kx)*3 + c for k < 147, zero for 147 <= k < 160; nearest resize fused
 // ---------------------------------------------------------------------------------------------
-__global__ void stem_im2col_kernel(const float* __restrict__ img, float* __restrict__ col, int64_t total, int H, int W,
+__global__ void stem_im2col_kernel(const float* __restrict__ img, float* __restrict__ col, int64_t total4, int H, int W,
                                    int Hv, int Wv, int Ho, int Wo) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int k = (int)(i % 160);
-    int64_t m = i / 160;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // one 16-byte piece of a 160-float row
+    if (i >= total4) return;
+    const int k4 = (int)(i % 40);
+    int64_t m = i / 40;
     const int ox = (int)(m % Wo); m /= Wo;
     const int oy = (int)(m % Ho);
     const int64_t n = m / Ho;
-    float v = 0.f;
-    if (k < 147) {
-        const int c = k % 3, tap = k / 3, ky = tap / 7, kx = tap % 7;
-        const int vy = 2 * oy - 3 + ky, vx = 2 * ox - 3 + kx;
-        if ((unsigned)vy < (unsigned)Hv && (unsigned)vx < (unsigned)Wv) {
-            const int sy = (vy * H) / Hv, sx = (vx * W) / Wv;
-            v = img[((n * 3 + c) * H + sy) * W + sx];
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = k4 * 4 + j;
+        if (k < 147) {
+            const int c = k % 3, tap = k / 3, ky = tap / 7, kx = tap % 7;
+            const int vy = 2 * oy - 3 + ky, vx = 2 * ox - 3 + kx;
+            if ((unsigned)vy < (unsigned)Hv && (unsigned)vx < (unsigned)Wv) {
+                const int sy = (vy * H) / Hv, sx = (vx * W) / Wv;
+                v[j] = img[((n * 3 + c) * H + sy) * W + sx];
+            }
         }
     }
-    col[i] = v;
+    ((f32x4*)col)[i] = v;
 }
 
 // OIHW [64][3][7][7] -> [64][160] rows in im2col k order (zero padded)
@@ -324,8 +367,8 @@ static inline unsigned ew_grid(int64_t n) {
 // Number of doubles of workspace the column reductions need for R rows x C channels.
 extern "C" int64_t ssad_colreduce_workspace(int64_t R, int C) {
     ColReduce g = col_geom(C);
-    int64_t nblk = cdiv64(R, (int64_t)g.RL * 64);
-    if (nblk > 1024) nblk = 1024;
+    int64_t nblk = cdiv64(R, (int64_t)g.RL * 32);
+    if (nblk > 2048) nblk = 2048;
     if (nblk < 1) nblk = 1;
     return nblk * 2 * C;
 }
@@ -333,8 +376,8 @@ extern "C" int64_t ssad_colreduce_workspace(int64_t R, int C) {
 static int launch_col_reduce(int mode, const float* a, const float* yact, const float* z, const float* mean,
                              const float* invstd, double* ws, int64_t R, int C, int* nblk_out, hipStream_t st) {
     ColReduce g = col_geom(C);
-    int64_t nblk = cdiv64(R, (int64_t)g.RL * 64);
-    if (nblk > 1024) nblk = 1024;
+    int64_t nblk = cdiv64(R, (int64_t)g.RL * 32);
+    if (nblk > 2048) nblk = 2048;
     if (nblk < 1) nblk = 1;
     int rows_per_block = (int)cdiv64(R, nblk);
     int gx = (C / 4 + g.TC - 1) / g.TC;
@@ -352,7 +395,7 @@ extern "C" int ssad_bn_stats(const float* z, int64_t R, int C, float eps, float 
     SSAD_CHECK_ARG(z && mean && invstd && workspace && R > 0 && C > 0 && C % 4 == 0, "bad argument");
     int nblk;
     launch_col_reduce(0, z, nullptr, nullptr, nullptr, nullptr, workspace, R, C, &nblk, (hipStream_t)stream);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace, nblk, R, C,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, workspace, nblk, R, C,
                        eps, momentum, mean, invstd, running_mean, running_var);
     SSAD_CHECK_LAUNCH();
     return 0;
@@ -375,7 +418,7 @@ extern "C" int ssad_bn_bwd_reduce(const float* dy, const float* yact, const floa
     SSAD_CHECK_ARG(!z || (mean && invstd), "z needs mean/invstd");
     int nblk;
     launch_col_reduce(1, dy, yact, z, mean, invstd, workspace, R, C, &nblk, (hipStream_t)stream);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace, nblk, C, dbeta,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, workspace, nblk, C, dbeta,
                        z ? dgamma : nullptr);
     SSAD_CHECK_LAUNCH();
     return 0;
@@ -396,10 +439,11 @@ extern "C" int ssad_bn_apply_bwd(const float* dy, const float* yact, const float
 extern "C" int ssad_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int64_t N, int H, int W, int C, void* stream) {
     SSAD_CHECK_ARG(x && dy && dx && N > 0 && H > 0 && W > 0 && C > 0, "bad argument");
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    const int64_t total = N * H * W * C;
+    SSAD_CHECK_ARG(C % 4 == 0, "C must be a multiple of 4");
+    const int64_t total = N * H * W * (C / 4);
     SSAD_CHECK_ARG(cdiv64(total, 256) < (int64_t)2147483647, "too large");
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, total,
-                       H, W, C, Ho, Wo);
+                       H, W, C / 4, Ho, Wo);
     SSAD_CHECK_LAUNCH();
     return 0;
 }
@@ -417,9 +461,9 @@ extern "C" int ssad_gap_bwd(const float* dpooled, float* dy, int64_t N, int HW, 
 extern "C" int ssad_stem_im2col(const float* img, float* col, int64_t B, int H, int W, int Hv, int Wv, void* stream) {
     SSAD_CHECK_ARG(img && col && B > 0 && H > 0 && W > 0 && Hv > 0 && Wv > 0, "bad argument");
     const int Ho = (Hv - 1) / 2 + 1, Wo = (Wv - 1) / 2 + 1;
-    const int64_t total = B * Ho * Wo * 160;
-    SSAD_CHECK_ARG(cdiv64(total, 256) < (int64_t)2147483647, "too large");
-    hipLaunchKernelGGL(stem_im2col_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, img, col, total,
+    const int64_t total4 = B * Ho * Wo * 40;
+    SSAD_CHECK_ARG(cdiv64(total4, 256) < (int64_t)2147483647, "too large");
+    hipLaunchKernelGGL(stem_im2col_kernel, dim3((unsigned)cdiv64(total4, 256)), dim3(256), 0, (hipStream_t)stream, img, col, total4,
                        H, W, Hv, Wv, Ho, Wo);
     SSAD_CHECK_LAUNCH();
     return 0;

@@ -17,6 +17,8 @@ namespace {
 
 constexpr int PK = 32;   // pixels per staging step
 
+__device__ __attribute__((aligned(16))) float g_wzero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
 struct WgradParams {
     const float* dy;
     const float* x;
@@ -58,24 +60,45 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(WgradParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    // Per-row pixel coordinates are carried incrementally (a step advances every row by PK pixels), so the pixel loop
+    // holds no integer division; out-of-range rows / padding taps read a zero page instead of branching.
+    const float* zero = g_wzero;
+    const int dn = PK / HoWo, rp = PK - dn * HoWo;          // PK pixels = dn samples + rp pixels
+    const int dyy = rp / p.Wo, dxx = rp - dyy * p.Wo;
+    int rn[NP], roy[NP], rox[NP];
+    const float* yptr[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int64_t m = m_begin + r0 + i * RPP;
+        const int64_t n = m / HoWo;
+        const int rem = (int)(m - n * HoWo);
+        rn[i] = (int)n;
+        roy[i] = rem / p.Wo;
+        rox[i] = rem - roy[i] * p.Wo;
+        yptr[i] = p.dy + m * p.Cout + co0 + c4 * 4;
+    }
+    const int64_t ystep = (int64_t)PK * p.Cout;
+    const float* xbase = p.x + ci0 + c4 * 4;
+    int64_t mrow = m_begin + r0;                              // flattened row of pass 0 at the step being loaded
+
     f32x4 ry[NP], rx[NP];
-    auto load_step = [&](int64_t mb) {
+    auto load_step = [&]() {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            const int64_t m = mb + r0 + i * RPP;
-            f32x4 vy = {0.f, 0.f, 0.f, 0.f}, vx = {0.f, 0.f, 0.f, 0.f};
-            if (m < m_end) {
-                if (co_ok) vy = *(const f32x4*)(p.dy + m * p.Cout + co0 + c4 * 4);
-                const int64_t n = m / HoWo;
-                const int rem = (int)(m - n * HoWo);
-                const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-                const int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
-                if (ci_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-                    vx = *(const f32x4*)(p.x + ((n * p.H + iy) * p.W + ix) * p.Cin + ci0 + c4 * 4);
-            }
-            ry[i] = vy;
-            rx[i] = vx;
+            const bool live = mrow + i * RPP < m_end;
+            const int iy = roy[i] * p.stride - p.pad + ky, ix = rox[i] * p.stride - p.pad + kx;
+            const bool inb = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const float* xs = xbase + (((int64_t)rn[i] * p.H + iy) * p.W + ix) * p.Cin;
+            ry[i] = *(const f32x4*)((live && co_ok) ? yptr[i] : zero);
+            rx[i] = *(const f32x4*)((live && inb && ci_ok) ? xs : zero);
+            // advance this row by PK pixels
+            yptr[i] += ystep;
+            int ox = rox[i] + dxx, oy = roy[i] + dyy, n = rn[i] + dn;
+            if (ox >= p.Wo) { ox -= p.Wo; ++oy; }
+            if (oy >= p.Ho) { oy -= p.Ho; ++n; }
+            rox[i] = ox; roy[i] = oy; rn[i] = n;
         }
+        mrow += PK;
     };
     auto store_step = [&](float* buf) {
 #pragma unroll
@@ -87,14 +110,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(WgradParams p) {
 
     const int nsteps = (int)((m_end - m_begin + PK - 1) / PK);
     if (nsteps > 0) {
-        load_step(m_begin);
+        load_step();
         store_step(lds);
     }
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
         const float* cur = lds + (s & 1) * STAGE;
         const bool more = s + 1 < nsteps;
-        if (more) load_step(m_begin + (int64_t)(s + 1) * PK);
+        if (more) load_step();
         const float* ya = cur + h * BT + wm * 32 * T + r;
         const float* xb = cur + PK * BT + h * BT + wn * 32 * T + r;
 #pragma unroll
