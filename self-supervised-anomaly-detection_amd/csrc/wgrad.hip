@@ -175,7 +175,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
 
 // Number of pixel splits the kernel will use for a problem (the caller sizes the slab with it).
 extern "C" int ssad_wgrad_splits(int64_t M, int Cin, int Cout, int KH, int KW) {
-    const int BT = (Cin <= 64 && Cout <= 64) ? 64 : 128;
+    const int BT = (Cin <= 64 || Cout <= 64) ? 64 : 128;   // a 128-wide tile would be half empty
     const int64_t tiles = (int64_t)KH * KW * ((Cout + BT - 1) / BT) * ((Cin + BT - 1) / BT);
     int64_t splits = (1024 + tiles - 1) / tiles;
     const int64_t max_splits = (M + 255) / 256;
@@ -200,7 +200,7 @@ extern "C" int ssad_conv_wgrad(const float* dy, const float* x, float* slab, int
     p.M = N * p.Ho * p.Wo;
     int64_t chunk = (p.M + splits - 1) / splits;
     p.chunk = (chunk + PK - 1) / PK * PK;
-    const int BT = (Cin <= 64 && Cout <= 64) ? 64 : 128;
+    const int BT = (Cin <= 64 || Cout <= 64) ? 64 : 128;   // a 128-wide tile would be half empty
     p.co_tiles = (Cout + BT - 1) / BT;
     p.ci_tiles = (Cin + BT - 1) / BT;
     dim3 grid((unsigned)(KH * KW * p.co_tiles * p.ci_tiles), (unsigned)splits);
