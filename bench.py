@@ -226,8 +226,12 @@ def main():
         fl = sum(r["flops"] for r in recs)
         allk = sum(r["ms"] for r in prof[phase]) * 1e-3
         ach = fl / t / 1e12
+        traffic = None          # HBM-side bytes per launch of this kernel from the committed PMC passes (same command line)
+        tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if phase == "score" and args.batch == 256 and args.size == 256 and os.path.exists(tj):
+            traffic = json.load(open(tj))["traffic_MB_per_launch"] * 1e6
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                           "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                            "kernel": "conv_igemm_f32_kernel", "phase": phase, "launches": len(recs),
                            "avg_launch_ms": round(1e3 * t / len(recs), 4),
                            "alg_gflop_per_launch": round(fl / len(recs) / 1e9, 3),
