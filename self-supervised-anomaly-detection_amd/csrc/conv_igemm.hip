@@ -40,6 +40,7 @@ struct ConvParams {
     int H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, relu;
     int K;              // KH*KW*Cin
     int hwnc;           // activations (in, out, residual) laid out [H][W][N][C] instead of [N][H][W][C]
+    int cls_start[5];   // TS == 2: first workgroup of each output-parity class (py, px) = (c >> 1, c & 1)
 };
 
 // TS   : 1 = convolution; 2 = transposed gather (dgrad of a stride-2 conv): tap (ky,kx) reads in[(oy-pad+ky)/2]
@@ -47,7 +48,9 @@ struct ConvParams {
 // POS  : a workgroup's rows are BM different samples at ONE output position, so the set of in-bounds taps is
 //        workgroup-uniform and taps in the zero padding are skipped as whole K-steps (exact: only x*0 is dropped).
 // BK   : floats per K-step (32: 144-byte LDS rows; 16: 80-byte rows -- both conflict-free for ds_read_b128).
-template <int BM, int BN, int TM, int TN, int BK, int TS, bool POS>
+// DB   : double-buffered LDS stages (one barrier per K-step) or a single stage (two barriers, half the LDS:
+//        more workgroups per CU).
+template <int BM, int BN, int TM, int TN, int BK, int TS, bool POS, bool DB = true>
 __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
     constexpr int LDK = BK + 4;     // LDS row stride in floats
     constexpr int CPR = BK / 4;     // 16-byte chunks per staged row
@@ -97,6 +100,45 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
     } else {
         m0 = (int64_t)blockIdx.x * BM;
     }
+    // TS == 2 (dgrad of a stride-2 conv): rows are grouped by the parity class of the output pixel.  Within a class
+    // the taps whose numerator (oy - pad + ky) is even are the same for every row, so the other 3/4 (3x3) or 3/4 (1x1)
+    // of the taps -- which would only multiply structural zeros -- are skipped as whole K-steps.
+    int cpy = 0, cpx = 0, Hc = 1, Wc = 1;
+    int64_t Mc = 0;
+    if (TS > 1) {
+        int c = 0;
+        while (c < 3 && (int)blockIdx.x >= p.cls_start[c + 1]) ++c;
+        cpy = c >> 1;
+        cpx = c & 1;
+        Hc = (p.Ho - cpy + 1) / 2;
+        Wc = (p.Wo - cpx + 1) / 2;
+        Mc = p.N * Hc * Wc;
+        m0 = (int64_t)((int)blockIdx.x - p.cls_start[c]) * BM;
+        tapmask = 0;
+        for (int ky = 0, t = 0; ky < p.KH; ++ky)
+            for (int kx = 0; kx < p.KW; ++kx, ++t)
+                if (((cpy - p.pad + ky) & 1) == 0 && ((cpx - p.pad + kx) & 1) == 0) tapmask |= 1u << t;
+    }
+    // flattened row -> (valid, sample, oy, ox) of the OUTPUT pixel it produces
+    auto decode_row = [&](int64_t m, int64_t& n, int& oy, int& ox) -> bool {
+        if (TS > 1) {
+            const bool ok = m < Mc;
+            const int64_t mm = ok ? m : 0;
+            n = mm / (Hc * Wc);
+            const int rem = (int)(mm - n * (Hc * Wc));
+            const int a = rem / Wc;
+            oy = 2 * a + cpy;
+            ox = 2 * (rem - a * Wc) + cpx;
+            return ok;
+        }
+        const bool ok = m < p.M;
+        const int64_t mm = ok ? m : 0;
+        n = mm / HoWo;
+        const int rem = (int)(mm - n * HoWo);
+        oy = rem / p.Wo;
+        ox = rem - oy * p.Wo;
+        return ok;
+    };
 
     // ---- per-thread staging rows (fixed across the K loop): base pointer at tap (0,0) + in-bounds tap mask ----
     const float* a_ptr[AR];
@@ -114,12 +156,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
             oy = pos / p.Wo;
             ox = pos - oy * p.Wo;
         } else {
-            ok = m < p.M;
-            const int64_t mm = ok ? m : 0;
-            n = mm / HoWo;
-            const int rem = (int)(mm - n * HoWo);
-            oy = rem / p.Wo;
-            ox = rem - oy * p.Wo;
+            ok = decode_row(m, n, oy, ox);
         }
         const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
         a_iy[i] = iy0;
@@ -139,6 +176,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
                     }
                     if (v && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) mk |= 1u << t;
                 }
+            mk &= tapmask;
         }
         a_mask[i] = mk;
         a_ptr[i] = TS > 1 ? p.in + n * in_sn + sc * 4 : p.in + n * in_sn + ((int64_t)iy0 * p.W + ix0) * in_sp + sc * 4;
@@ -202,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
     __syncthreads();
 
     for (int ks = 0; ks < nk; ++ks) {
-        float* cur = lds + (ks & 1) * STAGE;
+        float* cur = DB ? lds + (ks & 1) * STAGE : lds;
         const bool more = ks + 1 < nk;
         if (more) load_step();
         const float* As = cur + (wm * 32 * TM + r) * LDK + h * 4;
@@ -221,8 +259,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(a[i][e], b[j][e], acc[i][j]);
         }
-        if (more) store_step(lds + ((ks + 1) & 1) * STAGE);
-        __syncthreads();
+        if (DB) {
+            if (more) store_step(lds + ((ks + 1) & 1) * STAGE);
+            __syncthreads();
+        } else {
+            __syncthreads();                   // every wave is done reading the stage
+            if (more) store_step(lds);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: accumulators -> LDS tile [BM/TM][BN+4] -> 16-byte pieces of contiguous output rows; one pass per
@@ -258,6 +302,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
             if (POS) {
                 ok = ok && row < p.N;
                 row = p.hwnc ? (int64_t)pos * p.N + row : row * HoWo + pos;
+            } else if (TS > 1) {
+                int64_t n;
+                int oy, ox;
+                ok = decode_row(row, n, oy, ox) && ok;
+                row = (n * p.Ho + oy) * p.Wo + ox;
             } else {
                 ok = ok && row < p.M;
             }
@@ -285,20 +334,29 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
     }
 }
 
-template <int BM, int BN, int TM, int TN, int BK, int TS, bool POS>
+template <int BM, int BN, int TM, int TN, int BK, int TS, bool POS, bool DB = true>
 int launch(const ConvParams& p, hipStream_t st) {
-    constexpr int stage_bytes = 2 * (BM + BN) * (BK + 4) * 4;
+    constexpr int stage_bytes = (DB ? 2 : 1) * (BM + BN) * (BK + 4) * 4;
     constexpr int epi_bytes = (BM / TM) * (BN + 4) * 4;
     constexpr int lds_bytes = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_f32_kernel<BM, BN, TM, TN, BK, TS, POS>,
+        (void)hipFuncSetAttribute((const void*)conv_igemm_f32_kernel<BM, BN, TM, TN, BK, TS, POS, DB>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         attr_set = true;
     }
-    const int64_t gx = POS ? cdiv64(cdiv64(p.N, BM), 32) * 32 * p.Ho * p.Wo : cdiv64(p.M, BM);
+    int64_t gx = POS ? cdiv64(cdiv64(p.N, BM), 32) * 32 * p.Ho * p.Wo : cdiv64(p.M, BM);
+    ConvParams q = p;
+    if (TS > 1) {
+        gx = 0;
+        for (int c = 0; c < 4; ++c) {
+            q.cls_start[c] = (int)gx;
+            gx += cdiv64(p.N * ((p.Ho - (c >> 1) + 1) / 2) * ((p.Wo - (c & 1) + 1) / 2), BM);
+        }
+        q.cls_start[4] = (int)gx;
+    }
     dim3 grid((unsigned)gx, (unsigned)((p.Cout + BN - 1) / BN));
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, TM, TN, BK, TS, POS>), grid, dim3(256), lds_bytes, st, p);
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, TM, TN, BK, TS, POS, DB>), grid, dim3(256), lds_bytes, st, q);
     return 0;
 }
 
@@ -306,7 +364,8 @@ template <int TS, bool POS>
 void dispatch(const ConvParams& p, hipStream_t st) {
     static const int variant = getenv("SSAD_CONV64_VARIANT") ? atoi(getenv("SSAD_CONV64_VARIANT")) : 1;
     if (p.Cout <= 64) {
-        if (variant == 1) launch<256, 64, 2, 2, 16, TS, POS>(p, st);
+        if (variant == 2) launch<256, 64, 2, 2, 32, TS, POS, false>(p, st);
+        else if (variant == 1) launch<256, 64, 2, 2, 16, TS, POS>(p, st);
         else launch<128, 64, 1, 2, 32, TS, POS>(p, st);
     } else {
         launch<128, 128, 2, 2, 32, TS, POS>(p, st);
