@@ -140,6 +140,10 @@ int ssad_bn_apply_bwd(const float* dy, const float* yact, const float* z, const 
                       int eval_mode, void* stream);
 /* Replaces the backward of nn.MaxPool2d(3,2,1) and of adaptive_avg_pool2d + cat (models.py:224-245). */
 int ssad_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int64_t N, int H, int W, int C, void* stream);
+/* Same pair with the argmax recorded by the forward pass (one byte per output element: window slot dy*3+dx of the
+ * first maximum), so backward compares <= 4 indices per input element instead of rescanning 4 windows. */
+int ssad_maxpool3x3s2_fwd_idx(const float* in, float* out, uint8_t* idx, int64_t N, int H, int W, int C, void* stream);
+int ssad_maxpool3x3s2_bwd_idx(const uint8_t* idx, const float* dy, float* dx, int64_t N, int H, int W, int C, void* stream);
 int ssad_gap_bwd(const float* dpooled, float* dy, int64_t N, int HW, int C, int stride, int offset, int accumulate,
                  void* stream);
 /* Replaces F.cross_entropy + torchmetrics accuracy (models.py:261-262) and their backward: loss_acc[0] = mean NLL,

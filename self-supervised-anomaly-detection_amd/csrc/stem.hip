@@ -266,8 +266,8 @@ __global__ void pack_stem_weight_kernel(const float* __restrict__ w, float* __re
 }
 
 // NHWC 3x3 stride-2 pad-1 max-pool, 4 channels per thread.
-__global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t total4, int H, int W,
-                                    int C4, int Ho, int Wo, int64_t N, int hwnc) {
+__global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restrict__ out, uint8_t* __restrict__ idx,
+                                    int64_t total4, int H, int W, int C4, int Ho, int Wo, int64_t N, int hwnc) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total4) return;
     int c4 = (int)(i % C4);
@@ -286,6 +286,7 @@ __global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restr
         n = t / Ho;
     }
     f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int am[4] = {0, 0, 0, 0};                 // window slot (dy*3+dx) of the FIRST maximum, PyTorch's tie rule
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
         int y = oy * 2 - 1 + dy;
@@ -296,10 +297,13 @@ __global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restr
             if ((unsigned)x >= (unsigned)W) continue;
             const int64_t ip = hwnc ? ((int64_t)y * W + x) * N + n : (n * H + y) * W + x;
             f32x4 v = ((const f32x4*)in)[ip * C4 + c4];
-            m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (v[k] > m[k]) { m[k] = v[k]; am[k] = dy * 3 + dx; }
         }
     }
     ((f32x4*)out)[i] = m;
+    if (idx) ((uint32_t*)idx)[i] = (uint32_t)am[0] | ((uint32_t)am[1] << 8) | ((uint32_t)am[2] << 16) | ((uint32_t)am[3] << 24);
 }
 
 }  // namespace
@@ -375,14 +379,25 @@ extern "C" int ssad_stem_patch_pool_fwd(const float* img, int B, int H, int W, i
     return 0;
 }
 
-extern "C" int ssad_maxpool3x3s2_fwd(const float* in, float* out, int64_t N, int H, int W, int C, int hwnc, void* stream) {
+static int maxpool_fwd_impl(const float* in, float* out, uint8_t* idx, int64_t N, int H, int W, int C, int hwnc, void* stream) {
     SSAD_CHECK_ARG(in && out, "null pointer");
     SSAD_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "bad shape (C % 4)");
     int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     int64_t total4 = N * Ho * Wo * (C / 4);
     SSAD_CHECK_ARG(cdiv64(total4, 256) < (int64_t)2147483647, "too large");
-    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((unsigned)cdiv64(total4, 256)), dim3(256), 0, (hipStream_t)stream, in, out,
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((unsigned)cdiv64(total4, 256)), dim3(256), 0, (hipStream_t)stream, in, out, idx,
                        total4, H, W, C / 4, Ho, Wo, N, hwnc);
     SSAD_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int ssad_maxpool3x3s2_fwd(const float* in, float* out, int64_t N, int H, int W, int C, int hwnc, void* stream) {
+    return maxpool_fwd_impl(in, out, nullptr, N, H, W, C, hwnc, stream);
+}
+
+// Training forward: also records, per output element, which of the 9 window slots held the first maximum
+// (one byte each, [N][Ho][Wo][C]); ssad_maxpool3x3s2_bwd_idx routes gradients with it.
+extern "C" int ssad_maxpool3x3s2_fwd_idx(const float* in, float* out, uint8_t* idx, int64_t N, int H, int W, int C, void* stream) {
+    SSAD_CHECK_ARG(idx, "null index buffer");
+    return maxpool_fwd_impl(in, out, idx, N, H, W, C, 0, stream);
 }

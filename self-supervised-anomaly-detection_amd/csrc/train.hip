@@ -243,6 +243,34 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ xin, const float* _
     ((f32x4*)dx)[i] = acc;
 }
 
+// Index form: idx[n][oy][ox][c] = window slot (dy*3+dx) of the first maximum, written by the forward kernel.
+// dx[n][y][x][c] = sum over the <= 4 windows covering (y,x) whose recorded slot is (y,x).
+__global__ void maxpool_bwd_idx_kernel(const uint8_t* __restrict__ idx, const float* __restrict__ dy, float* __restrict__ dx,
+                                       int64_t total4, int H, int W, int C4, int Ho, int Wo) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total4) return;
+    const int c4 = (int)(i % C4);
+    int64_t t = i / C4;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H);
+    const int64_t n = t / H;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int oy0 = y / 2, oy1 = (y + 1) / 2, ox0 = x / 2, ox1 = (x + 1) / 2;
+    for (int oy = oy0; oy <= oy1; ++oy) {
+        if (oy >= Ho) continue;
+        for (int ox = ox0; ox <= ox1; ++ox) {
+            if (ox >= Wo) continue;
+            const uint32_t slot = (uint32_t)((y - (2 * oy - 1)) * 3 + (x - (2 * ox - 1)));
+            const int64_t o = ((n * Ho + oy) * Wo + ox) * C4 + c4;
+            const uint32_t packed = ((const uint32_t*)idx)[o];
+            const f32x4 g = ((const f32x4*)dy)[o];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] += ((packed >> (8 * k)) & 0xffu) == slot ? g[k] : 0.f;
+        }
+    }
+    ((f32x4*)dx)[i] = acc;
+}
+
 // dy[n][hw][c] (+)= dpooled[n*stride + off + c] / HW
 __global__ void gap_bwd_kernel(const float* __restrict__ dpooled, float* __restrict__ dy, int64_t total, int HW, int C,
                                int stride, int off, int accumulate) {
@@ -444,6 +472,18 @@ extern "C" int ssad_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx,
     SSAD_CHECK_ARG(cdiv64(total, 256) < (int64_t)2147483647, "too large");
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, total,
                        H, W, C / 4, Ho, Wo);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ssad_maxpool3x3s2_bwd_idx(const uint8_t* idx, const float* dy, float* dx, int64_t N, int H, int W, int C,
+                                        void* stream) {
+    SSAD_CHECK_ARG(idx && dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "bad argument");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int64_t total = N * H * W * (C / 4);
+    SSAD_CHECK_ARG(cdiv64(total, 256) < (int64_t)2147483647, "too large");
+    hipLaunchKernelGGL(maxpool_bwd_idx_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, idx, dy, dx,
+                       total, H, W, C / 4, Ho, Wo);
     SSAD_CHECK_LAUNCH();
     return 0;
 }

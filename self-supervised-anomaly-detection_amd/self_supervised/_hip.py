@@ -50,6 +50,8 @@ SIGNATURES = {
     "ssad_bn_bwd_reduce": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_fp, _c_fp],
     "ssad_bn_apply_bwd": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp],
     "ssad_maxpool3x3s2_bwd": [_c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_maxpool3x3s2_fwd_idx": [_c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_maxpool3x3s2_bwd_idx": [_c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_fp],
     "ssad_gap_bwd": [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
     "ssad_softmax_ce": [_c_fp, _c_fp, _c_i, _c_i, _c_fp, _c_fp, _c_i, _c_f, _c_fp],
     "ssad_sgd_step": [_c_fp, _c_fp, _c_fp, _c_l, _c_f, _c_f, _c_f, _c_f, _c_fp],

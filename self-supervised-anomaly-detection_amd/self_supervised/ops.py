@@ -317,6 +317,24 @@ def maxpool3x3s2_bwd(x, dy):
     return dx
 
 
+def maxpool3x3s2_fwd_idx(x):
+    """Training forward: pooled output + uint8 argmax slots."""
+    n, h, w, c = x.shape
+    out = _new((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), x)
+    idx = torch.empty(out.shape, dtype=torch.uint8, device=x.device)
+    _run("maxpool3x3s2", 0.0, 4.0 * (x.numel() + out.numel()) + idx.numel(),
+         lambda: _hip.lib().ssad_maxpool3x3s2_fwd_idx(_hip.ptr(x), _hip.ptr(out), idx.data_ptr(), n, h, w, c, _hip.stream()))
+    return out, idx
+
+
+def maxpool3x3s2_bwd_idx(idx, dy, x_shape):
+    n, h, w, c = x_shape
+    dx = _new(tuple(x_shape), dy)
+    _run("maxpool_bwd", 0.0, 4.0 * (dx.numel() + dy.numel()) + idx.numel(),
+         lambda: _hip.lib().ssad_maxpool3x3s2_bwd_idx(idx.data_ptr(), _hip.ptr(dy), _hip.ptr(dx), n, h, w, c, _hip.stream()))
+    return dx
+
+
 def gap_bwd(dpooled, dy, offset, accumulate):
     n, h, w, c = dy.shape
     _run("gap_bwd", 0.0, 4.0 * dy.numel() * (2 if accumulate else 1),

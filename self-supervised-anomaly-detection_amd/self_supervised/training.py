@@ -259,7 +259,7 @@ class TrainEngine:
         if not self.trunk_grad:
             self.stem.x = None
         self.a0 = a0
-        a = ops.maxpool3x3s2_fwd(a0)
+        a, self.pool_idx = ops.maxpool3x3s2_fwd_idx(a0)
         pooled = torch.empty((b, self.pooled_dim), device=x.device, dtype=torch.float32)
         self.stage_shapes = {}
         for i, d in enumerate(self.blocks):
@@ -317,13 +317,13 @@ class TrainEngine:
                 notify(a.offset[id(blk["c1"].lin.weight)][0] + blk["c1"].lin.weight.numel()
                        if blk["ds"] is None else
                        a.offset[id(blk["ds"].lin.weight)][0] + blk["ds"].lin.weight.numel())
-        da0 = ops.maxpool3x3s2_bwd(self.a0, dy)
+        da0 = ops.maxpool3x3s2_bwd_idx(self.pool_idx, dy, self.a0.shape)
         self.stem.bwd(da0, need_dx=False)
         notify(a.total)
         self._drop_tape()
 
     def _drop_trunk_tape(self):
-        self.a0 = None
+        self.a0 = self.pool_idx = None
         for d in self.blocks:
             for k in ("c1", "c2", "ds"):
                 if d[k] is not None:

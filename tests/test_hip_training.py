@@ -83,6 +83,9 @@ def test_bn_pool_kernels(dev):
     p.backward(dp)
     da = ops.maxpool3x3s2_bwd(nh(a), nh(dp))
     assert torch.equal(da.cpu(), nh(a.grad).cpu())
+    pooled, idx = ops.maxpool3x3s2_fwd_idx(nh(a))
+    assert torch.equal(pooled.cpu(), nh(p).cpu())
+    assert torch.equal(ops.maxpool3x3s2_bwd_idx(idx, nh(dp), nh(a).shape).cpu(), nh(a.grad).cpu())
 
 
 def test_training_step_matches_autograd(dev, golden, seeded_sd):
