@@ -245,19 +245,29 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
         if (more) load_step();
         const float* As = cur + (wm * 32 * TM + r) * LDK + h * 4;
         const float* Bs = cur + BM * LDK + (wn * 32 * TN + r) * LDK + h * 4;
+        // fragments of chunk kk+1 are requested before the MFMAs of chunk kk are issued (LDS latency under matrix work)
+        f32x4 a[2][TM], b[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[0][i] = *(const f32x4*)(As + i * 32 * LDK);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[0][j] = *(const f32x4*)(Bs + j * 32 * LDK);
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
-            f32x4 a[TM], b[TN];
+            const int cu = kk & 1, nx = cu ^ 1;
+            if (kk + 1 < BK / 8) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = *(const f32x4*)(As + i * 32 * LDK + kk * 8);
+                for (int i = 0; i < TM; ++i) a[nx][i] = *(const f32x4*)(As + i * 32 * LDK + (kk + 1) * 8);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = *(const f32x4*)(Bs + j * 32 * LDK + kk * 8);
+                for (int j = 0; j < TN; ++j) b[nx][j] = *(const f32x4*)(Bs + j * 32 * LDK + (kk + 1) * 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);       // keep the reads one chunk ahead (hipcc would sink them to first use)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(a[i][e], b[j][e], acc[i][j]);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(a[cu][i][e], b[cu][j][e], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (DB) {
             if (more) store_step(lds + ((ks + 1) & 1) * STAGE);

@@ -120,17 +120,30 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(WgradParams p) {
         if (more) load_step();
         const float* ya = cur + h * BT + wm * 32 * T + r;
         const float* xb = cur + PK * BT + h * BT + wn * 32 * T + r;
+        // fragments of pixel pair kk+1 are requested before the MFMAs of pair kk are issued, so the LDS latency of one
+        // pair hides under the matrix work of the previous one (the plain loop waits lgkmcnt(0) in front of every 4 MFMAs)
+        float a[2][T], b[2][T];
+#pragma unroll
+        for (int i = 0; i < T; ++i) a[0][i] = ya[i * 32];
+#pragma unroll
+        for (int j = 0; j < T; ++j) b[0][j] = xb[j * 32];
 #pragma unroll
         for (int kk = 0; kk < PK / 2; ++kk) {
-            float a[T], b[T];
+            const int cu = kk & 1, nx = cu ^ 1;
+            if (kk + 1 < PK / 2) {
 #pragma unroll
-            for (int i = 0; i < T; ++i) a[i] = ya[kk * 2 * BT + i * 32];
+                for (int i = 0; i < T; ++i) a[nx][i] = ya[(kk + 1) * 2 * BT + i * 32];
 #pragma unroll
-            for (int j = 0; j < T; ++j) b[j] = xb[kk * 2 * BT + j * 32];
+                for (int j = 0; j < T; ++j) b[nx][j] = xb[(kk + 1) * 2 * BT + j * 32];
+            }
+            // hipcc otherwise sinks those reads back in front of their first use (read, lgkmcnt(0), 4 MFMAs, repeat):
+            // nothing may be scheduled across this point, so the reads stay one pair ahead of the MFMAs below
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < T; ++i)
 #pragma unroll
-                for (int j = 0; j < T; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < T; ++j) acc[i][j] = mfma32(a[cu][i], b[cu][j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (more) store_step(lds + ((s + 1) & 1) * STAGE);
         __syncthreads();
