@@ -119,6 +119,9 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--phase", choices=["both", "train", "score"], default="both")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-precision", choices=["32", "16"], default="32",
+                    help="32: exact fp32 MFMA (headline); 16: bf16-operand MFMA, the reference's Trainer(precision=16)")
+    ap.add_argument("--no-bf16-extra", action="store_true", help="skip the additional precision=16 training measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -126,11 +129,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; SSAD_DIST_BACKEND=gloo + fewer GPUs than ranks is only for rehearsing the N>1 code path on a
+    # one-GPU box (ranks then share device 0 and gloo stages the all-reduce through the host)
+    backend = os.environ.get("SSAD_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev = torch.device("cuda", local_rank % max(ndev, 1))
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from self_supervised import ops
@@ -145,7 +155,7 @@ def main():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            torch.cuda.synchronize()  # noqa
 
     def timed(fn, steps, warmup):
         for _ in range(warmup):
@@ -180,7 +190,7 @@ def main():
         from self_supervised import training
         model.train()
         model.unfreeze()
-        trainer = training.DataParallelStep(model, lr=0.005, world_size=world)
+        trainer = training.DataParallelStep(model, lr=0.005, world_size=world, precision=int(args.train_precision))
         ops.PROFILE = None
         for _ in range(args.warmup):
             trainer.step(x, y)
@@ -188,6 +198,14 @@ def main():
         dt = timed(lambda: trainer.step(x, y), args.steps, 0)
         prof["train"] = ops.drain_profile()
         res["train_s"] = dt
+        if args.train_precision == "32" and not args.no_bf16_extra:
+            # extra, not the headline: the same step with bf16-operand MFMA (what the reference's precision=16 asks for)
+            ops.PROFILE = None
+            t16 = training.DataParallelStep(model, lr=0.005, world_size=world, precision=16)
+            for _ in range(max(args.warmup, 1)):
+                t16.step(x, y)
+            res["train16_s"] = timed(lambda: t16.step(x, y), args.steps, 0)
+            trainer.eng.bf16 = False
     ops.PROFILE = None
 
     if rank != 0:
@@ -209,6 +227,8 @@ def main():
         out["value"] = round(world * args.batch * args.steps / res["train_s"], 2)
         out["train_ms_per_step"] = round(1e3 * res["train_s"] / args.steps, 3)
         tot_s += res["train_s"]
+    if "train16_s" in res:
+        out["train_images_per_sec_precision16"] = round(world * args.batch * args.steps / res["train16_s"], 2)
     if "score_s" in res:
         out["anomaly_maps_per_sec"] = round(world * args.batch * args.steps / res["score_s"], 3)
         out["score_ms_per_step"] = round(1e3 * res["score_s"] / args.steps, 3)

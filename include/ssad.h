@@ -120,6 +120,16 @@ int ssad_conv_wgrad(const float* dy, const float* x, float* slab, int splits, in
                     int KH, int KW, int stride, int pad, void* stream);
 int ssad_wgrad_reduce(const float* slab, float* dw, int splits, int Cout, int Kpad, int KH, int KW, int Cin, int to_oihw,
                       int accumulate, void* stream);
+/* bf16-operand forms of the three MFMA entry points above (fp32 tensors in HBM; operands rounded to bf16 while staging,
+ * fp32 accumulate; v_mfma_f32_32x32x16_bf16).  This is what torch.autocast does to the same Conv2d / Linear call sites
+ * under the reference's pl.Trainer(precision=16) (src/self_supervised/tools.py:263, :296). */
+int ssad_conv_igemm_fwd_bf16(const float* in, const float* w_ohwi, float* out, const float* scale, const float* shift,
+                             const float* residual, int relu, int64_t N, int H, int W, int Cin, int Cout, int KH, int KW,
+                             int stride, int pad, void* stream);
+int ssad_conv_igemm_dgrad_bf16(const float* dy, const float* w_flipT, float* dx, const float* residual, int64_t N, int Hy,
+                               int Wy, int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride, int pad, void* stream);
+int ssad_conv_wgrad_bf16(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin, int Cout,
+                         int KH, int KW, int stride, int pad, void* stream);
 /* Stem in training: im2col rows of 160 floats (147 taps + zero pad, nearest resize fused) so that conv1 forward and
  * its weight gradient run on the generic MFMA kernels.  Replaces conv1 of torchvision resnet18 under autograd. */
 int ssad_stem_im2col(const float* img, float* col, int64_t B, int H, int W, int Hv, int Wv, void* stream);

@@ -50,16 +50,19 @@ struct ConvParams {
 // BK   : floats per K-step (32: 144-byte LDS rows; 16: 80-byte rows -- both conflict-free for ds_read_b128).
 // DB   : double-buffered LDS stages (one barrier per K-step) or a single stage (two barriers, half the LDS:
 //        more workgroups per CU).
-template <int BM, int BN, int TM, int TN, int BK, int TS, bool POS, bool DB = true>
+// BF   : operands are rounded to bf16 while staging (fp32 in HBM, fp32 accumulate): v_mfma_f32_32x32x16_bf16 runs 16x
+//        the fp32 rate, the kernel becomes load-bound.  Used by Trainer(precision=16), mirroring the reference's AMP.
+template <int BM, int BN, int TM, int TN, int BK, int TS, bool POS, bool DB = true, bool BF = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
-    constexpr int LDK = BK + 4;     // LDS row stride in floats
+    constexpr int LDK = BF ? BK + 8 : BK + 4;     // LDS row stride in elements (bf16: 80 / 48 bytes, f32: 144 / 80)
+    constexpr int ESZ = BF ? 2 : 4;
     constexpr int CPR = BK / 4;     // 16-byte chunks per staged row
     constexpr int RPP = 256 / CPR;  // rows staged per pass
     constexpr int WN = BN / (32 * TN);
     constexpr int AR = BM / RPP;    // 16-byte chunks of A staged per thread per K-step
     constexpr int BR = BN / RPP;
     static_assert(AR >= 1 && BR >= 1, "tile too small for the staging pattern");
-    constexpr int STAGE = (BM + BN) * LDK;
+    constexpr int STAGE = (BM + BN) * LDK * ESZ / 4;     // floats
     constexpr int LDC = BN + 4;     // epilogue tile row stride (floats)
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -225,6 +228,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
         }
     };
     auto store_step = [&](float* buf) {
+        if (BF) {
+            __bf16* As = (__bf16*)buf;
+            __bf16* Bs = As + BM * LDK;
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                bf16x4 v = {(__bf16)ra[i][0], (__bf16)ra[i][1], (__bf16)ra[i][2], (__bf16)ra[i][3]};
+                *(bf16x4*)(As + (sr + RPP * i) * LDK + sc * 4) = v;
+            }
+#pragma unroll
+            for (int i = 0; i < BR; ++i) {
+                bf16x4 v = {(__bf16)rb[i][0], (__bf16)rb[i][1], (__bf16)rb[i][2], (__bf16)rb[i][3]};
+                *(bf16x4*)(Bs + (sr + RPP * i) * LDK + sc * 4) = v;
+            }
+            return;
+        }
         float* As = buf;
         float* Bs = buf + BM * LDK;
 #pragma unroll
@@ -243,6 +261,24 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
         float* cur = DB ? lds + (ks & 1) * STAGE : lds;
         const bool more = ks + 1 < nk;
         if (more) load_step();
+        if (BF) {
+            // v_mfma_f32_32x32x16_bf16: lane (r, h) feeds A[row r][k = 8h .. 8h+7] and B[k = 8h .. 8h+7][col r]: 16 bytes each
+            const __bf16* Ab = (const __bf16*)cur + (wm * 32 * TM + r) * LDK + h * 8;
+            const __bf16* Bb = (const __bf16*)cur + BM * LDK + (wn * 32 * TN + r) * LDK + h * 8;
+#pragma unroll
+            for (int k16 = 0; k16 < BK / 16; ++k16) {
+                bf16x8 a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = *(const bf16x8*)(Ab + i * 32 * LDK + k16 * 16);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = *(const bf16x8*)(Bb + j * 32 * LDK + k16 * 16);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
         const float* As = cur + (wm * 32 * TM + r) * LDK + h * 4;
         const float* Bs = cur + BM * LDK + (wn * 32 * TN + r) * LDK + h * 4;
         // fragments of chunk kk+1 are requested before the MFMAs of chunk kk are issued (LDS latency under matrix work)
@@ -268,6 +304,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(a[cu][i][e], b[cu][j][e], acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
         if (DB) {
             if (more) store_step(lds + ((ks + 1) & 1) * STAGE);
@@ -344,14 +381,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
     }
 }
 
-template <int BM, int BN, int TM, int TN, int BK, int TS, bool POS, bool DB = true>
+template <int BM, int BN, int TM, int TN, int BK, int TS, bool POS, bool DB = true, bool BF = false>
 int launch(const ConvParams& p, hipStream_t st) {
-    constexpr int stage_bytes = (DB ? 2 : 1) * (BM + BN) * (BK + 4) * 4;
+    constexpr int stage_bytes = (DB ? 2 : 1) * (BM + BN) * (BF ? (BK + 8) * 2 : (BK + 4) * 4);
     constexpr int epi_bytes = (BM / TM) * (BN + 4) * 4;
     constexpr int lds_bytes = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_f32_kernel<BM, BN, TM, TN, BK, TS, POS, DB>,
+        (void)hipFuncSetAttribute((const void*)conv_igemm_f32_kernel<BM, BN, TM, TN, BK, TS, POS, DB, BF>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         attr_set = true;
     }
@@ -366,8 +403,14 @@ int launch(const ConvParams& p, hipStream_t st) {
         q.cls_start[4] = (int)gx;
     }
     dim3 grid((unsigned)gx, (unsigned)((p.Cout + BN - 1) / BN));
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, TM, TN, BK, TS, POS, DB>), grid, dim3(256), lds_bytes, st, q);
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, TM, TN, BK, TS, POS, DB, BF>), grid, dim3(256), lds_bytes, st, q);
     return 0;
+}
+
+template <int TS>
+void dispatch_bf16(const ConvParams& p, hipStream_t st) {
+    if (p.Cout <= 64) launch<256, 64, 2, 2, 32, TS, false, true, true>(p, st);
+    else launch<128, 128, 2, 2, 32, TS, false, true, true>(p, st);
 }
 
 template <int TS, bool POS>
@@ -384,7 +427,7 @@ void dispatch(const ConvParams& p, hipStream_t st) {
 
 int conv_fwd_impl(const float* in, const float* w_ohwi, float* out, const float* scale, const float* shift,
                   const float* residual, int relu, int64_t N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
-                  int pad, int hwnc, void* stream) {
+                  int pad, int hwnc, void* stream, bool bf16 = false) {
     SSAD_CHECK_ARG(in && w_ohwi && out, "null pointer");
     SSAD_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "empty shape");
     SSAD_CHECK_ARG(Cin % KALIGN == 0, "Cin must be a multiple of 32");
@@ -404,13 +447,25 @@ int conv_fwd_impl(const float* in, const float* w_ohwi, float* out, const float*
     const bool posmajor = hwnc || (pad > 0 && N >= 128 && p.Ho * p.Wo <= 4);
     SSAD_CHECK_ARG(cdiv64(p.M, 128) + 32 * p.Ho * p.Wo < (int64_t)2147483647, "M too large for one launch");
     hipStream_t st = (hipStream_t)stream;
-    if (posmajor) dispatch<1, true>(p, st);
+    if (bf16) {
+        SSAD_CHECK_ARG(!hwnc, "bf16 operands: NHWC only");
+        dispatch_bf16<1>(p, st);
+    } else if (posmajor) dispatch<1, true>(p, st);
     else dispatch<1, false>(p, st);
     SSAD_CHECK_LAUNCH();
     return 0;
 }
 
 }  // namespace
+
+// bf16-operand form of ssad_conv_igemm_fwd (fp32 tensors in HBM, operands rounded to bf16 in the loader, fp32
+// accumulate): what torch.autocast does to the same Conv2d / Linear call sites under Trainer(precision=16)
+// (src/self_supervised/tools.py:263).
+extern "C" int ssad_conv_igemm_fwd_bf16(const float* in, const float* w_ohwi, float* out, const float* scale,
+                                        const float* shift, const float* residual, int relu, int64_t N, int H, int W,
+                                        int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream) {
+    return conv_fwd_impl(in, w_ohwi, out, scale, shift, residual, relu, N, H, W, Cin, Cout, KH, KW, stride, pad, 0, stream, true);
+}
 
 extern "C" int ssad_conv_igemm_fwd(const float* in, const float* w_ohwi, float* out, const float* scale,
                                    const float* shift, const float* residual, int relu, int64_t N, int H, int W,
@@ -431,9 +486,9 @@ extern "C" int ssad_conv_igemm_fwd_hwnc(const float* in, const float* w_ohwi, fl
 // dgrad: dx[n][iy][ix][ci] = sum_{ky,kx,co} dy[n][(iy+pad-ky)/s][(ix+pad-kx)/s][co] * w[co][ky][kx][ci] (+ residual).
 // w_flipT is ssad_flip_transpose_weight(w): [Cin][KH][KW][Cout] with both taps reversed, so the sum becomes the
 // same gather-GEMM with k = (ky', kx', co), numerator row = iy - (KH-1-pad) + ky'.
-extern "C" int ssad_conv_igemm_dgrad(const float* dy, const float* w_flipT, float* dx, const float* residual, int64_t N,
+static int dgrad_impl(const float* dy, const float* w_flipT, float* dx, const float* residual, int64_t N,
                                      int Hy, int Wy, int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride,
-                                     int pad, void* stream) {
+                                     int pad, void* stream, bool bf16) {
     SSAD_CHECK_ARG(dy && w_flipT && dx, "null pointer");
     SSAD_CHECK_ARG(N > 0 && Hy > 0 && Wy > 0 && Hx > 0 && Wx > 0 && Cin > 0 && Cout > 0, "empty shape");
     SSAD_CHECK_ARG(Cout % KALIGN == 0, "Cout (the contraction) must be a multiple of 32");
@@ -450,8 +505,23 @@ extern "C" int ssad_conv_igemm_dgrad(const float* dy, const float* w_flipT, floa
     p.K = KH * KW * Cout;
     SSAD_CHECK_ARG(cdiv64(p.M, 128) < (int64_t)2147483647, "M too large for one launch");
     hipStream_t st = (hipStream_t)stream;
-    if (stride == 1) dispatch<1, false>(p, st);
+    if (bf16) {
+        if (stride == 1) dispatch_bf16<1>(p, st);
+        else dispatch_bf16<2>(p, st);
+    } else if (stride == 1) dispatch<1, false>(p, st);
     else dispatch<2, false>(p, st);
     SSAD_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int ssad_conv_igemm_dgrad(const float* dy, const float* w_flipT, float* dx, const float* residual, int64_t N,
+                                     int Hy, int Wy, int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride,
+                                     int pad, void* stream) {
+    return dgrad_impl(dy, w_flipT, dx, residual, N, Hy, Wy, Cout, Hx, Wx, Cin, KH, KW, stride, pad, stream, false);
+}
+
+extern "C" int ssad_conv_igemm_dgrad_bf16(const float* dy, const float* w_flipT, float* dx, const float* residual, int64_t N,
+                                          int Hy, int Wy, int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride,
+                                          int pad, void* stream) {
+    return dgrad_impl(dy, w_flipT, dx, residual, N, Hy, Wy, Cout, Hx, Wx, Cin, KH, KW, stride, pad, stream, true);
 }

@@ -25,7 +25,7 @@ struct WgradParams {
     float* slab;
     int64_t M, chunk;
     int H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
-    int co_tiles, ci_tiles;
+    int co_tiles, ci_tiles, splits;
 };
 
 template <int BT>
@@ -40,13 +40,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(WgradParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    int tile = blockIdx.x;
+    // XCD-aware mapping (workgroups are dealt round-robin to the 8 XCDs): XCD group g = block % 8 owns the pixel
+    // splits g, g+8, ... and runs ALL (tap, co-tile, ci-tile) tiles of a split back to back, so the dY / X rows that
+    // every tile of a split re-reads are fetched into one L2 instead of eight.
+    const int ntiles = p.KH * p.KW * p.co_tiles * p.ci_tiles;
+    const int64_t jj = blockIdx.x >> 3;
+    const int split = (int)(jj / ntiles) * 8 + (int)(blockIdx.x & 7);
+    if (split >= p.splits) return;
+    int tile = (int)(jj % ntiles);
     const int ci_t = tile % p.ci_tiles; tile /= p.ci_tiles;
     const int co_t = tile % p.co_tiles;
     const int tap = tile / p.co_tiles;
     const int ky = tap / p.KW, kx = tap - ky * p.KW;
     const int co0 = co_t * BT, ci0 = ci_t * BT;
-    const int64_t m_begin = (int64_t)blockIdx.y * p.chunk;
+    const int64_t m_begin = (int64_t)split * p.chunk;
     const int64_t m_end = m_begin + p.chunk < p.M ? m_begin + p.chunk : p.M;
     const int c4 = tid % F4, r0 = tid / F4;
     const int HoWo = p.Ho * p.Wo;
@@ -150,7 +157,138 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(WgradParams p) {
     }
 
     const int taps = p.KH * p.KW;
-    float* out = p.slab + (int64_t)blockIdx.y * p.Cout * taps * p.Cin;
+    float* out = p.slab + (int64_t)split * p.Cout * taps * p.Cin;
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        const int ci = ci0 + (wn * T + j) * 32 + r;
+        if (ci >= p.Cin) continue;
+#pragma unroll
+        for (int i = 0; i < T; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co0 + (wm * T + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (co < p.Cout) out[((int64_t)co * taps + tap) * p.Cin + ci] = acc[i][j][e];
+            }
+    }
+}
+
+// bf16-operand variant (Trainer(precision=16)): same contraction, operands rounded to bf16 while staging.
+// v_mfma_f32_32x32x16_bf16 wants 8 consecutive k (= pixels) per lane for a fixed channel, so the tiles are stored
+// TRANSPOSED in LDS, [channel][32 pixels + pad] bf16 (80-byte rows): each thread loads a 4-pixel x 4-channel block
+// (four 16-byte global loads), converts, and writes four 8-byte column pieces (lanes run over pixel groups first:
+// conflict-free).  fp32 accumulate, fp32 slabs, same deterministic reduce.
+template <int BT>
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams p) {
+    constexpr int T = BT / 64;
+    constexpr int LDP = PK + 8;                 // bf16 elements per LDS row
+    constexpr int STAGE = 2 * BT * LDP;         // bf16 elements per stage (dY^T tile + X^T tile)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __bf16* L = (__bf16*)lds;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntiles = p.KH * p.KW * p.co_tiles * p.ci_tiles;
+    const int64_t jj = blockIdx.x >> 3;
+    const int split = (int)(jj / ntiles) * 8 + (int)(blockIdx.x & 7);
+    if (split >= p.splits) return;
+    int tile = (int)(jj % ntiles);
+    const int ci_t = tile % p.ci_tiles; tile /= p.ci_tiles;
+    const int co_t = tile % p.co_tiles;
+    const int tap = tile / p.co_tiles;
+    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+    const int co0 = co_t * BT, ci0 = ci_t * BT;
+    const int64_t m_begin = (int64_t)split * p.chunk;
+    const int64_t m_end = m_begin + p.chunk < p.M ? m_begin + p.chunk : p.M;
+    const int HoWo = p.Ho * p.Wo;
+    const float* zero = g_wzero;
+
+    const int pg = tid & 7, c4 = tid >> 3;      // pixel group (4 pixels), channel quad
+    const bool stager = c4 < BT / 4;
+    const bool co_ok = stager && co0 + c4 * 4 < p.Cout, ci_ok = stager && ci0 + c4 * 4 < p.Cin;
+
+    f32x16 acc[T][T];
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // coordinates of this thread's first pixel, advanced by PK per step
+    int64_t m1 = m_begin + pg * 4;
+    int rn, roy, rox;
+    {
+        const int64_t n = m1 / HoWo;
+        const int rem = (int)(m1 - n * HoWo);
+        rn = (int)n; roy = rem / p.Wo; rox = rem - roy * p.Wo;
+    }
+    const int dn = PK / HoWo, rp = PK - dn * HoWo;
+    const int dyy = rp / p.Wo, dxx = rp - dyy * p.Wo;
+    const float* ybase = p.dy + co0 + c4 * 4;
+    const float* xbase = p.x + ci0 + c4 * 4;
+
+    f32x4 ry[4], rx[4];
+    auto load_step = [&]() {
+        int n = rn, oy = roy, ox = rox;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool live = m1 + q < m_end;
+            const int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
+            const bool inb = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            ry[q] = *(const f32x4*)((live && co_ok) ? ybase + (m1 + q) * p.Cout : zero);
+            rx[q] = *(const f32x4*)((live && inb && ci_ok) ? xbase + (((int64_t)n * p.H + iy) * p.W + ix) * p.Cin : zero);
+            if (++ox >= p.Wo) { ox = 0; if (++oy >= p.Ho) { oy = 0; ++n; } }
+        }
+        m1 += PK;
+        int ox2 = rox + dxx, oy2 = roy + dyy, n2 = rn + dn;
+        if (ox2 >= p.Wo) { ox2 -= p.Wo; ++oy2; }
+        if (oy2 >= p.Ho) { oy2 -= p.Ho; ++n2; }
+        rox = ox2; roy = oy2; rn = n2;
+    };
+    auto store_step = [&](__bf16* buf) {
+        if (!stager) return;
+        __bf16* Yt = buf;
+        __bf16* Xt = buf + BT * LDP;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            bf16x4 vy = {(__bf16)ry[0][k], (__bf16)ry[1][k], (__bf16)ry[2][k], (__bf16)ry[3][k]};
+            bf16x4 vx = {(__bf16)rx[0][k], (__bf16)rx[1][k], (__bf16)rx[2][k], (__bf16)rx[3][k]};
+            *(bf16x4*)(Yt + (c4 * 4 + k) * LDP + pg * 4) = vy;
+            *(bf16x4*)(Xt + (c4 * 4 + k) * LDP + pg * 4) = vx;
+        }
+    };
+
+    const int nsteps = (int)((m_end - m_begin + PK - 1) / PK);
+    if (nsteps > 0) {
+        load_step();
+        store_step(L);
+    }
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const __bf16* cur = L + (s & 1) * STAGE;
+        const bool more = s + 1 < nsteps;
+        if (more) load_step();
+        const __bf16* ya = cur + (wm * 32 * T + r) * LDP + h * 8;
+        const __bf16* xb = cur + BT * LDP + (wn * 32 * T + r) * LDP + h * 8;
+#pragma unroll
+        for (int k16 = 0; k16 < PK / 16; ++k16) {
+            bf16x8 a[T], b[T];
+#pragma unroll
+            for (int i = 0; i < T; ++i) a[i] = *(const bf16x8*)(ya + i * 32 * LDP + k16 * 16);
+#pragma unroll
+            for (int j = 0; j < T; ++j) b[j] = *(const bf16x8*)(xb + j * 32 * LDP + k16 * 16);
+#pragma unroll
+            for (int i = 0; i < T; ++i)
+#pragma unroll
+                for (int j = 0; j < T; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_step(L + ((s + 1) & 1) * STAGE);
+        __syncthreads();
+    }
+
+    const int taps = p.KH * p.KW;
+    float* out = p.slab + (int64_t)split * p.Cout * taps * p.Cin;
 #pragma unroll
     for (int j = 0; j < T; ++j) {
         const int ci = ci0 + (wn * T + j) * 32 + r;
@@ -198,8 +336,8 @@ extern "C" int ssad_wgrad_splits(int64_t M, int Cin, int Cout, int KH, int KW) {
     return (int)splits;
 }
 
-extern "C" int ssad_conv_wgrad(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin,
-                               int Cout, int KH, int KW, int stride, int pad, void* stream) {
+static int wgrad_impl(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin,
+                               int Cout, int KH, int KW, int stride, int pad, void* stream, bool bf16) {
     SSAD_CHECK_ARG(dy && x && slab, "null pointer");
     SSAD_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0, "bad shape");
     SSAD_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0, "channel counts must be multiples of 4");
@@ -216,9 +354,13 @@ extern "C" int ssad_conv_wgrad(const float* dy, const float* x, float* slab, int
     const int BT = (Cin <= 64 || Cout <= 64) ? 64 : 128;   // a 128-wide tile would be half empty
     p.co_tiles = (Cout + BT - 1) / BT;
     p.ci_tiles = (Cin + BT - 1) / BT;
-    dim3 grid((unsigned)(KH * KW * p.co_tiles * p.ci_tiles), (unsigned)splits);
+    p.splits = splits;
+    dim3 grid((unsigned)(KH * KW * p.co_tiles * p.ci_tiles * ((splits + 7) / 8) * 8));
     hipStream_t st = (hipStream_t)stream;
-    if (BT == 64) {
+    if (bf16) {
+        if (BT == 64) hipLaunchKernelGGL(wgrad_bf16_kernel<64>, grid, dim3(256), 2 * 2 * 64 * (PK + 8) * 2, st, p);
+        else hipLaunchKernelGGL(wgrad_bf16_kernel<128>, grid, dim3(256), 2 * 2 * 128 * (PK + 8) * 2, st, p);
+    } else if (BT == 64) {
         hipLaunchKernelGGL(wgrad_f32_kernel<64>, grid, dim3(256), 2 * 2 * PK * 64 * 4, st, p);
     } else {
         static bool attr_set = false;
@@ -231,6 +373,17 @@ extern "C" int ssad_conv_wgrad(const float* dy, const float* x, float* slab, int
     }
     SSAD_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int ssad_conv_wgrad(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin,
+                               int Cout, int KH, int KW, int stride, int pad, void* stream) {
+    return wgrad_impl(dy, x, slab, splits, N, H, W, Cin, Cout, KH, KW, stride, pad, stream, false);
+}
+
+// bf16-operand form (fp32 tensors, fp32 accumulate and slabs): Trainer(precision=16).
+extern "C" int ssad_conv_wgrad_bf16(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin,
+                                    int Cout, int KH, int KW, int stride, int pad, void* stream) {
+    return wgrad_impl(dy, x, slab, splits, N, H, W, Cin, Cout, KH, KW, stride, pad, stream, true);
 }
 
 extern "C" int ssad_wgrad_reduce(const float* slab, float* dw, int splits, int Cout, int Kpad, int KH, int KW, int Cin,

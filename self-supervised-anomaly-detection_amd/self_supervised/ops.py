@@ -146,18 +146,19 @@ def conv3x3_wino_hwnc(x, u, scale=None, shift=None, residual=None, relu=False):
     return out
 
 
-def conv_fwd(x, w_ohwi, scale=None, shift=None, residual=None, relu=False, stride=1, pad=0):
-    """x NHWC [N][H][W][Cin]; w OHWI [Cout][KH][KW][Cin] -> NHWC [N][Ho][Wo][Cout]."""
+def conv_fwd(x, w_ohwi, scale=None, shift=None, residual=None, relu=False, stride=1, pad=0, bf16=False):
+    """x NHWC [N][H][W][Cin]; w OHWI [Cout][KH][KW][Cin] -> NHWC [N][Ho][Wo][Cout].
+    bf16=True: operands rounded to bf16 in the loader (fp32 storage / accumulate), the Trainer(precision=16) path."""
     n, h, w, cin = x.shape
     cout, kh, kw, cin2 = w_ohwi.shape
     assert cin == cin2
     ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
     out = _new((n, ho, wo, cout), x)
     nb = 4.0 * (x.numel() + out.numel() * (2 if residual is not None else 1) + w_ohwi.numel())
-    _run("conv_igemm_f32", 2.0 * out.numel() * kh * kw * cin, nb,
-         lambda: _hip.lib().ssad_conv_igemm_fwd(_hip.ptr(x), _hip.ptr(w_ohwi), _hip.ptr(out), _hip.ptr(scale, True),
-                                                _hip.ptr(shift, True), _hip.ptr(residual, True), int(relu), n, h, w,
-                                                cin, cout, kh, kw, stride, pad, _hip.stream()))
+    fn = _hip.lib().ssad_conv_igemm_fwd_bf16 if bf16 else _hip.lib().ssad_conv_igemm_fwd
+    _run("conv_igemm_bf16" if bf16 else "conv_igemm_f32", 2.0 * out.numel() * kh * kw * cin, nb,
+         lambda: fn(_hip.ptr(x), _hip.ptr(w_ohwi), _hip.ptr(out), _hip.ptr(scale, True), _hip.ptr(shift, True),
+                    _hip.ptr(residual, True), int(relu), n, h, w, cin, cout, kh, kw, stride, pad, _hip.stream()))
     return out
 
 
@@ -216,20 +217,20 @@ def flip_transpose_weight(w_ohwi):
     return out
 
 
-def conv_dgrad(dy, w_flipT, x_shape, stride, pad, residual=None):
+def conv_dgrad(dy, w_flipT, x_shape, stride, pad, residual=None, bf16=False):
     """dy NHWC [N][Hy][Wy][Cout]; w_flipT [Cin][KH][KW][Cout] -> dx NHWC of x_shape (+ residual)."""
     n, hy, wy, cout = dy.shape
     cin, kh, kw, _ = w_flipT.shape
     dx = _new(tuple(x_shape), dy)
-    _run("conv_igemm_f32", 2.0 * dx.numel() * kh * kw * cout / (stride * stride),
+    fn = _hip.lib().ssad_conv_igemm_dgrad_bf16 if bf16 else _hip.lib().ssad_conv_igemm_dgrad
+    _run("conv_igemm_bf16" if bf16 else "conv_igemm_f32", 2.0 * dx.numel() * kh * kw * cout / (stride * stride),
          4.0 * (dy.numel() + dx.numel() * (2 if residual is not None else 1) + w_flipT.numel()),
-         lambda: _hip.lib().ssad_conv_igemm_dgrad(_hip.ptr(dy), _hip.ptr(w_flipT), _hip.ptr(dx), _hip.ptr(residual, True),
-                                                  n, hy, wy, cout, x_shape[1], x_shape[2], cin, kh, kw, stride, pad,
-                                                  _hip.stream()))
+         lambda: fn(_hip.ptr(dy), _hip.ptr(w_flipT), _hip.ptr(dx), _hip.ptr(residual, True), n, hy, wy, cout, x_shape[1],
+                    x_shape[2], cin, kh, kw, stride, pad, _hip.stream()))
     return dx
 
 
-def conv_wgrad(dy, x, dw_out, kh, kw, stride, pad, kreal=None, to_oihw=False, accumulate=False):
+def conv_wgrad(dy, x, dw_out, kh, kw, stride, pad, kreal=None, to_oihw=False, accumulate=False, bf16=False):
     """dy NHWC [N][Ho][Wo][Cout], x NHWC [N][H][W][Cin] -> dw_out (flat, Cout*KH*KW*Cin_real floats).
     kreal = (KH, KW, Cin) of the real filter when x rows are padded im2col rows (stem)."""
     n, h, w, cin = x.shape
@@ -237,9 +238,10 @@ def conv_wgrad(dy, x, dw_out, kh, kw, stride, pad, kreal=None, to_oihw=False, ac
     m = dy.numel() // cout
     splits = _hip.lib().ssad_wgrad_splits(m, cin, cout, kh, kw)
     slab = _new((splits, cout, kh * kw * cin), dy)
-    _run("wgrad_f32", 2.0 * m * cout * kh * kw * cin, 4.0 * (dy.numel() * kh * kw + x.numel() * kh * kw + slab.numel()),
-         lambda: _hip.lib().ssad_conv_wgrad(_hip.ptr(dy), _hip.ptr(x), _hip.ptr(slab), splits, n, h, w, cin, cout, kh, kw,
-                                            stride, pad, _hip.stream()))
+    fn = _hip.lib().ssad_conv_wgrad_bf16 if bf16 else _hip.lib().ssad_conv_wgrad
+    _run("wgrad_bf16" if bf16 else "wgrad_f32", 2.0 * m * cout * kh * kw * cin,
+         4.0 * (dy.numel() * kh * kw + x.numel() * kh * kw + slab.numel()),
+         lambda: fn(_hip.ptr(dy), _hip.ptr(x), _hip.ptr(slab), splits, n, h, w, cin, cout, kh, kw, stride, pad, _hip.stream()))
     rkh, rkw, rcin = kreal if kreal else (kh, kw, cin)
     _run("wgrad_reduce", 0.0, 4.0 * slab.numel(),
          lambda: _hip.lib().ssad_wgrad_reduce(_hip.ptr(slab), _hip.ptr(dw_out), splits, cout, kh * kw * cin, rkh, rkw, rcin,

@@ -62,7 +62,7 @@ class Trainer:
                  devices=1, max_epochs=1, check_val_every_n_epoch=1, limit_train_batches=None, limit_val_batches=None,
                  enable_progress=False):
         self.default_root_dir, self.callbacks, self.max_epochs = default_root_dir, list(callbacks or []), max_epochs
-        self.precision = precision          # accepted for signature parity; this build computes in fp32 (exact f32 MFMA)
+        self.precision = precision          # 32: exact fp32 MFMA; 16 (what the reference passes): bf16-operand MFMA
         self.check_val_every_n_epoch = check_val_every_n_epoch
         self.limit_train_batches, self.limit_val_batches = limit_train_batches, limit_val_batches
         self.logged_metrics, self.current_epoch, self.global_step, self.model = {}, 0, 0, None
@@ -92,7 +92,7 @@ class Trainer:
         model.train()                                   # PL puts the whole module in train mode at fit start
         (opt,), scheds = model.configure_optimizers()
         step = training.DataParallelStep(model, lr=opt.param_groups[0]['lr'], momentum=opt.momentum,
-                                         weight_decay=opt.weight_decay, world_size=self.world)
+                                         weight_decay=opt.weight_decay, world_size=self.world, precision=self.precision)
         step.opt = opt
         opt.grad_scale = 1.0 / self.world
         for epoch in range(self.max_epochs):

@@ -141,13 +141,14 @@ class _Affine:
         w = self.weight()
         self.x, self.res_used = x, residual is not None
         bias = getattr(self.lin, "bias", None)
+        bf = self.eng.bf16
         if bn is None:
-            y = ops.conv_fwd(x, w, None, a.w(bias) if bias is not None else None, None, self.relu, self.stride, self.pad)
+            y = ops.conv_fwd(x, w, None, a.w(bias) if bias is not None else None, None, self.relu, self.stride, self.pad, bf)
             self.z = self.y = None
             return y
         c = bn.num_features
         if bn.training:
-            z = ops.conv_fwd(x, w, None, a.w(bias) if bias is not None else None, None, False, self.stride, self.pad)
+            z = ops.conv_fwd(x, w, None, a.w(bias) if bias is not None else None, None, False, self.stride, self.pad, bf)
             mom = 0.1 if bn.momentum is None else bn.momentum
             self.mean, self.invstd = ops.bn_stats(z, c, bn.eps, mom, bn.running_mean, bn.running_var)
             with torch.no_grad():
@@ -162,7 +163,7 @@ class _Affine:
                 shift = bn.bias - bn.running_mean * scale
                 if bias is not None:
                     shift = shift + bias * scale
-            y = ops.conv_fwd(x, w, scale, shift.contiguous(), residual, self.relu, self.stride, self.pad)
+            y = ops.conv_fwd(x, w, scale, shift.contiguous(), residual, self.relu, self.stride, self.pad, bf)
             self.z = None
         self.y = y if self.relu else None
         return y
@@ -192,14 +193,15 @@ class _Affine:
         cout = dz.shape[-1]
         if bias is not None and bias.requires_grad:
             ops.bn_bwd_reduce(dz, None, None, None, None, a.grad(bias), None, cout)
+        bf = self.eng.bf16
         if self.lin.weight.requires_grad:
             if self.stem:
-                ops.conv_wgrad(dz, self.x, a.grad(self.lin.weight), 1, 1, 1, 0, kreal=(7, 7, 3))
+                ops.conv_wgrad(dz, self.x, a.grad(self.lin.weight), 1, 1, 1, 0, kreal=(7, 7, 3), bf16=bf)
             elif self.is_conv:
                 k = self.lin.kernel_size[0]
-                ops.conv_wgrad(dz, self.x, a.grad(self.lin.weight), k, k, self.stride, self.pad)
+                ops.conv_wgrad(dz, self.x, a.grad(self.lin.weight), k, k, self.stride, self.pad, bf16=bf)
             else:
-                ops.conv_wgrad(dz, self.x, a.grad(self.lin.weight), 1, 1, 1, 0)
+                ops.conv_wgrad(dz, self.x, a.grad(self.lin.weight), 1, 1, 1, 0, bf16=bf)
         dx = None
         if need_dx:
             w = self.weight()
@@ -210,7 +212,7 @@ class _Affine:
                 dzz[..., :cout] = dz
                 wt = torch.zeros((padc,) + tuple(w.shape[1:]), device=dz.device)
                 wt[:cout] = w
-            dx = ops.conv_dgrad(dzz, ops.flip_transpose_weight(wt), self.x.shape, self.stride, self.pad, dx_residual)
+            dx = ops.conv_dgrad(dzz, ops.flip_transpose_weight(wt), self.x.shape, self.stride, self.pad, dx_residual, bf)
         self.x = self.z = self.y = None
         return dx, dres
 
@@ -221,6 +223,9 @@ class TrainEngine:
     def __init__(self, model):
         self.model = model
         self.arena = ParamArena(model)
+        # precision=16 (the reference's pl.Trainer setting, tools.py:263): conv / linear operands are rounded to bf16 in
+        # the kernels' loaders (fp32 tensors, master weights, accumulation, BatchNorm, loss and SGD stay fp32)
+        self.bf16 = False
         fe = model.feature_extractor
         self.stem = _Affine(self, fe.conv1, fe.bn1, 1, 0, True, stem=True)   # 1x1 over im2col rows
         self.blocks = []
@@ -488,9 +493,10 @@ class DataParallelStep:
     continues with the next stage.  The 1/world factor is applied inside the SGD kernel.  BatchNorm statistics
     stay per rank (the reference has no SyncBN; DDP-default semantics)."""
 
-    def __init__(self, model, lr, momentum=0.9, weight_decay=0.0005, world_size=None, process_group=None):
+    def __init__(self, model, lr, momentum=0.9, weight_decay=0.0005, world_size=None, process_group=None, precision=32):
         self.model = model
         self.eng = get_engine(model)
+        self.eng.bf16 = str(precision) in ("16", "bf16", "16-mixed", "bf16-mixed")
         self.opt = FusedSGD(model, lr, momentum, weight_decay)
         self.world = world_size if world_size is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
         self.opt.grad_scale = 1.0 / self.world

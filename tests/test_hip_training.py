@@ -197,3 +197,73 @@ def test_autograd_bridge(dev, seeded_sd):
         assert rel_err(p.grad, ref_params[name].grad, grad_floor(ref)) < 1e-3, name
     (opt,), _ = m.configure_optimizers()
     opt.step()
+
+
+def _bf(t):
+    return t.bfloat16().float()
+
+
+def test_bf16_operand_kernels(dev):
+    """precision=16 path: conv fwd / dgrad / wgrad with operands rounded to bf16 == fp32 math on bf16-rounded inputs."""
+    from self_supervised import ops
+    for (n, h, w, cin, cout, k, s, p) in [(3, 8, 8, 64, 64, 3, 1, 1), (2, 9, 9, 64, 128, 3, 2, 1), (4, 6, 6, 128, 256, 3, 1, 1),
+                                           (2, 8, 8, 64, 128, 1, 2, 0), (300, 1, 1, 896, 512, 1, 1, 0), (64, 16, 16, 160, 64, 1, 1, 0)]:
+        g = torch.Generator().manual_seed(n + k)
+        x = torch.randn(n, cin, h, w, generator=g)
+        wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+        xr, wr = _bf(x).requires_grad_(), _bf(wt).requires_grad_()
+        y = F.conv2d(xr, wr, None, s, p)
+        dy = torch.randn(y.shape, generator=g)
+        nh = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().to(dev)
+        w_ohwi = ops.repack_oihw_to_ohwi(wt.to(dev))
+        got = ops.conv_fwd(nh(x), w_ohwi, None, None, None, False, s, p, bf16=True)
+        assert rel_err(got.permute(0, 3, 1, 2), y) < 2e-5
+        # backward operands are rounded too: reference = fp32 math on bf16(dy), bf16(w), bf16(x)
+        dyr = _bf(dy)
+        gx, = torch.autograd.grad(F.conv2d(xr, wr, None, s, p), xr, dyr)
+        gw, = torch.autograd.grad(F.conv2d(xr, wr, None, s, p), wr, dyr)
+        dx = ops.conv_dgrad(nh(dy), ops.flip_transpose_weight(w_ohwi), nh(x).shape, s, p, None, bf16=True)
+        assert rel_err(dx.permute(0, 3, 1, 2), gx) < 2e-5
+        dw = torch.empty(cout * k * k * cin, device=dev)
+        ops.conv_wgrad(nh(dy), nh(x), dw, k, k, s, p, bf16=True)
+        assert rel_err(dw.view(cout, k, k, cin).permute(0, 3, 1, 2), gw) < 2e-5
+
+
+def test_bf16_training_matches_emulation(dev, seeded_sd):
+    """Trainer(precision=16): loss and every gradient against the torch-CPU emulation (fp32 math on bf16-rounded
+    operands in forward and backward, oracle/bf16_emul.py); and the loss goes down."""
+    from self_supervised import training
+    from oracle import weights as ow
+    from oracle.peranet import train_step
+    from oracle.bf16_emul import emulate_bf16
+    ref, m = _pair(seeded_sd, dev)
+    emulate_bf16(ref)
+    x, y = ow.synthetic_images(16, 64, seed=55), ow.synthetic_labels(16, seed=56)
+    loss_ref, _, _ = train_step(ref, x, y)
+    loss_ref.backward()
+    m.unfreeze()
+    step = training.DataParallelStep(m, lr=0.01, world_size=1, precision=16)
+    assert step.eng.bf16
+    la = step.step(x.to(dev), y.to(dev))
+    np.testing.assert_allclose(la[0].item(), loss_ref.item(), rtol=1e-2)   # bf16 rounding boundaries flip with summation order
+    ref_params = dict(ref.named_parameters())
+    floor = grad_floor(ref)
+    flat_h, flat_r = [], []
+    for name, p in m.named_parameters():
+        flat_h.append(p.grad.detach().cpu().flatten()); flat_r.append(ref_params[name].grad.flatten())
+    cos = torch.nn.functional.cosine_similarity(torch.cat(flat_h), torch.cat(flat_r), dim=0).item()
+    # Every kernel is exact against this emulation in isolation (test_bf16_operand_kernels).  End to end, 20 layers of
+    # batch-16 BatchNorm on random weights make the bf16 chain chaotic at the 1e-2 level: an activation that sits on a
+    # bf16 rounding boundary flips with the fp32 summation order.  Measured: cosine 0.96 against the emulation, 0.90
+    # against the fp32 step -- the HIP path follows the emulated arithmetic, not just "something near fp32".
+    ref32, _ = _pair(seeded_sd, dev)
+    l32, _, _ = train_step(ref32, x, y)
+    l32.backward()
+    p32 = dict(ref32.named_parameters())
+    flat_32 = torch.cat([p32[n].grad.flatten() for n, _ in m.named_parameters()])
+    cos32 = torch.nn.functional.cosine_similarity(torch.cat(flat_h), flat_32, dim=0).item()
+    assert cos > 0.93 and cos > cos32, (cos, cos32)
+    first = la[0].item()
+    for _ in range(8):
+        last = step.step(x.to(dev), y.to(dev))[0].item()
+    assert last < first
