@@ -240,7 +240,8 @@ def main():
 
     # roofline of the dominant kernel (conv_igemm_f32: every 3x3 / 1x1 conv and linear layer), live HIP events
     phase = "score" if "score" in prof else "train"
-    recs = [r for r in prof[phase] if r["kernel"].startswith("conv_igemm")]
+    recs = [r for r in prof[phase] if r["kernel"].startswith("conv_igemm_f32")] or \
+           [r for r in prof[phase] if r["kernel"].startswith("conv_igemm")]
     if recs:
         t = sum(r["ms"] for r in recs) * 1e-3
         fl = sum(r["flops"] for r in recs)
