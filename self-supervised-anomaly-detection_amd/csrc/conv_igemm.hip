@@ -53,11 +53,13 @@ struct ConvParams {
 // BF   : operands are rounded to bf16 while staging (fp32 in HBM, fp32 accumulate): v_mfma_f32_32x32x16_bf16 runs 16x
 //        the fp32 rate, the kernel becomes load-bound.  Used by Trainer(precision=16), mirroring the reference's AMP.
 template <int BM, int BN, int TM, int TN, int BK, int TS, bool POS, bool DB = true, bool BF = false>
-__global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
+__global__ __launch_bounds__((BM / (32 * TM)) * (BN / (32 * TN)) * 64, (BM / (32 * TM)) * (BN / (32 * TN)) == 8 ? 2 : 2)
+void conv_igemm_f32_kernel(ConvParams p) {
+    constexpr int NT = (BM / (32 * TM)) * (BN / (32 * TN)) * 64;   // threads: one wave per (32 TM) x (32 TN) sub-tile
     constexpr int LDK = BF ? BK + 8 : BK + 4;     // LDS row stride in elements (bf16: 80 / 48 bytes, f32: 144 / 80)
     constexpr int ESZ = BF ? 2 : 4;
     constexpr int CPR = BK / 4;     // 16-byte chunks per staged row
-    constexpr int RPP = 256 / CPR;  // rows staged per pass
+    constexpr int RPP = NT / CPR;   // rows staged per pass
     constexpr int WN = BN / (32 * TN);
     constexpr int AR = BM / RPP;    // 16-byte chunks of A staged per thread per K-step
     constexpr int BR = BN / RPP;
@@ -321,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvParams p) {
     float* C = lds;
     constexpr int EM = BM / TM;                // rows per epilogue pass: wave wm contributes rows [wm*32, wm*32+32)
     constexpr int C4 = BN / 4;                 // 16-byte pieces per tile row
-    constexpr int RP = 256 / C4;               // tile rows covered per sweep
+    constexpr int RP = NT / C4;                // tile rows covered per sweep
     constexpr int NPASS = EM / RP;
     const int c4 = tid % C4, rr = tid / C4;
     const int col = n0 + c4 * 4;
@@ -403,7 +405,8 @@ int launch(const ConvParams& p, hipStream_t st) {
         q.cls_start[4] = (int)gx;
     }
     dim3 grid((unsigned)gx, (unsigned)((p.Cout + BN - 1) / BN));
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, TM, TN, BK, TS, POS, DB, BF>), grid, dim3(256), lds_bytes, st, q);
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, TM, TN, BK, TS, POS, DB, BF>), grid,
+                       dim3((BM / (32 * TM)) * (BN / (32 * TN)) * 64), lds_bytes, st, q);
     return 0;
 }
 
@@ -421,7 +424,9 @@ void dispatch(const ConvParams& p, hipStream_t st) {
         else if (variant == 1) launch<256, 64, 2, 2, 16, TS, POS>(p, st);
         else launch<128, 64, 1, 2, 32, TS, POS>(p, st);
     } else {
-        launch<128, 128, 2, 2, 32, TS, POS>(p, st);
+        static const int big = getenv("SSAD_CONV128_VARIANT") ? atoi(getenv("SSAD_CONV128_VARIANT")) : 0;
+        if (big == 1) launch<256, 128, 2, 2, 32, TS, POS>(p, st);
+        else launch<128, 128, 2, 2, 32, TS, POS>(p, st);
     }
 }
 

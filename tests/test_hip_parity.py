@@ -284,3 +284,25 @@ def test_errors_are_python_exceptions(dev):
         ops.conv_fwd(torch.zeros(1, 2, 2, 3, device=dev), torch.zeros(8, 1, 1, 3, device=dev))   # Cin % 32
     with pytest.raises(_hip.HipExtensionError):
         ops.conv_fwd(torch.zeros(1, 2, 2, 32), torch.zeros(8, 1, 1, 32))                           # CPU tensors
+
+
+def test_full_batch_properties(dev, seeded_sd):
+    """BASELINE size (256 images x 841 patches, 588-row bank) through size-independent properties: the map of an image
+    does not depend on its position in the batch, on the batch size, or on how the trunk passes are chunked."""
+    from self_supervised.models import AnomalyDetector
+    from self_supervised import tools
+    from oracle import weights as ow
+    m = _model(seeded_sd, dev, True)
+    base = ow.synthetic_images(4, 256, seed=77).to(dev)
+    perm = torch.randperm(256, generator=torch.Generator().manual_seed(0))
+    big = base.repeat(64, 1, 1, 1)[perm.to(dev)].contiguous()          # 256 images: 64 shuffled copies of 4
+    det = AnomalyDetector(patch_level=True, batch=4, num_patches=841)
+    det.fit_bank(ow.synthetic_bank(588, 512, seed=2))
+    with torch.no_grad():
+        small_maps = tools.upsample(det.predict(m(base)["latent_space"]), 256, verbose=False)
+        det.batch = 256
+        big_maps = tools.upsample(det.predict(m(big)["latent_space"]), 256, verbose=False)
+    assert tuple(big_maps.shape) == (256, 1, 256, 256)
+    which = (torch.arange(256) % 4)[perm]
+    assert torch.equal(big_maps.cpu(), small_maps.cpu()[which])
+    assert torch.isfinite(big_maps).all() and float(big_maps.min()) >= 0
