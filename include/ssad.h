@@ -107,6 +107,13 @@ int ssad_cosine_knn_mean(const float* sim, float* out, int64_t Nq, int Nb, int k
  * reflect)) then bilinear (align_corners=False) to target x target.  maps [n][h][w] -> out [n][target][target]. */
 int ssad_blur_relu_bilinear(const float* maps, float* out, int n, int h, int w, int ksize, int target, void* stream);
 
+/* Replaces sklearn roc_curve + auc as called for pixel / image AUROC (src/self_supervised/metrics.py:49-56,
+ * src/self_supervised/tools.py:76-98) when the scores are already on the GPU: radix sort + tie-aware rank sum, exact
+ * integer counts reduced in fp64.  labels: uint8, non-zero = anomalous.  out[0] = AUROC, out[1] = #positives. */
+int64_t ssad_auroc_workspace(int64_t n);
+int ssad_auroc(const float* scores, const uint8_t* labels, int64_t n, void* workspace, int64_t workspace_bytes, double* out,
+               void* stream);
+
 /* ---- training step (forward in train mode, backward, update) ---- */
 /* Replaces autograd's conv2d/linear input-gradient (loss.backward() inside pl.Trainer.fit, tools.py:270,:303).
  * w_flipT = ssad_flip_transpose_weight(w_ohwi).  dx = dgrad(dy) (+ residual).  Cout % 32 == 0. */

@@ -60,12 +60,14 @@ SIGNATURES = {
     "ssad_gap_bwd": [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
     "ssad_softmax_ce": [_c_fp, _c_fp, _c_i, _c_i, _c_fp, _c_fp, _c_i, _c_f, _c_fp],
     "ssad_sgd_step": [_c_fp, _c_fp, _c_fp, _c_l, _c_f, _c_f, _c_f, _c_f, _c_fp],
+    "ssad_auroc_workspace": [_c_l],
+    "ssad_auroc": [_c_fp, _c_fp, _c_l, _c_fp, _c_l, _c_fp, _c_fp],
     "ssad_aug_params_size": [],
     "ssad_cutpaste_augment": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i,
                               ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _c_fp],
     "ssad_u8hwc_to_f32chw": [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_fp],
 }
-RESTYPES = {"ssad_colreduce_workspace": _c_l}
+RESTYPES = {"ssad_colreduce_workspace": _c_l, "ssad_auroc_workspace": _c_l}
 
 _lib = None
 

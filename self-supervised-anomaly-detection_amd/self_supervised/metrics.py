@@ -102,3 +102,18 @@ def trapezoid(x, y, x_max: float = None) -> float:
 
 def compute_aupro(all_fprs, all_pros, integration_limit: float) -> float:
     return trapezoid(all_fprs, all_pros, x_max=integration_limit) / integration_limit
+
+
+def auroc_gpu(labels, scores) -> float:
+    """AUROC of GPU-resident scores without leaving the device (csrc/auroc.hip): equals compute_auc(*compute_roc(...))."""
+    from . import _hip
+    s = scores.detach().reshape(-1).float().contiguous()
+    l = (labels.detach().reshape(-1) > 0).to(torch.uint8).to(s.device).contiguous()
+    if not s.is_cuda:
+        raise RuntimeError("auroc_gpu needs GPU tensors; use compute_roc / compute_auc on the host")
+    n = s.numel()
+    nbytes = _hip.lib().ssad_auroc_workspace(n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=s.device)
+    out = torch.empty(2, dtype=torch.float64, device=s.device)
+    _hip.check(_hip.lib().ssad_auroc(s.data_ptr(), l.data_ptr(), n, ws.data_ptr(), nbytes, out.data_ptr(), _hip.stream()))
+    return float(out[0].item())

@@ -40,6 +40,8 @@ class Evaluator:
         if patch_level:
             targets = torch.flatten(output_container.ground_truths, 0, -1)
             scores = torch.flatten(scores, 0, -1)
+        on_gpu = scores.is_cuda
+        targets_dev, scores_dev = targets, scores
         targets, scores = targets.detach().cpu(), scores.detach().cpu()
         for m in self.evaluation_metrics:
             if m != 'auroc' and ((m == 'f1-score') == patch_level):
@@ -47,9 +49,12 @@ class Evaluator:
         threshold = self._get_threshold(scores, targets)
         if 'auroc' in self.evaluation_metrics:
             print(' pixel auroc' if patch_level else '>>> image auroc')
-            fpr, tpr, _ = mtr.compute_roc(targets, scores)
-            self.scores.auroc = mtr.compute_auc(fpr, tpr)
-            self.curves['roc'] = (fpr, tpr)
+            if on_gpu:       # maps still on the device (e.g. straight from tools.upsample): sort-based AUROC kernel
+                self.scores.auroc = mtr.auroc_gpu(targets_dev.to(scores_dev.device), scores_dev)
+            else:
+                fpr, tpr, _ = mtr.compute_roc(targets, scores)
+                self.scores.auroc = mtr.compute_auc(fpr, tpr)
+                self.curves['roc'] = (fpr, tpr)
         if 'f1-score' in self.evaluation_metrics:
             self.scores.f1_score = mtr.compute_f1(targets, scores, threshold)
         if 'aupro' in self.evaluation_metrics:

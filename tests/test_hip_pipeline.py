@@ -65,3 +65,23 @@ def test_predict_and_validation_steps(seeded_sd):
     v = m.validation_step((x.to(dev), y.to(dev), None), 0)
     want = torch.nn.functional.cross_entropy(ro["classifier"], y)
     assert abs(v["val_loss"].item() - want.item()) < 1e-4 and m.training
+
+
+def test_gpu_auroc_matches_sklearn(golden):
+    from sklearn.metrics import roc_auc_score
+    from self_supervised import metrics as m
+    dev = torch.device("cuda:0")
+    g = golden("auroc")
+    got = m.auroc_gpu(torch.from_numpy(g["labels"]).to(dev), torch.from_numpy(g["scores"]).to(dev))
+    assert abs(got - float(g["auroc"])) < 1e-12
+    gen = torch.Generator().manual_seed(1)
+    for n, levels in ((1 << 20, 0), (300000, 17), (5000, 3), (2, 0)):
+        y = (torch.rand(n, generator=gen) > 0.9)
+        y[0], y[-1] = True, False
+        s = torch.rand(n, generator=gen) + 0.3 * y
+        if levels:                       # heavy ties: quantised scores
+            s = (s * levels).floor() / levels
+        want = roc_auc_score(y.numpy(), s.numpy())
+        assert abs(m.auroc_gpu(y.to(dev), s.to(dev)) - want) < 1e-10, (n, levels)
+    fpr, tpr, _ = m.compute_roc(y, s)
+    assert abs(m.compute_auc(fpr, tpr) - want) < 1e-12
