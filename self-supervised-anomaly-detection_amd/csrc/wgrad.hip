@@ -12,6 +12,7 @@
 // and one pixel range; partial tiles go to slab[split] and ssad_wgrad_reduce sums the splits in a fixed order
 // (deterministic, no float atomics), writing OIHW (checkpoint layout) or OHWI.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -328,7 +329,8 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
 extern "C" int ssad_wgrad_splits(int64_t M, int Cin, int Cout, int KH, int KW) {
     const int BT = (Cin <= 64 || Cout <= 64) ? 64 : 128;   // a 128-wide tile would be half empty
     const int64_t tiles = (int64_t)KH * KW * ((Cout + BT - 1) / BT) * ((Cin + BT - 1) / BT);
-    int64_t splits = (1024 + tiles - 1) / tiles;
+    static const int target = getenv("SSAD_WGRAD_BLOCKS") ? atoi(getenv("SSAD_WGRAD_BLOCKS")) : 2048;   // measured: 2048 > 1024 > 4096
+    int64_t splits = (target + tiles - 1) / tiles;
     const int64_t max_splits = (M + 255) / 256;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;

@@ -193,3 +193,45 @@ class GpuCutPaste:
         _hip.check(lib.ssad_u8hwc_to_f32chw(batch.data_ptr(), orig.data_ptr(), b, H, W, _hip.stream()))
         y = torch.from_numpy(recs["label"].astype(np.int64)).to(self.device)
         return out, y, orig
+
+
+class GpuPretextLoader:
+    """GPU-resident replacement for ``DataLoader(PretextTaskDataset)``: the category's images are decoded and resized
+    once, kept on the GPU as uint8, and every batch is synthesised there (GpuCutPaste).  Yields the same triple the
+    Dataset does -- (x normalised fp32, y int64, original fp32 in [0,1]) -- already on the device, so the 8 PIL worker
+    processes of the reference's DataLoader (src/self_supervised/datasets.py:501-533) are not needed and host-side data
+    feeding stops limiting multi-GPU scaling (SURVEY s.8e)."""
+
+    def __init__(self, dataset, batch_size, shuffle=True, drop_last=True, device="cuda", rank=0, world=1):
+        from PIL import Image
+        from .dataset_generator import obj_mask
+        self.dataset, self.batch_size, self.shuffle, self.drop_last = dataset, batch_size, shuffle, drop_last
+        self.rank, self.world, self.epoch = rank, world, 0
+        names = list(dict.fromkeys(dataset.images_filenames))            # duplicated file lists decode once
+        self.slot = {n: i for i, n in enumerate(names)}
+        imgs = [np.asarray(Image.open(n).resize(dataset.imsize).convert('RGB')) for n in names]
+        if dataset.subject in constants.NON_FIXED_OBJECTS():
+            masks = [np.asarray(obj_mask(Image.fromarray(im)).convert('1')) for im in imgs]
+        else:
+            masks = [np.asarray(dataset.fixed_segmentation.convert('1'))] * len(imgs)
+        cuts = np.stack([np.asarray(c) for c in dataset.images_for_cut]) if dataset.subject in constants.TEXTURES() else None
+        self.aug = GpuCutPaste(dataset.subject, np.stack(imgs), np.stack(masks), cuts, dataset.patch_localization,
+                               dataset.patch_size, device)
+        self.index = np.array([self.slot[n] for n in dataset.images_filenames])
+        self.num_workers = 0
+
+    def shard(self, world, rank, epoch):
+        self.world, self.rank, self.epoch = world, rank, epoch
+        return self
+
+    def __len__(self):
+        n = len(self.index) // self.world
+        return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
+
+    def __iter__(self):
+        order = np.arange(len(self.index))
+        if self.shuffle:
+            order = np.random.RandomState(1234 + self.epoch).permutation(len(order))
+        order = order[self.rank::self.world]
+        for i in range(len(self)):
+            yield self.aug(self.index[order[i * self.batch_size:(i + 1) * self.batch_size]])

@@ -292,7 +292,7 @@ class PretextTaskDatamodule(_DataModule):
     def __init__(self, subject: str, root_dir: str, imsize: tuple = (256, 256), batch_size: int = 32,
                  train_val_split: float = 0.2, seed: int = 0, min_dataset_length: int = 1000, duplication: bool = True,
                  patch_localization: bool = False, patch_size: tuple = 64, dataset_root: str = None,
-                 swap_train_val: bool = True):
+                 swap_train_val: bool = True, gpu_pipeline: bool = False):
         self.root_dir_train, self.root_dir_test = root_dir + '/train/good/', root_dir + '/test/good/'
         self.subject, self.imsize, self.batch_size, self.train_val_split = subject, imsize, batch_size, train_val_split
         self.seed, self.min_dataset_length, self.duplication = seed, min_dataset_length, duplication
@@ -300,6 +300,7 @@ class PretextTaskDatamodule(_DataModule):
         # the reference's Dataset reads sibling categories from a hard-coded 'dataset/' (datasets.py:189-200)
         self.dataset_root = dataset_root if dataset_root is not None else os.path.dirname(os.path.normpath(root_dir)) + '/'
         self.swap_train_val = swap_train_val      # quirk Q1: setup() builds train from the val names and vice versa
+        self.gpu_pipeline = gpu_pipeline          # synthesise training batches on the GPU (augment.GpuPretextLoader)
         self.transform = _default_transform()
         self.prepare_filenames()
 
@@ -328,9 +329,15 @@ class PretextTaskDatamodule(_DataModule):
             self.test_dataset = self._ds(self.test_images_filenames)
 
     def train_dataloader(self):
+        if self.gpu_pipeline:
+            from .augment import GpuPretextLoader
+            return GpuPretextLoader(self.train_dataset, self.batch_size, shuffle=True, drop_last=True)
         return self._loader(self.train_dataset, True, drop_last=True)
 
     def val_dataloader(self):
+        if self.gpu_pipeline:
+            from .augment import GpuPretextLoader
+            return GpuPretextLoader(self.val_dataset, self.batch_size, shuffle=False, drop_last=True)
         return self._loader(self.val_dataset, False, drop_last=True)
 
     def test_dataloader(self):

@@ -83,7 +83,7 @@ def _seed_everything(seed):
 
 def training(dataset_dir: str, outputs_dir: str, subject: str, imsize: tuple = (256, 256), patch_localization: bool = False,
              patchsize: int = 32, seed: int = 0, batch_size: int = 96, projection_training_params: tuple = (10, 0.03),
-             fine_tune_params: tuple = (30, 0.005), trainer_kwargs: dict = None) -> dict:
+             fine_tune_params: tuple = (30, 0.005), trainer_kwargs: dict = None, gpu_pipeline: bool = False) -> dict:
     """tools.py:204-306.  Returns the two metric histories (the reference plots them)."""
     print('>>> initializing training')
     checkpoint_name = 'best_model.ckpt'
@@ -96,7 +96,7 @@ def training(dataset_dir: str, outputs_dir: str, subject: str, imsize: tuple = (
     _seed_everything(seed)
     print('>>> preparing datamodule')
     datamodule = PretextTaskDatamodule(subject, dataset_dir, imsize=imsize, batch_size=batch_size, seed=seed,
-                                       patch_localization=patch_localization, patch_size=patchsize)
+                                       patch_localization=patch_localization, patch_size=patchsize, gpu_pipeline=gpu_pipeline)
     datamodule.setup()
     tk = dict(trainer_kwargs or {})
     print('>>> preparing model')

@@ -73,6 +73,8 @@ class Trainer:
         self.device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
 
     def _shard(self, loader, epoch):
+        if hasattr(loader, "shard"):                    # GPU-resident loader: shards / reshuffles itself
+            return loader.shard(self.world, self.global_rank, epoch)
         if self.world == 1:
             return loader
         sampler = DistributedSampler(loader.dataset, num_replicas=self.world, rank=self.global_rank, shuffle=True)

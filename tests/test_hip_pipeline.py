@@ -85,3 +85,19 @@ def test_gpu_auroc_matches_sklearn(golden):
         assert abs(m.auroc_gpu(y.to(dev), s.to(dev)) - want) < 1e-10, (n, levels)
     fpr, tpr, _ = m.compute_roc(y, s)
     assert abs(m.compute_auc(fpr, tpr) - want) < 1e-12
+
+
+def test_training_with_gpu_resident_pipeline(tmp_path):
+    """tools.training(gpu_pipeline=True): batches are synthesised on the GPU (no DataLoader workers), precision=16 as the
+    reference's Trainer asks; both stages run and the checkpoint loads."""
+    from self_supervised import tools, datasets
+    from self_supervised.models import PeraNet
+    datasets._DataModule.num_workers = 0
+    root = make_tree(str(tmp_path / "data"), n_train=12, n_test_good=2, n_test_bad=2, size=96)
+    out = str(tmp_path / "out") + "/"
+    hist = tools.training(root + "carpet/", out, "carpet", imsize=(64, 64), batch_size=4, seed=1, patch_localization=True,
+                          patchsize=32, projection_training_params=(1, 0.03), fine_tune_params=(2, 0.005),
+                          trainer_kwargs={"limit_val_batches": 2}, gpu_pipeline=True)
+    assert len(hist["fine_tune"]["train"]["loss"]) == 2 and np.isfinite(hist["fine_tune"]["val"]["loss"]).all()
+    m = PeraNet.load_from_checkpoint(out + "best_model.ckpt")
+    assert m.stage == "fine_tune" and m.memory_bank.ndim in (1, 2)
