@@ -267,3 +267,29 @@ def test_bf16_training_matches_emulation(dev, seeded_sd):
     for _ in range(8):
         last = step.step(x.to(dev), y.to(dev))[0].item()
     assert last < first
+
+
+def test_layer1_in_layer_outputs(dev):
+    """layer_outputs=['layer1','layer2','layer3'] (960-d concat, models.py:119-132): eval forward and training gradients."""
+    from self_supervised.models import PeraNet
+    from self_supervised import training
+    from oracle import weights as ow
+    from oracle.peranet import OraclePeraNet, train_step
+    lo = ['layer1', 'layer2', 'layer3']
+    sd = ow.seeded_state_dict(3, layer_outputs=lo)
+    ref = OraclePeraNet(layer_outputs=lo); ref.load_state_dict(sd)
+    m = PeraNet(layer_outputs=lo); m.load_state_dict(sd); m.to(dev)
+    x, y = ow.synthetic_images(8, 64, seed=21), ow.synthetic_labels(8, seed=22)
+    ref.eval(); m.eval()
+    with torch.no_grad():
+        want, got = ref(x), m(x.to(dev))
+    assert rel_err(got["latent_space"], want["latent_space"]) < 1e-4 and rel_err(got["classifier"], want["classifier"]) < 1e-4
+    ref.train(); m.train(); m.unfreeze()
+    loss_ref, _, _ = train_step(ref, x, y)
+    loss_ref.backward()
+    step = training.DataParallelStep(m, lr=0.01, world_size=1)
+    la = step.step(x.to(dev), y.to(dev))
+    np.testing.assert_allclose(la[0].item(), loss_ref.item(), rtol=1e-5)
+    ref_params, floor = dict(ref.named_parameters()), grad_floor(ref)
+    for name, p in m.named_parameters():
+        assert rel_err(p.grad, ref_params[name].grad, floor) < 1e-3, name
