@@ -148,6 +148,15 @@ int ssad_pack_stem_weight_2d(const float* w_oihw, float* out, void* stream);
 int64_t ssad_colreduce_workspace(int64_t R, int C);
 int ssad_bn_stats(const float* z, int64_t R, int C, float eps, float momentum, float* mean, float* invstd,
                   float* running_mean, float* running_var, double* workspace, void* stream);
+/* Conv2d (bias-free, as in every BasicBlock: torchvision resnet.py conv3x3/conv1x1) + the batch statistics of the
+ * train-mode BatchNorm2d that follows it (models.py:224-243 under trainer.fit) in one pass: the conv kernel leaves
+ * per-workgroup double-precision column sums in `workspace` (ssad_conv_stats_workspace(N, Ho, Wo, Cout) doubles), a
+ * finalize launch produces mean / invstd and updates the running statistics exactly as ssad_bn_stats does.
+ * `out` receives the raw convolution z (NHWC).  bf16 != 0 selects the bf16-operand kernel. */
+int64_t ssad_conv_stats_workspace(int64_t N, int Ho, int Wo, int Cout);
+int ssad_conv_igemm_fwd_stats(const float* in, const float* w_ohwi, float* out, int64_t N, int H, int W, int Cin, int Cout,
+                              int KH, int KW, int stride, int pad, int bf16, float eps, float momentum, float* mean,
+                              float* invstd, float* running_mean, float* running_var, double* workspace, void* stream);
 int ssad_bn_apply_fwd(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
                       const float* residual, float* y, int64_t R, int C, int relu, void* stream);
 int ssad_bn_bwd_reduce(const float* dy, const float* yact, const float* z, const float* mean, const float* invstd,
@@ -155,6 +164,15 @@ int ssad_bn_bwd_reduce(const float* dy, const float* yact, const float* z, const
 int ssad_bn_apply_bwd(const float* dy, const float* yact, const float* z, const float* mean, const float* invstd,
                       const float* gamma, const float* dbeta, const float* dgamma, float* dz, float* dres, int64_t R, int C,
                       int eval_mode, void* stream);
+/* The same two calls for a BatchNorm + ReLU with NO residual in between (conv1 of a BasicBlock, the stem, the head's
+ * Linear+BN+ReLU): the ReLU mask is recomputed as (z - mean) * invstd * gamma + beta > 0 -- the expression the forward
+ * evaluated -- so the saved activation is not read again. */
+int ssad_bn_bwd_reduce_zmask(const float* dy, const float* z, const float* mean, const float* invstd, const float* gamma,
+                             const float* beta, float* dbeta, float* dgamma, int64_t R, int C, double* workspace,
+                             void* stream);
+int ssad_bn_apply_bwd_zmask(const float* dy, const float* z, const float* mean, const float* invstd, const float* gamma,
+                            const float* beta, const float* dbeta, const float* dgamma, float* dz, int64_t R, int C,
+                            void* stream);
 /* Replaces the backward of nn.MaxPool2d(3,2,1) and of adaptive_avg_pool2d + cat (models.py:224-245). */
 int ssad_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int64_t N, int H, int W, int C, void* stream);
 /* Same pair with the argmax recorded by the forward pass (one byte per output element: window slot dy*3+dx of the

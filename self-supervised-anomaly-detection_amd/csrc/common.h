@@ -28,6 +28,10 @@ void ssad_set_error(const char* fmt, ...);
         }                                                             \
     } while (0)
 
+// train.hip: mean / invstd / running statistics from `nblk` rows of [2][C] double partial sums over R samples
+int ssad_bn_finalize_partials(const double* partial, int nblk, int64_t R, int C, float eps, float momentum, float* mean,
+                              float* invstd, float* running_mean, float* running_var, void* stream);
+
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // v_mfma_f32_32x32x2_f32: lane l feeds A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];

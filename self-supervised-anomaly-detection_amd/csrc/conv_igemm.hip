@@ -41,6 +41,7 @@ struct ConvParams {
     int K;              // KH*KW*Cin
     int hwnc;           // activations (in, out, residual) laid out [H][W][N][C] instead of [N][H][W][C]
     int cls_start[5];   // TS == 2: first workgroup of each output-parity class (py, px) = (c >> 1, c & 1)
+    double* stats;      // optional [gridDim.x][2][Cout]: per-workgroup column sums / sums of squares of the raw output
 };
 
 // TS   : 1 = convolution; 2 = transposed gather (dgrad of a stride-2 conv): tap (ky,kx) reads in[(oy-pad+ky)/2]
@@ -329,6 +330,11 @@ void conv_igemm_f32_kernel(ConvParams p) {
     const int col = n0 + c4 * 4;
     const bool aligned = (p.Cout & 3) == 0;    // otherwise rows are not 16-byte aligned (odd-sized k-NN bank): element-wise
     const bool col_ok = col < p.Cout;
+    // train-mode BatchNorm statistics taken while the tile is in LDS (raw accumulators; rows past M are exact zeros):
+    // thread -> one column, one slice of the pass's rows, summed in double in a fixed order
+    constexpr int SL = NT / BN, RS = EM / SL;
+    const int scol = tid % BN, ssl = tid / BN;
+    double st0 = 0.0, st1 = 0.0;
     f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
     if (aligned && col_ok && p.scale) s4 = *(const f32x4*)(p.scale + col);
     if (aligned && col_ok && p.shift) t4 = *(const f32x4*)(p.shift + col);
@@ -341,6 +347,13 @@ void conv_igemm_f32_kernel(ConvParams p) {
             for (int e = 0; e < 16; ++e)
                 C[(wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + (wn * TN + j) * 32 + r] = acc[i][j][e];
         __syncthreads();
+        if (p.stats) {
+            for (int rw = 0; rw < RS; ++rw) {
+                const double v = (double)C[(ssl * RS + rw) * LDC + scol];
+                st0 += v;
+                st1 += v * v;
+            }
+        }
         int64_t o[NPASS];
         f32x4 res[NPASS];
 #pragma unroll
@@ -381,6 +394,20 @@ void conv_igemm_f32_kernel(ConvParams p) {
             }
         }
     }
+    if (p.stats) {
+        __syncthreads();
+        double* S = (double*)lds;                       // [SL][2][BN]
+        S[(ssl * 2 + 0) * BN + scol] = st0;
+        S[(ssl * 2 + 1) * BN + scol] = st1;
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, cc = tid % BN;
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < SL; ++q) t += S[(q * 2 + which) * BN + cc];
+            if (n0 + cc < p.Cout) p.stats[((int64_t)blockIdx.x * 2 + which) * p.Cout + n0 + cc] = t;
+        }
+    }
 }
 
 template <int BM, int BN, int TM, int TN, int BK, int TS, bool POS, bool DB = true, bool BF = false>
@@ -407,32 +434,32 @@ int launch(const ConvParams& p, hipStream_t st) {
     dim3 grid((unsigned)gx, (unsigned)((p.Cout + BN - 1) / BN));
     hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, TM, TN, BK, TS, POS, DB, BF>), grid,
                        dim3((BM / (32 * TM)) * (BN / (32 * TN)) * 64), lds_bytes, st, q);
-    return 0;
+    return (int)gx;
 }
 
+// every dispatch returns the number of row workgroups launched (= rows of the statistics partials)
 template <int TS>
-void dispatch_bf16(const ConvParams& p, hipStream_t st) {
-    if (p.Cout <= 64) launch<256, 64, 2, 2, 32, TS, false, true, true>(p, st);
-    else launch<128, 128, 2, 2, 32, TS, false, true, true>(p, st);
+int dispatch_bf16(const ConvParams& p, hipStream_t st) {
+    if (p.Cout <= 64) return launch<256, 64, 2, 2, 32, TS, false, true, true>(p, st);
+    return launch<128, 128, 2, 2, 32, TS, false, true, true>(p, st);
 }
 
 template <int TS, bool POS>
-void dispatch(const ConvParams& p, hipStream_t st) {
+int dispatch(const ConvParams& p, hipStream_t st) {
     static const int variant = getenv("SSAD_CONV64_VARIANT") ? atoi(getenv("SSAD_CONV64_VARIANT")) : 1;
     if (p.Cout <= 64) {
-        if (variant == 2) launch<256, 64, 2, 2, 32, TS, POS, false>(p, st);
-        else if (variant == 1) launch<256, 64, 2, 2, 16, TS, POS>(p, st);
-        else launch<128, 64, 1, 2, 32, TS, POS>(p, st);
-    } else {
-        static const int big = getenv("SSAD_CONV128_VARIANT") ? atoi(getenv("SSAD_CONV128_VARIANT")) : 0;
-        if (big == 1) launch<256, 128, 2, 2, 32, TS, POS>(p, st);
-        else launch<128, 128, 2, 2, 32, TS, POS>(p, st);
+        if (variant == 2) return launch<256, 64, 2, 2, 32, TS, POS, false>(p, st);
+        if (variant == 1) return launch<256, 64, 2, 2, 16, TS, POS>(p, st);
+        return launch<128, 64, 1, 2, 32, TS, POS>(p, st);
     }
+    static const int big = getenv("SSAD_CONV128_VARIANT") ? atoi(getenv("SSAD_CONV128_VARIANT")) : 0;
+    if (big == 1) return launch<256, 128, 2, 2, 32, TS, POS>(p, st);
+    return launch<128, 128, 2, 2, 32, TS, POS>(p, st);
 }
 
 int conv_fwd_impl(const float* in, const float* w_ohwi, float* out, const float* scale, const float* shift,
                   const float* residual, int relu, int64_t N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
-                  int pad, int hwnc, void* stream, bool bf16 = false) {
+                  int pad, int hwnc, void* stream, bool bf16 = false, double* stats = nullptr, int* stat_rows = nullptr) {
     SSAD_CHECK_ARG(in && w_ohwi && out, "null pointer");
     SSAD_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "empty shape");
     SSAD_CHECK_ARG(Cin % KALIGN == 0, "Cin must be a multiple of 32");
@@ -447,16 +474,19 @@ int conv_fwd_impl(const float* in, const float* w_ohwi, float* out, const float*
     p.N = N;
     p.K = KH * KW * Cin;
     p.hwnc = hwnc;
+    p.stats = stats;
     // position-major rows pay off when padding is a visible share of the taps (small maps, many samples); in the
     // [H][W][N][C] layout they are also what makes a workgroup's rows contiguous
-    const bool posmajor = hwnc || (pad > 0 && N >= 128 && p.Ho * p.Wo <= 4);
+    const bool posmajor = hwnc || (!stats && pad > 0 && N >= 128 && p.Ho * p.Wo <= 4);
     SSAD_CHECK_ARG(cdiv64(p.M, 128) + 32 * p.Ho * p.Wo < (int64_t)2147483647, "M too large for one launch");
     hipStream_t st = (hipStream_t)stream;
+    int rows;
     if (bf16) {
         SSAD_CHECK_ARG(!hwnc, "bf16 operands: NHWC only");
-        dispatch_bf16<1>(p, st);
-    } else if (posmajor) dispatch<1, true>(p, st);
-    else dispatch<1, false>(p, st);
+        rows = dispatch_bf16<1>(p, st);
+    } else if (posmajor) rows = dispatch<1, true>(p, st);
+    else rows = dispatch<1, false>(p, st);
+    if (stat_rows) *stat_rows = rows;
     SSAD_CHECK_LAUNCH();
     return 0;
 }
@@ -476,6 +506,27 @@ extern "C" int ssad_conv_igemm_fwd(const float* in, const float* w_ohwi, float* 
                                    const float* shift, const float* residual, int relu, int64_t N, int H, int W,
                                    int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream) {
     return conv_fwd_impl(in, w_ohwi, out, scale, shift, residual, relu, N, H, W, Cin, Cout, KH, KW, stride, pad, 0, stream);
+}
+
+// Convolution (no epilogue) + train-mode BatchNorm statistics of its output in one pass: every workgroup leaves the
+// double-precision column sums of its tile in `workspace` (ssad_conv_stats_workspace doubles) and the finalize kernel of
+// ssad_bn_stats turns them into mean / invstd / running statistics.  Saves the separate read of z.
+extern "C" int64_t ssad_conv_stats_workspace(int64_t N, int Ho, int Wo, int Cout) {
+    return cdiv64(N * Ho * Wo, 128) * 2 * Cout;          // 128 = the smallest row tile any instantiation uses
+}
+
+extern "C" int ssad_conv_igemm_fwd_stats(const float* in, const float* w_ohwi, float* out, int64_t N, int H, int W, int Cin,
+                                         int Cout, int KH, int KW, int stride, int pad, int bf16, float eps, float momentum,
+                                         float* mean, float* invstd, float* running_mean, float* running_var,
+                                         double* workspace, void* stream) {
+    SSAD_CHECK_ARG(mean && invstd && workspace, "null pointer");
+    int rows = 0;
+    int rc = conv_fwd_impl(in, w_ohwi, out, nullptr, nullptr, nullptr, 0, N, H, W, Cin, Cout, KH, KW, stride, pad, 0, stream,
+                           bf16 != 0, workspace, &rows);
+    if (rc) return rc;
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    return ssad_bn_finalize_partials(workspace, rows, N * Ho * Wo, Cout, eps, momentum, mean, invstd, running_mean,
+                                     running_var, stream);
 }
 
 // Same contraction with every activation tensor (in, out, residual) stored position-major, [H][W][N][C].
@@ -505,7 +556,7 @@ static int dgrad_impl(const float* dy, const float* w_flipT, float* dx, const fl
     p.in = dy; p.wt = w_flipT; p.out = dx; p.scale = nullptr; p.shift = nullptr; p.residual = residual;
     p.H = Hy; p.W = Wy; p.Cin = Cout; p.Cout = Cin; p.KH = KH; p.KW = KW; p.relu = 0;
     p.stride = 1; p.pad = KH - 1 - pad; p.N = N; p.hwnc = 0;
-    p.Ho = Hx; p.Wo = Wx;
+    p.Ho = Hx; p.Wo = Wx; p.stats = nullptr;
     p.M = N * Hx * Wx;
     p.K = KH * KW * Cout;
     SSAD_CHECK_ARG(cdiv64(p.M, 128) < (int64_t)2147483647, "M too large for one launch");

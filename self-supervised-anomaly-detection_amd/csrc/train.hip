@@ -25,9 +25,12 @@ static inline ColReduce col_geom(int C) {
 
 // mode 0: s0 = sum z, s1 = sum z^2
 // mode 1: g = dy * (yact > 0 if yact) ; s0 = sum g ; s1 = sum g * (z - mean) * invstd   (z may be null -> s1 = 0)
+//         mask source: yact (the saved activation) or, when zmask_gamma is given (no residual fed the ReLU), the
+//         sign of (z - mean) * invstd * gamma + beta recomputed from z -- one tensor less to read
 template <int MODE>
 __global__ void col_reduce_kernel(const float* __restrict__ a, const float* __restrict__ yact, const float* __restrict__ z,
                                   const float* __restrict__ mean, const float* __restrict__ invstd,
+                                  const float* __restrict__ zmask_gamma, const float* __restrict__ zmask_beta,
                                   double* __restrict__ partial, int64_t R, int C, int TC, int RL, int rows_per_block) {
     __shared__ double sh[2][256][4];
     const int tid = threadIdx.x;
@@ -36,7 +39,9 @@ __global__ void col_reduce_kernel(const float* __restrict__ a, const float* __re
     for (int cq = blockIdx.x * TC + tx; cq < C4 && ty < RL; cq += gridDim.x * TC) {
         double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
         f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {1.f, 1.f, 1.f, 1.f};
+        f32x4 mg = {0.f, 0.f, 0.f, 0.f}, mb = {0.f, 0.f, 0.f, 0.f};
         if (MODE == 1 && z) { mu = ((const f32x4*)mean)[cq]; is = ((const f32x4*)invstd)[cq]; }
+        if (MODE == 1 && zmask_gamma) { mg = ((const f32x4*)zmask_gamma)[cq]; mb = ((const f32x4*)zmask_beta)[cq]; }
         const int64_t rb = (int64_t)blockIdx.y * rows_per_block;
         const int64_t re = rb + rows_per_block < R ? rb + rows_per_block : R;
         // 4 rows per iteration: all loads of an iteration are issued before any is consumed (latency-bound otherwise)
@@ -61,6 +66,9 @@ __global__ void col_reduce_kernel(const float* __restrict__ a, const float* __re
                     if (yact) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) v[u][k] = ya[u][k] > 0.f ? v[u][k] : 0.f;
+                    } else if (zmask_gamma) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[u][k] = (zz[u][k] - mu[k]) * is[k] * mg[k] + mb[k] > 0.f ? v[u][k] : 0.f;
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) s0[k] += (double)v[u][k];
@@ -168,7 +176,7 @@ __global__ void bn_apply_bwd_kernel(const float* __restrict__ dy, const float* _
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ gamma, const float* __restrict__ dbeta,
                                     const float* __restrict__ dgamma, float* __restrict__ dz, float* __restrict__ dres,
-                                    int64_t total4, int C4, float invR, int eval_mode) {
+                                    int64_t total4, int C4, float invR, int eval_mode, const float* __restrict__ zmask_beta) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
         const int cq = (int)(i % C4);
         const f32x4 mu = ((const f32x4*)mean)[cq], is = ((const f32x4*)invstd)[cq], ga = ((const f32x4*)gamma)[cq];
@@ -177,6 +185,11 @@ __global__ void bn_apply_bwd_kernel(const float* __restrict__ dy, const float* _
             const f32x4 ya = ((const f32x4*)yact)[i];
 #pragma unroll
             for (int k = 0; k < 4; ++k) g[k] = ya[k] > 0.f ? g[k] : 0.f;
+        } else if (zmask_beta) {                 // ReLU mask recomputed from z (layer without residual)
+            const f32x4 zb = ((const f32x4*)zmask_beta)[cq];
+            const f32x4 zm = ((const f32x4*)z)[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g[k] = (zm[k] - mu[k]) * is[k] * ga[k] + zb[k] > 0.f ? g[k] : 0.f;
         }
         if (dres) ((f32x4*)dres)[i] = g;
         f32x4 o;
@@ -402,7 +415,8 @@ extern "C" int64_t ssad_colreduce_workspace(int64_t R, int C) {
 }
 
 static int launch_col_reduce(int mode, const float* a, const float* yact, const float* z, const float* mean,
-                             const float* invstd, double* ws, int64_t R, int C, int* nblk_out, hipStream_t st) {
+                             const float* invstd, double* ws, int64_t R, int C, int* nblk_out, hipStream_t st,
+                             const float* zg = nullptr, const float* zb = nullptr) {
     ColReduce g = col_geom(C);
     int64_t nblk = cdiv64(R, (int64_t)g.RL * 32);
     if (nblk > 2048) nblk = 2048;
@@ -411,10 +425,18 @@ static int launch_col_reduce(int mode, const float* a, const float* yact, const 
     int gx = (C / 4 + g.TC - 1) / g.TC;
     dim3 grid(gx, (unsigned)nblk);
     if (mode == 0)
-        hipLaunchKernelGGL(col_reduce_kernel<0>, grid, dim3(256), 0, st, a, yact, z, mean, invstd, ws, R, C, g.TC, g.RL, rows_per_block);
+        hipLaunchKernelGGL(col_reduce_kernel<0>, grid, dim3(256), 0, st, a, yact, z, mean, invstd, zg, zb, ws, R, C, g.TC, g.RL, rows_per_block);
     else
-        hipLaunchKernelGGL(col_reduce_kernel<1>, grid, dim3(256), 0, st, a, yact, z, mean, invstd, ws, R, C, g.TC, g.RL, rows_per_block);
+        hipLaunchKernelGGL(col_reduce_kernel<1>, grid, dim3(256), 0, st, a, yact, z, mean, invstd, zg, zb, ws, R, C, g.TC, g.RL, rows_per_block);
     *nblk_out = (int)nblk;
+    return 0;
+}
+
+int ssad_bn_finalize_partials(const double* partial, int nblk, int64_t R, int C, float eps, float momentum, float* mean,
+                              float* invstd, float* running_mean, float* running_var, void* stream) {
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, nblk, R, C,
+                       eps, momentum, mean, invstd, running_mean, running_var);
+    SSAD_CHECK_LAUNCH();
     return 0;
 }
 
@@ -440,14 +462,42 @@ extern "C" int ssad_bn_apply_fwd(const float* z, const float* mean, const float*
 }
 
 // dbeta/dgamma over rows of g = dy*(yact>0); with z == NULL only dbeta (= column sums: Linear bias gradient).
-extern "C" int ssad_bn_bwd_reduce(const float* dy, const float* yact, const float* z, const float* mean, const float* invstd,
-                                  float* dbeta, float* dgamma, int64_t R, int C, double* workspace, void* stream) {
+static int bn_bwd_reduce_impl(const float* dy, const float* yact, const float* z, const float* mean, const float* invstd,
+                              float* dbeta, float* dgamma, int64_t R, int C, double* workspace, void* stream,
+                              const float* zg, const float* zb) {
     SSAD_CHECK_ARG(dy && workspace && R > 0 && C > 0 && C % 4 == 0, "bad argument");
     SSAD_CHECK_ARG(!z || (mean && invstd), "z needs mean/invstd");
+    SSAD_CHECK_ARG(!zg || (z && zb && !yact), "mask-from-z needs z, gamma, beta and no yact");
     int nblk;
-    launch_col_reduce(1, dy, yact, z, mean, invstd, workspace, R, C, &nblk, (hipStream_t)stream);
+    launch_col_reduce(1, dy, yact, z, mean, invstd, workspace, R, C, &nblk, (hipStream_t)stream, zg, zb);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, workspace, nblk, C, dbeta,
                        z ? dgamma : nullptr);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ssad_bn_bwd_reduce(const float* dy, const float* yact, const float* z, const float* mean, const float* invstd,
+                                  float* dbeta, float* dgamma, int64_t R, int C, double* workspace, void* stream) {
+    return bn_bwd_reduce_impl(dy, yact, z, mean, invstd, dbeta, dgamma, R, C, workspace, stream, nullptr, nullptr);
+}
+
+// Same reductions with the ReLU mask recomputed from z: mask = (z - mean) * invstd * gamma + beta > 0 (a BN + ReLU with no
+// residual in between), so the saved activation does not have to be read again.
+extern "C" int ssad_bn_bwd_reduce_zmask(const float* dy, const float* z, const float* mean, const float* invstd,
+                                        const float* gamma, const float* beta, float* dbeta, float* dgamma, int64_t R, int C,
+                                        double* workspace, void* stream) {
+    SSAD_CHECK_ARG(gamma && beta, "null gamma/beta");
+    return bn_bwd_reduce_impl(dy, nullptr, z, mean, invstd, dbeta, dgamma, R, C, workspace, stream, gamma, beta);
+}
+
+static int bn_apply_bwd_impl(const float* dy, const float* yact, const float* z, const float* mean, const float* invstd,
+                                 const float* gamma, const float* dbeta, const float* dgamma, float* dz, float* dres,
+                                 int64_t R, int C, int eval_mode, void* stream, const float* zmask_beta) {
+    SSAD_CHECK_ARG(dy && mean && invstd && gamma && dz && R > 0 && C > 0 && C % 4 == 0, "bad argument");
+    SSAD_CHECK_ARG(eval_mode || (z && dbeta && dgamma), "train-mode backward needs z, dbeta, dgamma");
+    const int64_t total4 = R * (C / 4);
+    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, dy, yact, z, mean, invstd,
+                       gamma, dbeta, dgamma, dz, dres, total4, C / 4, 1.f / (float)R, eval_mode, zmask_beta);
     SSAD_CHECK_LAUNCH();
     return 0;
 }
@@ -455,13 +505,14 @@ extern "C" int ssad_bn_bwd_reduce(const float* dy, const float* yact, const floa
 extern "C" int ssad_bn_apply_bwd(const float* dy, const float* yact, const float* z, const float* mean, const float* invstd,
                                  const float* gamma, const float* dbeta, const float* dgamma, float* dz, float* dres,
                                  int64_t R, int C, int eval_mode, void* stream) {
-    SSAD_CHECK_ARG(dy && mean && invstd && gamma && dz && R > 0 && C > 0 && C % 4 == 0, "bad argument");
-    SSAD_CHECK_ARG(eval_mode || (z && dbeta && dgamma), "train-mode backward needs z, dbeta, dgamma");
-    const int64_t total4 = R * (C / 4);
-    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, dy, yact, z, mean, invstd,
-                       gamma, dbeta, dgamma, dz, dres, total4, C / 4, 1.f / (float)R, eval_mode);
-    SSAD_CHECK_LAUNCH();
-    return 0;
+    return bn_apply_bwd_impl(dy, yact, z, mean, invstd, gamma, dbeta, dgamma, dz, dres, R, C, eval_mode, stream, nullptr);
+}
+
+extern "C" int ssad_bn_apply_bwd_zmask(const float* dy, const float* z, const float* mean, const float* invstd,
+                                       const float* gamma, const float* beta, const float* dbeta, const float* dgamma, float* dz,
+                                       int64_t R, int C, void* stream) {
+    SSAD_CHECK_ARG(z && beta, "mask-from-z needs z and beta");
+    return bn_apply_bwd_impl(dy, nullptr, z, mean, invstd, gamma, dbeta, dgamma, dz, nullptr, R, C, 0, stream, beta);
 }
 
 extern "C" int ssad_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int64_t N, int H, int W, int C, void* stream) {

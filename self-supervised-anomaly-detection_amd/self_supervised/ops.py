@@ -162,6 +162,25 @@ def conv_fwd(x, w_ohwi, scale=None, shift=None, residual=None, relu=False, strid
     return out
 
 
+def conv_fwd_stats(x, w_ohwi, eps, momentum, running_mean, running_var, stride=1, pad=0, bf16=False):
+    """Bias-free conv + the train-mode BatchNorm statistics of its output in one pass.  Returns (z, mean, invstd)."""
+    n, h, w, cin = x.shape
+    cout, kh, kw, cin2 = w_ohwi.shape
+    assert cin == cin2
+    ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+    out = _new((n, ho, wo, cout), x)
+    mean, invstd = _new((cout,), x), _new((cout,), x)
+    lib = _hip.lib()
+    ws = torch.empty(lib.ssad_conv_stats_workspace(n, ho, wo, cout), device=x.device, dtype=torch.float64)
+    nb = 4.0 * (x.numel() + out.numel() + w_ohwi.numel())
+    _run("conv_igemm_bf16" if bf16 else "conv_igemm_f32", 2.0 * out.numel() * kh * kw * cin, nb,
+         lambda: lib.ssad_conv_igemm_fwd_stats(_hip.ptr(x), _hip.ptr(w_ohwi), _hip.ptr(out), n, h, w, cin, cout, kh, kw,
+                                               stride, pad, int(bf16), eps, momentum, _hip.ptr(mean), _hip.ptr(invstd),
+                                               _hip.ptr(running_mean, True), _hip.ptr(running_var, True), ws.data_ptr(),
+                                               _hip.stream()))
+    return out, mean, invstd
+
+
 def linear_fwd(x, w, scale=None, shift=None, relu=False):
     """x [N][Cin], w [Cout][Cin] -> [N][Cout] (the same MFMA kernel with H=W=KH=KW=1)."""
     n, cin = x.shape
@@ -309,6 +328,24 @@ def bn_apply_bwd(dy, yact, z, mean, invstd, gamma, dbeta, dgamma, want_dres, eva
                                               _hip.ptr(dz), _hip.ptr(dres, True), dy.numel() // c, c, int(eval_mode),
                                               _hip.stream()))
     return dz, dres
+
+
+def bn_bwd_zmask(dy, z, mean, invstd, gamma, beta, dbeta, dgamma):
+    """BatchNorm(train) + ReLU backward with the mask recomputed from z (no residual): returns dz."""
+    c = mean.numel()
+    r = dy.numel() // c
+    ws = _colreduce_ws(r, c, dy)
+    lib = _hip.lib()
+    _run("bn_bwd_reduce", 0.0, 8.0 * dy.numel(),
+         lambda: lib.ssad_bn_bwd_reduce_zmask(_hip.ptr(dy), _hip.ptr(z), _hip.ptr(mean), _hip.ptr(invstd), _hip.ptr(gamma),
+                                              _hip.ptr(beta), _hip.ptr(dbeta), _hip.ptr(dgamma), r, c, ws.data_ptr(),
+                                              _hip.stream()))
+    dz = torch.empty_like(dy)
+    _run("bn_apply_bwd", 0.0, 12.0 * dy.numel(),
+         lambda: lib.ssad_bn_apply_bwd_zmask(_hip.ptr(dy), _hip.ptr(z), _hip.ptr(mean), _hip.ptr(invstd), _hip.ptr(gamma),
+                                             _hip.ptr(beta), _hip.ptr(dbeta), _hip.ptr(dgamma), _hip.ptr(dz), r, c,
+                                             _hip.stream()))
+    return dz
 
 
 def maxpool3x3s2_bwd(x, dy):

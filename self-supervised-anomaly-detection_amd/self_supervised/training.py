@@ -148,9 +148,14 @@ class _Affine:
             return y
         c = bn.num_features
         if bn.training:
-            z = ops.conv_fwd(x, w, None, a.w(bias) if bias is not None else None, None, False, self.stride, self.pad, bf)
             mom = 0.1 if bn.momentum is None else bn.momentum
-            self.mean, self.invstd = ops.bn_stats(z, c, bn.eps, mom, bn.running_mean, bn.running_var)
+            if bias is None and c % 4 == 0:
+                # batch statistics taken in the conv epilogue (no second pass over z)
+                z, self.mean, self.invstd = ops.conv_fwd_stats(x, w, bn.eps, mom, bn.running_mean, bn.running_var,
+                                                               self.stride, self.pad, bf)
+            else:
+                z = ops.conv_fwd(x, w, None, a.w(bias) if bias is not None else None, None, False, self.stride, self.pad, bf)
+                self.mean, self.invstd = ops.bn_stats(z, c, bn.eps, mom, bn.running_mean, bn.running_var)
             with torch.no_grad():
                 bn.num_batches_tracked += 1
             y = ops.bn_apply_fwd(z, self.mean, self.invstd, a.w(bn.weight), a.w(bn.bias), residual, self.relu)
@@ -179,17 +184,23 @@ class _Affine:
             c = bn.num_features
             train_stats = self.z is not None
             wg, bg = bn.weight.requires_grad, bn.bias.requires_grad
-            if train_stats or wg or bg:
+            if train_stats and self.relu and not self.res_used and not want_dres:
+                # y = relu(bn(z)) with nothing added in between: take the mask from z, skip re-reading y
+                dbeta = a.grad(bn.bias) if bg else torch.empty(c, device=dy.device)
+                dgamma = a.grad(bn.weight) if wg else torch.empty(c, device=dy.device)
+                dz = ops.bn_bwd_zmask(dy, self.z, self.mean, self.invstd, a.w(bn.weight), a.w(bn.bias), dbeta, dgamma)
+            elif train_stats or wg or bg:
                 dbeta = a.grad(bn.bias) if bg else torch.empty(c, device=dy.device)
                 dgamma = a.grad(bn.weight) if wg else torch.empty(c, device=dy.device)
                 zsrc = self.z if train_stats else None
                 if zsrc is None and wg:
                     raise NotImplementedError("BatchNorm weight gradient with eval-mode statistics")
                 ops.bn_bwd_reduce(dy, self.y, zsrc, self.mean, self.invstd, dbeta, dgamma, c)
+                dz, dres = ops.bn_apply_bwd(dy, self.y, self.z, self.mean, self.invstd, a.w(bn.weight), dbeta, dgamma,
+                                            want_dres, eval_mode=not train_stats)
             else:
-                dbeta = dgamma = None
-            dz, dres = ops.bn_apply_bwd(dy, self.y, self.z, self.mean, self.invstd, a.w(bn.weight), dbeta, dgamma,
-                                        want_dres, eval_mode=not train_stats)
+                dz, dres = ops.bn_apply_bwd(dy, self.y, self.z, self.mean, self.invstd, a.w(bn.weight), None, None,
+                                            want_dres, eval_mode=True)
         cout = dz.shape[-1]
         if bias is not None and bias.requires_grad:
             ops.bn_bwd_reduce(dz, None, None, None, None, a.grad(bias), None, cout)

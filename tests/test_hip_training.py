@@ -88,6 +88,40 @@ def test_bn_pool_kernels(dev):
     assert torch.equal(ops.maxpool3x3s2_bwd_idx(idx, nh(dp), nh(a).shape).cpu(), nh(a.grad).cpu())
 
 
+def test_fused_stats_and_zmask_kernels(dev):
+    """Conv epilogue statistics == separate bn_stats (bit-for-bit inputs, fp64 sums); BN backward with the ReLU mask
+    recomputed from z == the same kernels reading the saved activation."""
+    from self_supervised import ops
+    for (n, h, w, cin, cout, k, s, p, bf) in [(5, 9, 9, 64, 64, 3, 1, 1, False), (3, 8, 8, 64, 128, 3, 2, 1, False),
+                                               (130, 2, 2, 256, 512, 3, 1, 1, False), (4, 16, 16, 160, 64, 1, 1, 0, False),
+                                               (3, 8, 8, 64, 128, 3, 1, 1, True)]:
+        g = torch.Generator().manual_seed(n + cout)
+        x = (torch.randn(n, h, w, cin, generator=g) + 0.3).to(dev)
+        wt = (torch.randn(cout, k, k, cin, generator=g) / (cin * k * k) ** 0.5).to(dev)
+        rm1, rv1 = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)
+        rm2, rv2 = rm1.clone(), rv1.clone()
+        z1 = ops.conv_fwd(x, wt, None, None, None, False, s, p, bf)
+        m1, i1 = ops.bn_stats(z1, cout, 1e-5, 0.1, rm1, rv1)
+        z2, m2, i2 = ops.conv_fwd_stats(x, wt, 1e-5, 0.1, rm2, rv2, s, p, bf)
+        assert torch.equal(z1, z2)
+        # both are fp64 sums of the same fp32 values, only the summation tree differs
+        assert rel_err(m2, m1) < 1e-6 and rel_err(i2, i1) < 1e-6
+        assert rel_err(rm2, rm1) < 1e-6 and rel_err(rv2, rv1) < 1e-6
+        zd = z1.double()
+        assert rel_err(m2, zd.mean((0, 1, 2))) < 1e-6
+        assert rel_err(i2, (zd.var((0, 1, 2), unbiased=False) + 1e-5).rsqrt()) < 1e-6
+        # mask-from-z backward
+        gamma, beta = torch.rand(cout, generator=g).to(dev) + 0.5, torch.randn(cout, generator=g).to(dev) * 0.3
+        y = ops.bn_apply_fwd(z1, m1, i1, gamma, beta, None, True)
+        dy = torch.randn(z1.shape, generator=g).to(dev)
+        db1, dg1 = torch.empty(cout, device=dev), torch.empty(cout, device=dev)
+        ops.bn_bwd_reduce(dy, y, z1, m1, i1, db1, dg1, cout)
+        dz1, _ = ops.bn_apply_bwd(dy, y, z1, m1, i1, gamma, db1, dg1, False)
+        db2, dg2 = torch.empty(cout, device=dev), torch.empty(cout, device=dev)
+        dz2 = ops.bn_bwd_zmask(dy, z1, m1, i1, gamma, beta, db2, dg2)
+        assert torch.equal(db1, db2) and torch.equal(dg1, dg2) and torch.equal(dz1, dz2)
+
+
 def test_training_step_matches_autograd(dev, golden, seeded_sd):
     from self_supervised import training
     from oracle import weights as ow
