@@ -140,6 +140,13 @@ int ssad_conv_wgrad_bf16(const float* dy, const float* x, float* slab, int split
 /* Stem in training: im2col rows of 160 floats (147 taps + zero pad, nearest resize fused) so that conv1 forward and
  * its weight gradient run on the generic MFMA kernels.  Replaces conv1 of torchvision resnet18 under autograd. */
 int ssad_stem_im2col(const float* img, float* col, int64_t B, int H, int W, int Hv, int Wv, void* stream);
+/* Weight gradient of resnet conv1 (7x7/2, 3 -> 64; autograd node of models.py:224 inside trainer.fit) straight from the
+ * NCHW image -- no im2col buffer.  dz NHWC [B][Ho][Wo][64] with Ho, Wo as ssad_stem_fwd computes them (images below
+ * 64x64 go through the same nearest resize).  dw receives 64*7*7*3 floats, OHWI or (to_oihw) OIHW, optionally
+ * accumulated.  workspace: ssad_stem_wgrad_workspace(B, H, W) floats (per-workgroup slabs, summed in a fixed order). */
+int64_t ssad_stem_wgrad_workspace(int B, int H, int W);
+int ssad_stem_wgrad(const float* img, const float* dz, float* dw, int B, int H, int W, int to_oihw, int accumulate,
+                    float* workspace, void* stream);
 int ssad_pack_stem_weight_2d(const float* w_oihw, float* out, void* stream);
 /* Replaces nn.BatchNorm2d / nn.BatchNorm1d in training mode (models.py:65-95 + torchvision BasicBlock):
  * batch statistics over R rows (biased variance for normalisation, unbiased for running_var, momentum),

@@ -46,10 +46,14 @@ class _Linear(torch.autograd.Function):
         return dyr @ bf(w), dyr.t() @ bf(x)
 
 
-def emulate_bf16(model):
-    """Patches every Conv2d / Linear of ``model`` in place to compute on bf16-rounded operands (bias stays fp32)."""
+def emulate_bf16(model, fp32_stem=True):
+    """Patches every Conv2d / Linear of ``model`` in place to compute on bf16-rounded operands (bias stays fp32).
+    fp32_stem: the 3-channel conv1 stays fp32, as in the HIP path (its image-space kernels are fp32 MFMA in both
+    precisions: 2 % of the step, and the raw pixels keep full precision)."""
     for m in model.modules():
         if isinstance(m, nn.Conv2d):
+            if fp32_stem and m.in_channels == 3:
+                continue
             m.forward = (lambda mod: lambda x: _Conv.apply(x, mod.weight, mod.stride[0], mod.padding[0]))(m)
         elif isinstance(m, nn.Linear):
             m.forward = (lambda mod: lambda x: _Linear.apply(x, mod.weight) + (mod.bias if mod.bias is not None else 0.0))(m)

@@ -50,6 +50,32 @@ __global__ void gap_kernel(const float* __restrict__ in, float* __restrict__ out
     out[n * out_stride + out_offset + c] = s / (float)HW;
 }
 
+// Few samples, large maps (training batches): one workgroup per (sample, 64-channel slab); 16 pixel lanes x 16 float4
+// channel lanes, lane sums added in a fixed order through LDS.
+__global__ __launch_bounds__(256) void gap_wide_kernel(const float* __restrict__ in, float* __restrict__ out, int HW, int C,
+                                                       int out_stride, int out_offset) {
+    __shared__ f32x4 part[16][16];
+    const int cq = threadIdx.x & 15, pg = threadIdx.x >> 4;
+    const int64_t n = blockIdx.x;
+    const int c0 = blockIdx.y * 64 + cq * 4;
+    const float* p = in + n * HW * C + c0;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int k = pg; k < HW; k += 16) {
+        const f32x4 v = *(const f32x4*)(p + (int64_t)k * C);
+        s += v;
+    }
+    part[pg][cq] = s;
+    __syncthreads();
+    if (pg == 0) {
+        f32x4 t = part[0][cq];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) t += part[q][cq];
+        float* o = out + n * out_stride + out_offset + c0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = t[k] / (float)HW;
+    }
+}
+
 // one wave per row
 __global__ void l2norm_rows_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t N, int D) {
     int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -181,8 +207,12 @@ extern "C" int ssad_gap_fwd(const float* in, float* out, int64_t N, int HW, int 
                             int hwnc, void* stream) {
     SSAD_CHECK_ARG(in && out && N > 0 && HW > 0 && C > 0, "bad argument");
     SSAD_CHECK_ARG(out_offset >= 0 && out_offset + C <= out_stride, "slice does not fit the output row");
-    hipLaunchKernelGGL(gap_kernel, dim3((unsigned)cdiv64(N * C, 256)), dim3(256), 0, (hipStream_t)stream, in, out, N, HW, C,
-                       out_stride, out_offset, hwnc);
+    if (!hwnc && C % 64 == 0 && HW >= 64 && N * C < 256 * 1024)
+        hipLaunchKernelGGL(gap_wide_kernel, dim3((unsigned)N, C / 64), dim3(256), 0, (hipStream_t)stream, in, out, HW, C,
+                           out_stride, out_offset);
+    else
+        hipLaunchKernelGGL(gap_kernel, dim3((unsigned)cdiv64(N * C, 256)), dim3(256), 0, (hipStream_t)stream, in, out, N, HW, C,
+                           out_stride, out_offset, hwnc);
     SSAD_CHECK_LAUNCH();
     return 0;
 }

@@ -1,0 +1,152 @@
+// Weight gradient of the stem convolution (7x7 stride 2 pad 3, 3 -> 64) straight from the NCHW image:
+//   dW[co][ky][kx][c] = sum_{n,oy,ox} dz[n][oy][ox][co] * img[n][c][2oy+ky-3][2ox+kx-3]      (zero outside the image)
+// -- the autograd node of resnet conv1 inside trainer.fit (src/self_supervised/tools.py:270,:303; forward at
+// models.py:224).  No im2col buffer: a workgroup stages a 4x32 tile of dz and the 13x69 input pixels under it in LDS and
+// contracts over the tile's 128 pixels with v_mfma_f32_32x32x2_f32:  D[co][k] += dz[px][co] * patch[px][k],
+// k = (ky*7+kx)*3+c padded 147 -> 160.  The patch operand is pure LDS addressing: lane (r, h) reads
+// tin[pixel(h) + koff(r)], and with 213 floats per tile row the 32 k-lanes fall on 32 different banks.
+// Workgroups are persistent (grid-stride over tiles), accumulate in registers and leave one [64][160] slab each;
+// ssad_wgrad_reduce's kernel adds the slabs in a fixed order (deterministic).
+#include "common.h"
+#include "ssad.h"
+
+namespace {
+
+constexpr int TH = 4, TW = 32;                 // output pixels per tile
+constexpr int IH = 2 * TH + 5;                 // 13 input rows
+constexpr int IW = 71;                         // >= 2*TW + 5 = 69; 71*3 = 213 = 21 (mod 32): conflict-free k-lanes
+constexpr int IN_FLOATS = IH * IW * 3;         // 2769
+constexpr int DY_FLOATS = TH * TW * 64;        // 8192
+constexpr int KT = 5;                          // 32-wide k tiles (160 >= 147)
+constexpr int KPAD = KT * 32;
+
+struct StemWgradParams {
+    const float* img;
+    const float* dz;
+    float* slab;
+    int B, H, W, Hv, Wv, Ho, Wo, tiles_y, tiles_x;
+    int64_t total_tiles;
+};
+
+__global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemWgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* dys = lds;                    // [128 px][64 co]
+    float* tin = lds + DY_FLOATS;        // [IH][IW][3]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    int koff[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        const int k = kt * 32 + r;
+        const int tap = k / 3, c = k - tap * 3, ky = tap / 7, kx = tap - ky * 7;
+        koff[kt] = k < 147 ? (ky * IW + kx) * 3 + c : 0;        // padded columns read something finite; never stored
+    }
+    f32x16 acc[2][KT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < KT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int tiles_per_sample = p.tiles_y * p.tiles_x;
+    const int64_t plane = (int64_t)p.H * p.W;
+    for (int64_t t = blockIdx.x; t < p.total_tiles; t += gridDim.x) {
+        const int64_t n = t / tiles_per_sample;
+        const int tt = (int)(t - n * tiles_per_sample);
+        const int ty0 = (tt / p.tiles_x) * TH, tx0 = (tt % p.tiles_x) * TW;
+        const float* src = p.img + n * 3 * plane;
+
+        __syncthreads();                 // the previous tile's readers are done
+        // dz tile: TH rows of TW*64 contiguous floats; pixels outside the map contribute zeros
+        for (int i = tid; i < DY_FLOATS / 4; i += 256) {
+            const int px = i >> 4, q = i & 15;
+            const int oy = ty0 + (px >> 5), ox = tx0 + (px & 31);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (oy < p.Ho && ox < p.Wo) v = *(const f32x4*)(p.dz + ((n * p.Ho + oy) * p.Wo + ox) * 64 + q * 4);
+            ((f32x4*)dys)[i] = v;
+        }
+        // input tile (virtual, i.e. after the nearest resize of models.py:217-219 when the image is below 64x64)
+        for (int i = tid; i < IH * IW; i += 256) {
+            const int iy = i / IW, ix = i - iy * IW;
+            const int vy = 2 * ty0 - 3 + iy, vx = 2 * tx0 - 3 + ix;
+            float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+            if ((unsigned)vy < (unsigned)p.Hv && (unsigned)vx < (unsigned)p.Wv) {
+                const int sy = (vy * p.H) / p.Hv, sx = (vx * p.W) / p.Wv;
+                const float* s = src + (int64_t)sy * p.W + sx;
+                v0 = s[0]; v1 = s[plane]; v2 = s[2 * plane];
+            }
+            float* d = tin + i * 3;
+            d[0] = v0; d[1] = v1; d[2] = v2;
+        }
+        __syncthreads();
+
+        // wave w contracts pixel pairs w, w+4, ...: the lane halves hold the pair's two pixels
+#pragma unroll 2
+        for (int pp = wave; pp < TH * TW / 2; pp += 4) {
+            const int px = 2 * pp + h;
+            const float a0 = dys[px * 64 + r], a1 = dys[px * 64 + 32 + r];
+            const float* bp = tin + (2 * (px >> 5) * IW + 2 * (px & 31)) * 3;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const float b = bp[koff[kt]];
+                acc[0][kt] = mfma32(a0, b, acc[0][kt]);
+                acc[1][kt] = mfma32(a1, b, acc[1][kt]);
+            }
+        }
+    }
+
+    // ---- the four waves hold partial sums over disjoint pixels: add them through LDS, one 32x32 tile at a time ----
+    float* red = lds;                    // [4 waves][32][32]
+    float* out = p.slab + (int64_t)blockIdx.x * 64 * KPAD;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * 32 + r] = acc[i][kt][e];
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = tid + 256 * q, row = idx >> 5, col = idx & 31;
+                const float v = ((red[idx] + red[1024 + idx]) + red[2048 + idx]) + red[3072 + idx];
+                out[(i * 32 + row) * KPAD + kt * 32 + col] = v;
+            }
+        }
+}
+
+int stem_wgrad_blocks(int64_t total_tiles) {
+    static const int target = getenv("SSAD_STEM_WGRAD_BLOCKS") ? atoi(getenv("SSAD_STEM_WGRAD_BLOCKS")) : 512;
+    return (int)(total_tiles < target ? total_tiles : target);
+}
+
+}  // namespace
+
+extern "C" int64_t ssad_stem_wgrad_workspace(int B, int H, int W) {
+    const int Hv = (H < 64 || W < 64) ? 64 : H, Wv = (H < 64 || W < 64) ? 64 : W;
+    const int Ho = (Hv - 1) / 2 + 1, Wo = (Wv - 1) / 2 + 1;
+    const int64_t tiles = (int64_t)B * ((Ho + TH - 1) / TH) * ((Wo + TW - 1) / TW);
+    return (int64_t)stem_wgrad_blocks(tiles) * 64 * KPAD;
+}
+
+extern "C" int ssad_stem_wgrad(const float* img, const float* dz, float* dw, int B, int H, int W, int to_oihw, int accumulate,
+                               float* workspace, void* stream) {
+    SSAD_CHECK_ARG(img && dz && dw && workspace, "null pointer");
+    SSAD_CHECK_ARG(B > 0 && H > 0 && W > 0, "empty shape");
+    StemWgradParams p;
+    p.img = img; p.dz = dz; p.slab = workspace;
+    p.B = B; p.H = H; p.W = W;
+    p.Hv = (H < 64 || W < 64) ? 64 : H;
+    p.Wv = (H < 64 || W < 64) ? 64 : W;
+    p.Ho = (p.Hv - 1) / 2 + 1;
+    p.Wo = (p.Wv - 1) / 2 + 1;
+    p.tiles_y = (p.Ho + TH - 1) / TH;
+    p.tiles_x = (p.Wo + TW - 1) / TW;
+    p.total_tiles = (int64_t)B * p.tiles_y * p.tiles_x;
+    const int nblk = stem_wgrad_blocks(p.total_tiles);
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nblk), dim3(256), (DY_FLOATS + IN_FLOATS) * 4, (hipStream_t)stream, p);
+    SSAD_CHECK_LAUNCH();
+    return ssad_wgrad_reduce(workspace, dw, nblk, 64, KPAD, 7, 7, 3, to_oihw, accumulate, stream);
+}

@@ -96,12 +96,14 @@ __global__ void col_reduce_kernel(const float* __restrict__ a, const float* __re
     }
 }
 
-// Sum of the per-block partials of one channel: one wave per channel, lane l adds partials l, l+64, ... in order and
-// the 64 lane sums are combined by a fixed xor-butterfly (deterministic; every lane ends with the total).
-__device__ __forceinline__ void channel_totals(const double* __restrict__ partial, int nblk, int C, int c, double& s0, double& s1) {
-    const int lane = threadIdx.x & 63;
+// Sum of the per-block partials of one channel by one 256-thread workgroup: thread t adds partials t, t+256, ... in
+// order, a fixed xor-butterfly combines the 64 lanes of a wave and thread 0 adds the four wave sums in order
+// (deterministic).  The conv epilogue leaves up to M/128 partial rows, so a single wave per channel would spend
+// tens of microseconds in dependent loads.
+__device__ __forceinline__ bool channel_totals(const double* __restrict__ partial, int nblk, int C, int c, double& s0, double& s1) {
+    __shared__ double wsum[4][2];
     double a = 0, b = 0;
-    for (int k = lane; k < nblk; k += 64) {
+    for (int k = threadIdx.x; k < nblk; k += 256) {
         a += partial[(int64_t)k * 2 * C + c];
         b += partial[(int64_t)k * 2 * C + C + c];
     }
@@ -110,19 +112,20 @@ __device__ __forceinline__ void channel_totals(const double* __restrict__ partia
         a += __shfl_xor(a, o);
         b += __shfl_xor(b, o);
     }
-    s0 = a;
-    s1 = b;
+    if ((threadIdx.x & 63) == 0) { wsum[threadIdx.x >> 6][0] = a; wsum[threadIdx.x >> 6][1] = b; }
+    __syncthreads();
+    s0 = ((wsum[0][0] + wsum[1][0]) + wsum[2][0]) + wsum[3][0];
+    s1 = ((wsum[0][1] + wsum[1][1]) + wsum[2][1]) + wsum[3][1];
+    return threadIdx.x == 0;
 }
 
-// BN forward statistics: mean, invstd (biased var), running stats (unbiased var, momentum).  4 waves = 4 channels / block
-__global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, int nblk, int64_t R, int C, float eps,
+// BN forward statistics: mean, invstd (biased var), running stats (unbiased var, momentum).  One workgroup per channel.
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __restrict__ partial, int nblk, int64_t R, int C, float eps,
                                          float momentum, float* __restrict__ mean, float* __restrict__ invstd,
                                          float* __restrict__ running_mean, float* __restrict__ running_var) {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= C) return;
+    const int c = blockIdx.x;
     double s0, s1;
-    channel_totals(partial, nblk, C, c, s0, s1);
-    if ((threadIdx.x & 63) != 0) return;
+    if (!channel_totals(partial, nblk, C, c, s0, s1)) return;
     const double m = s0 / (double)R;
     double var = s1 / (double)R - m * m;
     if (var < 0) var = 0;
@@ -135,13 +138,11 @@ __global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, int
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblk, int C, float* __restrict__ dbeta,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblk, int C, float* __restrict__ dbeta,
                                        float* __restrict__ dgamma) {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= C) return;
+    const int c = blockIdx.x;
     double s0, s1;
-    channel_totals(partial, nblk, C, c, s0, s1);
-    if ((threadIdx.x & 63) != 0) return;
+    if (!channel_totals(partial, nblk, C, c, s0, s1)) return;
     if (dbeta) dbeta[c] = (float)s0;
     if (dgamma) dgamma[c] = (float)s1;
 }
@@ -434,7 +435,7 @@ static int launch_col_reduce(int mode, const float* a, const float* yact, const 
 
 int ssad_bn_finalize_partials(const double* partial, int nblk, int64_t R, int C, float eps, float momentum, float* mean,
                               float* invstd, float* running_mean, float* running_var, void* stream) {
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, nblk, R, C,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, nblk, R, C,
                        eps, momentum, mean, invstd, running_mean, running_var);
     SSAD_CHECK_LAUNCH();
     return 0;
@@ -445,7 +446,7 @@ extern "C" int ssad_bn_stats(const float* z, int64_t R, int C, float eps, float 
     SSAD_CHECK_ARG(z && mean && invstd && workspace && R > 0 && C > 0 && C % 4 == 0, "bad argument");
     int nblk;
     launch_col_reduce(0, z, nullptr, nullptr, nullptr, nullptr, workspace, R, C, &nblk, (hipStream_t)stream);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, workspace, nblk, R, C,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, workspace, nblk, R, C,
                        eps, momentum, mean, invstd, running_mean, running_var);
     SSAD_CHECK_LAUNCH();
     return 0;
@@ -470,7 +471,7 @@ static int bn_bwd_reduce_impl(const float* dy, const float* yact, const float* z
     SSAD_CHECK_ARG(!zg || (z && zb && !yact), "mask-from-z needs z, gamma, beta and no yact");
     int nblk;
     launch_col_reduce(1, dy, yact, z, mean, invstd, workspace, R, C, &nblk, (hipStream_t)stream, zg, zb);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, workspace, nblk, C, dbeta,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, workspace, nblk, C, dbeta,
                        z ? dgamma : nullptr);
     SSAD_CHECK_LAUNCH();
     return 0;

@@ -305,22 +305,34 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams p) {
 }
 
 // out[...] = sum_s slab[s][co][k] for k < KH*KW*Cin_real; slab rows are Kpad floats long.
+// 256 threads = 32 consecutive outputs x 8 split lanes: lane g adds splits g, g+8, ... in order, the 8 lane sums are
+// added in a fixed order through LDS (deterministic), so a reduction over ~1000 splits is not one long serial chain.
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int splits, int Cout, int Kpad,
                                     int KH, int KW, int Cin, int to_oihw, int accumulate) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float part[8][33];
+    const int lx = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int64_t idx = (int64_t)blockIdx.x * 32 + lx;
     const int Kreal = KH * KW * Cin;
-    if (idx >= (int64_t)Cout * Kreal) return;
-    const int co = (int)(idx / Kreal), k = (int)(idx - (int64_t)co * Kreal);
+    const bool ok = idx < (int64_t)Cout * Kreal;
+    const int co = ok ? (int)(idx / Kreal) : 0, k = ok ? (int)(idx - (int64_t)co * Kreal) : 0;
     const int64_t stride = (int64_t)Cout * Kpad;
     const float* s = slab + (int64_t)co * Kpad + k;
     float v = 0.f;
-    for (int i = 0; i < splits; ++i) v += s[i * stride];
-    int64_t o = idx;
-    if (to_oihw) {
-        const int tap = k / Cin, ci = k - tap * Cin;
-        o = ((int64_t)co * Cin + ci) * (KH * KW) + tap;
+    if (ok)
+        for (int i = g; i < splits; i += 8) v += s[i * stride];
+    part[g][lx] = v;
+    __syncthreads();
+    if (g == 0 && ok) {
+        float t = part[0][lx];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) t += part[q][lx];
+        int64_t o = idx;
+        if (to_oihw) {
+            const int tap = k / Cin, ci = k - tap * Cin;
+            o = ((int64_t)co * Cin + ci) * (KH * KW) + tap;
+        }
+        out[o] = accumulate ? out[o] + t : t;
     }
-    out[o] = accumulate ? out[o] + v : v;
 }
 
 }  // namespace
@@ -393,7 +405,7 @@ extern "C" int ssad_wgrad_reduce(const float* slab, float* dw, int splits, int C
     SSAD_CHECK_ARG(slab && dw && splits >= 1 && Cout > 0 && KH > 0 && KW > 0 && Cin > 0, "bad argument");
     SSAD_CHECK_ARG(Kpad >= KH * KW * Cin, "slab rows shorter than the filter");
     const int64_t total = (int64_t)Cout * KH * KW * Cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, slab, dw,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(total, 32)), dim3(256), 0, (hipStream_t)stream, slab, dw,
                        splits, Cout, Kpad, KH, KW, Cin, to_oihw, accumulate);
     SSAD_CHECK_LAUNCH();
     return 0;

@@ -53,6 +53,8 @@ SIGNATURES = {
     "ssad_bn_stats": [_c_fp, _c_l, _c_i, _c_f, _c_f, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
     "ssad_bn_apply_fwd": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp],
     "ssad_bn_bwd_reduce": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_fp, _c_fp],
+    "ssad_stem_wgrad_workspace": [_c_i, _c_i, _c_i],
+    "ssad_stem_wgrad": [_c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp],
     "ssad_conv_stats_workspace": [_c_l, _c_i, _c_i, _c_i],
     "ssad_conv_igemm_fwd_stats": [_c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
                                   _c_f, _c_f, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
@@ -72,7 +74,7 @@ SIGNATURES = {
                               ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _c_fp],
     "ssad_u8hwc_to_f32chw": [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_fp],
 }
-RESTYPES = {"ssad_colreduce_workspace": _c_l, "ssad_conv_stats_workspace": _c_l, "ssad_auroc_workspace": _c_l}
+RESTYPES = {"ssad_colreduce_workspace": _c_l, "ssad_conv_stats_workspace": _c_l, "ssad_stem_wgrad_workspace": _c_l, "ssad_auroc_workspace": _c_l}
 
 _lib = None
 

@@ -268,6 +268,18 @@ def conv_wgrad(dy, x, dw_out, kh, kw, stride, pad, kreal=None, to_oihw=False, ac
     return dw_out
 
 
+def stem_wgrad(img, dz, dw_out, to_oihw=False, accumulate=False):
+    """Weight gradient of the stem conv from the NCHW image and dz [B][Ho][Wo][64] -> dw_out (64*147 floats)."""
+    b, c, h, w = img.shape
+    assert c == 3 and dz.shape[0] == b and dz.shape[-1] == 64
+    lib = _hip.lib()
+    ws = torch.empty(lib.ssad_stem_wgrad_workspace(b, h, w), device=img.device, dtype=torch.float32)
+    _run("stem_wgrad", 2.0 * dz.numel() * 147, 4.0 * (dz.numel() + img.numel() * 1.6),
+         lambda: lib.ssad_stem_wgrad(_hip.ptr(img), _hip.ptr(dz), _hip.ptr(dw_out), b, h, w, int(to_oihw), int(accumulate),
+                                     _hip.ptr(ws), _hip.stream()))
+    return dw_out
+
+
 def stem_im2col(img, hv, wv):
     b, c, h, w = img.shape
     ho, wo = (hv - 1) // 2 + 1, (wv - 1) // 2 + 1

@@ -131,14 +131,40 @@ class _Affine:
     def weight(self):
         a = self.eng.arena
         if self.stem:
-            return ops.pack_stem_weight_2d(self.lin.weight.detach().contiguous())
+            return ops.pack_stem_weight(self.lin.weight.detach().contiguous())
         w = a.w(self.lin.weight)
         return w if self.is_conv else w.view(w.shape[0], 1, 1, w.shape[1])
 
+    def _stem_fwd(self, img, w):
+        """conv1 straight from the NCHW image (fp32 MFMA also under precision=16); train or eval BatchNorm + ReLU."""
+        bn = self.bn
+        self.x, self.res_used = img, False
+        if bn.training:
+            z = ops.stem_fwd(img, w, None, None, relu=False)
+            mom = 0.1 if bn.momentum is None else bn.momentum
+            self.mean, self.invstd = ops.bn_stats(z, 64, bn.eps, mom, bn.running_mean, bn.running_var)
+            with torch.no_grad():
+                bn.num_batches_tracked += 1
+            a = self.eng.arena
+            y = ops.bn_apply_fwd(z, self.mean, self.invstd, a.w(bn.weight), a.w(bn.bias), None, True)
+            self.z = z
+        else:
+            with torch.no_grad():
+                self.invstd = torch.rsqrt(bn.running_var + bn.eps)
+                self.mean = bn.running_mean
+                scale = (bn.weight * self.invstd).contiguous()
+                shift = (bn.bias - bn.running_mean * scale).contiguous()
+            y = ops.stem_fwd(img, w, scale, shift, relu=True)
+            self.z = None
+        self.y = y
+        return y
+
     def fwd(self, x, residual=None):
-        """x NHWC (4-D).  Returns y NHWC."""
+        """x NHWC (4-D; the stem takes the NCHW image).  Returns y NHWC."""
         a, bn = self.eng.arena, self.bn
         w = self.weight()
+        if self.stem:
+            return self._stem_fwd(x, w)
         self.x, self.res_used = x, residual is not None
         bias = getattr(self.lin, "bias", None)
         bf = self.eng.bf16
@@ -207,7 +233,7 @@ class _Affine:
         bf = self.eng.bf16
         if self.lin.weight.requires_grad:
             if self.stem:
-                ops.conv_wgrad(dz, self.x, a.grad(self.lin.weight), 1, 1, 1, 0, kreal=(7, 7, 3), bf16=bf)
+                ops.stem_wgrad(self.x, dz, a.grad(self.lin.weight))
             elif self.is_conv:
                 k = self.lin.kernel_size[0]
                 ops.conv_wgrad(dz, self.x, a.grad(self.lin.weight), k, k, self.stride, self.pad, bf16=bf)
@@ -238,7 +264,7 @@ class TrainEngine:
         # the kernels' loaders (fp32 tensors, master weights, accumulation, BatchNorm, loss and SGD stay fp32)
         self.bf16 = False
         fe = model.feature_extractor
-        self.stem = _Affine(self, fe.conv1, fe.bn1, 1, 0, True, stem=True)   # 1x1 over im2col rows
+        self.stem = _Affine(self, fe.conv1, fe.bn1, 2, 3, True, stem=True)   # dedicated image-space kernels
         self.blocks = []
         for name, _, _, _ in engine.BLOCKS:
             for blk in getattr(fe, name):
@@ -268,10 +294,8 @@ class TrainEngine:
     def forward(self, x):
         m = self.model
         b, _, h, w = x.shape
-        _, hv, wv, ho, wo = ops.stem_geometry(h, w, 0, 0)
         self.trunk_grad = any(p.requires_grad for p in m.feature_extractor.parameters())
-        col = ops.stem_im2col(x, hv, wv)
-        a0 = self.stem.fwd(col)
+        a0 = self.stem.fwd(x.contiguous())
         if not self.trunk_grad:
             self.stem.x = None
         self.a0 = a0

@@ -186,6 +186,13 @@ def test_gap(dev):
     ops.gap_fwd(x.to(dev), out, 128)
     assert_close(out[:, 128:256], x.mean(dim=(1, 2)), 1e-6)
     assert out[:, :128].abs().max().item() == 0 and out[:, 256:].abs().max().item() == 0
+    # the few-samples / large-map kernel (training batches), a small map and an odd channel count
+    for (n, hw, c) in [(5, 8, 128), (3, 2, 512), (4, 7, 36)]:
+        x = torch.randn(n, hw, hw, c) + 0.5
+        out = torch.zeros(n, c + 8, device=dev)
+        ops.gap_fwd(x.to(dev), out, 4)
+        assert_close(out[:, 4:4 + c], x.double().mean(dim=(1, 2)).float(), 2e-6)
+        assert out[:, :4].abs().max().item() == 0 and out[:, 4 + c:].abs().max().item() == 0
 
 
 def _model(sd, dev, patch):

@@ -88,6 +88,29 @@ def test_bn_pool_kernels(dev):
     assert torch.equal(ops.maxpool3x3s2_bwd_idx(idx, nh(dp), nh(a).shape).cpu(), nh(a.grad).cpu())
 
 
+def test_stem_wgrad_kernel(dev):
+    """conv1 weight gradient straight from the NCHW image vs torch autograd (incl. ragged tiles and the <64 px resize)."""
+    from self_supervised import ops
+    for (b, h, w) in [(3, 64, 64), (2, 70, 90), (5, 32, 32), (2, 256, 256)]:
+        g = torch.Generator().manual_seed(b * h)
+        img = torch.randn(b, 3, h, w, generator=g)
+        wt = (torch.randn(64, 3, 7, 7, generator=g) / 12).requires_grad_()
+        src = F.interpolate(img, (64, 64), mode="nearest") if (h < 64 or w < 64) else img
+        z = F.conv2d(src, wt, None, 2, 3)
+        dz = torch.randn(z.shape, generator=g)
+        z.backward(dz)
+        dzd = dz.permute(0, 2, 3, 1).contiguous().to(dev)
+        dw = torch.empty(64 * 147, device=dev)
+        ops.stem_wgrad(img.to(dev), dzd, dw)
+        assert rel_err(dw.view(64, 7, 7, 3).permute(0, 3, 1, 2), wt.grad) < 2e-5
+        dw2 = torch.ones(64 * 147, device=dev)
+        ops.stem_wgrad(img.to(dev), dzd, dw2, to_oihw=True, accumulate=True)
+        assert rel_err(dw2.view(64, 3, 7, 7) - 1, wt.grad) < 2e-5
+        dw3 = torch.empty(64 * 147, device=dev)
+        ops.stem_wgrad(img.to(dev), dzd, dw3)
+        assert torch.equal(dw, dw3)            # deterministic
+
+
 def test_fused_stats_and_zmask_kernels(dev):
     """Conv epilogue statistics == separate bn_stats (bit-for-bit inputs, fp64 sums); BN backward with the ReLU mask
     recomputed from z == the same kernels reading the saved activation."""
