@@ -107,6 +107,12 @@ int ssad_cosine_knn_mean(const float* sim, float* out, int64_t Nq, int Nb, int k
  * reflect)) then bilinear (align_corners=False) to target x target.  maps [n][h][w] -> out [n][target][target]. */
 int ssad_blur_relu_bilinear(const float* maps, float* out, int n, int h, int w, int ksize, int target, void* stream);
 
+/* Grad-CAM contraction (src/self_supervised/gradcam.py:39-43): out[b][pos] = sum_k alpha[b][k] * act[b][pos][k] for the
+ * NHWC layer4 activations act [B][HW][C]; alpha rows are alpha_stride floats apart (a slice of the pooled-feature
+ * gradient).  ReLU + the bilinear resize to the input size are ssad_blur_relu_bilinear with ksize = 1. */
+int ssad_gradcam_map(const float* act, const float* alpha, float* out, int64_t B, int HW, int C, int alpha_stride,
+                     void* stream);
+
 /* Replaces sklearn roc_curve + auc as called for pixel / image AUROC (src/self_supervised/metrics.py:49-56,
  * src/self_supervised/tools.py:76-98) when the scores are already on the GPU: radix sort + tie-aware rank sum, exact
  * integer counts reduced in fp64.  labels: uint8, non-zero = anomalous.  out[0] = AUROC, out[1] = #positives. */

@@ -127,6 +127,22 @@ __global__ void knn_mean_kernel(const float* __restrict__ sim, float* __restrict
     }
 }
 
+// Grad-CAM channel contraction: out[b][pos] = sum_k alpha[b][k] * act[b][pos][k]   (act NHWC).  One wave per position;
+// lane l adds channels l, l+64, ... in order, fixed butterfly across lanes.
+__global__ void gradcam_map_kernel(const float* __restrict__ act, const float* __restrict__ alpha, float* __restrict__ out,
+                                   int64_t rows, int HW, int C, int alpha_stride) {
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* a = act + row * C;
+    const float* w = alpha + (row / HW) * alpha_stride;
+    float s = 0.f;
+    for (int k = lane; k < C; k += 64) s += a[k] * w[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) out[row] = s;
+}
+
 // relu(gaussian_blur(reflect pad)) then bilinear(align_corners=False).  One workgroup per map.
 __global__ void blur_relu_bilinear_kernel(const float* __restrict__ maps, float* __restrict__ out, int h, int w, int ks,
                                           int target) {
@@ -213,6 +229,16 @@ extern "C" int ssad_gap_fwd(const float* in, float* out, int64_t N, int HW, int 
     else
         hipLaunchKernelGGL(gap_kernel, dim3((unsigned)cdiv64(N * C, 256)), dim3(256), 0, (hipStream_t)stream, in, out, N, HW, C,
                            out_stride, out_offset, hwnc);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ssad_gradcam_map(const float* act, const float* alpha, float* out, int64_t B, int HW, int C, int alpha_stride,
+                                void* stream) {
+    SSAD_CHECK_ARG(act && alpha && out && B > 0 && HW > 0 && C > 0 && alpha_stride >= C, "bad argument");
+    const int64_t rows = B * HW;
+    hipLaunchKernelGGL(gradcam_map_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, (hipStream_t)stream, act, alpha, out,
+                       rows, HW, C, alpha_stride);
     SSAD_CHECK_LAUNCH();
     return 0;
 }

@@ -226,6 +226,17 @@ def blur_relu_bilinear(maps, ksize=7, target=256):
     return out
 
 
+def gradcam_map(act, alpha):
+    """act NHWC [B][U][V][C], alpha [B][C] (may be a column slice of a wider matrix) -> [B][1][U][V] weighted sums."""
+    b, u, v, c = act.shape
+    assert alpha.shape == (b, c) and alpha.stride(1) == 1
+    out = _new((b, 1, u, v), act)
+    _run("gradcam_map", 2.0 * act.numel(), 4.0 * act.numel(),
+         lambda: _hip.lib().ssad_gradcam_map(_hip.ptr(act), _hip.ptr(alpha), _hip.ptr(out), b, u * v, c, alpha.stride(0),
+                                             _hip.stream()))
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # training kernels
 # ---------------------------------------------------------------------------------------------

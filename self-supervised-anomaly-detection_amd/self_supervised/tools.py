@@ -183,3 +183,20 @@ def upsample(anomaly_maps: Tensor, target_size: int = 256, verbose: bool = True)
             raise RuntimeError("tools.upsample runs on the MI355X HIP kernel only (no CPU fallback)")
         m = m.cuda()
     return ops.blur_relu_bilinear(m.contiguous(), 7, target_size)
+
+
+def gradcam_maps(model: PeraNet, images: Tensor, y_hat: Tensor, chunk: int = 64) -> Tensor:
+    """Image-level localisation (src/evaluator.py:268-282 of the reference): a Grad-CAM saliency of the predicted class
+    for every image predicted anomalous (y_hat != 0), an all-zero map otherwise; NaNs of constant maps become 0.
+    images [N][3][H][H], y_hat [N] -> [N][1][H][H] on the model's device."""
+    from .gradcam import GradCam
+    cam = GradCam(model)
+    dev = next(model.parameters()).device
+    y_hat = torch.as_tensor(y_hat).reshape(-1).long()
+    n, _, h, w = images.shape
+    maps = torch.zeros((n, 1, h, w), device=dev, dtype=torch.float32)
+    sel = torch.nonzero(y_hat != 0).reshape(-1)
+    for i in range(0, sel.numel(), chunk):
+        idx = sel[i:i + chunk]
+        maps[idx.to(dev)] = cam(images[idx.to(images.device)], y_hat[idx])
+    return torch.nan_to_num(maps)

@@ -209,7 +209,8 @@ class _Affine:
         else:
             c = bn.num_features
             train_stats = self.z is not None
-            wg, bg = bn.weight.requires_grad, bn.bias.requires_grad
+            pg = self.eng.param_grads
+            wg, bg = bn.weight.requires_grad and pg, bn.bias.requires_grad and pg
             if train_stats and self.relu and not self.res_used and not want_dres:
                 # y = relu(bn(z)) with nothing added in between: take the mask from z, skip re-reading y
                 dbeta = a.grad(bn.bias) if bg else torch.empty(c, device=dy.device)
@@ -228,10 +229,10 @@ class _Affine:
                 dz, dres = ops.bn_apply_bwd(dy, self.y, self.z, self.mean, self.invstd, a.w(bn.weight), None, None,
                                             want_dres, eval_mode=True)
         cout = dz.shape[-1]
-        if bias is not None and bias.requires_grad:
+        if bias is not None and bias.requires_grad and self.eng.param_grads:
             ops.bn_bwd_reduce(dz, None, None, None, None, a.grad(bias), None, cout)
         bf = self.eng.bf16
-        if self.lin.weight.requires_grad:
+        if self.lin.weight.requires_grad and self.eng.param_grads:
             if self.stem:
                 ops.stem_wgrad(self.x, dz, a.grad(self.lin.weight))
             elif self.is_conv:
@@ -263,6 +264,7 @@ class TrainEngine:
         # precision=16 (the reference's pl.Trainer setting, tools.py:263): conv / linear operands are rounded to bf16 in
         # the kernels' loaders (fp32 tensors, master weights, accumulation, BatchNorm, loss and SGD stay fp32)
         self.bf16 = False
+        self.param_grads = True       # False: backward produces input gradients only (Grad-CAM)
         fe = model.feature_extractor
         self.stem = _Affine(self, fe.conv1, fe.bn1, 2, 3, True, stem=True)   # dedicated image-space kernels
         self.blocks = []
@@ -312,6 +314,7 @@ class TrainEngine:
                 ops.gap_fwd(a, pooled, self.gap_off[d["name"]])
                 self.stage_shapes[d["name"]] = a.shape
         self.last_shape = a.shape
+        self.last_act = a             # layer4 output (NHWC): Grad-CAM's activations
         if not self.trunk_grad:
             self._drop_trunk_tape()
         f = pooled.view(b, 1, 1, -1)
@@ -361,6 +364,22 @@ class TrainEngine:
         self.stem.bwd(da0, need_dx=False)
         notify(a.total)
         self._drop_tape()
+
+    def head_input_grad(self, dlogits):
+        """d(sum(logits * dlogits)) / d(pooled features) [B][pooled_dim]: the head's backward without touching any
+        parameter gradient (gradcam.py:36: score.backward() up to the layer4 hook).  Consumes the tape."""
+        b = self.batch
+        self.param_grads = False
+        try:
+            d, _ = self.cls.bwd(dlogits.view(b, 1, 1, -1), need_dx=True)
+            for layer in reversed(self.head):
+                d, _ = layer.bwd(d, need_dx=True)
+        finally:
+            self.param_grads = True
+        act = self.last_act
+        self._drop_tape()
+        self.last_act = None
+        return d.view(b, -1), act
 
     def _drop_trunk_tape(self):
         self.a0 = self.pool_idx = None

@@ -14,9 +14,10 @@ as-is; third-party packages that are missing here are replaced by throw-away
   skimage / torchvision.transforms  -> empty shells (only names are imported)
 
 Outputs are data only (inputs are regenerated from seeds by oracle.weights):
-  forward.npz, train_step.npz, detector.npz, patches.npz, upsample.npz, cutpaste.npz, auroc.npz
+  forward.npz, train_step.npz, detector.npz, patches.npz, upsample.npz, cutpaste.npz, auroc.npz, gradcam.npz
 
-    python tests/golden/make_fixtures.py
+    python tests/golden/make_fixtures.py            # everything
+    python tests/golden/make_fixtures.py gradcam    # one section
 """
 import os
 import random
@@ -88,11 +89,37 @@ def t2n(t):
     return t.detach().cpu().numpy().copy()
 
 
+def make_gradcam(rm, sd):
+    """(viii) Grad-CAM (gradcam.py:25-48): the reference class on the seeded model, one image per call."""
+    import warnings
+    from self_supervised import gradcam as rgc
+    model = rm.PeraNet()
+    model.load_state_dict(sd, strict=True)
+    cam = rgc.GradCam(model)
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")               # register_backward_hook deprecation
+        x = ow.synthetic_images(2, 64, seed=301)
+        out["cam64_auto"] = t2n(cam(x[0:1]))          # class_idx None -> arg-max logit
+        out["cam64_c1"] = t2n(cam(x[1:2], 1))
+        out["cam64_c2"] = t2n(cam(x[1:2], torch.tensor(2)))
+        x128 = ow.synthetic_images(1, 128, seed=302)
+        out["cam128_auto"] = t2n(cam(x128))
+        x32 = ow.synthetic_images(1, 32, seed=303)    # below 64 px: nearest-resize branch, saliency back at 32x32
+        out["cam32_c1"] = t2n(cam(x32, 1))
+    np.savez_compressed(os.path.join(HERE, "gradcam.npz"), **out)
+
+
 def main():
     assert os.path.isdir(REF_SRC), "reference not present: fixtures can only be made in the build container"
     install_stubs()
     sys.path.insert(0, REF_SRC)
     from self_supervised import models as rm                     # reference
+    if sys.argv[1:] == ["gradcam"]:
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        make_gradcam(rm, ow.seeded_state_dict(0))
+        return
     from self_supervised import functional as rf
     from self_supervised import converters as rc
     from self_supervised import dataset_generator as rg
@@ -267,6 +294,7 @@ def main():
     scores = (torch.rand(4096, generator=g) + 0.5 * torch.from_numpy(labels)).numpy().astype(np.float32)
     fpr, tpr, _ = roc_curve(labels, scores)
     np.savez_compressed(os.path.join(HERE, "auroc.npz"), labels=labels, scores=scores, auroc=np.float64(auc(fpr, tpr)))
+    make_gradcam(rm, sd)
     print("fixtures written to", HERE)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

@@ -127,3 +127,15 @@ def test_auroc_case(golden):
     g = golden("auroc")
     fpr, tpr, _ = roc_curve(g["labels"], g["scores"])
     assert abs(auc(fpr, tpr) - float(g["auroc"])) < 1e-12
+
+
+def test_gradcam_oracle_matches_reference(golden, seeded_sd):
+    """oracle/gradcam.py against the reference's GradCam outputs (src/self_supervised/gradcam.py:25-48)."""
+    from oracle.gradcam import gradcam
+    from oracle.peranet import OraclePeraNet
+    g = golden("gradcam")
+    m = OraclePeraNet(); m.load_state_dict(seeded_sd)
+    x = ow.synthetic_images(2, 64, seed=301)
+    for key, xx, c in [("cam64_auto", x[0:1], None), ("cam64_c1", x[1:2], 1), ("cam64_c2", x[1:2], 2),
+                       ("cam32_c1", ow.synthetic_images(1, 32, seed=303), 1)]:
+        np.testing.assert_allclose(gradcam(m, xx, c).numpy(), g[key], atol=1e-6, rtol=0, err_msg=key)
