@@ -4,6 +4,7 @@ Drop-in for src/self_supervised/models.py of gabry1998/Self-Supervised-Anomaly-D
 same constructor arguments, method names, return types and state_dict keys.  Numerics run in
 libssad_hip.so (see engine.py / ops.py); there is no CPU fallback -- inputs must live on the GPU.
 """
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -78,6 +79,26 @@ class PeraNet(_Base):
         self.max_samples_per_pass = 16384      # patches pushed through the trunk per kernel sequence
         self._plan = None
         self._frozen = set()
+        # models.py:59 asks torchvision for IMAGENET1K_V1; there is no hub here, so the same file is taken from
+        # $SSAD_RESNET18_WEIGHTS or torch's hub cache when it exists (random init otherwise)
+        for cand in (os.environ.get("SSAD_RESNET18_WEIGHTS"),
+                     os.path.expanduser("~/.cache/torch/hub/checkpoints/resnet18-f37072fd.pth")):
+            if cand and os.path.isfile(cand):
+                self.load_backbone(cand)
+                break
+
+    def load_backbone(self, weights) -> None:
+        """Load a torchvision ``resnet18`` state dict (or a path to one, e.g. resnet18-f37072fd.pth) into the trunk:
+        what ``models.resnet18(weights="IMAGENET1K_V1")`` + ``fc = Identity`` leave behind (models.py:59-61)."""
+        sd = torch.load(weights, map_location="cpu", weights_only=True) if isinstance(weights, (str, os.PathLike)) else weights
+        sd = {k: v for k, v in sd.items() if not k.startswith("fc.")}
+        own = self.feature_extractor.state_dict()
+        missing = sorted(set(own) - set(sd))
+        extra = sorted(set(sd) - set(own))
+        if missing or extra:
+            raise KeyError(f"not a resnet18 state dict: missing {missing[:4]}, unexpected {extra[:4]}")
+        self.feature_extractor.load_state_dict(sd, strict=True)
+        self._plan = None
 
     # ---- mode switches (models.py:149-172) ----
     def enable_patch_level_mode(self):

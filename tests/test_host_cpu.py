@@ -141,3 +141,28 @@ def test_scheduler_matches_torch():
     for _ in range(65):
         to.step(); ts.step(); s.step()
         assert abs(ts.get_last_lr()[0] - s.get_last_lr()[0]) < 1e-12
+
+
+def test_load_torchvision_backbone(tmp_path, monkeypatch):
+    """f-2: a torchvision resnet18 state dict (keys conv1.*, bn1.*, layerN.*, fc.*) drops into the trunk."""
+    import torch
+    from oracle.resnet18 import ResNet18
+    from self_supervised.models import PeraNet
+    tv = ResNet18()                                  # same key set as torchvision.models.resnet18 (incl. fc)
+    with torch.no_grad():
+        for p in tv.parameters():
+            p.add_(0.25)
+    m = PeraNet()
+    m.load_backbone(tv.state_dict())
+    got = m.state_dict()
+    for k, v in tv.state_dict().items():
+        if not k.startswith("fc."):
+            assert torch.equal(got["feature_extractor." + k], v), k
+    path = tmp_path / "resnet18.pth"
+    torch.save(tv.state_dict(), path)
+    monkeypatch.setenv("SSAD_RESNET18_WEIGHTS", str(path))
+    m2 = PeraNet()
+    assert torch.equal(m2.state_dict()["feature_extractor.layer3.1.conv2.weight"], tv.state_dict()["layer3.1.conv2.weight"])
+    import pytest
+    with pytest.raises(KeyError):
+        m.load_backbone({"conv1.weight": torch.zeros(64, 3, 7, 7)})
