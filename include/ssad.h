@@ -129,6 +129,7 @@ int ssad_conv_igemm_dgrad(const float* dy, const float* w_flipT, float* dx, cons
 /* Replaces autograd's conv2d/linear weight-gradient.  Two launches: partial tiles per pixel split into
  * slab[splits][Cout][KH*KW*Cin], then a fixed-order sum written as OIHW (to_oihw=1, checkpoint layout) or OHWI. */
 int ssad_wgrad_splits(int64_t M, int Cin, int Cout, int KH, int KW);
+int ssad_wgrad_splits_bf16(int64_t M, int Cin, int Cout, int KH, int KW);   /* for ssad_conv_wgrad_bf16 */
 int ssad_conv_wgrad(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin, int Cout,
                     int KH, int KW, int stride, int pad, void* stream);
 int ssad_wgrad_reduce(const float* slab, float* dw, int splits, int Cout, int Kpad, int KH, int KW, int Cin, int to_oihw,

@@ -414,7 +414,11 @@ template <int BM, int BN, int TM, int TN, int BK, int TS, bool POS, bool DB = tr
 int launch(const ConvParams& p, hipStream_t st) {
     constexpr int stage_bytes = (DB ? 2 : 1) * (BM + BN) * (BF ? (BK + 8) * 2 : (BK + 4) * 4);
     constexpr int epi_bytes = (BM / TM) * (BN + 4) * 4;
-    constexpr int lds_bytes = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
+    constexpr int lds_min = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
+    // SSAD_CONV_LDS_PAD_<BN>: extra LDS bytes per workgroup = fewer resident workgroups (launch-quantisation experiments)
+    static const int lds_pad = getenv(BN == 64 ? "SSAD_CONV_LDS_PAD_64" : "SSAD_CONV_LDS_PAD_128")
+                                   ? atoi(getenv(BN == 64 ? "SSAD_CONV_LDS_PAD_64" : "SSAD_CONV_LDS_PAD_128")) : 0;
+    const int lds_bytes = lds_min + lds_pad;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv_igemm_f32_kernel<BM, BN, TM, TN, BK, TS, POS, DB, BF>,

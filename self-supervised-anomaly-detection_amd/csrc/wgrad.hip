@@ -12,6 +12,7 @@
 // and one pixel range; partial tiles go to slab[split] and ssad_wgrad_reduce sums the splits in a fixed order
 // (deterministic, no float atomics), writing OIHW (checkpoint layout) or OHWI.
 #include "common.h"
+#include <math.h>
 #include <stdlib.h>
 
 namespace {
@@ -68,45 +69,48 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(WgradParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // Per-row pixel coordinates are carried incrementally (a step advances every row by PK pixels), so the pixel loop
-    // holds no integer division; out-of-range rows / padding taps read a zero page instead of branching.
+    // Per-row pixel coordinates AND both row pointers are carried incrementally (a step advances every row by PK
+    // pixels: a uniform pointer delta plus uniform corrections when the column / row wraps), so the pixel loop holds
+    // no division and no 64-bit multiply; out-of-range rows / padding taps read a zero page instead of branching.
     const float* zero = g_wzero;
     const int dn = PK / HoWo, rp = PK - dn * HoWo;          // PK pixels = dn samples + rp pixels
     const int dyy = rp / p.Wo, dxx = rp - dyy * p.Wo;
-    int rn[NP], roy[NP], rox[NP];
+    const int64_t d_main = (((int64_t)dn * p.H + dyy * p.stride) * p.W + dxx * p.stride) * p.Cin;
+    const int64_t d_wx = ((int64_t)p.stride * p.W - (int64_t)p.Wo * p.stride) * p.Cin;      // ox -= Wo, oy += 1
+    const int64_t d_wy = ((int64_t)p.H - (int64_t)p.Ho * p.stride) * p.W * p.Cin;           // oy -= Ho, n += 1
+    const int len = (int)(m_end - m_begin);
+    int roy[NP], rox[NP];
     const float* yptr[NP];
+    const float* xptr[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int64_t m = m_begin + r0 + i * RPP;
         const int64_t n = m / HoWo;
         const int rem = (int)(m - n * HoWo);
-        rn[i] = (int)n;
         roy[i] = rem / p.Wo;
         rox[i] = rem - roy[i] * p.Wo;
         yptr[i] = p.dy + m * p.Cout + co0 + c4 * 4;
+        xptr[i] = p.x + ci0 + c4 * 4 +
+                  ((n * p.H + (roy[i] * p.stride - p.pad + ky)) * p.W + (rox[i] * p.stride - p.pad + kx)) * p.Cin;
     }
     const int64_t ystep = (int64_t)PK * p.Cout;
-    const float* xbase = p.x + ci0 + c4 * 4;
-    int64_t mrow = m_begin + r0;                              // flattened row of pass 0 at the step being loaded
+    int lrow = r0;                                            // row of pass 0 at the step being loaded, relative to m_begin
 
     f32x4 ry[NP], rx[NP];
-    auto load_step = [&]() {
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const bool live = mrow + i * RPP < m_end;
-            const int iy = roy[i] * p.stride - p.pad + ky, ix = rox[i] * p.stride - p.pad + kx;
-            const bool inb = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const float* xs = xbase + (((int64_t)rn[i] * p.H + iy) * p.W + ix) * p.Cin;
-            ry[i] = *(const f32x4*)((live && co_ok) ? yptr[i] : zero);
-            rx[i] = *(const f32x4*)((live && inb && ci_ok) ? xs : zero);
-            // advance this row by PK pixels
-            yptr[i] += ystep;
-            int ox = rox[i] + dxx, oy = roy[i] + dyy, n = rn[i] + dn;
-            if (ox >= p.Wo) { ox -= p.Wo; ++oy; }
-            if (oy >= p.Ho) { oy -= p.Ho; ++n; }
-            rox[i] = ox; roy[i] = oy; rn[i] = n;
-        }
-        mrow += PK;
+    // loads row-pass i of the next step and advances its state; called between MFMA groups so that its ~25 integer
+    // instructions issue in the shadow of the matrix pipe instead of in front of the whole step
+    auto load_row = [&](int i) {
+        const bool live = lrow + i * RPP < len;
+        const int iy = roy[i] * p.stride - p.pad + ky, ix = rox[i] * p.stride - p.pad + kx;
+        const bool inb = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        ry[i] = *(const f32x4*)((live && co_ok) ? yptr[i] : zero);
+        rx[i] = *(const f32x4*)((live && inb && ci_ok) ? xptr[i] : zero);
+        yptr[i] += ystep;
+        xptr[i] += d_main;
+        int ox = rox[i] + dxx, oy = roy[i] + dyy;
+        if (ox >= p.Wo) { ox -= p.Wo; ++oy; xptr[i] += d_wx; }
+        if (oy >= p.Ho) { oy -= p.Ho; xptr[i] += d_wy; }
+        rox[i] = ox; roy[i] = oy;
     };
     auto store_step = [&](float* buf) {
 #pragma unroll
@@ -116,16 +120,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(WgradParams p) {
         }
     };
 
-    const int nsteps = (int)((m_end - m_begin + PK - 1) / PK);
+    const int nsteps = (len + PK - 1) / PK;
     if (nsteps > 0) {
-        load_step();
+#pragma unroll
+        for (int i = 0; i < NP; ++i) load_row(i);
+        lrow += PK;
         store_step(lds);
     }
     __syncthreads();
+    constexpr int LOAD_EVERY = (PK / 2) / NP;                 // one row-pass per LOAD_EVERY pixel pairs
     for (int s = 0; s < nsteps; ++s) {
         const float* cur = lds + (s & 1) * STAGE;
         const bool more = s + 1 < nsteps;
-        if (more) load_step();
         const float* ya = cur + h * BT + wm * 32 * T + r;
         const float* xb = cur + PK * BT + h * BT + wn * 32 * T + r;
         // fragments of pixel pair kk+1 are requested before the MFMAs of pair kk are issued, so the LDS latency of one
@@ -144,6 +150,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(WgradParams p) {
 #pragma unroll
                 for (int j = 0; j < T; ++j) b[nx][j] = xb[(kk + 1) * 2 * BT + j * 32];
             }
+            if (kk % LOAD_EVERY == 0) load_row(kk / LOAD_EVERY);      // past the end: zero-page loads, never stored
             // hipcc otherwise sinks those reads back in front of their first use (read, lgkmcnt(0), 4 MFMAs, repeat):
             // nothing may be scheduled across this point, so the reads stay one pair ahead of the MFMAs below
             __builtin_amdgcn_sched_barrier(0);
@@ -153,6 +160,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(WgradParams p) {
                 for (int j = 0; j < T; ++j) acc[i][j] = mfma32(a[cu][i], b[cu][j], acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        lrow += PK;
         if (more) store_step(lds + ((s + 1) & 1) * STAGE);
         __syncthreads();
     }
@@ -337,17 +345,56 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
 
 }  // namespace
 
-// Number of pixel splits the kernel will use for a problem (the caller sizes the slab with it).
-extern "C" int ssad_wgrad_splits(int64_t M, int Cin, int Cout, int KH, int KW) {
+// Number of pixel splits for a problem (the caller sizes the slab with it).  Workgroups are dealt round-robin to the 8
+// XCDs and XCD g runs the tiles of splits g, g+8, ..., so with splits = 8 s every CU receives b = tiles * s / 32 equal
+// workgroups and finishes after ceil(b) of them: a launch with b = 4.5 costs as much as b = 5.  More splits also mean a
+// larger slab (written once, read once by the reduction).  The count minimises
+//     W * occ(b) * ceil(b) / b  +  2 * slab_bytes(s) / 4.5 TB/s  +  1.5 us * ceil(b) ,   W = FLOPs / sustained MFMA rate
+// (occ: penalty for resident slots of a CU left empty; the last term is a workgroup's prologue + epilogue), which reproduces the optimum of a measured sweep over the ResNet-18 shapes (tools/wgrad_sweep.py) within ~2 %.
+static int resident_per_cu(int BT, bool bf16) {
+    // from the kernels' LDS bytes / VGPRs (wave64, 512 VGPRs per SIMD, 160 KB LDS per CU)
+    if (bf16) return BT == 64 ? 6 : 3;      // 82 / 154 VGPRs; 20 / 40 KB
+    return BT == 64 ? 5 : 2;                // 60 / 151 VGPRs; 32 / 64 KB
+}
+
+static int choose_splits(int64_t M, int Cin, int Cout, int KH, int KW, bool bf16) {
     const int BT = (Cin <= 64 || Cout <= 64) ? 64 : 128;   // a 128-wide tile would be half empty
     const int64_t tiles = (int64_t)KH * KW * ((Cout + BT - 1) / BT) * ((Cin + BT - 1) / BT);
-    static const int target = getenv("SSAD_WGRAD_BLOCKS") ? atoi(getenv("SSAD_WGRAD_BLOCKS")) : 2048;   // measured: 2048 > 1024 > 4096
-    int64_t splits = (target + tiles - 1) / tiles;
-    const int64_t max_splits = (M + 255) / 256;
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    if (splits > 65535) splits = 65535;
-    return (int)splits;
+    static const int target = getenv("SSAD_WGRAD_BLOCKS") ? atoi(getenv("SSAD_WGRAD_BLOCKS")) : 0;
+    const int64_t max_splits = (M + 255) / 256;            // at least 256 pixels per workgroup
+    if (const char* e = getenv("SSAD_WGRAD_SPLITS")) {     // tuning sweeps (tools/wgrad_sweep.py)
+        const int v = atoi(e);
+        if (v > 0) return (int)(v > max_splits ? max_splits : v);
+    }
+    if (target > 0 || max_splits < 16) {                   // explicit target / tiny problems (the head's Linear layers)
+        int64_t splits = ((target > 0 ? target : 2048) + tiles - 1) / tiles;
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+        return (int)(splits > 65535 ? 65535 : splits);
+    }
+    const double rate = bf16 ? 3.0e14 : (BT == 64 ? 1.05e14 : 1.25e14);            // sustained FLOP/s of the tile kernels
+    const double W = 2.0 * (double)M * Cout * KH * KW * Cin / rate;
+    const double slab_per_split = 4.0 * (double)Cout * KH * KW * Cin;
+    int best_s = 1;
+    double best_t = 1e30;
+    const int res = resident_per_cu(BT, bf16);
+    const double occ_k = BT == 64 ? 0.15 : 0.5;            // cost of CU slots left empty (sweep: l1 +9 % at 2 of 5)
+    for (int s = 1; s <= 1024 && (int64_t)s * 8 <= max_splits; ++s) {
+        const double bpc = (double)tiles * s / 32.0;        // workgroups per CU
+        const double occ = 1.0 + occ_k * (bpc < res ? (res - bpc) / res : 0.0);
+        const double t = W * occ * ceil(bpc) / bpc + 2.0 * slab_per_split * 8.0 * s / 4.5e12 + 1.5e-6 * ceil(bpc);
+        if (t < best_t * 0.999) { best_t = t; best_s = s; }
+    }
+    return best_s * 8;
+}
+
+extern "C" int ssad_wgrad_splits(int64_t M, int Cin, int Cout, int KH, int KW) {
+    return choose_splits(M, Cin, Cout, KH, KW, false);
+}
+
+// The same for the bf16-operand kernel (more workgroups resident per CU).
+extern "C" int ssad_wgrad_splits_bf16(int64_t M, int Cin, int Cout, int KH, int KW) {
+    return choose_splits(M, Cin, Cout, KH, KW, true);
 }
 
 static int wgrad_impl(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin,

@@ -40,6 +40,7 @@ SIGNATURES = {
     "ssad_conv_igemm_dgrad": [_c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
                               _c_fp],
     "ssad_wgrad_splits": [_c_l, _c_i, _c_i, _c_i, _c_i],
+    "ssad_wgrad_splits_bf16": [_c_l, _c_i, _c_i, _c_i, _c_i],
     "ssad_conv_wgrad": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
     "ssad_conv_igemm_fwd_bf16": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
                                  _c_i, _c_i, _c_fp],

@@ -266,7 +266,7 @@ def conv_wgrad(dy, x, dw_out, kh, kw, stride, pad, kreal=None, to_oihw=False, ac
     n, h, w, cin = x.shape
     cout = dy.shape[-1]
     m = dy.numel() // cout
-    splits = _hip.lib().ssad_wgrad_splits(m, cin, cout, kh, kw)
+    splits = (_hip.lib().ssad_wgrad_splits_bf16 if bf16 else _hip.lib().ssad_wgrad_splits)(m, cin, cout, kh, kw)
     slab = _new((splits, cout, kh * kw * cin), dy)
     fn = _hip.lib().ssad_conv_wgrad_bf16 if bf16 else _hip.lib().ssad_conv_wgrad
     _run("wgrad_bf16" if bf16 else "wgrad_f32", 2.0 * m * cout * kh * kw * cin,
