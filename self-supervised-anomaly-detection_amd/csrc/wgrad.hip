@@ -30,21 +30,26 @@ struct WgradParams {
     int co_tiles, ci_tiles, splits;
 };
 
+// Wave-specialised: 8 waves, waves 0-3 ("consumers", one per SIMD) issue nothing but LDS fragment reads and MFMAs,
+// waves 4-7 ("loaders", the second wave of each SIMD) do the address arithmetic, the global loads and the LDS stores of
+// the NEXT steps.  Measured on the first, 4-wave form of this kernel (every wave loads and computes): each
+// global_load_dwordx4 costs the issuing wave ~60-70 cycles of its in-order stream -- 8 per 64 MFMAs = 14 % of the
+// step, wherever in the step they are placed -- and here those cycles are spent by a wave that has no MFMAs to delay
+// (layer2-4 wgrad 0.74 -> 0.69 ms).  One block-wide barrier per step hands buffer
+// (s+1)&1 from the loaders to the consumers; loads for step s+2 are in flight during step s+1's hand-over.
 template <int BT>
-__global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(WgradParams p) {
-    constexpr int T = BT / 64;            // 32x32 tiles per wave per dim (waves 2x2)
+__global__ __launch_bounds__(512, 4) void wgrad_f32_kernel(WgradParams p) {
+    constexpr int T = BT / 64;            // 32x32 tiles per consumer wave per dim (consumer waves 2x2)
     constexpr int F4 = BT / 4;            // float4 per staged row
-    constexpr int RPP = 256 / F4;         // rows per pass
+    constexpr int RPP = 256 / F4;         // rows per pass (256 loader threads)
     constexpr int NP = PK / RPP;          // passes
     constexpr int STAGE = 2 * PK * BT;    // floats per stage (dY tile + X tile)
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool loader = wave >= 4;
     const int r = lane & 31, h = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
-    // XCD-aware mapping (workgroups are dealt round-robin to the 8 XCDs): XCD group g = block % 8 owns the pixel
-    // splits g, g+8, ... and runs ALL (tap, co-tile, ci-tile) tiles of a split back to back, so the dY / X rows that
-    // every tile of a split re-reads are fetched into one L2 instead of eight.
+    const int wm = (wave & 3) >> 1, wn = wave & 1;
     const int ntiles = p.KH * p.KW * p.co_tiles * p.ci_tiles;
     const int64_t jj = blockIdx.x >> 3;
     const int split = (int)(jj / ntiles) * 8 + (int)(blockIdx.x & 7);
@@ -57,10 +62,76 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(WgradParams p) {
     const int co0 = co_t * BT, ci0 = ci_t * BT;
     const int64_t m_begin = (int64_t)split * p.chunk;
     const int64_t m_end = m_begin + p.chunk < p.M ? m_begin + p.chunk : p.M;
-    const int c4 = tid % F4, r0 = tid / F4;
+    const int len = (int)(m_end - m_begin);
+    const int nsteps = (len + PK - 1) / PK;
     const int HoWo = p.Ho * p.Wo;
-    const bool co_ok = co0 + c4 * 4 < p.Cout, ci_ok = ci0 + c4 * 4 < p.Cin;
 
+    if (loader) {
+        const int lt = tid - 256;
+        const int c4 = lt % F4, r0 = lt / F4;
+        const bool co_ok = co0 + c4 * 4 < p.Cout, ci_ok = ci0 + c4 * 4 < p.Cin;
+        const float* zero = g_wzero;
+        const int dn = PK / HoWo, rp = PK - dn * HoWo;
+        const int dyy = rp / p.Wo, dxx = rp - dyy * p.Wo;
+        const int64_t d_main = (((int64_t)dn * p.H + dyy * p.stride) * p.W + dxx * p.stride) * p.Cin;
+        const int64_t d_wx = ((int64_t)p.stride * p.W - (int64_t)p.Wo * p.stride) * p.Cin;
+        const int64_t d_wy = ((int64_t)p.H - (int64_t)p.Ho * p.stride) * p.W * p.Cin;
+        int roy[NP], rox[NP];
+        const float* yptr[NP];
+        const float* xptr[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int64_t m = m_begin + r0 + i * RPP;
+            const int64_t n = m / HoWo;
+            const int rem = (int)(m - n * HoWo);
+            roy[i] = rem / p.Wo;
+            rox[i] = rem - roy[i] * p.Wo;
+            yptr[i] = p.dy + m * p.Cout + co0 + c4 * 4;
+            xptr[i] = p.x + ci0 + c4 * 4 +
+                      ((n * p.H + (roy[i] * p.stride - p.pad + ky)) * p.W + (rox[i] * p.stride - p.pad + kx)) * p.Cin;
+        }
+        const int64_t ystep = (int64_t)PK * p.Cout;
+        int lrow = r0;
+        f32x4 ry[NP], rx[NP];
+        auto load_step = [&]() {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const bool live = lrow + i * RPP < len;
+                const int iy = roy[i] * p.stride - p.pad + ky, ix = rox[i] * p.stride - p.pad + kx;
+                const bool inb = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                ry[i] = *(const f32x4*)((live && co_ok) ? yptr[i] : zero);
+                rx[i] = *(const f32x4*)((live && inb && ci_ok) ? xptr[i] : zero);
+                yptr[i] += ystep;
+                xptr[i] += d_main;
+                int ox = rox[i] + dxx, oy = roy[i] + dyy;
+                if (ox >= p.Wo) { ox -= p.Wo; ++oy; xptr[i] += d_wx; }
+                if (oy >= p.Ho) { oy -= p.Ho; xptr[i] += d_wy; }
+                rox[i] = ox; roy[i] = oy;
+            }
+            lrow += PK;
+        };
+        auto store_step = [&](float* buf) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                *(f32x4*)(buf + (r0 + i * RPP) * BT + c4 * 4) = ry[i];
+                *(f32x4*)(buf + PK * BT + (r0 + i * RPP) * BT + c4 * 4) = rx[i];
+            }
+        };
+        if (nsteps > 0) {
+            load_step();
+            store_step(lds);
+            if (nsteps > 1) load_step();                      // step 1 in flight
+        }
+        __syncthreads();
+        for (int s = 0; s < nsteps; ++s) {
+            if (s + 1 < nsteps) store_step(lds + ((s + 1) & 1) * STAGE);
+            if (s + 2 < nsteps) load_step();
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---- consumers ----
     f32x16 acc[T][T];
 #pragma unroll
     for (int i = 0; i < T; ++i)
@@ -68,74 +139,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(WgradParams p) {
         for (int j = 0; j < T; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    // Per-row pixel coordinates AND both row pointers are carried incrementally (a step advances every row by PK
-    // pixels: a uniform pointer delta plus uniform corrections when the column / row wraps), so the pixel loop holds
-    // no division and no 64-bit multiply; out-of-range rows / padding taps read a zero page instead of branching.
-    const float* zero = g_wzero;
-    const int dn = PK / HoWo, rp = PK - dn * HoWo;          // PK pixels = dn samples + rp pixels
-    const int dyy = rp / p.Wo, dxx = rp - dyy * p.Wo;
-    const int64_t d_main = (((int64_t)dn * p.H + dyy * p.stride) * p.W + dxx * p.stride) * p.Cin;
-    const int64_t d_wx = ((int64_t)p.stride * p.W - (int64_t)p.Wo * p.stride) * p.Cin;      // ox -= Wo, oy += 1
-    const int64_t d_wy = ((int64_t)p.H - (int64_t)p.Ho * p.stride) * p.W * p.Cin;           // oy -= Ho, n += 1
-    const int len = (int)(m_end - m_begin);
-    int roy[NP], rox[NP];
-    const float* yptr[NP];
-    const float* xptr[NP];
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        const int64_t m = m_begin + r0 + i * RPP;
-        const int64_t n = m / HoWo;
-        const int rem = (int)(m - n * HoWo);
-        roy[i] = rem / p.Wo;
-        rox[i] = rem - roy[i] * p.Wo;
-        yptr[i] = p.dy + m * p.Cout + co0 + c4 * 4;
-        xptr[i] = p.x + ci0 + c4 * 4 +
-                  ((n * p.H + (roy[i] * p.stride - p.pad + ky)) * p.W + (rox[i] * p.stride - p.pad + kx)) * p.Cin;
-    }
-    const int64_t ystep = (int64_t)PK * p.Cout;
-    int lrow = r0;                                            // row of pass 0 at the step being loaded, relative to m_begin
-
-    f32x4 ry[NP], rx[NP];
-    // loads row-pass i of the next step and advances its state; called between MFMA groups so that its ~25 integer
-    // instructions issue in the shadow of the matrix pipe instead of in front of the whole step
-    auto load_row = [&](int i) {
-        const bool live = lrow + i * RPP < len;
-        const int iy = roy[i] * p.stride - p.pad + ky, ix = rox[i] * p.stride - p.pad + kx;
-        const bool inb = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        ry[i] = *(const f32x4*)((live && co_ok) ? yptr[i] : zero);
-        rx[i] = *(const f32x4*)((live && inb && ci_ok) ? xptr[i] : zero);
-        yptr[i] += ystep;
-        xptr[i] += d_main;
-        int ox = rox[i] + dxx, oy = roy[i] + dyy;
-        if (ox >= p.Wo) { ox -= p.Wo; ++oy; xptr[i] += d_wx; }
-        if (oy >= p.Ho) { oy -= p.Ho; xptr[i] += d_wy; }
-        rox[i] = ox; roy[i] = oy;
-    };
-    auto store_step = [&](float* buf) {
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            *(f32x4*)(buf + (r0 + i * RPP) * BT + c4 * 4) = ry[i];
-            *(f32x4*)(buf + PK * BT + (r0 + i * RPP) * BT + c4 * 4) = rx[i];
-        }
-    };
-
-    const int nsteps = (len + PK - 1) / PK;
-    if (nsteps > 0) {
-#pragma unroll
-        for (int i = 0; i < NP; ++i) load_row(i);
-        lrow += PK;
-        store_step(lds);
-    }
     __syncthreads();
-    constexpr int LOAD_EVERY = (PK / 2) / NP;                 // one row-pass per LOAD_EVERY pixel pairs
     for (int s = 0; s < nsteps; ++s) {
         const float* cur = lds + (s & 1) * STAGE;
-        const bool more = s + 1 < nsteps;
         const float* ya = cur + h * BT + wm * 32 * T + r;
         const float* xb = cur + PK * BT + h * BT + wn * 32 * T + r;
-        // fragments of pixel pair kk+1 are requested before the MFMAs of pair kk are issued, so the LDS latency of one
-        // pair hides under the matrix work of the previous one (the plain loop waits lgkmcnt(0) in front of every 4 MFMAs)
         float a[2][T], b[2][T];
 #pragma unroll
         for (int i = 0; i < T; ++i) a[0][i] = ya[i * 32];
@@ -150,18 +158,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(WgradParams p) {
 #pragma unroll
                 for (int j = 0; j < T; ++j) b[nx][j] = xb[(kk + 1) * 2 * BT + j * 32];
             }
-            if (kk % LOAD_EVERY == 0) load_row(kk / LOAD_EVERY);      // past the end: zero-page loads, never stored
-            // hipcc otherwise sinks those reads back in front of their first use (read, lgkmcnt(0), 4 MFMAs, repeat):
-            // nothing may be scheduled across this point, so the reads stay one pair ahead of the MFMAs below
-            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);      // keep the reads one pixel pair ahead of the MFMAs (see above)
 #pragma unroll
             for (int i = 0; i < T; ++i)
 #pragma unroll
                 for (int j = 0; j < T; ++j) acc[i][j] = mfma32(a[cu][i], b[cu][j], acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        lrow += PK;
-        if (more) store_step(lds + ((s + 1) & 1) * STAGE);
         __syncthreads();
     }
 
@@ -354,7 +357,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
 static int resident_per_cu(int BT, bool bf16) {
     // from the kernels' LDS bytes / VGPRs (wave64, 512 VGPRs per SIMD, 160 KB LDS per CU)
     if (bf16) return BT == 64 ? 6 : 3;      // 82 / 154 VGPRs; 20 / 40 KB
-    return BT == 64 ? 5 : 2;                // 60 / 151 VGPRs; 32 / 64 KB
+    return BT == 64 ? 4 : 2;                // 8-wave workgroups: 32 waves per CU / 64 KB LDS
 }
 
 static int choose_splits(int64_t M, int Cin, int Cout, int KH, int KW, bool bf16) {
@@ -422,7 +425,7 @@ static int wgrad_impl(const float* dy, const float* x, float* slab, int splits, 
         if (BT == 64) hipLaunchKernelGGL(wgrad_bf16_kernel<64>, grid, dim3(256), 2 * 2 * 64 * (PK + 8) * 2, st, p);
         else hipLaunchKernelGGL(wgrad_bf16_kernel<128>, grid, dim3(256), 2 * 2 * 128 * (PK + 8) * 2, st, p);
     } else if (BT == 64) {
-        hipLaunchKernelGGL(wgrad_f32_kernel<64>, grid, dim3(256), 2 * 2 * PK * 64 * 4, st, p);
+        hipLaunchKernelGGL(wgrad_f32_kernel<64>, grid, dim3(512), 2 * 2 * PK * 64 * 4, st, p);
     } else {
         static bool attr_set = false;
         if (!attr_set) {
@@ -430,7 +433,7 @@ static int wgrad_impl(const float* dy, const float* x, float* slab, int splits, 
                                       2 * 2 * PK * 128 * 4);
             attr_set = true;
         }
-        hipLaunchKernelGGL(wgrad_f32_kernel<128>, grid, dim3(256), 2 * 2 * PK * 128 * 4, st, p);
+        hipLaunchKernelGGL(wgrad_f32_kernel<128>, grid, dim3(512), 2 * 2 * PK * 128 * 4, st, p);
     }
     SSAD_CHECK_LAUNCH();
     return 0;
