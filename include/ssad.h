@@ -192,6 +192,17 @@ int ssad_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int64_t N,
 /* Same pair with the argmax recorded by the forward pass (one byte per output element: window slot dy*3+dx of the
  * first maximum), so backward compares <= 4 indices per input element instead of rescanning 4 windows. */
 int ssad_maxpool3x3s2_fwd_idx(const float* in, float* out, uint8_t* idx, int64_t N, int H, int W, int C, void* stream);
+/* Stem tail / head of a TRAINING step, fused around the max-pool (models.py:224 under trainer.fit: bn1, relu, maxpool and
+ * their autograd nodes).  Forward: BatchNorm (batch statistics mean / invstd already taken) + ReLU + max-pool 3x3/2 over
+ * the raw conv1 output z [N][H][W][C]; only the pooled map and the argmax slots are written.  Backward: from the pooled
+ * gradient dpool [N][Ho][Wo][C], the slots and z: dbeta, dgamma and dz (gradient of z) -- the max-pool backward, the
+ * ReLU mask (recomputed from z) and both BatchNorm passes; the 128x128 activation and its gradient never exist in HBM.
+ * workspace: ssad_colreduce_workspace(N*H*W, C) doubles. */
+int ssad_bn_relu_maxpool_fwd(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                             float* out, uint8_t* idx, int64_t N, int H, int W, int C, void* stream);
+int ssad_pool_bn_relu_bwd(const uint8_t* idx, const float* dpool, const float* z, const float* mean, const float* invstd,
+                          const float* gamma, const float* beta, float* dbeta, float* dgamma, float* dz, int64_t N, int H,
+                          int W, int C, double* workspace, void* stream);
 int ssad_maxpool3x3s2_bwd_idx(const uint8_t* idx, const float* dy, float* dx, int64_t N, int H, int W, int C, void* stream);
 int ssad_gap_bwd(const float* dpooled, float* dy, int64_t N, int HW, int C, int stride, int offset, int accumulate,
                  void* stream);

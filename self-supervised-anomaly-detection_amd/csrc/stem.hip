@@ -266,8 +266,13 @@ __global__ void pack_stem_weight_kernel(const float* __restrict__ w, float* __re
 }
 
 // NHWC 3x3 stride-2 pad-1 max-pool, 4 channels per thread.
+// With `bn` (mean, invstd, gamma, beta of a train-mode BatchNorm) the input is the raw convolution z and every tap is
+// first mapped through relu((z - mean) * invstd * gamma + beta) -- the expression of bn_apply_fwd -- so the activation
+// between conv1/bn1/relu and the pool never exists in HBM.
+struct PoolBN { const float* mean; const float* invstd; const float* gamma; const float* beta; };
+
 __global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restrict__ out, uint8_t* __restrict__ idx,
-                                    int64_t total4, int H, int W, int C4, int Ho, int Wo, int64_t N, int hwnc) {
+                                    int64_t total4, int H, int W, int C4, int Ho, int Wo, int64_t N, int hwnc, PoolBN bn) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total4) return;
     int c4 = (int)(i % C4);
@@ -287,6 +292,11 @@ __global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restr
     }
     f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     int am[4] = {0, 0, 0, 0};                 // window slot (dy*3+dx) of the FIRST maximum, PyTorch's tie rule
+    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = mu, ga = mu, be = mu;
+    if (bn.mean) {
+        mu = ((const f32x4*)bn.mean)[c4]; is = ((const f32x4*)bn.invstd)[c4];
+        ga = ((const f32x4*)bn.gamma)[c4]; be = ((const f32x4*)bn.beta)[c4];
+    }
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
         int y = oy * 2 - 1 + dy;
@@ -297,6 +307,10 @@ __global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restr
             if ((unsigned)x >= (unsigned)W) continue;
             const int64_t ip = hwnc ? ((int64_t)y * W + x) * N + n : (n * H + y) * W + x;
             f32x4 v = ((const f32x4*)in)[ip * C4 + c4];
+            if (bn.mean) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = fmaxf((v[k] - mu[k]) * is[k] * ga[k] + be[k], 0.f);
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (v[k] > m[k]) { m[k] = v[k]; am[k] = dy * 3 + dx; }
@@ -379,16 +393,26 @@ extern "C" int ssad_stem_patch_pool_fwd(const float* img, int B, int H, int W, i
     return 0;
 }
 
-static int maxpool_fwd_impl(const float* in, float* out, uint8_t* idx, int64_t N, int H, int W, int C, int hwnc, void* stream) {
+static int maxpool_fwd_impl(const float* in, float* out, uint8_t* idx, int64_t N, int H, int W, int C, int hwnc, void* stream,
+                            PoolBN bn = PoolBN{nullptr, nullptr, nullptr, nullptr}) {
     SSAD_CHECK_ARG(in && out, "null pointer");
     SSAD_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "bad shape (C % 4)");
     int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     int64_t total4 = N * Ho * Wo * (C / 4);
     SSAD_CHECK_ARG(cdiv64(total4, 256) < (int64_t)2147483647, "too large");
     hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((unsigned)cdiv64(total4, 256)), dim3(256), 0, (hipStream_t)stream, in, out, idx,
-                       total4, H, W, C / 4, Ho, Wo, N, hwnc);
+                       total4, H, W, C / 4, Ho, Wo, N, hwnc, bn);
     SSAD_CHECK_LAUNCH();
     return 0;
+}
+
+// Stem tail of the training forward in one pass: BatchNorm (batch statistics already known) + ReLU + max-pool 3x3/2
+// over the raw conv1 output z; writes the pooled map and the argmax slots only.
+extern "C" int ssad_bn_relu_maxpool_fwd(const float* z, const float* mean, const float* invstd, const float* gamma,
+                                        const float* beta, float* out, uint8_t* idx, int64_t N, int H, int W, int C,
+                                        void* stream) {
+    SSAD_CHECK_ARG(mean && invstd && gamma && beta && idx, "null pointer");
+    return maxpool_fwd_impl(z, out, idx, N, H, W, C, 0, stream, PoolBN{mean, invstd, gamma, beta});
 }
 
 extern "C" int ssad_maxpool3x3s2_fwd(const float* in, float* out, int64_t N, int H, int W, int C, int hwnc, void* stream) {

@@ -285,6 +285,88 @@ __global__ void maxpool_bwd_idx_kernel(const uint8_t* __restrict__ idx, const fl
     ((f32x4*)dx)[i] = acc;
 }
 
+// ---- stem head of the backward pass, fused: max-pool backward (index form) feeding BatchNorm + ReLU backward ----
+// g[n][y][x][c] = (sum of the pooled gradients whose argmax slot is (y,x)) * [relu mask recomputed from z]; the 1 GB
+// gradient map between the two never exists in HBM.
+__device__ __forceinline__ f32x4 pool_grad(const uint8_t* __restrict__ idx, const float* __restrict__ dpool, int64_t n, int y,
+                                           int x, int c4, int C4, int Ho, int Wo) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int oy0 = y / 2, oy1 = (y + 1) / 2, ox0 = x / 2, ox1 = (x + 1) / 2;
+    for (int oy = oy0; oy <= oy1; ++oy) {
+        if (oy >= Ho) continue;
+        for (int ox = ox0; ox <= ox1; ++ox) {
+            if (ox >= Wo) continue;
+            const uint32_t slot = (uint32_t)((y - (2 * oy - 1)) * 3 + (x - (2 * ox - 1)));
+            const int64_t o = ((n * Ho + oy) * Wo + ox) * C4 + c4;
+            const uint32_t packed = ((const uint32_t*)idx)[o];
+            const f32x4 g = ((const f32x4*)dpool)[o];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] += ((packed >> (8 * k)) & 0xffu) == slot ? g[k] : 0.f;
+        }
+    }
+    return acc;
+}
+
+// APPLY == 0: per-block partial sums  s0 = sum g, s1 = sum g * xhat  (double, [gridDim.x][2][C])
+// APPLY == 1: dz = gamma * invstd * (g - dbeta / R - xhat * dgamma / R)
+// (two rows per iteration were tried: no faster -- the gathers, not their latency, set the pace)
+template <int APPLY>
+__global__ __launch_bounds__(256) void pool_bn_bwd_kernel(const uint8_t* __restrict__ idx, const float* __restrict__ dpool,
+                                                          const float* __restrict__ z, const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ dbeta,
+                                                          const float* __restrict__ dgamma, float* __restrict__ dz,
+                                                          double* __restrict__ partial, int64_t R, int H, int W, int C,
+                                                          int Ho, int Wo, int64_t rows_per_block) {
+    __shared__ double sh[2][256][4];
+    const int C4 = C / 4, RL = 256 / C4;
+    const int tid = threadIdx.x, c4 = tid % C4, ty = tid / C4;
+    const f32x4 mu = ((const f32x4*)mean)[c4], is = ((const f32x4*)invstd)[c4];
+    const f32x4 ga = ((const f32x4*)gamma)[c4], be = ((const f32x4*)beta)[c4];
+    f32x4 db = {0.f, 0.f, 0.f, 0.f}, dg = db;
+    if (APPLY) { db = ((const f32x4*)dbeta)[c4]; dg = ((const f32x4*)dgamma)[c4]; }
+    const float invR = 1.f / (float)R;
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    const int64_t rb = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t re = rb + rows_per_block < R ? rb + rows_per_block : R;
+    for (int64_t row = rb + ty; row < re; row += RL) {
+        const int x = (int)(row % W);
+        const int64_t t = row / W;
+        const int y = (int)(t % H);
+        const int64_t n = t / H;
+        f32x4 g = pool_grad(idx, dpool, n, y, x, c4, C4, Ho, Wo);
+        const f32x4 zz = ((const f32x4*)z)[row * C4 + c4];
+        f32x4 xh;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            xh[k] = (zz[k] - mu[k]) * is[k];
+            g[k] = (zz[k] - mu[k]) * is[k] * ga[k] + be[k] > 0.f ? g[k] : 0.f;      // the forward's expression
+        }
+        if (APPLY) {
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = ga[k] * is[k] * (g[k] - db[k] * invR - xh[k] * dg[k] * invR);
+            ((f32x4*)dz)[row * C4 + c4] = o;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { s0[k] += (double)g[k]; s1[k] += (double)g[k] * (double)xh[k]; }
+        }
+    }
+    if (APPLY) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sh[0][tid][k] = s0[k]; sh[1][tid][k] = s1[k]; }
+    __syncthreads();
+    if (ty == 0) {
+        double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+        for (int l = 0; l < RL; ++l)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a0[k] += sh[0][l * C4 + c4][k]; a1[k] += sh[1][l * C4 + c4][k]; }
+        double* pp = partial + (int64_t)blockIdx.x * 2 * C;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { pp[c4 * 4 + k] = a0[k]; pp[C + c4 * 4 + k] = a1[k]; }
+    }
+}
+
 // dy[n][hw][c] (+)= dpooled[n*stride + off + c] / HW
 __global__ void gap_bwd_kernel(const float* __restrict__ dpooled, float* __restrict__ dy, int64_t total, int HW, int C,
                                int stride, int off, int accumulate) {
@@ -536,6 +618,30 @@ extern "C" int ssad_maxpool3x3s2_bwd_idx(const uint8_t* idx, const float* dy, fl
     SSAD_CHECK_ARG(cdiv64(total, 256) < (int64_t)2147483647, "too large");
     hipLaunchKernelGGL(maxpool_bwd_idx_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, idx, dy, dx,
                        total, H, W, C / 4, Ho, Wo);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+// Stem head of the backward pass: dz (gradient of the raw conv1 output) and the BatchNorm parameter gradients from the
+// POOLED gradient, the argmax slots and z -- max-pool backward, the ReLU mask and both BatchNorm passes without ever
+// storing the gradient of the 128x128 activation.  workspace: ssad_colreduce_workspace(N*H*W, C) doubles.
+extern "C" int ssad_pool_bn_relu_bwd(const uint8_t* idx, const float* dpool, const float* z, const float* mean,
+                                     const float* invstd, const float* gamma, const float* beta, float* dbeta, float* dgamma,
+                                     float* dz, int64_t N, int H, int W, int C, double* workspace, void* stream) {
+    SSAD_CHECK_ARG(idx && dpool && z && mean && invstd && gamma && beta && dbeta && dgamma && dz && workspace, "null pointer");
+    SSAD_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0, "bad shape");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int64_t R = N * H * W;
+    const int RL = 256 / (C / 4);
+    int64_t nblk = cdiv64(R, (int64_t)RL * 32);
+    if (nblk > 2048) nblk = 2048;
+    const int64_t rows_per_block = cdiv64(R, nblk);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(pool_bn_bwd_kernel<0>, dim3((unsigned)nblk), dim3(256), 0, st, idx, dpool, z, mean, invstd, gamma, beta,
+                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr, workspace, R, H, W, C, Ho, Wo, rows_per_block);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, workspace, (int)nblk, C, dbeta, dgamma);
+    hipLaunchKernelGGL(pool_bn_bwd_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, st, idx, dpool, z, mean, invstd, gamma, beta,
+                       dbeta, dgamma, dz, (double*)nullptr, R, H, W, C, Ho, Wo, rows_per_block);
     SSAD_CHECK_LAUNCH();
     return 0;
 }

@@ -54,6 +54,9 @@ SIGNATURES = {
     "ssad_bn_stats": [_c_fp, _c_l, _c_i, _c_f, _c_f, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
     "ssad_bn_apply_fwd": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp],
     "ssad_bn_bwd_reduce": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_fp, _c_fp],
+    "ssad_bn_relu_maxpool_fwd": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_pool_bn_relu_bwd": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i,
+                              _c_fp, _c_fp],
     "ssad_gradcam_map": [_c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_fp],
     "ssad_stem_wgrad_workspace": [_c_i, _c_i, _c_i],
     "ssad_stem_wgrad": [_c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp],

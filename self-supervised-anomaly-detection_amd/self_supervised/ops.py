@@ -371,6 +371,30 @@ def bn_bwd_zmask(dy, z, mean, invstd, gamma, beta, dbeta, dgamma):
     return dz
 
 
+def bn_relu_maxpool_fwd(z, mean, invstd, gamma, beta):
+    """Training stem tail: pooled = maxpool3x3s2(relu(bn(z))) + argmax slots, without storing the activation."""
+    n, h, w, c = z.shape
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    out = _new((n, ho, wo, c), z)
+    idx = torch.empty((n, ho, wo, c), device=z.device, dtype=torch.uint8)
+    _run("maxpool3x3s2", 0.0, 4.0 * (z.numel() + out.numel()) + idx.numel(),
+         lambda: _hip.lib().ssad_bn_relu_maxpool_fwd(_hip.ptr(z), _hip.ptr(mean), _hip.ptr(invstd), _hip.ptr(gamma),
+                                                     _hip.ptr(beta), _hip.ptr(out), idx.data_ptr(), n, h, w, c, _hip.stream()))
+    return out, idx
+
+
+def pool_bn_relu_bwd(idx, dpool, z, mean, invstd, gamma, beta, dbeta, dgamma):
+    """Training stem head of the backward pass: (idx, dpool, z) -> dz, filling dbeta / dgamma."""
+    n, h, w, c = z.shape
+    dz = torch.empty_like(z)
+    ws = _colreduce_ws(n * h * w, c, z)
+    _run("pool_bn_bwd", 0.0, 4.0 * (3 * z.numel() + 2 * dpool.numel()),
+         lambda: _hip.lib().ssad_pool_bn_relu_bwd(idx.data_ptr(), _hip.ptr(dpool), _hip.ptr(z), _hip.ptr(mean), _hip.ptr(invstd),
+                                                  _hip.ptr(gamma), _hip.ptr(beta), _hip.ptr(dbeta), _hip.ptr(dgamma),
+                                                  _hip.ptr(dz), n, h, w, c, ws.data_ptr(), _hip.stream()))
+    return dz
+
+
 def maxpool3x3s2_bwd(x, dy):
     n, h, w, c = x.shape
     dx = torch.empty_like(x)

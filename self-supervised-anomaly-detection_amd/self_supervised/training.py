@@ -159,6 +159,36 @@ class _Affine:
         self.y = y
         return y
 
+    def fwd_pool(self, img):
+        """Stem + max-pool: (pooled NHWC, argmax slots).  With batch statistics the BatchNorm + ReLU run inside the
+        pooling kernel and the 128x128 activation is never stored (its backward recomputes the mask from z)."""
+        bn = self.bn
+        if not bn.training:
+            return ops.maxpool3x3s2_fwd_idx(self._stem_fwd(img, self.weight()))
+        self.x, self.res_used = img, False
+        z = ops.stem_fwd(img, self.weight(), None, None, relu=False)
+        mom = 0.1 if bn.momentum is None else bn.momentum
+        self.mean, self.invstd = ops.bn_stats(z, 64, bn.eps, mom, bn.running_mean, bn.running_var)
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+        a = self.eng.arena
+        self.z, self.y = z, None
+        return ops.bn_relu_maxpool_fwd(z, self.mean, self.invstd, a.w(bn.weight), a.w(bn.bias))
+
+    def bwd_pool(self, idx, dpool, a0_shape):
+        """Backward of fwd_pool: fills the BatchNorm and conv1 gradients (no input gradient: the image)."""
+        a, bn = self.eng.arena, self.bn
+        if self.z is None:                       # eval-mode statistics: unfused path
+            self.bwd(ops.maxpool3x3s2_bwd_idx(idx, dpool, a0_shape), need_dx=False)
+            return
+        pg = self.eng.param_grads
+        dbeta = a.grad(bn.bias) if (bn.bias.requires_grad and pg) else torch.empty(64, device=dpool.device)
+        dgamma = a.grad(bn.weight) if (bn.weight.requires_grad and pg) else torch.empty(64, device=dpool.device)
+        dz = ops.pool_bn_relu_bwd(idx, dpool, self.z, self.mean, self.invstd, a.w(bn.weight), a.w(bn.bias), dbeta, dgamma)
+        if self.lin.weight.requires_grad and pg:
+            ops.stem_wgrad(self.x, dz, a.grad(self.lin.weight))
+        self.x = self.z = self.y = None
+
     def fwd(self, x, residual=None):
         """x NHWC (4-D; the stem takes the NCHW image).  Returns y NHWC."""
         a, bn = self.eng.arena, self.bn
@@ -297,11 +327,11 @@ class TrainEngine:
         m = self.model
         b, _, h, w = x.shape
         self.trunk_grad = any(p.requires_grad for p in m.feature_extractor.parameters())
-        a0 = self.stem.fwd(x.contiguous())
+        a, self.pool_idx = self.stem.fwd_pool(x.contiguous())
         if not self.trunk_grad:
             self.stem.x = None
-        self.a0 = a0
-        a, self.pool_idx = ops.maxpool3x3s2_fwd_idx(a0)
+        _, _, _, ho, wo = ops.stem_geometry(h, w, 0, 0)
+        self.a0_shape = (b, ho, wo, 64)
         pooled = torch.empty((b, self.pooled_dim), device=x.device, dtype=torch.float32)
         self.stage_shapes = {}
         for i, d in enumerate(self.blocks):
@@ -360,8 +390,7 @@ class TrainEngine:
                 notify(a.offset[id(blk["c1"].lin.weight)][0] + blk["c1"].lin.weight.numel()
                        if blk["ds"] is None else
                        a.offset[id(blk["ds"].lin.weight)][0] + blk["ds"].lin.weight.numel())
-        da0 = ops.maxpool3x3s2_bwd_idx(self.pool_idx, dy, self.a0.shape)
-        self.stem.bwd(da0, need_dx=False)
+        self.stem.bwd_pool(self.pool_idx, dy, self.a0_shape)
         notify(a.total)
         self._drop_tape()
 
@@ -382,7 +411,7 @@ class TrainEngine:
         return d.view(b, -1), act
 
     def _drop_trunk_tape(self):
-        self.a0 = self.pool_idx = None
+        self.pool_idx = None
         for d in self.blocks:
             for k in ("c1", "c2", "ds"):
                 if d[k] is not None:

@@ -111,6 +111,28 @@ def test_stem_wgrad_kernel(dev):
         assert torch.equal(dw, dw3)            # deterministic
 
 
+def test_fused_stem_pool_kernels(dev):
+    """BN + ReLU + max-pool forward and pool + ReLU + BN backward in one pass each == the unfused kernel chain."""
+    from self_supervised import ops
+    for (n, h, w) in [(3, 16, 16), (2, 9, 13)]:
+        g = torch.Generator().manual_seed(n * h)
+        z = (torch.randn(n, h, w, 64, generator=g) * 1.5 + 0.2).to(dev)
+        gamma, beta = (torch.rand(64, generator=g) + 0.5).to(dev), (torch.randn(64, generator=g) * 0.3).to(dev)
+        mean, invstd = ops.bn_stats(z, 64, 1e-5, 0.1, None, None)
+        y = ops.bn_apply_fwd(z, mean, invstd, gamma, beta, None, True)
+        p1, i1 = ops.maxpool3x3s2_fwd_idx(y)
+        p2, i2 = ops.bn_relu_maxpool_fwd(z, mean, invstd, gamma, beta)
+        assert torch.equal(p1, p2) and torch.equal(i1, i2)
+        dpool = torch.randn(p1.shape, generator=g).to(dev)
+        da = ops.maxpool3x3s2_bwd_idx(i1, dpool, z.shape)
+        db1, dg1 = torch.empty(64, device=dev), torch.empty(64, device=dev)
+        dz1 = ops.bn_bwd_zmask(da, z, mean, invstd, gamma, beta, db1, dg1)
+        db2, dg2 = torch.empty(64, device=dev), torch.empty(64, device=dev)
+        dz2 = ops.pool_bn_relu_bwd(i1, dpool, z, mean, invstd, gamma, beta, db2, dg2)
+        assert rel_err(db2, db1) < 1e-6 and rel_err(dg2, dg1) < 1e-6      # fp64 sums, different block partition
+        assert rel_err(dz2, dz1) < 1e-6
+
+
 def test_fused_stats_and_zmask_kernels(dev):
     """Conv epilogue statistics == separate bn_stats (bit-for-bit inputs, fp64 sums); BN backward with the ReLU mask
     recomputed from z == the same kernels reading the saved activation."""
