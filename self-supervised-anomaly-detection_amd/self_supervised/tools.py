@@ -18,7 +18,7 @@ from . import ops
 from .constants import METRICS, EvaluationOutputContainer, ModelOutputsContainer
 from .datasets import MVTecDatamodule, PretextTaskDatamodule
 from .models import AnomalyDetector, PeraNet
-from .trainer import MetricTracker, ModelCheckpoint, Trainer
+from .trainer import MetricTracker, ModelCheckpoint, Trainer, broadcast_bank, gather_in_order, world_info
 
 
 class Evaluator:
@@ -146,7 +146,10 @@ def inference(model_input_dir: str, dataset_dir: str, subject: str, mvtec_infere
     else:
         datamodule = PretextTaskDatamodule(subject=subject, root_dir=dataset_dir, min_dataset_length=500, batch_size=1)
     print('>>> doing prediction')
-    predictions = tester.predict(model, datamodule=datamodule)
+    # under torch.distributed (one process per GPU) every rank scores its own round-robin share of the images; the
+    # per-image containers are exchanged once at the end so that every rank returns the full output
+    rank, world = world_info()
+    predictions = tester.predict(model, datamodule=datamodule, shard=world > 1)
     output = ModelOutputsContainer()
     output.from_list(predictions)
     print('>>> anomaly detection phase')
@@ -167,10 +170,39 @@ def inference(model_input_dir: str, dataset_dir: str, subject: str, mvtec_infere
         output_normality.to_cpu()
         normality = output_normality.embedding_vectors
     output.to_cpu()
-    detector.fit(normality)
+    if world > 1:
+        # one bank for everybody: rank 0 draws the 70/30 split and fits, the others receive (bank, threshold)
+        if rank == 0:
+            detector.fit(normality)
+        state = broadcast_bank((detector.bank.cpu(), detector.threshold) if rank == 0 else None)
+        if rank != 0:
+            detector.bank, detector.threshold = AnomalyDetector._dev(state[0]), state[1]
+    else:
+        detector.fit(normality)
     print(' computing anomaly scores')
     output.anomaly_maps = detector.predict(output.embedding_vectors).cpu()
+    if world > 1:
+        n_total = len(datamodule.predict_dataloader())
+        per_image = gather_in_order(_split_container(output, len(predictions)), n_total)
+        output = ModelOutputsContainer()
+        output.from_list(per_image)
     return output
+
+
+def _split_container(output: ModelOutputsContainer, n_images: int):
+    """One container per scored image (inverse of ModelOutputsContainer.from_list for tensors whose first axis is a
+    multiple of the image count: patch-level fields carry 841 rows per image)."""
+    parts = []
+    for i in range(n_images):
+        c = ModelOutputsContainer()
+        for name, value in vars(output).items():
+            if isinstance(value, torch.Tensor) and value.dim() > 0 and n_images and value.shape[0] % n_images == 0 and value.shape[0]:
+                k = value.shape[0] // n_images
+                setattr(c, name, value[i * k:(i + 1) * k].clone())
+            else:
+                setattr(c, name, value)
+        parts.append(c)
+    return parts
 
 
 def upsample(anomaly_maps: Tensor, target_size: int = 256, verbose: bool = True):

@@ -132,7 +132,9 @@ class Trainer:
                 s.step()
         model.eval()
 
-    def predict(self, model, datamodule=None, dataloaders=None):
+    def predict(self, model, datamodule=None, dataloaders=None, shard=False):
+        """shard=True (multi-GPU scoring, SURVEY s.8e): this rank scores batches rank, rank + world, ... only -- images
+        are independent, no data-path collective -- and returns its own list; `gather_in_order` rebuilds the full one."""
         self.model = model
         model.trainer = self
         model.to(self.device).eval()
@@ -143,6 +145,8 @@ class Trainer:
         outs = []
         with torch.no_grad():
             for i, batch in enumerate(dataloaders):
+                if shard and i % self.world != self.global_rank:
+                    continue
                 outs.append(model.predict_step(_to_device(batch, self.device), i))
         return outs
 
@@ -156,3 +160,40 @@ class Trainer:
         m.on_save_checkpoint(ck)
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
         torch.save(ck, path)
+
+
+
+# ---------------------------------------------------------------------------------------------
+# multi-GPU scoring helpers (one process per GPU; units = images, round-robin over ranks)
+# ---------------------------------------------------------------------------------------------
+def world_info():
+    """(rank, world) of the default process group, (0, 1) when torch.distributed is not initialised."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def gather_in_order(local_items, total):
+    """Every rank holds the items of global indices rank, rank + world, ... (in that order); returns the full list in
+    global order on every rank.  One all_gather_object at the END of scoring -- the only exchange of the scoring path."""
+    rank, world = world_info()
+    if world == 1:
+        assert len(local_items) == total
+        return list(local_items)
+    parts = [None] * world
+    dist.all_gather_object(parts, list(local_items))
+    out = []
+    for i in range(total):
+        out.append(parts[i % world][i // world])
+    return out
+
+
+def broadcast_bank(obj, src=0):
+    """The normality bank (<= 1000 x 512 fp32, plus its threshold) is fitted on one rank -- the 70/30 split draws from
+    the global numpy RNG -- and sent to the others once.  `obj` is any picklable object on `src`, ignored elsewhere."""
+    rank, world = world_info()
+    if world == 1:
+        return obj
+    box = [obj if rank == src else None]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]

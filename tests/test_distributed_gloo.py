@@ -61,3 +61,50 @@ def test_backward_order_covers_all_parameters():
     assert len({id(p) for p in params}) == len(list(m.parameters()))
     assert sum(p.numel() for p in params[:head]) == 1515012          # head: 459 776 + 1 053 184 + 2 052
     assert params[0] is m.classifier.weight and params[-1] is m.feature_extractor.conv1.weight
+
+
+def _score_worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "self-supervised-anomaly-detection_amd"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from self_supervised import tools
+    from self_supervised.constants import ModelOutputsContainer
+    from self_supervised.trainer import broadcast_bank, gather_in_order, world_info
+    assert world_info() == (rank, world)
+    total = 7                                            # ragged: rank 0 scores images 0,2,4,6, rank 1 scores 1,3,5
+    mine = [i for i in range(total) if i % world == rank]
+    local = ModelOutputsContainer()                      # what tools.inference holds after scoring its share (3 patches/img)
+    from self_supervised.constants import _FIELDS
+    for f in _FIELDS:                                    # predict_step fills every field; one row per image here
+        setattr(local, f, torch.tensor(mine, dtype=torch.float32).view(-1, 1))
+    local.embedding_vectors = torch.cat([torch.full((3, 4), float(i)) for i in mine])
+    local.anomaly_maps = torch.cat([torch.full((1, 1, 2, 2), 10.0 + i) for i in mine])
+    local.y_hat = torch.tensor(mine)
+    parts = tools._split_container(local, len(mine))
+    full = ModelOutputsContainer()
+    full.from_list(gather_in_order(parts, total))
+    ok = (full.y_hat.tolist() == list(range(total))
+          and full.anomaly_maps[:, 0, 0, 0].tolist() == [10.0 + i for i in range(total)]
+          and full.embedding_vectors[::3, 0].tolist() == [float(i) for i in range(total)]
+          and tuple(full.embedding_vectors.shape) == (21, 4))
+    bank = broadcast_bank((torch.arange(6.0).view(2, 3), 0.25) if rank == 0 else None)
+    ok = ok and torch.equal(bank[0], torch.arange(6.0).view(2, 3)) and bank[1] == 0.25
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_sharded_scoring_gather_world2():
+    """Scoring shards images round-robin over ranks and exchanges the per-image results once at the end."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_score_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
