@@ -218,6 +218,36 @@ def test_training_step_matches_autograd(dev, golden, seeded_sd):
     print("worst grad rel err", worst)
 
 
+def test_training_step_ragged_shapes(dev, seeded_sd):
+    """Edge shapes through the whole step: odd batch, non-square images whose maps shrink to odd sizes (96x80 ->
+    48x40 -> 24x20 -> 12x10 -> 6x5 -> 3x3), i.e. ragged stem tiles, clipped pool windows, odd stride-2 parity classes,
+    rows < one tile; and a 48x48 batch that goes through the nearest-resize branch.  Loss + every gradient vs autograd."""
+    from self_supervised import training, ops
+    from oracle.peranet import train_step
+    for (b, h, w, seed) in [(5, 96, 80, 71), (8, 48, 48, 72)]:
+        ref, m = _pair(seeded_sd, dev)
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(b, 3, h, w, generator=g)
+        y = torch.randint(0, 4, (b,), generator=g)
+        loss_ref, _, out_ref = train_step(ref, x, y)
+        loss_ref.backward()
+        m.unfreeze()
+        eng = training.DataParallelStep(m, lr=0.03, world_size=1).eng
+        logits, emb = eng.forward(x.to(dev))
+        # BatchNorm1d over 3-5 rows divides by a tiny batch variance: fp32 summation order alone shows at ~1e-4
+        assert rel_err(logits, out_ref["classifier"]) < 5e-4 and rel_err(emb, out_ref["latent_space"]) < 5e-4
+        dlogits = torch.empty_like(logits)
+        la = ops.softmax_ce(logits, y.to(dev), dlogits, 1.0 / b)
+        np.testing.assert_allclose(la[0].item(), loss_ref.item(), rtol=1e-4)
+        eng.backward(dlogits)
+        ref_params = dict(ref.named_parameters())
+        floor = grad_floor(ref)
+        for name, p in m.named_parameters():
+            # tiny batches make the BN chain ill-conditioned: fp32 summation order alone moves gradients by ~1e-3
+            e = rel_err(p.grad, ref_params[name].grad, floor)
+            assert e < 5e-3, f"{(b, h, w)} {name}: grad rel err {e:.3e}"
+
+
 def test_two_sgd_steps_match_reference(dev, golden, seeded_sd):
     from self_supervised import training
     from oracle import weights as ow
