@@ -34,6 +34,23 @@ class ModelOutputsContainer:
             setattr(self, f, torch.cat(cols[f]) if len(cols[f]) else None)
 
 
+    def split(self, n_images: int) -> list:
+        """One container per image: the inverse of ``from_list`` for a container that holds ``n_images`` images
+        (patch-level fields carry num_patches rows per image, image-level fields one)."""
+        parts = []
+        for i in range(n_images):
+            c = ModelOutputsContainer()
+            for f in _FIELDS:
+                v = getattr(self, f)
+                if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] and v.shape[0] % n_images == 0:
+                    k = v.shape[0] // n_images
+                    setattr(c, f, v[i * k:(i + 1) * k].clone())
+                else:
+                    setattr(c, f, v)
+            parts.append(c)
+        return parts
+
+
 class EvaluationOutputContainer:
     def __init__(self) -> None:
         self.auroc = None

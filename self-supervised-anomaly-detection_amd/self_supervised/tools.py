@@ -190,19 +190,7 @@ def inference(model_input_dir: str, dataset_dir: str, subject: str, mvtec_infere
 
 
 def _split_container(output: ModelOutputsContainer, n_images: int):
-    """One container per scored image (inverse of ModelOutputsContainer.from_list for tensors whose first axis is a
-    multiple of the image count: patch-level fields carry 841 rows per image)."""
-    parts = []
-    for i in range(n_images):
-        c = ModelOutputsContainer()
-        for name, value in vars(output).items():
-            if isinstance(value, torch.Tensor) and value.dim() > 0 and n_images and value.shape[0] % n_images == 0 and value.shape[0]:
-                k = value.shape[0] // n_images
-                setattr(c, name, value[i * k:(i + 1) * k].clone())
-            else:
-                setattr(c, name, value)
-        parts.append(c)
-    return parts
+    return output.split(n_images)
 
 
 def upsample(anomaly_maps: Tensor, target_size: int = 256, verbose: bool = True):

@@ -142,12 +142,47 @@ class Trainer:
             if not hasattr(datamodule, 'test_dataset'):
                 datamodule.setup('predict')
             dataloaders = datamodule.predict_dataloader()
-        outs = []
+        # The reference predicts with batch_size=1 (tools.py:336); the kernels want thousands of patches per launch.
+        # Eval-mode outputs are per-sample independent, so up to `predict_group` images of consecutive batches run
+        # through predict_step together and the result is split back: one container per ORIGINAL batch, as before.
+        group = int(getattr(self, "predict_group", 16))
+        outs, pend = [], []
+
+        def flush():
+            if not pend:
+                return
+            if len(pend) == 1:
+                outs.append(model.predict_step(pend[0][1], pend[0][0]))
+            else:
+                sizes = [b[0].shape[0] for _, b in pend]
+                merged = tuple(torch.cat([b[k] for _, b in pend]) for k in range(len(pend[0][1])))
+                per_image = model.predict_step(merged, pend[0][0]).split(sum(sizes))
+                o = 0
+                for n in sizes:
+                    c = type(per_image[0])()
+                    c.from_list(per_image[o:o + n])
+                    outs.append(c)
+                    o += n
+            pend.clear()
+
+        def mergeable(a, b):
+            return (isinstance(a, (tuple, list)) and len(a) == len(b) and
+                    all(torch.is_tensor(u) and torch.is_tensor(v) and u.shape[1:] == v.shape[1:] and u.dtype == v.dtype
+                        for u, v in zip(a, b)))
+
         with torch.no_grad():
             for i, batch in enumerate(dataloaders):
                 if shard and i % self.world != self.global_rank:
                     continue
-                outs.append(model.predict_step(_to_device(batch, self.device), i))
+                batch = _to_device(batch, self.device)
+                if pend and (not mergeable(pend[-1][1], batch) or sum(b[0].shape[0] for _, b in pend) >= group):
+                    flush()
+                if group <= 1 or not isinstance(batch, (tuple, list)) or not all(torch.is_tensor(t) for t in batch):
+                    flush()
+                    outs.append(model.predict_step(batch, i))
+                else:
+                    pend.append((i, batch))
+            flush()
         return outs
 
     def save_checkpoint(self, path, weights_only=False):

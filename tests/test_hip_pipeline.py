@@ -67,6 +67,32 @@ def test_predict_and_validation_steps(seeded_sd):
     assert abs(v["val_loss"].item() - want.item()) < 1e-4 and m.training
 
 
+def test_predict_groups_batches_without_changing_results(seeded_sd):
+    """Trainer.predict runs up to 16 images of consecutive bs=1 batches through one kernel sequence; the containers it
+    returns (one per original batch) equal the ungrouped ones."""
+    from oracle import weights as ow
+    from self_supervised.models import PeraNet
+    from self_supervised.trainer import Trainer
+    m = PeraNet(); m.load_state_dict(seeded_sd); m.eval(); m.enable_patch_level_mode(); m.enable_mvtec_inference()
+    imgs = ow.synthetic_images(5, 64, seed=81)
+    gts = torch.zeros(5, 1, 64, 64); gts[1, 0, 3:9, 4:8] = 1; gts[4, 0, 30:40, 30:33] = 1
+    loader = [(imgs[i:i + 1], gts[i:i + 1], imgs[i:i + 1] * 0.5) for i in range(4)] + [(imgs[3:5], gts[3:5], imgs[3:5])]
+    t = Trainer(accelerator='auto', devices=1)
+    t.predict_group = 1
+    single = t.predict(m, dataloaders=loader)
+    t.predict_group = 16
+    grouped = t.predict(m, dataloaders=loader)
+    assert len(single) == len(grouped) == 5
+    for a, b in zip(single, grouped):
+        a.to_cpu(); b.to_cpu()
+        for f in ("original_data", "tensor_data", "y_true_binary_labels", "raw_predictions", "y_hat",
+                  "y_true_multiclass_labels", "ground_truths", "embedding_vectors"):
+            va, vb = getattr(a, f), getattr(b, f)
+            assert va.shape == vb.shape, f
+            assert torch.allclose(va.float(), vb.float(), atol=1e-6, rtol=0), f
+    assert tuple(grouped[4].embedding_vectors.shape) == (2 * 25, 512)       # 64x64 image: 5x5 windows
+
+
 def test_gpu_auroc_matches_sklearn(golden):
     from sklearn.metrics import roc_auc_score
     from self_supervised import metrics as m
