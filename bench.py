@@ -122,6 +122,8 @@ def main():
     ap.add_argument("--train-precision", choices=["32", "16"], default="32",
                     help="32: exact fp32 MFMA (headline); 16: bf16-operand MFMA, the reference's Trainer(precision=16)")
     ap.add_argument("--no-bf16-extra", action="store_true", help="skip the additional precision=16 training measurement")
+    ap.add_argument("--no-x3-extra", action="store_true",
+                    help="skip the additional split-bf16 (bf16x3: hi*hi + hi*lo + lo*hi, fp32-class accuracy) measurements")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -185,6 +187,13 @@ def main():
         dt = timed(lambda: score_batch(model, det, x, args.size), args.steps, 0)
         prof["score"] = ops.drain_profile()
         res["score_s"] = dt
+        if not args.no_x3_extra:
+            # extra, not the headline: the same scoring pass with split-bf16 products on the bf16 matrix cores
+            ops.PROFILE = None
+            os.environ["SSAD_MATH"] = "bf16x3"
+            score_batch(model, det, x, args.size)
+            res["score_x3_s"] = timed(lambda: score_batch(model, det, x, args.size), args.steps, 0)
+            os.environ["SSAD_MATH"] = "f32"
         model.disable_patch_level_mode()
     if args.phase in ("both", "train"):
         from self_supervised import training
@@ -205,6 +214,13 @@ def main():
             for _ in range(max(args.warmup, 1)):
                 t16.step(x, y)
             res["train16_s"] = timed(lambda: t16.step(x, y), args.steps, 0)
+            trainer.eng.bf16 = False
+        if args.train_precision == "32" and not args.no_x3_extra:
+            ops.PROFILE = None
+            t3 = training.DataParallelStep(model, lr=0.005, world_size=world, precision="bf16x3")
+            for _ in range(max(args.warmup, 1)):
+                t3.step(x, y)
+            res["train_x3_s"] = timed(lambda: t3.step(x, y), args.steps, 0)
             trainer.eng.bf16 = False
     ops.PROFILE = None
 
@@ -229,6 +245,10 @@ def main():
         tot_s += res["train_s"]
     if "train16_s" in res:
         out["train_images_per_sec_precision16"] = round(world * args.batch * args.steps / res["train16_s"], 2)
+    if "train_x3_s" in res:
+        out["train_images_per_sec_bf16x3"] = round(world * args.batch * args.steps / res["train_x3_s"], 2)
+    if "score_x3_s" in res:
+        out["anomaly_maps_per_sec_bf16x3"] = round(world * args.batch * args.steps / res["score_x3_s"], 3)
     if "score_s" in res:
         out["anomaly_maps_per_sec"] = round(world * args.batch * args.steps / res["score_s"], 3)
         out["score_ms_per_step"] = round(1e3 * res["score_s"] / args.steps, 3)

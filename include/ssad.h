@@ -126,12 +126,23 @@ int ssad_auroc(const float* scores, const uint8_t* labels, int64_t n, void* work
 int ssad_flip_transpose_weight(const float* w_ohwi, float* out, int O, int I, int KH, int KW, void* stream);
 int ssad_conv_igemm_dgrad(const float* dy, const float* w_flipT, float* dx, const float* residual, int64_t N, int Hy, int Wy,
                           int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride, int pad, void* stream);
+/* Split-bf16 ("bf16x3") forms of the forward / position-major forward (hwnc != 0) and dgrad contractions: fp32 tensors in
+ * and out; every operand x is staged as hi = bf16(x), lo = bf16(x - hi) and every product is hi*hi + hi*lo + lo*hi on
+ * the bf16 matrix cores with fp32 accumulation -- ~2^-17 relative error per product at 3/16 of the fp32-MFMA time.
+ * Opt-in (SSAD_MATH=bf16x3 / Trainer(precision="bf16x3")); held to the same 1e-4 parity bar as the exact fp32 path. */
+int ssad_conv_igemm_fwd_x3(const float* in, const float* w_ohwi, float* out, const float* scale, const float* shift,
+                           const float* residual, int relu, int64_t N, int H, int W, int Cin, int Cout, int KH, int KW,
+                           int stride, int pad, int hwnc, void* stream);
+int ssad_conv_igemm_dgrad_x3(const float* dy, const float* w_flipT, float* dx, const float* residual, int64_t N, int Hy,
+                             int Wy, int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride, int pad, void* stream);
 /* Replaces autograd's conv2d/linear weight-gradient.  Two launches: partial tiles per pixel split into
  * slab[splits][Cout][KH*KW*Cin], then a fixed-order sum written as OIHW (to_oihw=1, checkpoint layout) or OHWI. */
 int ssad_wgrad_splits(int64_t M, int Cin, int Cout, int KH, int KW);
-int ssad_wgrad_splits_bf16(int64_t M, int Cin, int Cout, int KH, int KW);   /* for ssad_conv_wgrad_bf16 */
+int ssad_wgrad_splits_bf16(int64_t M, int Cin, int Cout, int KH, int KW);   /* for ssad_conv_wgrad_bf16 / _x3 */
 int ssad_conv_wgrad(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin, int Cout,
                     int KH, int KW, int stride, int pad, void* stream);
+int ssad_conv_wgrad_x3(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin, int Cout,
+                       int KH, int KW, int stride, int pad, void* stream);   /* split-bf16 products, see ssad_conv_igemm_fwd_x3 */
 int ssad_wgrad_reduce(const float* slab, float* dw, int splits, int Cout, int Kpad, int KH, int KW, int Cin, int to_oihw,
                       int accumulate, void* stream);
 /* bf16-operand forms of the three MFMA entry points above (fp32 tensors in HBM; operands rounded to bf16 while staging,

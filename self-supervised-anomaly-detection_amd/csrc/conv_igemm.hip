@@ -51,13 +51,18 @@ struct ConvParams {
 // BK   : floats per K-step (32: 144-byte LDS rows; 16: 80-byte rows -- both conflict-free for ds_read_b128).
 // DB   : double-buffered LDS stages (one barrier per K-step) or a single stage (two barriers, half the LDS:
 //        more workgroups per CU).
-// BF   : operands are rounded to bf16 while staging (fp32 in HBM, fp32 accumulate): v_mfma_f32_32x32x16_bf16 runs 16x
-//        the fp32 rate, the kernel becomes load-bound.  Used by Trainer(precision=16), mirroring the reference's AMP.
-template <int BM, int BN, int TM, int TN, int BK, int TS, bool POS, bool DB = true, bool BF = false>
+// BF   : 1 = operands are rounded to bf16 while staging (fp32 in HBM, fp32 accumulate): v_mfma_f32_32x32x16_bf16 runs
+//        16x the fp32 rate, the kernel becomes load-bound.  Used by Trainer(precision=16), mirroring the reference's AMP.
+//        3 = split-bf16 emulation of the fp32 product: every operand x is staged as hi = bf16(x), lo = bf16(x - hi)
+//        (16 significant bits together; a row keeps its fp32 footprint: [BK hi | BK lo] bf16) and each 32x32x16 tile
+//        takes three MFMAs, lo*hi + hi*lo + hi*hi, accumulated in fp32: per-product relative error ~2^-17 instead of
+//        2^-24 at 3/16 of the fp32-MFMA time ("bf16x3"; opt-in, parity-tested at the same 1e-4 bar).
+template <int BM, int BN, int TM, int TN, int BK, int TS, bool POS, bool DB = true, int BF = 0>
 __global__ __launch_bounds__((BM / (32 * TM)) * (BN / (32 * TN)) * 64, (BM / (32 * TM)) * (BN / (32 * TN)) == 8 ? 2 : 2)
 void conv_igemm_f32_kernel(ConvParams p) {
     constexpr int NT = (BM / (32 * TM)) * (BN / (32 * TN)) * 64;   // threads: one wave per (32 TM) x (32 TN) sub-tile
-    constexpr int LDK = BF ? BK + 8 : BK + 4;     // LDS row stride in elements (bf16: 80 / 48 bytes, f32: 144 / 80)
+    // LDS row stride in elements (f32: 144 / 80 bytes; bf16: 80 / 48 bytes; bf16x3: hi and lo halves, the f32 bytes)
+    constexpr int LDK = BF == 3 ? 2 * BK + 8 : (BF ? BK + 8 : BK + 4);
     constexpr int ESZ = BF ? 2 : 4;
     constexpr int CPR = BK / 4;     // 16-byte chunks per staged row
     constexpr int RPP = NT / CPR;   // rows staged per pass
@@ -231,6 +236,22 @@ void conv_igemm_f32_kernel(ConvParams p) {
         }
     };
     auto store_step = [&](float* buf) {
+        if (BF == 3) {
+            __bf16* As = (__bf16*)buf;
+            __bf16* Bs = As + BM * LDK;
+            auto split = [&](const f32x4& x, __bf16* row) {
+                bf16x4 hi = {(__bf16)x[0], (__bf16)x[1], (__bf16)x[2], (__bf16)x[3]};
+                bf16x4 lo = {(__bf16)(x[0] - (float)hi[0]), (__bf16)(x[1] - (float)hi[1]), (__bf16)(x[2] - (float)hi[2]),
+                             (__bf16)(x[3] - (float)hi[3])};
+                *(bf16x4*)(row + sc * 4) = hi;
+                *(bf16x4*)(row + BK + sc * 4) = lo;
+            };
+#pragma unroll
+            for (int i = 0; i < AR; ++i) split(ra[i], As + (sr + RPP * i) * LDK);
+#pragma unroll
+            for (int i = 0; i < BR; ++i) split(rb[i], Bs + (sr + RPP * i) * LDK);
+            return;
+        }
         if (BF) {
             __bf16* As = (__bf16*)buf;
             __bf16* Bs = As + BM * LDK;
@@ -264,7 +285,32 @@ void conv_igemm_f32_kernel(ConvParams p) {
         float* cur = DB ? lds + (ks & 1) * STAGE : lds;
         const bool more = ks + 1 < nk;
         if (more) load_step();
-        if (BF) {
+        if (BF == 3) {
+            const __bf16* Ab = (const __bf16*)cur + (wm * 32 * TM + r) * LDK + h * 8;
+            const __bf16* Bb = (const __bf16*)cur + BM * LDK + (wn * 32 * TN + r) * LDK + h * 8;
+#pragma unroll
+            for (int k16 = 0; k16 < BK / 16; ++k16) {
+                bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[i] = *(const bf16x8*)(Ab + i * 32 * LDK + k16 * 16);
+                    al[i] = *(const bf16x8*)(Ab + i * 32 * LDK + BK + k16 * 16);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bh[j] = *(const bf16x8*)(Bb + j * 32 * LDK + k16 * 16);
+                    bl[j] = *(const bf16x8*)(Bb + j * 32 * LDK + BK + k16 * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {          // small terms first
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else if (BF) {
             // v_mfma_f32_32x32x16_bf16: lane (r, h) feeds A[row r][k = 8h .. 8h+7] and B[k = 8h .. 8h+7][col r]: 16 bytes each
             const __bf16* Ab = (const __bf16*)cur + (wm * 32 * TM + r) * LDK + h * 8;
             const __bf16* Bb = (const __bf16*)cur + BM * LDK + (wn * 32 * TN + r) * LDK + h * 8;
@@ -410,9 +456,9 @@ void conv_igemm_f32_kernel(ConvParams p) {
     }
 }
 
-template <int BM, int BN, int TM, int TN, int BK, int TS, bool POS, bool DB = true, bool BF = false>
+template <int BM, int BN, int TM, int TN, int BK, int TS, bool POS, bool DB = true, int BF = 0>
 int launch(const ConvParams& p, hipStream_t st) {
-    constexpr int stage_bytes = (DB ? 2 : 1) * (BM + BN) * (BF ? (BK + 8) * 2 : (BK + 4) * 4);
+    constexpr int stage_bytes = (DB ? 2 : 1) * (BM + BN) * (BF == 3 ? (2 * BK + 8) * 2 : (BF ? (BK + 8) * 2 : (BK + 4) * 4));
     constexpr int epi_bytes = (BM / TM) * (BN + 4) * 4;
     constexpr int lds_min = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     // SSAD_CONV_LDS_PAD_<BN>: extra LDS bytes per workgroup = fewer resident workgroups (launch-quantisation experiments)
@@ -444,8 +490,15 @@ int launch(const ConvParams& p, hipStream_t st) {
 // every dispatch returns the number of row workgroups launched (= rows of the statistics partials)
 template <int TS>
 int dispatch_bf16(const ConvParams& p, hipStream_t st) {
-    if (p.Cout <= 64) return launch<256, 64, 2, 2, 32, TS, false, true, true>(p, st);
-    return launch<128, 128, 2, 2, 32, TS, false, true, true>(p, st);
+    if (p.Cout <= 64) return launch<256, 64, 2, 2, 32, TS, false, true, 1>(p, st);
+    return launch<128, 128, 2, 2, 32, TS, false, true, 1>(p, st);
+}
+
+// split-bf16 ("bf16x3") form of every fp32 tile: same LDS bytes per row, so the same tiles and residency
+template <int TS, bool POS>
+int dispatch_x3(const ConvParams& p, hipStream_t st) {
+    if (p.Cout <= 64) return launch<256, 64, 2, 2, 16, TS, POS, true, 3>(p, st);
+    return launch<128, 128, 2, 2, 32, TS, POS, true, 3>(p, st);
 }
 
 template <int TS, bool POS>
@@ -463,7 +516,7 @@ int dispatch(const ConvParams& p, hipStream_t st) {
 
 int conv_fwd_impl(const float* in, const float* w_ohwi, float* out, const float* scale, const float* shift,
                   const float* residual, int relu, int64_t N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
-                  int pad, int hwnc, void* stream, bool bf16 = false, double* stats = nullptr, int* stat_rows = nullptr) {
+                  int pad, int hwnc, void* stream, int bf16 = 0, double* stats = nullptr, int* stat_rows = nullptr) {
     SSAD_CHECK_ARG(in && w_ohwi && out, "null pointer");
     SSAD_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "empty shape");
     SSAD_CHECK_ARG(Cin % KALIGN == 0, "Cin must be a multiple of 32");
@@ -485,7 +538,10 @@ int conv_fwd_impl(const float* in, const float* w_ohwi, float* out, const float*
     SSAD_CHECK_ARG(cdiv64(p.M, 128) + 32 * p.Ho * p.Wo < (int64_t)2147483647, "M too large for one launch");
     hipStream_t st = (hipStream_t)stream;
     int rows;
-    if (bf16) {
+    SSAD_CHECK_ARG(bf16 == 0 || bf16 == 1 || bf16 == 3, "operand mode: 0 (fp32), 1 (bf16) or 3 (bf16x3)");
+    if (bf16 == 3) {
+        rows = posmajor ? dispatch_x3<1, true>(p, st) : dispatch_x3<1, false>(p, st);
+    } else if (bf16) {
         SSAD_CHECK_ARG(!hwnc, "bf16 operands: NHWC only");
         rows = dispatch_bf16<1>(p, st);
     } else if (posmajor) rows = dispatch<1, true>(p, st);
@@ -503,7 +559,15 @@ int conv_fwd_impl(const float* in, const float* w_ohwi, float* out, const float*
 extern "C" int ssad_conv_igemm_fwd_bf16(const float* in, const float* w_ohwi, float* out, const float* scale,
                                         const float* shift, const float* residual, int relu, int64_t N, int H, int W,
                                         int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream) {
-    return conv_fwd_impl(in, w_ohwi, out, scale, shift, residual, relu, N, H, W, Cin, Cout, KH, KW, stride, pad, 0, stream, true);
+    return conv_fwd_impl(in, w_ohwi, out, scale, shift, residual, relu, N, H, W, Cin, Cout, KH, KW, stride, pad, 0, stream, 1);
+}
+
+// Split-bf16 ("bf16x3") form: fp32 tensors in and out, every product formed from (hi, lo) bf16 pairs on the bf16 matrix
+// cores, fp32 accumulate.  hwnc != 0 selects the position-major layout of ssad_conv_igemm_fwd_hwnc.
+extern "C" int ssad_conv_igemm_fwd_x3(const float* in, const float* w_ohwi, float* out, const float* scale, const float* shift,
+                                      const float* residual, int relu, int64_t N, int H, int W, int Cin, int Cout, int KH,
+                                      int KW, int stride, int pad, int hwnc, void* stream) {
+    return conv_fwd_impl(in, w_ohwi, out, scale, shift, residual, relu, N, H, W, Cin, Cout, KH, KW, stride, pad, hwnc, stream, 3);
 }
 
 extern "C" int ssad_conv_igemm_fwd(const float* in, const float* w_ohwi, float* out, const float* scale,
@@ -526,7 +590,7 @@ extern "C" int ssad_conv_igemm_fwd_stats(const float* in, const float* w_ohwi, f
     SSAD_CHECK_ARG(mean && invstd && workspace, "null pointer");
     int rows = 0;
     int rc = conv_fwd_impl(in, w_ohwi, out, nullptr, nullptr, nullptr, 0, N, H, W, Cin, Cout, KH, KW, stride, pad, 0, stream,
-                           bf16 != 0, workspace, &rows);
+                           bf16, workspace, &rows);
     if (rc) return rc;
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
     return ssad_bn_finalize_partials(workspace, rows, N * Ho * Wo, Cout, eps, momentum, mean, invstd, running_mean,
@@ -548,7 +612,7 @@ extern "C" int ssad_conv_igemm_fwd_hwnc(const float* in, const float* w_ohwi, fl
 // same gather-GEMM with k = (ky', kx', co), numerator row = iy - (KH-1-pad) + ky'.
 static int dgrad_impl(const float* dy, const float* w_flipT, float* dx, const float* residual, int64_t N,
                                      int Hy, int Wy, int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride,
-                                     int pad, void* stream, bool bf16) {
+                                     int pad, void* stream, int bf16) {
     SSAD_CHECK_ARG(dy && w_flipT && dx, "null pointer");
     SSAD_CHECK_ARG(N > 0 && Hy > 0 && Wy > 0 && Hx > 0 && Wx > 0 && Cin > 0 && Cout > 0, "empty shape");
     SSAD_CHECK_ARG(Cout % KALIGN == 0, "Cout (the contraction) must be a multiple of 32");
@@ -565,7 +629,10 @@ static int dgrad_impl(const float* dy, const float* w_flipT, float* dx, const fl
     p.K = KH * KW * Cout;
     SSAD_CHECK_ARG(cdiv64(p.M, 128) < (int64_t)2147483647, "M too large for one launch");
     hipStream_t st = (hipStream_t)stream;
-    if (bf16) {
+    if (bf16 == 3) {
+        if (stride == 1) dispatch_x3<1, false>(p, st);
+        else dispatch_x3<2, false>(p, st);
+    } else if (bf16) {
         if (stride == 1) dispatch_bf16<1>(p, st);
         else dispatch_bf16<2>(p, st);
     } else if (stride == 1) dispatch<1, false>(p, st);
@@ -577,11 +644,17 @@ static int dgrad_impl(const float* dy, const float* w_flipT, float* dx, const fl
 extern "C" int ssad_conv_igemm_dgrad(const float* dy, const float* w_flipT, float* dx, const float* residual, int64_t N,
                                      int Hy, int Wy, int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride,
                                      int pad, void* stream) {
-    return dgrad_impl(dy, w_flipT, dx, residual, N, Hy, Wy, Cout, Hx, Wx, Cin, KH, KW, stride, pad, stream, false);
+    return dgrad_impl(dy, w_flipT, dx, residual, N, Hy, Wy, Cout, Hx, Wx, Cin, KH, KW, stride, pad, stream, 0);
 }
 
 extern "C" int ssad_conv_igemm_dgrad_bf16(const float* dy, const float* w_flipT, float* dx, const float* residual, int64_t N,
                                           int Hy, int Wy, int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride,
                                           int pad, void* stream) {
-    return dgrad_impl(dy, w_flipT, dx, residual, N, Hy, Wy, Cout, Hx, Wx, Cin, KH, KW, stride, pad, stream, true);
+    return dgrad_impl(dy, w_flipT, dx, residual, N, Hy, Wy, Cout, Hx, Wx, Cin, KH, KW, stride, pad, stream, 1);
+}
+
+extern "C" int ssad_conv_igemm_dgrad_x3(const float* dy, const float* w_flipT, float* dx, const float* residual, int64_t N,
+                                        int Hy, int Wy, int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride,
+                                        int pad, void* stream) {
+    return dgrad_impl(dy, w_flipT, dx, residual, N, Hy, Wy, Cout, Hx, Wx, Cin, KH, KW, stride, pad, stream, 3);
 }

@@ -189,10 +189,12 @@ __global__ __launch_bounds__(512, 4) void wgrad_f32_kernel(WgradParams p) {
 // TRANSPOSED in LDS, [channel][32 pixels + pad] bf16 (80-byte rows): each thread loads a 4-pixel x 4-channel block
 // (four 16-byte global loads), converts, and writes four 8-byte column pieces (lanes run over pixel groups first:
 // conflict-free).  fp32 accumulate, fp32 slabs, same deterministic reduce.
-template <int BT>
+// X3: split-bf16 products (hi = bf16(x), lo = bf16(x - hi) staged side by side, three MFMAs per tile: lo*hi + hi*lo +
+// hi*hi) -- fp32-class accuracy (~2^-17 per product) from the bf16 matrix cores; see conv_igemm.hip, BF = 3.
+template <int BT, bool X3 = false>
 __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams p) {
     constexpr int T = BT / 64;
-    constexpr int LDP = PK + 8;                 // bf16 elements per LDS row
+    constexpr int LDP = X3 ? 2 * PK + 8 : PK + 8;     // bf16 elements per LDS row ([32 hi | 32 lo] + pad when X3)
     constexpr int STAGE = 2 * BT * LDP;         // bf16 elements per stage (dY^T tile + X^T tile)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __bf16* L = (__bf16*)lds;
@@ -268,6 +270,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams p) {
             bf16x4 vx = {(__bf16)rx[0][k], (__bf16)rx[1][k], (__bf16)rx[2][k], (__bf16)rx[3][k]};
             *(bf16x4*)(Yt + (c4 * 4 + k) * LDP + pg * 4) = vy;
             *(bf16x4*)(Xt + (c4 * 4 + k) * LDP + pg * 4) = vx;
+            if (X3) {
+                bf16x4 ly = {(__bf16)(ry[0][k] - (float)vy[0]), (__bf16)(ry[1][k] - (float)vy[1]),
+                             (__bf16)(ry[2][k] - (float)vy[2]), (__bf16)(ry[3][k] - (float)vy[3])};
+                bf16x4 lx = {(__bf16)(rx[0][k] - (float)vx[0]), (__bf16)(rx[1][k] - (float)vx[1]),
+                             (__bf16)(rx[2][k] - (float)vx[2]), (__bf16)(rx[3][k] - (float)vx[3])};
+                *(bf16x4*)(Yt + (c4 * 4 + k) * LDP + PK + pg * 4) = ly;
+                *(bf16x4*)(Xt + (c4 * 4 + k) * LDP + PK + pg * 4) = lx;
+            }
         }
     };
 
@@ -290,6 +300,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams p) {
             for (int i = 0; i < T; ++i) a[i] = *(const bf16x8*)(ya + i * 32 * LDP + k16 * 16);
 #pragma unroll
             for (int j = 0; j < T; ++j) b[j] = *(const bf16x8*)(xb + j * 32 * LDP + k16 * 16);
+            if (X3) {
+                bf16x8 al[T], bl[T];
+#pragma unroll
+                for (int i = 0; i < T; ++i) al[i] = *(const bf16x8*)(ya + i * 32 * LDP + PK + k16 * 16);
+#pragma unroll
+                for (int j = 0; j < T; ++j) bl[j] = *(const bf16x8*)(xb + j * 32 * LDP + PK + k16 * 16);
+#pragma unroll
+                for (int i = 0; i < T; ++i)
+#pragma unroll
+                    for (int j = 0; j < T; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], b[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
+            }
 #pragma unroll
             for (int i = 0; i < T; ++i)
 #pragma unroll
@@ -401,7 +425,7 @@ extern "C" int ssad_wgrad_splits_bf16(int64_t M, int Cin, int Cout, int KH, int 
 }
 
 static int wgrad_impl(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin,
-                               int Cout, int KH, int KW, int stride, int pad, void* stream, bool bf16) {
+                               int Cout, int KH, int KW, int stride, int pad, void* stream, int bf16) {
     SSAD_CHECK_ARG(dy && x && slab, "null pointer");
     SSAD_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0, "bad shape");
     SSAD_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0, "channel counts must be multiples of 4");
@@ -421,7 +445,19 @@ static int wgrad_impl(const float* dy, const float* x, float* slab, int splits, 
     p.splits = splits;
     dim3 grid((unsigned)(KH * KW * p.co_tiles * p.ci_tiles * ((splits + 7) / 8) * 8));
     hipStream_t st = (hipStream_t)stream;
-    if (bf16) {
+    if (bf16 == 3) {
+        if (BT == 64) {
+            hipLaunchKernelGGL((wgrad_bf16_kernel<64, true>), grid, dim3(256), 2 * 2 * 64 * (2 * PK + 8) * 2, st, p);
+        } else {
+            static bool x3_attr = false;
+            if (!x3_attr) {
+                (void)hipFuncSetAttribute((const void*)wgrad_bf16_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          2 * 2 * 128 * (2 * PK + 8) * 2);
+                x3_attr = true;
+            }
+            hipLaunchKernelGGL((wgrad_bf16_kernel<128, true>), grid, dim3(256), 2 * 2 * 128 * (2 * PK + 8) * 2, st, p);
+        }
+    } else if (bf16) {
         if (BT == 64) hipLaunchKernelGGL(wgrad_bf16_kernel<64>, grid, dim3(256), 2 * 2 * 64 * (PK + 8) * 2, st, p);
         else hipLaunchKernelGGL(wgrad_bf16_kernel<128>, grid, dim3(256), 2 * 2 * 128 * (PK + 8) * 2, st, p);
     } else if (BT == 64) {
@@ -441,13 +477,19 @@ static int wgrad_impl(const float* dy, const float* x, float* slab, int splits, 
 
 extern "C" int ssad_conv_wgrad(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin,
                                int Cout, int KH, int KW, int stride, int pad, void* stream) {
-    return wgrad_impl(dy, x, slab, splits, N, H, W, Cin, Cout, KH, KW, stride, pad, stream, false);
+    return wgrad_impl(dy, x, slab, splits, N, H, W, Cin, Cout, KH, KW, stride, pad, stream, 0);
 }
 
 // bf16-operand form (fp32 tensors, fp32 accumulate and slabs): Trainer(precision=16).
 extern "C" int ssad_conv_wgrad_bf16(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin,
                                     int Cout, int KH, int KW, int stride, int pad, void* stream) {
-    return wgrad_impl(dy, x, slab, splits, N, H, W, Cin, Cout, KH, KW, stride, pad, stream, true);
+    return wgrad_impl(dy, x, slab, splits, N, H, W, Cin, Cout, KH, KW, stride, pad, stream, 1);
+}
+
+// split-bf16 ("bf16x3") form: fp32-class accuracy from the bf16 matrix cores (use ssad_wgrad_splits_bf16 for the slab).
+extern "C" int ssad_conv_wgrad_x3(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin,
+                                  int Cout, int KH, int KW, int stride, int pad, void* stream) {
+    return wgrad_impl(dy, x, slab, splits, N, H, W, Cin, Cout, KH, KW, stride, pad, stream, 3);
 }
 
 extern "C" int ssad_wgrad_reduce(const float* slab, float* dw, int splits, int Cout, int Kpad, int KH, int KW, int Cin,

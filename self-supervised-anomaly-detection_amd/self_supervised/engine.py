@@ -19,6 +19,13 @@ import os as _os
 WINO_STAGES = ("layer2", "layer3") if _os.environ.get("SSAD_WINOGRAD") == "1" else ()
 
 
+def math_mode():
+    """Product arithmetic of the eval-mode trunk / head: "f32" (default: exact fp32 MFMA) or "bf16x3" (split-bf16
+    emulation on the bf16 matrix cores: ~3x the fp32 error against fp64, 2.1-2.4x the conv throughput).  Read per call
+    so that tests and bench.py can switch it: SSAD_MATH=bf16x3."""
+    return "bf16x3" if _os.environ.get("SSAD_MATH", "f32").lower() in ("bf16x3", "x3") else "f32"
+
+
 class _Block(nn.Module):
     """Parameter holder with torchvision BasicBlock names; never called."""
 
@@ -114,7 +121,11 @@ def trunk_eval(plan, x, patch_dim, patch_stride, layer_outputs, pooled):
     b, _, h, w = x.shape
     p, hv, wv, _, _ = ops.stem_geometry(h, w, patch_dim, patch_stride)
     hwnc = b * p >= 128 and hv * wv <= 64 * 64
-    conv = ops.conv_fwd_hwnc if hwnc else ops.conv_fwd
+    x3 = math_mode() == "bf16x3"
+    if hwnc:
+        conv = (lambda *a: ops.conv_fwd_hwnc(*a, x3=True)) if x3 else ops.conv_fwd_hwnc
+    else:
+        conv = (lambda *a: ops.conv_fwd(*a, 3)) if x3 else ops.conv_fwd
     win = (patch_dim, patch_dim) if patch_dim else (h, w)
     if win == (32, 32):
         # exact 2x nearest upsample: folded 4x4 conv + BN + ReLU + max-pool fused, the conv map never reaches HBM
@@ -150,7 +161,8 @@ def trunk_eval(plan, x, patch_dim, patch_stride, layer_outputs, pooled):
 
 def head_eval(plan, pooled):
     f = pooled
+    x3 = math_mode() == "bf16x3"
     for w, s, t, relu in plan.head:
-        f = ops.linear_fwd(f, w, s, t, relu)
-    logits = ops.linear_fwd(f, plan.cls_w, None, plan.cls_b, False)
+        f = ops.linear_fwd(f, w, s, t, relu, x3)
+    logits = ops.linear_fwd(f, plan.cls_w, None, plan.cls_b, False, x3)
     return logits, f

@@ -579,7 +579,8 @@ class DataParallelStep:
     def __init__(self, model, lr, momentum=0.9, weight_decay=0.0005, world_size=None, process_group=None, precision=32):
         self.model = model
         self.eng = get_engine(model)
-        self.eng.bf16 = str(precision) in ("16", "bf16", "16-mixed", "bf16-mixed")
+        # 32: exact fp32 MFMA; 16: bf16 operands (the reference's AMP setting); "bf16x3": split-bf16 fp32 emulation
+        self.eng.bf16 = 3 if str(precision) in ("bf16x3", "32x3") else str(precision) in ("16", "bf16", "16-mixed", "bf16-mixed")
         self.opt = FusedSGD(model, lr, momentum, weight_decay)
         self.world = world_size if world_size is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
         self.opt.grad_scale = 1.0 / self.world
