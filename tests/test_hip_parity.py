@@ -270,8 +270,10 @@ def test_scoring_path_golden(dev, golden, seeded_sd):
     assert d.bank.shape[0] == int(g["bank_rows"])
     maps = d.predict(q)
     assert tuple(maps.shape) == (2, 1, 29, 29)
-    np.testing.assert_allclose(maps.cpu().numpy(), g["scores"], atol=1e-4)
-    np.testing.assert_allclose(d.threshold, g["threshold"], atol=1e-4)
+    # north-star bar: 1e-4 absolute.  With seeded random weights the embeddings are nearly parallel (map values 7e-5 ..
+    # 1.9e-4), so the bar alone would be weak here: hold the maps to 5e-6 (measured 7e-7 = fp32 cancellation in 1 - cos)
+    np.testing.assert_allclose(maps.cpu().numpy(), g["scores"], atol=5e-6)
+    np.testing.assert_allclose(d.threshold, g["threshold"], atol=5e-6)
     up = tools.upsample(maps, 256)
     want = osc.upsample(torch.from_numpy(g["scores"]), 256)
     assert_close(up, want, 1e-4)

@@ -62,7 +62,8 @@ def test_x3_forward_and_scoring_match_reference_vectors(golden, seeded_sd, monke
     d = AnomalyDetector(patch_level=True, batch=2, num_patches=m.num_patches)
     d.fit(bank_src.cpu())
     maps = d.predict(q)
-    np.testing.assert_allclose(maps.cpu().numpy(), gd["scores"], atol=1e-4)       # the north-star bar on anomaly maps
+    # north-star bar 1e-4; the fixture's maps are 7e-5 .. 1.9e-4, so hold them to 5e-6 as the exact path's test does
+    np.testing.assert_allclose(maps.cpu().numpy(), gd["scores"], atol=5e-6)
 
 
 def test_x3_training_step_matches_autograd(seeded_sd):
