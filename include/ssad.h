@@ -135,6 +135,13 @@ int ssad_conv_igemm_fwd_x3(const float* in, const float* w_ohwi, float* out, con
                            int stride, int pad, int hwnc, void* stream);
 int ssad_conv_igemm_dgrad_x3(const float* dy, const float* w_flipT, float* dx, const float* residual, int64_t N, int Hy,
                              int Wy, int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride, int pad, void* stream);
+/* Three-way split ("bf16x6"): x = hi + mid + lo (24 significant bits) and the six products of weight >= 2^-18; what is
+ * dropped is ~2^-25 of each product, i.e. fp32-faithful products at 6/16 of the fp32-MFMA time. */
+int ssad_conv_igemm_fwd_x6(const float* in, const float* w_ohwi, float* out, const float* scale, const float* shift,
+                           const float* residual, int relu, int64_t N, int H, int W, int Cin, int Cout, int KH, int KW,
+                           int stride, int pad, int hwnc, void* stream);
+int ssad_conv_igemm_dgrad_x6(const float* dy, const float* w_flipT, float* dx, const float* residual, int64_t N, int Hy,
+                             int Wy, int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride, int pad, void* stream);
 /* Replaces autograd's conv2d/linear weight-gradient.  Two launches: partial tiles per pixel split into
  * slab[splits][Cout][KH*KW*Cin], then a fixed-order sum written as OIHW (to_oihw=1, checkpoint layout) or OHWI. */
 int ssad_wgrad_splits(int64_t M, int Cin, int Cout, int KH, int KW);

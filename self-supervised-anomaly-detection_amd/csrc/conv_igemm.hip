@@ -57,12 +57,15 @@ struct ConvParams {
 //        (16 significant bits together; a row keeps its fp32 footprint: [BK hi | BK lo] bf16) and each 32x32x16 tile
 //        takes three MFMAs, lo*hi + hi*lo + hi*hi, accumulated in fp32: per-product relative error ~2^-17 instead of
 //        2^-24 at 3/16 of the fp32-MFMA time ("bf16x3"; opt-in, parity-tested at the same 1e-4 bar).
+//        6 = three-way split hi + mid + lo (24 significant bits, rows [BK hi | BK mid | BK lo]) and the six products
+//        of weight >= 2^-18 (hh, hm, mh, hl, lh, mm): what is dropped is ~2^-25 of the product, i.e. fp32-faithful
+//        products at 6/16 of the fp32-MFMA time ("bf16x6").
 template <int BM, int BN, int TM, int TN, int BK, int TS, bool POS, bool DB = true, int BF = 0>
 __global__ __launch_bounds__((BM / (32 * TM)) * (BN / (32 * TN)) * 64, (BM / (32 * TM)) * (BN / (32 * TN)) == 8 ? 2 : 2)
 void conv_igemm_f32_kernel(ConvParams p) {
     constexpr int NT = (BM / (32 * TM)) * (BN / (32 * TN)) * 64;   // threads: one wave per (32 TM) x (32 TN) sub-tile
     // LDS row stride in elements (f32: 144 / 80 bytes; bf16: 80 / 48 bytes; bf16x3: hi and lo halves, the f32 bytes)
-    constexpr int LDK = BF == 3 ? 2 * BK + 8 : (BF ? BK + 8 : BK + 4);
+    constexpr int LDK = BF == 6 ? 3 * BK + 8 : (BF == 3 ? 2 * BK + 8 : (BF ? BK + 8 : BK + 4));
     constexpr int ESZ = BF ? 2 : 4;
     constexpr int CPR = BK / 4;     // 16-byte chunks per staged row
     constexpr int RPP = NT / CPR;   // rows staged per pass
@@ -236,6 +239,28 @@ void conv_igemm_f32_kernel(ConvParams p) {
         }
     };
     auto store_step = [&](float* buf) {
+        if (BF == 6) {
+            __bf16* As = (__bf16*)buf;
+            __bf16* Bs = As + BM * LDK;
+            auto split3 = [&](const f32x4& x, __bf16* row) {
+                bf16x4 hi, mi, lo;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    hi[k] = (__bf16)x[k];
+                    const float r1 = x[k] - (float)hi[k];
+                    mi[k] = (__bf16)r1;
+                    lo[k] = (__bf16)(r1 - (float)mi[k]);
+                }
+                *(bf16x4*)(row + sc * 4) = hi;
+                *(bf16x4*)(row + BK + sc * 4) = mi;
+                *(bf16x4*)(row + 2 * BK + sc * 4) = lo;
+            };
+#pragma unroll
+            for (int i = 0; i < AR; ++i) split3(ra[i], As + (sr + RPP * i) * LDK);
+#pragma unroll
+            for (int i = 0; i < BR; ++i) split3(rb[i], Bs + (sr + RPP * i) * LDK);
+            return;
+        }
         if (BF == 3) {
             __bf16* As = (__bf16*)buf;
             __bf16* Bs = As + BM * LDK;
@@ -285,7 +310,33 @@ void conv_igemm_f32_kernel(ConvParams p) {
         float* cur = DB ? lds + (ks & 1) * STAGE : lds;
         const bool more = ks + 1 < nk;
         if (more) load_step();
-        if (BF == 3) {
+        if (BF == 6) {
+            const __bf16* Ab = (const __bf16*)cur + (wm * 32 * TM + r) * LDK + h * 8;
+            const __bf16* Bb = (const __bf16*)cur + BM * LDK + (wn * 32 * TN + r) * LDK + h * 8;
+#pragma unroll
+            for (int k16 = 0; k16 < BK / 16; ++k16) {
+                bf16x8 a3[TM][3], b3[TN][3];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) a3[i][q] = *(const bf16x8*)(Ab + i * 32 * LDK + q * BK + k16 * 16);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) b3[j][q] = *(const bf16x8*)(Bb + j * 32 * LDK + q * BK + k16 * 16);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {          // smallest terms first
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[i][1], b3[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[i][2], b3[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[i][0], b3[j][2], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[i][1], b3[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[i][0], b3[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[i][0], b3[j][0], acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else if (BF == 3) {
             const __bf16* Ab = (const __bf16*)cur + (wm * 32 * TM + r) * LDK + h * 8;
             const __bf16* Bb = (const __bf16*)cur + BM * LDK + (wn * 32 * TN + r) * LDK + h * 8;
 #pragma unroll
@@ -458,7 +509,8 @@ void conv_igemm_f32_kernel(ConvParams p) {
 
 template <int BM, int BN, int TM, int TN, int BK, int TS, bool POS, bool DB = true, int BF = 0>
 int launch(const ConvParams& p, hipStream_t st) {
-    constexpr int stage_bytes = (DB ? 2 : 1) * (BM + BN) * (BF == 3 ? (2 * BK + 8) * 2 : (BF ? (BK + 8) * 2 : (BK + 4) * 4));
+    constexpr int stage_bytes = (DB ? 2 : 1) * (BM + BN) *
+                                (BF == 6 ? (3 * BK + 8) * 2 : (BF == 3 ? (2 * BK + 8) * 2 : (BF ? (BK + 8) * 2 : (BK + 4) * 4)));
     constexpr int epi_bytes = (BM / TM) * (BN + 4) * 4;
     constexpr int lds_min = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     // SSAD_CONV_LDS_PAD_<BN>: extra LDS bytes per workgroup = fewer resident workgroups (launch-quantisation experiments)
@@ -492,6 +544,13 @@ template <int TS>
 int dispatch_bf16(const ConvParams& p, hipStream_t st) {
     if (p.Cout <= 64) return launch<256, 64, 2, 2, 32, TS, false, true, 1>(p, st);
     return launch<128, 128, 2, 2, 32, TS, false, true, 1>(p, st);
+}
+
+// three-way split ("bf16x6"): rows are 1.5x the fp32 bytes, so BK = 16 keeps two workgroups per CU
+template <int TS, bool POS>
+int dispatch_x6(const ConvParams& p, hipStream_t st) {
+    if (p.Cout <= 64) return launch<256, 64, 2, 2, 16, TS, POS, true, 6>(p, st);
+    return launch<128, 128, 2, 2, 16, TS, POS, true, 6>(p, st);
 }
 
 // split-bf16 ("bf16x3") form of every fp32 tile: same LDS bytes per row, so the same tiles and residency
@@ -538,8 +597,10 @@ int conv_fwd_impl(const float* in, const float* w_ohwi, float* out, const float*
     SSAD_CHECK_ARG(cdiv64(p.M, 128) + 32 * p.Ho * p.Wo < (int64_t)2147483647, "M too large for one launch");
     hipStream_t st = (hipStream_t)stream;
     int rows;
-    SSAD_CHECK_ARG(bf16 == 0 || bf16 == 1 || bf16 == 3, "operand mode: 0 (fp32), 1 (bf16) or 3 (bf16x3)");
-    if (bf16 == 3) {
+    SSAD_CHECK_ARG(bf16 == 0 || bf16 == 1 || bf16 == 3 || bf16 == 6, "operand mode: 0 (fp32), 1 (bf16), 3 (bf16x3), 6 (bf16x6)");
+    if (bf16 == 6) {
+        rows = posmajor ? dispatch_x6<1, true>(p, st) : dispatch_x6<1, false>(p, st);
+    } else if (bf16 == 3) {
         rows = posmajor ? dispatch_x3<1, true>(p, st) : dispatch_x3<1, false>(p, st);
     } else if (bf16) {
         SSAD_CHECK_ARG(!hwnc, "bf16 operands: NHWC only");
@@ -568,6 +629,13 @@ extern "C" int ssad_conv_igemm_fwd_x3(const float* in, const float* w_ohwi, floa
                                       const float* residual, int relu, int64_t N, int H, int W, int Cin, int Cout, int KH,
                                       int KW, int stride, int pad, int hwnc, void* stream) {
     return conv_fwd_impl(in, w_ohwi, out, scale, shift, residual, relu, N, H, W, Cin, Cout, KH, KW, stride, pad, hwnc, stream, 3);
+}
+
+// Three-way split ("bf16x6"): fp32-faithful products (what is dropped is ~2^-25 of each product).
+extern "C" int ssad_conv_igemm_fwd_x6(const float* in, const float* w_ohwi, float* out, const float* scale, const float* shift,
+                                      const float* residual, int relu, int64_t N, int H, int W, int Cin, int Cout, int KH,
+                                      int KW, int stride, int pad, int hwnc, void* stream) {
+    return conv_fwd_impl(in, w_ohwi, out, scale, shift, residual, relu, N, H, W, Cin, Cout, KH, KW, stride, pad, hwnc, stream, 6);
 }
 
 extern "C" int ssad_conv_igemm_fwd(const float* in, const float* w_ohwi, float* out, const float* scale,
@@ -629,7 +697,10 @@ static int dgrad_impl(const float* dy, const float* w_flipT, float* dx, const fl
     p.K = KH * KW * Cout;
     SSAD_CHECK_ARG(cdiv64(p.M, 128) < (int64_t)2147483647, "M too large for one launch");
     hipStream_t st = (hipStream_t)stream;
-    if (bf16 == 3) {
+    if (bf16 == 6) {
+        if (stride == 1) dispatch_x6<1, false>(p, st);
+        else dispatch_x6<2, false>(p, st);
+    } else if (bf16 == 3) {
         if (stride == 1) dispatch_x3<1, false>(p, st);
         else dispatch_x3<2, false>(p, st);
     } else if (bf16) {
@@ -651,6 +722,12 @@ extern "C" int ssad_conv_igemm_dgrad_bf16(const float* dy, const float* w_flipT,
                                           int Hy, int Wy, int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride,
                                           int pad, void* stream) {
     return dgrad_impl(dy, w_flipT, dx, residual, N, Hy, Wy, Cout, Hx, Wx, Cin, KH, KW, stride, pad, stream, 1);
+}
+
+extern "C" int ssad_conv_igemm_dgrad_x6(const float* dy, const float* w_flipT, float* dx, const float* residual, int64_t N,
+                                        int Hy, int Wy, int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride,
+                                        int pad, void* stream) {
+    return dgrad_impl(dy, w_flipT, dx, residual, N, Hy, Wy, Cout, Hx, Wx, Cin, KH, KW, stride, pad, stream, 6);
 }
 
 extern "C" int ssad_conv_igemm_dgrad_x3(const float* dy, const float* w_flipT, float* dx, const float* residual, int64_t N,

@@ -46,7 +46,11 @@ SIGNATURES = {
                                  _c_i, _c_i, _c_fp],
     "ssad_conv_igemm_fwd_x3": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
                                _c_i, _c_i, _c_i, _c_fp],
+    "ssad_conv_igemm_fwd_x6": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
+                               _c_i, _c_i, _c_i, _c_fp],
     "ssad_conv_igemm_dgrad_x3": [_c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
+                                 _c_i, _c_fp],
+    "ssad_conv_igemm_dgrad_x6": [_c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
                                  _c_i, _c_fp],
     "ssad_conv_igemm_dgrad_bf16": [_c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
                                    _c_i, _c_fp],

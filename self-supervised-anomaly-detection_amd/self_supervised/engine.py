@@ -20,10 +20,12 @@ WINO_STAGES = ("layer2", "layer3") if _os.environ.get("SSAD_WINOGRAD") == "1" el
 
 
 def math_mode():
-    """Product arithmetic of the eval-mode trunk / head: "f32" (default: exact fp32 MFMA) or "bf16x3" (split-bf16
-    emulation on the bf16 matrix cores: ~3x the fp32 error against fp64, 2.1-2.4x the conv throughput).  Read per call
-    so that tests and bench.py can switch it: SSAD_MATH=bf16x3."""
-    return "bf16x3" if _os.environ.get("SSAD_MATH", "f32").lower() in ("bf16x3", "x3") else "f32"
+    """Product arithmetic of the eval-mode trunk / head, read per call (tests and bench.py switch it): SSAD_MATH =
+    "f32" (default: exact fp32 MFMA), "bf16x6" (three-way bf16 split, six MFMAs: fp32-faithful products, 1.2e-6 against
+    fp64 where the fp32 MFMA shows 1.5e-6, ~1.4x the conv throughput) or "bf16x3" (two-way split, three MFMAs: 4.6e-6,
+    2.1-2.4x).  Returns 0, 6 or 3."""
+    m = _os.environ.get("SSAD_MATH", "f32").lower()
+    return 6 if m in ("bf16x6", "x6") else 3 if m in ("bf16x3", "x3") else 0
 
 
 class _Block(nn.Module):
@@ -121,11 +123,11 @@ def trunk_eval(plan, x, patch_dim, patch_stride, layer_outputs, pooled):
     b, _, h, w = x.shape
     p, hv, wv, _, _ = ops.stem_geometry(h, w, patch_dim, patch_stride)
     hwnc = b * p >= 128 and hv * wv <= 64 * 64
-    x3 = math_mode() == "bf16x3"
+    x3 = math_mode()
     if hwnc:
-        conv = (lambda *a: ops.conv_fwd_hwnc(*a, x3=True)) if x3 else ops.conv_fwd_hwnc
+        conv = (lambda *a: ops.conv_fwd_hwnc(*a, x3=x3)) if x3 else ops.conv_fwd_hwnc
     else:
-        conv = (lambda *a: ops.conv_fwd(*a, 3)) if x3 else ops.conv_fwd
+        conv = (lambda *a: ops.conv_fwd(*a, x3)) if x3 else ops.conv_fwd
     win = (patch_dim, patch_dim) if patch_dim else (h, w)
     if win == (32, 32):
         # exact 2x nearest upsample: folded 4x4 conv + BN + ReLU + max-pool fused, the conv map never reaches HBM
@@ -161,7 +163,7 @@ def trunk_eval(plan, x, patch_dim, patch_stride, layer_outputs, pooled):
 
 def head_eval(plan, pooled):
     f = pooled
-    x3 = math_mode() == "bf16x3"
+    x3 = math_mode()
     for w, s, t, relu in plan.head:
         f = ops.linear_fwd(f, w, s, t, relu, x3)
     logits = ops.linear_fwd(f, plan.cls_w, None, plan.cls_b, False, x3)

@@ -110,6 +110,10 @@ def maxpool3x3s2_fwd(x, hwnc=False):
     return out
 
 
+def _split_fwd(mode):
+    return _hip.lib().ssad_conv_igemm_fwd_x6 if mode == 6 else _hip.lib().ssad_conv_igemm_fwd_x3
+
+
 def conv_fwd_hwnc(x, w_ohwi, scale=None, shift=None, residual=None, relu=False, stride=1, pad=0, x3=False):
     """Position-major activations: x [H][W][N][Cin] -> [Ho][Wo][N][Cout] (patch-scoring trunk layout).
     x3: split-bf16 products (SSAD_MATH=bf16x3)."""
@@ -119,11 +123,11 @@ def conv_fwd_hwnc(x, w_ohwi, scale=None, shift=None, residual=None, relu=False, 
     ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
     out = _new((ho, wo, n, cout), x)
     nb = 4.0 * (x.numel() + out.numel() * (2 if residual is not None else 1) + w_ohwi.numel())
-    if x3:
-        _run("conv_igemm_x3", 2.0 * out.numel() * kh * kw * cin, nb,
-             lambda: _hip.lib().ssad_conv_igemm_fwd_x3(_hip.ptr(x), _hip.ptr(w_ohwi), _hip.ptr(out), _hip.ptr(scale, True),
-                                                       _hip.ptr(shift, True), _hip.ptr(residual, True), int(relu), n, h, w,
-                                                       cin, cout, kh, kw, stride, pad, 1, _hip.stream()))
+    if x3:                                       # True / 3: bf16x3, 6: bf16x6
+        _run("conv_igemm_x6" if x3 == 6 else "conv_igemm_x3", 2.0 * out.numel() * kh * kw * cin, nb,
+             lambda: _split_fwd(x3)(_hip.ptr(x), _hip.ptr(w_ohwi), _hip.ptr(out), _hip.ptr(scale, True),
+                                    _hip.ptr(shift, True), _hip.ptr(residual, True), int(relu), n, h, w,
+                                    cin, cout, kh, kw, stride, pad, 1, _hip.stream()))
         return out
     _run("conv_igemm_f32", 2.0 * out.numel() * kh * kw * cin, nb,
          lambda: _hip.lib().ssad_conv_igemm_fwd_hwnc(_hip.ptr(x), _hip.ptr(w_ohwi), _hip.ptr(out), _hip.ptr(scale, True),
@@ -163,11 +167,11 @@ def conv_fwd(x, w_ohwi, scale=None, shift=None, residual=None, relu=False, strid
     ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
     out = _new((n, ho, wo, cout), x)
     nb = 4.0 * (x.numel() + out.numel() * (2 if residual is not None else 1) + w_ohwi.numel())
-    if bf16 == 3:
-        _run("conv_igemm_x3", 2.0 * out.numel() * kh * kw * cin, nb,
-             lambda: _hip.lib().ssad_conv_igemm_fwd_x3(_hip.ptr(x), _hip.ptr(w_ohwi), _hip.ptr(out), _hip.ptr(scale, True),
-                                                       _hip.ptr(shift, True), _hip.ptr(residual, True), int(relu), n, h, w,
-                                                       cin, cout, kh, kw, stride, pad, 0, _hip.stream()))
+    if bf16 in (3, 6):
+        _run("conv_igemm_x6" if bf16 == 6 else "conv_igemm_x3", 2.0 * out.numel() * kh * kw * cin, nb,
+             lambda: _split_fwd(bf16)(_hip.ptr(x), _hip.ptr(w_ohwi), _hip.ptr(out), _hip.ptr(scale, True),
+                                      _hip.ptr(shift, True), _hip.ptr(residual, True), int(relu), n, h, w,
+                                      cin, cout, kh, kw, stride, pad, 0, _hip.stream()))
         return out
     fn = _hip.lib().ssad_conv_igemm_fwd_bf16 if bf16 else _hip.lib().ssad_conv_igemm_fwd
     _run("conv_igemm_bf16" if bf16 else "conv_igemm_f32", 2.0 * out.numel() * kh * kw * cin, nb,
@@ -187,7 +191,8 @@ def conv_fwd_stats(x, w_ohwi, eps, momentum, running_mean, running_var, stride=1
     lib = _hip.lib()
     ws = torch.empty(lib.ssad_conv_stats_workspace(n, ho, wo, cout), device=x.device, dtype=torch.float64)
     nb = 4.0 * (x.numel() + out.numel() + w_ohwi.numel())
-    _run("conv_igemm_x3" if bf16 == 3 else "conv_igemm_bf16" if bf16 else "conv_igemm_f32", 2.0 * out.numel() * kh * kw * cin, nb,
+    _run("conv_igemm_x6" if bf16 == 6 else "conv_igemm_x3" if bf16 == 3 else "conv_igemm_bf16" if bf16 else "conv_igemm_f32",
+         2.0 * out.numel() * kh * kw * cin, nb,
          lambda: lib.ssad_conv_igemm_fwd_stats(_hip.ptr(x), _hip.ptr(w_ohwi), _hip.ptr(out), n, h, w, cin, cout, kh, kw,
                                                stride, pad, int(bf16), eps, momentum, _hip.ptr(mean), _hip.ptr(invstd),
                                                _hip.ptr(running_mean, True), _hip.ptr(running_var, True), ws.data_ptr(),
@@ -201,10 +206,10 @@ def linear_fwd(x, w, scale=None, shift=None, relu=False, x3=False):
     cout = w.shape[0]
     out = _new((n, cout), x)
     if x3 and cout % 4 == 0:
-        _run("conv_igemm_x3", 2.0 * n * cin * cout, 4.0 * (x.numel() + out.numel() + w.numel()),
-             lambda: _hip.lib().ssad_conv_igemm_fwd_x3(_hip.ptr(x), _hip.ptr(w), _hip.ptr(out), _hip.ptr(scale, True),
-                                                       _hip.ptr(shift, True), None, int(relu), n, 1, 1, cin, cout, 1, 1, 1,
-                                                       0, 0, _hip.stream()))
+        _run("conv_igemm_x6" if x3 == 6 else "conv_igemm_x3", 2.0 * n * cin * cout, 4.0 * (x.numel() + out.numel() + w.numel()),
+             lambda: _split_fwd(x3)(_hip.ptr(x), _hip.ptr(w), _hip.ptr(out), _hip.ptr(scale, True),
+                                    _hip.ptr(shift, True), None, int(relu), n, 1, 1, cin, cout, 1, 1, 1,
+                                    0, 0, _hip.stream()))
         return out
     _run("conv_igemm_f32", 2.0 * n * cin * cout, 4.0 * (x.numel() + out.numel() + w.numel()),
          lambda: _hip.lib().ssad_conv_igemm_fwd(_hip.ptr(x), _hip.ptr(w), _hip.ptr(out), _hip.ptr(scale, True),
@@ -272,9 +277,9 @@ def conv_dgrad(dy, w_flipT, x_shape, stride, pad, residual=None, bf16=False):
     n, hy, wy, cout = dy.shape
     cin, kh, kw, _ = w_flipT.shape
     dx = _new(tuple(x_shape), dy)
-    fn = (_hip.lib().ssad_conv_igemm_dgrad_x3 if bf16 == 3 else
+    fn = (_hip.lib().ssad_conv_igemm_dgrad_x6 if bf16 == 6 else _hip.lib().ssad_conv_igemm_dgrad_x3 if bf16 == 3 else
           _hip.lib().ssad_conv_igemm_dgrad_bf16 if bf16 else _hip.lib().ssad_conv_igemm_dgrad)
-    _run("conv_igemm_x3" if bf16 == 3 else "conv_igemm_bf16" if bf16 else "conv_igemm_f32",
+    _run("conv_igemm_x6" if bf16 == 6 else "conv_igemm_x3" if bf16 == 3 else "conv_igemm_bf16" if bf16 else "conv_igemm_f32",
          2.0 * dx.numel() * kh * kw * cout / (stride * stride),
          4.0 * (dy.numel() + dx.numel() * (2 if residual is not None else 1) + w_flipT.numel()),
          lambda: fn(_hip.ptr(dy), _hip.ptr(w_flipT), _hip.ptr(dx), _hip.ptr(residual, True), n, hy, wy, cout, x_shape[1],
@@ -288,8 +293,10 @@ def conv_wgrad(dy, x, dw_out, kh, kw, stride, pad, kreal=None, to_oihw=False, ac
     n, h, w, cin = x.shape
     cout = dy.shape[-1]
     m = dy.numel() // cout
-    splits = (_hip.lib().ssad_wgrad_splits_bf16 if bf16 else _hip.lib().ssad_wgrad_splits)(m, cin, cout, kh, kw)
+    splits = (_hip.lib().ssad_wgrad_splits_bf16 if bf16 and bf16 != 6 else _hip.lib().ssad_wgrad_splits)(m, cin, cout, kh, kw)
     slab = _new((splits, cout, kh * kw * cin), dy)
+    if bf16 == 6:          # bf16x6 mode keeps every result fp32-class: weight gradients stay on the exact fp32 kernel
+        bf16 = False
     fn = (_hip.lib().ssad_conv_wgrad_x3 if bf16 == 3 else
           _hip.lib().ssad_conv_wgrad_bf16 if bf16 else _hip.lib().ssad_conv_wgrad)
     _run("wgrad_x3" if bf16 == 3 else "wgrad_bf16" if bf16 else "wgrad_f32", 2.0 * m * cout * kh * kw * cin,

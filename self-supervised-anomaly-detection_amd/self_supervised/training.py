@@ -579,8 +579,10 @@ class DataParallelStep:
     def __init__(self, model, lr, momentum=0.9, weight_decay=0.0005, world_size=None, process_group=None, precision=32):
         self.model = model
         self.eng = get_engine(model)
-        # 32: exact fp32 MFMA; 16: bf16 operands (the reference's AMP setting); "bf16x3": split-bf16 fp32 emulation
-        self.eng.bf16 = 3 if str(precision) in ("bf16x3", "32x3") else str(precision) in ("16", "bf16", "16-mixed", "bf16-mixed")
+        # 32: exact fp32 MFMA; 16: bf16 operands (the reference's AMP setting); "bf16x6" / "bf16x3": split-bf16 emulation of
+        # the fp32 product (x6: fp32-faithful, forward + dgrad, wgrad stays exact; x3: 4.6e-6, all three contractions)
+        self.eng.bf16 = (6 if str(precision) in ("bf16x6", "32x6") else 3 if str(precision) in ("bf16x3", "32x3") else
+                         str(precision) in ("16", "bf16", "16-mixed", "bf16-mixed"))
         self.opt = FusedSGD(model, lr, momentum, weight_decay)
         self.world = world_size if world_size is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
         self.opt.grad_scale = 1.0 / self.world

@@ -40,10 +40,64 @@ def test_x3_kernels_against_fp64(case):
         assert rel(yh.permute(2, 3, 0, 1), y) < 2e-5
 
 
-def test_x3_forward_and_scoring_match_reference_vectors(golden, seeded_sd, monkeypatch):
+@pytest.mark.parametrize("case", [(3, 9, 9, 64, 64, 3, 1, 1), (2, 9, 9, 64, 128, 3, 2, 1), (5, 4, 4, 256, 512, 3, 1, 1),
+                                  (300, 1, 1, 896, 512, 1, 1, 0), (130, 2, 2, 512, 512, 3, 1, 1)])
+def test_x6_kernels_are_fp32_faithful(case):
+    """Three-way split, six products: as close to fp64 as the exact fp32 MFMA kernel (which sits at ~1e-6)."""
+    from self_supervised import ops
+    n, h, w, cin, cout, k, s, p = case
+    g = torch.Generator().manual_seed(n * 13 + k)
+    x = torch.randn(n, cin, h, w, generator=g).double().requires_grad_()
+    wt = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).double().requires_grad_()
+    y = F.conv2d(x, wt, None, s, p)
+    dy = torch.randn(y.shape, generator=g).double()
+    y.backward(dy)
+    nh = lambda t: t.detach().float().permute(0, 2, 3, 1).contiguous().to(dev)
+    w_ohwi = ops.repack_oihw_to_ohwi(wt.detach().float().to(dev))
+    wft = ops.flip_transpose_weight(w_ohwi)
+    e6 = rel(ops.conv_fwd(nh(x), w_ohwi, None, None, None, False, s, p, 6).permute(0, 3, 1, 2), y)
+    e0 = rel(ops.conv_fwd(nh(x), w_ohwi, None, None, None, False, s, p, False).permute(0, 3, 1, 2), y)
+    assert e6 < 5e-6 and e6 < 2 * e0 + 1e-7, (e6, e0)
+    d6 = rel(ops.conv_dgrad(nh(dy), wft, nh(x).shape, s, p, bf16=6).permute(0, 3, 1, 2), x.grad)
+    d0 = rel(ops.conv_dgrad(nh(dy), wft, nh(x).shape, s, p).permute(0, 3, 1, 2), x.grad)
+    assert d6 < 5e-6 and d6 < 2 * d0 + 1e-7, (d6, d0)
+    if n >= 128 and h <= 4:
+        xh = nh(x).permute(1, 2, 0, 3).contiguous()
+        assert rel(ops.conv_fwd_hwnc(xh, w_ohwi, None, None, None, False, s, p, x3=6).permute(2, 3, 0, 1), y) < 5e-6
+
+
+def test_x6_training_step_holds_the_exact_bars(seeded_sd):
+    """precision="bf16x6" (forward + dgrad on six-product bf16 MFMAs, wgrad exact): the bars of the exact fp32 step."""
+    from oracle import weights as ow
+    from oracle.peranet import OraclePeraNet, train_step
+    from self_supervised import ops, training
+    from self_supervised.models import PeraNet
+    ref = OraclePeraNet(); ref.load_state_dict(seeded_sd); ref.train()
+    m = PeraNet(); m.load_state_dict(seeded_sd); m.to(dev).train(); m.unfreeze()
+    x, y = ow.synthetic_images(8, 64, seed=55), ow.synthetic_labels(8, seed=56)
+    loss_ref, _, out_ref = train_step(ref, x, y)
+    loss_ref.backward()
+    step = training.DataParallelStep(m, lr=0.03, world_size=1, precision="bf16x6")
+    assert step.eng.bf16 == 6
+    logits, emb = step.eng.forward(x.to(dev))
+    assert rel(logits, out_ref["classifier"]) < 1e-4 and rel(emb, out_ref["latent_space"]) < 1e-4
+    dlogits = torch.empty_like(logits)
+    la = ops.softmax_ce(logits, y.to(dev), dlogits, 1.0 / 8)
+    np.testing.assert_allclose(la[0].item(), loss_ref.item(), rtol=1e-5)
+    step.eng.backward(dlogits)
+    ref_params = dict(ref.named_parameters())
+    floor = 1e-4 * max(p.grad.abs().max().item() for p in ref.parameters())
+    for name, p in m.named_parameters():
+        want = ref_params[name].grad
+        e = (p.grad.detach().cpu() - want).abs().max().item() / max(want.abs().max().item(), floor)
+        assert e < 1e-3, f"{name}: grad rel err {e:.3e}"
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16x6"])
+def test_x3_forward_and_scoring_match_reference_vectors(golden, seeded_sd, monkeypatch, mode):
     from oracle import weights as ow
     from self_supervised.models import AnomalyDetector, PeraNet
-    monkeypatch.setenv("SSAD_MATH", "bf16x3")
+    monkeypatch.setenv("SSAD_MATH", mode)
     m = PeraNet(); m.load_state_dict(seeded_sd); m.eval().to(dev)
     g = golden("forward")
     with torch.no_grad():

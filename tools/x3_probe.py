@@ -25,7 +25,7 @@ def timeit(fn, reps=5):
 g = torch.Generator().manual_seed(0)
 x = torch.randn(4, 12, 12, 128, generator=g); w = torch.randn(128, 3, 3, 128, generator=g) / (128 * 9) ** 0.5
 ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), None, 1, 1).permute(0, 2, 3, 1)
-for mode, name in ((False, "fp32"), (True, "bf16"), (3, "bf16x3")):
+for mode, name in ((False, "fp32"), (True, "bf16"), (3, "bf16x3"), (6, "bf16x6")):
     y = ops.conv_fwd(x.to(dev), w.to(dev), None, None, None, False, 1, 1, mode).cpu().double()
     print(f"accuracy {name:7s}: max |err| / max|ref| = {(y - ref).abs().max().item() / ref.abs().max().item():.3e}", flush=True)
 
@@ -37,11 +37,11 @@ for name, h, cin, cout, k, s, p in [("l1 3x3", 64, 64, 64, 3, 1, 1), ("l2 3x3", 
     dy = torch.randn(B, ho, ho, cout, device=dev); wft = ops.flip_transpose_weight(w)
     fl = 2.0 * B * ho * ho * cout * k * k * cin
     row = []
-    for mode in (False, True, 3):
+    for mode in (False, True, 3, 6):
         tf = timeit(lambda: ops.conv_fwd(x, w, None, None, None, False, s, p, mode))
         td = timeit(lambda: ops.conv_dgrad(dy, wft, x.shape, s, p, bf16=mode))
         row.append(f"{tf:.3f}/{td:.3f} ms ({fl / tf / 1e9:.0f}/{fl / td / 1e9:.0f} TF/s)")
-    print(f"{name:9s} fwd/dgrad  fp32 {row[0]} | bf16 {row[1]} | x3 {row[2]}", flush=True)
+    print(f"{name:9s} fwd/dgrad  fp32 {row[0]} | bf16 {row[1]} | x3 {row[2]} | x6 {row[3]}", flush=True)
 # scoring layout
 n = 15979
 for name, h, c in [("s-l1", 16, 64), ("s-l2", 8, 128), ("s-l3", 4, 256), ("s-l4", 2, 512)]:
@@ -49,4 +49,5 @@ for name, h, c in [("s-l1", 16, 64), ("s-l2", 8, 128), ("s-l3", 4, 256), ("s-l4"
     fl = 2.0 * n * h * h * c * 9 * c
     t0 = timeit(lambda: ops.conv_fwd_hwnc(x, w, None, None, None, True, 1, 1))
     t3 = timeit(lambda: ops.conv_fwd_hwnc(x, w, None, None, None, True, 1, 1, x3=True))
-    print(f"{name:9s} hwnc fwd   fp32 {t0:.3f} ms ({fl / t0 / 1e9:.0f}) | x3 {t3:.3f} ms ({fl / t3 / 1e9:.0f} TF/s alg)", flush=True)
+    t6 = timeit(lambda: ops.conv_fwd_hwnc(x, w, None, None, None, True, 1, 1, x3=6))
+    print(f"{name:9s} hwnc fwd   fp32 {t0:.3f} ms ({fl / t0 / 1e9:.0f}) | x3 {t3:.3f} ms ({fl / t3 / 1e9:.0f}) | x6 {t6:.3f} ms ({fl / t6 / 1e9:.0f} TF/s alg)", flush=True)
