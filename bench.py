@@ -176,26 +176,6 @@ def main():
 
     res = {}
     prof = {}
-    if args.phase in ("both", "score"):
-        model.eval(); model.enable_patch_level_mode()
-        det = AnomalyDetector(patch_level=True, batch=args.batch, num_patches=841)
-        det.fit_bank(bank)
-        ops.PROFILE = None
-        for _ in range(args.warmup):
-            score_batch(model, det, x, args.size)
-        ops.PROFILE = []
-        dt = timed(lambda: score_batch(model, det, x, args.size), args.steps, 0)
-        prof["score"] = ops.drain_profile()
-        res["score_s"] = dt
-        if not args.no_x3_extra:
-            # extra, not the headline: the same scoring pass with split-bf16 products on the bf16 matrix cores
-            ops.PROFILE = None
-            for tag in ("x3", "x6"):
-                os.environ["SSAD_MATH"] = "bf16" + tag
-                score_batch(model, det, x, args.size)
-                res[f"score_{tag}_s"] = timed(lambda: score_batch(model, det, x, args.size), args.steps, 0)
-            os.environ["SSAD_MATH"] = "f32"
-        model.disable_patch_level_mode()
     if args.phase in ("both", "train"):
         from self_supervised import training
         model.train()
@@ -224,6 +204,27 @@ def main():
                     t3.step(x, y)
                 res[f"train_{tag}_s"] = timed(lambda: t3.step(x, y), args.steps, 0)
             trainer.eng.bf16 = False
+    torch.cuda.empty_cache()
+    if args.phase in ("both", "score"):
+        model.eval(); model.enable_patch_level_mode()
+        det = AnomalyDetector(patch_level=True, batch=args.batch, num_patches=841)
+        det.fit_bank(bank)
+        ops.PROFILE = None
+        for _ in range(args.warmup):
+            score_batch(model, det, x, args.size)
+        ops.PROFILE = []
+        dt = timed(lambda: score_batch(model, det, x, args.size), args.steps, 0)
+        prof["score"] = ops.drain_profile()
+        res["score_s"] = dt
+        if not args.no_x3_extra:
+            # extra, not the headline: the same scoring pass with split-bf16 products on the bf16 matrix cores
+            ops.PROFILE = None
+            for tag in ("x3", "x6"):
+                os.environ["SSAD_MATH"] = "bf16" + tag
+                score_batch(model, det, x, args.size)
+                res[f"score_{tag}_s"] = timed(lambda: score_batch(model, det, x, args.size), args.steps, 0)
+            os.environ["SSAD_MATH"] = "f32"
+        model.disable_patch_level_mode()
     ops.PROFILE = None
 
     if rank != 0:

@@ -546,9 +546,15 @@ int dispatch_bf16(const ConvParams& p, hipStream_t st) {
     return launch<128, 128, 2, 2, 32, TS, false, true, 1>(p, st);
 }
 
-// three-way split ("bf16x6"): rows are 1.5x the fp32 bytes, so BK = 16 keeps two workgroups per CU
+// three-way split ("bf16x6"): rows are 1.5x the fp32 bytes.  Measured: one LDS stage with BK = 32 (53 KB, three
+// workgroups per CU, 48 MFMAs per wave between barriers) beats two stages with BK = 16 by 7-10 %
 template <int TS, bool POS>
 int dispatch_x6(const ConvParams& p, hipStream_t st) {
+    static const int v = getenv("SSAD_X6_VARIANT") ? atoi(getenv("SSAD_X6_VARIANT")) : 1;
+    if (v == 1) {
+        if (p.Cout <= 64) return launch<256, 64, 2, 2, 32, TS, POS, false, 6>(p, st);
+        return launch<128, 128, 2, 2, 32, TS, POS, false, 6>(p, st);
+    }
     if (p.Cout <= 64) return launch<256, 64, 2, 2, 16, TS, POS, true, 6>(p, st);
     return launch<128, 128, 2, 2, 16, TS, POS, true, 6>(p, st);
 }
