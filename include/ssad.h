@@ -150,6 +150,8 @@ int ssad_conv_wgrad(const float* dy, const float* x, float* slab, int splits, in
                     int KH, int KW, int stride, int pad, void* stream);
 int ssad_conv_wgrad_x3(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin, int Cout,
                        int KH, int KW, int stride, int pad, void* stream);   /* split-bf16 products, see ssad_conv_igemm_fwd_x3 */
+int ssad_conv_wgrad_x6(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin, int Cout,
+                       int KH, int KW, int stride, int pad, void* stream);   /* three-way split, see ssad_conv_igemm_fwd_x6 */
 int ssad_wgrad_reduce(const float* slab, float* dw, int splits, int Cout, int Kpad, int KH, int KW, int Cin, int to_oihw,
                       int accumulate, void* stream);
 /* bf16-operand forms of the three MFMA entry points above (fp32 tensors in HBM; operands rounded to bf16 while staging,

@@ -189,13 +189,17 @@ __global__ __launch_bounds__(512, 4) void wgrad_f32_kernel(WgradParams p) {
 // TRANSPOSED in LDS, [channel][32 pixels + pad] bf16 (80-byte rows): each thread loads a 4-pixel x 4-channel block
 // (four 16-byte global loads), converts, and writes four 8-byte column pieces (lanes run over pixel groups first:
 // conflict-free).  fp32 accumulate, fp32 slabs, same deterministic reduce.
-// X3: split-bf16 products (hi = bf16(x), lo = bf16(x - hi) staged side by side, three MFMAs per tile: lo*hi + hi*lo +
-// hi*hi) -- fp32-class accuracy (~2^-17 per product) from the bf16 matrix cores; see conv_igemm.hip, BF = 3.
-template <int BT, bool X3 = false>
+// NS: number of bf16 parts per operand, staged side by side in the LDS row (see conv_igemm.hip, BF = 3 / 6):
+//     1  bf16 operands;  2  hi, lo and three MFMAs per tile (lo*hi + hi*lo + hi*hi: ~2^-17 per product, "bf16x3");
+//     3  hi, mid, lo and the six products of weight >= 2^-18 (fp32-faithful, "bf16x6"; one LDS stage so that two
+//        workgroups still fit a CU).
+template <int BT, int NS = 1>
 __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams p) {
+    constexpr bool X3 = NS >= 2;
+    constexpr bool DBUF = NS < 3;                // bf16x6: single stage (53 KB at BT = 128)
     constexpr int T = BT / 64;
-    constexpr int LDP = X3 ? 2 * PK + 8 : PK + 8;     // bf16 elements per LDS row ([32 hi | 32 lo] + pad when X3)
-    constexpr int STAGE = 2 * BT * LDP;         // bf16 elements per stage (dY^T tile + X^T tile)
+    constexpr int LDP = NS * PK + 8;             // bf16 elements per LDS row ([32 hi | 32 mid | 32 lo] + pad)
+    constexpr int STAGE = DBUF ? 2 * BT * LDP : 0;      // bf16 elements between the two stages (dY^T tile + X^T tile each)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __bf16* L = (__bf16*)lds;
 
@@ -277,6 +281,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams p) {
                              (__bf16)(rx[2][k] - (float)vx[2]), (__bf16)(rx[3][k] - (float)vx[3])};
                 *(bf16x4*)(Yt + (c4 * 4 + k) * LDP + PK + pg * 4) = ly;
                 *(bf16x4*)(Xt + (c4 * 4 + k) * LDP + PK + pg * 4) = lx;
+                if (NS == 3) {
+                    bf16x4 my, mx;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        my[q] = (__bf16)(ry[q][k] - (float)vy[q] - (float)ly[q]);
+                        mx[q] = (__bf16)(rx[q][k] - (float)vx[q] - (float)lx[q]);
+                    }
+                    *(bf16x4*)(Yt + (c4 * 4 + k) * LDP + 2 * PK + pg * 4) = my;
+                    *(bf16x4*)(Xt + (c4 * 4 + k) * LDP + 2 * PK + pg * 4) = mx;
+                }
             }
         }
     };
@@ -288,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams p) {
     }
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
-        const __bf16* cur = L + (s & 1) * STAGE;
+        const __bf16* cur = L + (DBUF ? (s & 1) * STAGE : 0);
         const bool more = s + 1 < nsteps;
         if (more) load_step();
         const __bf16* ya = cur + (wm * 32 * T + r) * LDP + h * 8;
@@ -300,7 +314,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams p) {
             for (int i = 0; i < T; ++i) a[i] = *(const bf16x8*)(ya + i * 32 * LDP + k16 * 16);
 #pragma unroll
             for (int j = 0; j < T; ++j) b[j] = *(const bf16x8*)(xb + j * 32 * LDP + k16 * 16);
-            if (X3) {
+            if (NS == 3) {                      // parts: a / al / am = hi / mid / lo  (x = hi + mid + lo)
+                bf16x8 al[T], bl[T], am[T], bm[T];
+#pragma unroll
+                for (int i = 0; i < T; ++i) {
+                    al[i] = *(const bf16x8*)(ya + i * 32 * LDP + PK + k16 * 16);
+                    am[i] = *(const bf16x8*)(ya + i * 32 * LDP + 2 * PK + k16 * 16);
+                }
+#pragma unroll
+                for (int j = 0; j < T; ++j) {
+                    bl[j] = *(const bf16x8*)(xb + j * 32 * LDP + PK + k16 * 16);
+                    bm[j] = *(const bf16x8*)(xb + j * 32 * LDP + 2 * PK + k16 * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < T; ++i)
+#pragma unroll
+                    for (int j = 0; j < T; ++j) {          // smallest terms first; hi*hi is added by the common tail below
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], b[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bm[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], b[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
+            } else if (X3) {
                 bf16x8 al[T], bl[T];
 #pragma unroll
                 for (int i = 0; i < T; ++i) al[i] = *(const bf16x8*)(ya + i * 32 * LDP + PK + k16 * 16);
@@ -319,8 +355,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams p) {
 #pragma unroll
                 for (int j = 0; j < T; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (more) store_step(L + ((s + 1) & 1) * STAGE);
-        __syncthreads();
+        if (DBUF) {
+            if (more) store_step(L + ((s + 1) & 1) * STAGE);
+            __syncthreads();
+        } else {
+            __syncthreads();                    // every wave is done reading the stage
+            if (more) store_step(L);
+            __syncthreads();
+        }
     }
 
     const int taps = p.KH * p.KW;
@@ -445,17 +487,20 @@ static int wgrad_impl(const float* dy, const float* x, float* slab, int splits, 
     p.splits = splits;
     dim3 grid((unsigned)(KH * KW * p.co_tiles * p.ci_tiles * ((splits + 7) / 8) * 8));
     hipStream_t st = (hipStream_t)stream;
-    if (bf16 == 3) {
+    if (bf16 == 6) {
+        if (BT == 64) hipLaunchKernelGGL((wgrad_bf16_kernel<64, 3>), grid, dim3(256), 2 * 64 * (3 * PK + 8) * 2, st, p);
+        else hipLaunchKernelGGL((wgrad_bf16_kernel<128, 3>), grid, dim3(256), 2 * 128 * (3 * PK + 8) * 2, st, p);
+    } else if (bf16 == 3) {
         if (BT == 64) {
-            hipLaunchKernelGGL((wgrad_bf16_kernel<64, true>), grid, dim3(256), 2 * 2 * 64 * (2 * PK + 8) * 2, st, p);
+            hipLaunchKernelGGL((wgrad_bf16_kernel<64, 2>), grid, dim3(256), 2 * 2 * 64 * (2 * PK + 8) * 2, st, p);
         } else {
             static bool x3_attr = false;
             if (!x3_attr) {
-                (void)hipFuncSetAttribute((const void*)wgrad_bf16_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                (void)hipFuncSetAttribute((const void*)wgrad_bf16_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           2 * 2 * 128 * (2 * PK + 8) * 2);
                 x3_attr = true;
             }
-            hipLaunchKernelGGL((wgrad_bf16_kernel<128, true>), grid, dim3(256), 2 * 2 * 128 * (2 * PK + 8) * 2, st, p);
+            hipLaunchKernelGGL((wgrad_bf16_kernel<128, 2>), grid, dim3(256), 2 * 2 * 128 * (2 * PK + 8) * 2, st, p);
         }
     } else if (bf16) {
         if (BT == 64) hipLaunchKernelGGL(wgrad_bf16_kernel<64>, grid, dim3(256), 2 * 2 * 64 * (PK + 8) * 2, st, p);
@@ -487,6 +532,12 @@ extern "C" int ssad_conv_wgrad_bf16(const float* dy, const float* x, float* slab
 }
 
 // split-bf16 ("bf16x3") form: fp32-class accuracy from the bf16 matrix cores (use ssad_wgrad_splits_bf16 for the slab).
+// three-way split ("bf16x6"): fp32-faithful products.
+extern "C" int ssad_conv_wgrad_x6(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin,
+                                  int Cout, int KH, int KW, int stride, int pad, void* stream) {
+    return wgrad_impl(dy, x, slab, splits, N, H, W, Cin, Cout, KH, KW, stride, pad, stream, 6);
+}
+
 extern "C" int ssad_conv_wgrad_x3(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin,
                                   int Cout, int KH, int KW, int stride, int pad, void* stream) {
     return wgrad_impl(dy, x, slab, splits, N, H, W, Cin, Cout, KH, KW, stride, pad, stream, 3);

@@ -287,19 +287,21 @@ def conv_dgrad(dy, w_flipT, x_shape, stride, pad, residual=None, bf16=False):
     return dx
 
 
-def conv_wgrad(dy, x, dw_out, kh, kw, stride, pad, kreal=None, to_oihw=False, accumulate=False, bf16=False):
+def conv_wgrad(dy, x, dw_out, kh, kw, stride, pad, kreal=None, to_oihw=False, accumulate=False, bf16=False, force_x6=False):
     """dy NHWC [N][Ho][Wo][Cout], x NHWC [N][H][W][Cin] -> dw_out (flat, Cout*KH*KW*Cin_real floats).
     kreal = (KH, KW, Cin) of the real filter when x rows are padded im2col rows (stem)."""
     n, h, w, cin = x.shape
     cout = dy.shape[-1]
     m = dy.numel() // cout
-    splits = (_hip.lib().ssad_wgrad_splits_bf16 if bf16 and bf16 != 6 else _hip.lib().ssad_wgrad_splits)(m, cin, cout, kh, kw)
-    slab = _new((splits, cout, kh * kw * cin), dy)
-    if bf16 == 6:          # bf16x6 mode keeps every result fp32-class: weight gradients stay on the exact fp32 kernel
+    if bf16 == 6 and not force_x6:
+        # bf16x6 training keeps weight gradients on the exact fp32 kernel: the wave-specialised fp32 wgrad (110 TFLOP/s) is
+        # as fast as the six-product bf16 form (measured), and exact; ssad_conv_wgrad_x6 stays available (tests)
         bf16 = False
-    fn = (_hip.lib().ssad_conv_wgrad_x3 if bf16 == 3 else
+    splits = (_hip.lib().ssad_wgrad_splits_bf16 if bf16 else _hip.lib().ssad_wgrad_splits)(m, cin, cout, kh, kw)
+    slab = _new((splits, cout, kh * kw * cin), dy)
+    fn = (_hip.lib().ssad_conv_wgrad_x6 if bf16 == 6 else _hip.lib().ssad_conv_wgrad_x3 if bf16 == 3 else
           _hip.lib().ssad_conv_wgrad_bf16 if bf16 else _hip.lib().ssad_conv_wgrad)
-    _run("wgrad_x3" if bf16 == 3 else "wgrad_bf16" if bf16 else "wgrad_f32", 2.0 * m * cout * kh * kw * cin,
+    _run("wgrad_x6" if bf16 == 6 else "wgrad_x3" if bf16 == 3 else "wgrad_bf16" if bf16 else "wgrad_f32", 2.0 * m * cout * kh * kw * cin,
          4.0 * (dy.numel() * kh * kw + x.numel() * kh * kw + slab.numel()),
          lambda: fn(_hip.ptr(dy), _hip.ptr(x), _hip.ptr(slab), splits, n, h, w, cin, cout, kh, kw, stride, pad, _hip.stream()))
     rkh, rkw, rcin = kreal if kreal else (kh, kw, cin)

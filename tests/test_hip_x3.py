@@ -61,6 +61,12 @@ def test_x6_kernels_are_fp32_faithful(case):
     d6 = rel(ops.conv_dgrad(nh(dy), wft, nh(x).shape, s, p, bf16=6).permute(0, 3, 1, 2), x.grad)
     d0 = rel(ops.conv_dgrad(nh(dy), wft, nh(x).shape, s, p).permute(0, 3, 1, 2), x.grad)
     assert d6 < 5e-6 and d6 < 2 * d0 + 1e-7, (d6, d0)
+    dw6, dw0 = torch.empty(cout * k * k * cin, device=dev), torch.empty(cout * k * k * cin, device=dev)
+    ops.conv_wgrad(nh(dy), nh(x), dw6, k, k, s, p, bf16=6, force_x6=True)
+    ops.conv_wgrad(nh(dy), nh(x), dw0, k, k, s, p)
+    w6 = rel(dw6.view(cout, k, k, cin).permute(0, 3, 1, 2), wt.grad)
+    w0 = rel(dw0.view(cout, k, k, cin).permute(0, 3, 1, 2), wt.grad)
+    assert w6 < 5e-6 and w6 < 2 * w0 + 1e-7, (w6, w0)
     if n >= 128 and h <= 4:
         xh = nh(x).permute(1, 2, 0, 3).contiguous()
         assert rel(ops.conv_fwd_hwnc(xh, w_ohwi, None, None, None, False, s, p, x3=6).permute(2, 3, 0, 1), y) < 5e-6
