@@ -193,17 +193,22 @@ __global__ __launch_bounds__(512, 4) void wgrad_f32_kernel(WgradParams p) {
 //     1  bf16 operands;  2  hi, lo and three MFMAs per tile (lo*hi + hi*lo + hi*hi: ~2^-17 per product, "bf16x3");
 //     3  hi, mid, lo and the six products of weight >= 2^-18 (fp32-faithful, "bf16x6"; one LDS stage so that two
 //        workgroups still fit a CU).
-template <int BT, int NS = 1>
-__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams p) {
+// WS: wave-specialised like wgrad_f32_kernel (4 MFMA waves + 4 loader waves): with MFMAs 16x shorter than the fp32 ones
+// the loads, converts and transposed LDS stores dominate a 4-wave step.
+template <int BT, int NS = 1, bool WS = false>
+__global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void wgrad_bf16_kernel(WgradParams p) {
     constexpr bool X3 = NS >= 2;
     constexpr bool DBUF = NS < 3;                // bf16x6: single stage (53 KB at BT = 128)
+    static_assert(!WS || DBUF, "wave specialisation needs the double-buffered stages");
     constexpr int T = BT / 64;
     constexpr int LDP = NS * PK + 8;             // bf16 elements per LDS row ([32 hi | 32 mid | 32 lo] + pad)
     constexpr int STAGE = DBUF ? 2 * BT * LDP : 0;      // bf16 elements between the two stages (dY^T tile + X^T tile each)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __bf16* L = (__bf16*)lds;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
+    const bool loader = WS && tid >= 256;
+    const int lt = tid & 255;
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int ntiles = p.KH * p.KW * p.co_tiles * p.ci_tiles;
@@ -221,8 +226,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams p) {
     const int HoWo = p.Ho * p.Wo;
     const float* zero = g_wzero;
 
-    const int pg = tid & 7, c4 = tid >> 3;      // pixel group (4 pixels), channel quad
-    const bool stager = c4 < BT / 4;
+    const int pg = lt & 7, c4 = lt >> 3;        // pixel group (4 pixels), channel quad
+    const bool stager = c4 < BT / 4 && (!WS || loader);
     const bool co_ok = stager && co0 + c4 * 4 < p.Cout, ci_ok = stager && ci0 + c4 * 4 < p.Cin;
 
     f32x16 acc[T][T];
@@ -296,15 +301,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams p) {
     };
 
     const int nsteps = (int)((m_end - m_begin + PK - 1) / PK);
-    if (nsteps > 0) {
-        load_step();
-        store_step(L);
-    }
-    __syncthreads();
-    for (int s = 0; s < nsteps; ++s) {
-        const __bf16* cur = L + (DBUF ? (s & 1) * STAGE : 0);
-        const bool more = s + 1 < nsteps;
-        if (more) load_step();
+    auto compute_step = [&](const __bf16* cur) {
         const __bf16* ya = cur + (wm * 32 * T + r) * LDP + h * 8;
         const __bf16* xb = cur + BT * LDP + (wn * 32 * T + r) * LDP + h * 8;
 #pragma unroll
@@ -355,6 +352,38 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams p) {
 #pragma unroll
                 for (int j = 0; j < T; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+    };
+    if (WS) {
+        if (loader) {
+            if (nsteps > 0) {
+                load_step();
+                store_step(L);
+                if (nsteps > 1) load_step();
+            }
+            __syncthreads();
+            for (int s = 0; s < nsteps; ++s) {
+                if (s + 1 < nsteps) store_step(L + ((s + 1) & 1) * STAGE);
+                if (s + 2 < nsteps) load_step();
+                __syncthreads();
+            }
+            return;
+        }
+        __syncthreads();
+        for (int s = 0; s < nsteps; ++s) {
+            compute_step(L + (s & 1) * STAGE);
+            __syncthreads();
+        }
+    } else {
+    if (nsteps > 0) {
+        load_step();
+        store_step(L);
+    }
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const __bf16* cur = L + (DBUF ? (s & 1) * STAGE : 0);
+        const bool more = s + 1 < nsteps;
+        if (more) load_step();
+        compute_step(cur);
         if (DBUF) {
             if (more) store_step(L + ((s + 1) & 1) * STAGE);
             __syncthreads();
@@ -363,6 +392,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams p) {
             if (more) store_step(L);
             __syncthreads();
         }
+    }
     }
 
     const int taps = p.KH * p.KW;
@@ -422,7 +452,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
 // (occ: penalty for resident slots of a CU left empty; the last term is a workgroup's prologue + epilogue), which reproduces the optimum of a measured sweep over the ResNet-18 shapes (tools/wgrad_sweep.py) within ~2 %.
 static int resident_per_cu(int BT, bool bf16) {
     // from the kernels' LDS bytes / VGPRs (wave64, 512 VGPRs per SIMD, 160 KB LDS per CU)
-    if (bf16) return BT == 64 ? 6 : 3;      // 82 / 154 VGPRs; 20 / 40 KB
+    if (bf16) return BT == 64 ? 4 : 3;      // 8-wave workgroups (32 waves per CU); 20-37 / 40-74 KB LDS
     return BT == 64 ? 4 : 2;                // 8-wave workgroups: 32 waves per CU / 64 KB LDS
 }
 
@@ -492,19 +522,19 @@ static int wgrad_impl(const float* dy, const float* x, float* slab, int splits, 
         else hipLaunchKernelGGL((wgrad_bf16_kernel<128, 3>), grid, dim3(256), 2 * 128 * (3 * PK + 8) * 2, st, p);
     } else if (bf16 == 3) {
         if (BT == 64) {
-            hipLaunchKernelGGL((wgrad_bf16_kernel<64, 2>), grid, dim3(256), 2 * 2 * 64 * (2 * PK + 8) * 2, st, p);
+            hipLaunchKernelGGL((wgrad_bf16_kernel<64, 2, true>), grid, dim3(512), 2 * 2 * 64 * (2 * PK + 8) * 2, st, p);
         } else {
             static bool x3_attr = false;
             if (!x3_attr) {
-                (void)hipFuncSetAttribute((const void*)wgrad_bf16_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                (void)hipFuncSetAttribute((const void*)wgrad_bf16_kernel<128, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           2 * 2 * 128 * (2 * PK + 8) * 2);
                 x3_attr = true;
             }
-            hipLaunchKernelGGL((wgrad_bf16_kernel<128, 2>), grid, dim3(256), 2 * 2 * 128 * (2 * PK + 8) * 2, st, p);
+            hipLaunchKernelGGL((wgrad_bf16_kernel<128, 2, true>), grid, dim3(512), 2 * 2 * 128 * (2 * PK + 8) * 2, st, p);
         }
     } else if (bf16) {
-        if (BT == 64) hipLaunchKernelGGL(wgrad_bf16_kernel<64>, grid, dim3(256), 2 * 2 * 64 * (PK + 8) * 2, st, p);
-        else hipLaunchKernelGGL(wgrad_bf16_kernel<128>, grid, dim3(256), 2 * 2 * 128 * (PK + 8) * 2, st, p);
+        if (BT == 64) hipLaunchKernelGGL((wgrad_bf16_kernel<64, 1, true>), grid, dim3(512), 2 * 2 * 64 * (PK + 8) * 2, st, p);
+        else hipLaunchKernelGGL((wgrad_bf16_kernel<128, 1, true>), grid, dim3(512), 2 * 2 * 128 * (PK + 8) * 2, st, p);
     } else if (BT == 64) {
         hipLaunchKernelGGL(wgrad_f32_kernel<64>, grid, dim3(512), 2 * 2 * PK * 64 * 4, st, p);
     } else {
