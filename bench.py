@@ -227,7 +227,10 @@ def main():
                 os.environ["SSAD_MATH"] = "bf16" + tag
                 try:
                     score_batch(model, det, x, args.size)
+                    ops.PROFILE = []
                     res[f"score_{tag}_s"] = timed(lambda: score_batch(model, det, x, args.size), args.steps, 0)
+                    prof[f"score_{tag}"] = ops.drain_profile()
+                    ops.PROFILE = None
                 except Exception as e:      # noqa: BLE001
                     if world > 1:
                         raise
@@ -291,8 +294,19 @@ def main():
                            "alg_gflop_per_launch": round(fl / len(recs) / 1e9, 3),
                            "alg_GBps": round(sum(r["bytes"] for r in recs) / t / 1e9, 1),
                            "share_of_gpu_time": round(t / allk, 4)}
+        # the split-bf16 extras against the bf16 matrix-core peak: executed MFMA FLOPs = 3x / 6x the algorithmic ones
+        for tag, mult in (("x3", 3), ("x6", 6)):
+            rx = [r for r in prof.get(f"score_{tag}", []) if r["kernel"].startswith("conv_igemm_x")]
+            if rx:
+                tx = sum(r["ms"] for r in rx) * 1e-3
+                alg = sum(r["flops"] for r in rx) / tx / 1e12
+                out[f"roofline_bf16{tag}"] = {"bound": "mfma", "kernel": f"conv_igemm (bf16{tag})", "phase": "score",
+                                              "alg_TFLOPs": round(alg, 1), "achieved": round(mult * alg, 1), "peak": 2500.0,
+                                              "unit": "TFLOP/s (bf16 MFMA, executed)", "frac": round(mult * alg / 2500.0, 4)}
         out["kernel_ms"] = {}
         for ph in prof:
+            if ph.startswith("score_x"):
+                continue
             by = {}
             for r in prof[ph]:
                 e = by.setdefault(r["kernel"], [0.0, 0, 0.0]); e[0] += r["ms"]; e[1] += 1; e[2] += r["flops"]
