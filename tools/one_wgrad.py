@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run one training-conv op a few times (for rocprofv3 --pmc runs).
-usage: one_wgrad.py op(wgrad|dgrad|fwd) N H Cin Cout k s p [iters]"""
+usage: one_wgrad.py op(wgrad|dgrad|fwd|fwd1|fwd3|fwd6) N H Cin Cout k s p [iters]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "self-supervised-anomaly-detection_amd"))
@@ -21,6 +21,8 @@ for _ in range(iters):
         ops.conv_wgrad(dy, x, dw, k, k, s, p)
     elif op == "dgrad":
         ops.conv_dgrad(dy, wft, x.shape, s, p)
+    elif op in ("fwd3", "fwd6", "fwd1"):
+        ops.conv_fwd(x, w, None, None, None, False, s, p, {"fwd3": 3, "fwd6": 6, "fwd1": True}[op])
     else:
         ops.conv_fwd(x, w, None, None, None, False, s, p)
 torch.cuda.synchronize()
