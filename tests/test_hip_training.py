@@ -402,3 +402,39 @@ def test_layer1_in_layer_outputs(dev):
     ref_params, floor = dict(ref.named_parameters()), grad_floor(ref)
     for name, p in m.named_parameters():
         assert rel_err(p.grad, ref_params[name].grad, floor) < 1e-3, name
+
+
+def test_rccl_bucketed_allreduce_single_rank(dev, seeded_sd):
+    """The N > 1 code path on real RCCL: a one-rank "nccl" group, world_size forced to 2 so that the bucket hooks are
+    live -- async all-reduces of arena prefixes interleaved with the backward kernels on the compute stream, waits,
+    then the SGD kernel with the 1/2 scale.  A one-rank sum is the identity, so the gradients must equal the plain step's."""
+    import os, socket
+    import torch.distributed as dist
+    from oracle import weights as ow
+    from self_supervised import training
+    from self_supervised.models import PeraNet
+    x, y = ow.synthetic_images(8, 64, seed=55).to(dev), ow.synthetic_labels(8, seed=56).to(dev)
+    m0 = PeraNet(); m0.load_state_dict(seeded_sd); m0.to(dev).train(); m0.unfreeze()
+    s0 = training.DataParallelStep(m0, lr=0.03, world_size=1)
+    s0.step(x, y)
+    g0 = s0.eng.arena.g.clone()
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        m1 = PeraNet(); m1.load_state_dict(seeded_sd); m1.to(dev).train(); m1.unfreeze()
+        s1 = training.DataParallelStep(m1, lr=0.03, world_size=2)
+        la = s1.step(x, y)
+        torch.cuda.synchronize()
+        assert len(s1.bucketer.launched) >= 2                       # several buckets went out during backward
+        covered = sum(e - b for b, e in s1.bucketer.launched)
+        assert covered == s1.eng.arena.total
+        assert torch.equal(s1.eng.arena.g, g0)                      # identity all-reduce, same deterministic kernels
+        assert torch.isfinite(la[0]).item()
+        # the update used grad / 2: p1 = p - lr * (g / 2 + wd * p)  vs  p0 = p - lr * (g + wd * p)
+        p_init = torch.cat([seeded_sd[n].flatten() for n in ("classifier.weight",)]).to(dev)
+        w0 = dict(m0.named_parameters())["classifier.weight"].detach().flatten()
+        w1 = dict(m1.named_parameters())["classifier.weight"].detach().flatten()
+        assert torch.allclose((p_init - w1) * 2 - 0.03 * 0.0005 * p_init, (p_init - w0), atol=1e-7)
+    finally:
+        dist.destroy_process_group()
