@@ -8,6 +8,29 @@ import torch
 from scipy import ndimage
 
 
+def metrics_to_dataframe(metric_dict: dict, objects: list = None):
+    """metrics.py:15-20 of the reference: one column per metric, one row per category."""
+    import pandas as pd
+    if objects is None:
+        return pd.DataFrame(metric_dict, columns=metric_dict.keys())
+    return pd.DataFrame(metric_dict, columns=metric_dict.keys(), index=objects)
+
+
+def export_dataframe(dataframe, saving_path: str = None, name: str = 'report.csv', mode='csv') -> None:
+    """metrics.py:23-39: csv / latex / markdown export (markdown needs `tabulate`, as in pandas)."""
+    import os
+    if saving_path and not os.path.exists(saving_path):
+        os.makedirs(saving_path)
+    target = (saving_path + name) if saving_path else name
+    fmt = "%.2f" if (saving_path or mode == 'csv') else "%.3f"
+    if mode == 'latex':
+        dataframe.to_latex(target, float_format=fmt)
+    if mode == 'markdown':
+        dataframe.to_markdown(target)
+    if mode == 'csv':
+        dataframe.to_csv(target, float_format="%.2f")
+
+
 def _np(a):
     return a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
 

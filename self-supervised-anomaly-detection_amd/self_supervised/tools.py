@@ -18,7 +18,7 @@ from . import ops
 from .constants import METRICS, EvaluationOutputContainer, ModelOutputsContainer
 from .datasets import MVTecDatamodule, PretextTaskDatamodule
 from .models import AnomalyDetector, PeraNet
-from .trainer import MetricTracker, ModelCheckpoint, Trainer, broadcast_bank, gather_in_order, world_info
+from .trainer import MetricTracker, ModelCheckpoint, Trainer, broadcast_bank, gather_in_order, local_only, world_info
 
 
 class Evaluator:
@@ -220,3 +220,49 @@ def gradcam_maps(model: PeraNet, images: Tensor, y_hat: Tensor, chunk: int = 64)
         idx = sel[i:i + chunk]
         maps[idx.to(dev)] = cam(images[idx.to(images.device)], y_hat[idx])
     return torch.nan_to_num(maps)
+
+
+def sweep(dataset_dir: str, outputs_dir: str, categories: list, imsize: tuple = (256, 256), patch_localization: bool = True,
+          seed: int = 0, batch_size: int = 96, projection_training_params=(10, 0.03), fine_tune_params=(30, 0.005),
+          metrics=('auroc', 'aupro', 'iou'), trainer_kwargs=None, tables_output: str = None, train: bool = True):
+    """Category sweep (BASELINE configs[4]; the loop of src/evaluator.py:432-564 without its plots): per category
+    training -> inference -> upsample -> Evaluator, one row of scores each plus an 'average' row, exported as csv /
+    markdown when `tables_output` is given.  Categories are independent models: under torch.distributed (one process per
+    GPU) rank r takes categories r, r + world, ... and the rows are exchanged once at the end -- no collective inside a
+    category.  Returns the pandas DataFrame (identical on every rank)."""
+    rank, world = world_info()
+    mine = [c for i, c in enumerate(categories) if i % world == rank]
+    rows = {}
+    for subject in mine:
+        sub_out = os.path.join(outputs_dir, subject) + '/'
+        data = os.path.join(dataset_dir, subject) + '/'
+        with local_only():          # a category is a single-GPU job: no sharding / all-reduce with ranks on other categories
+            if train:
+                training(data, sub_out, subject, imsize=imsize, patch_localization=patch_localization, seed=seed,
+                         batch_size=batch_size, projection_training_params=projection_training_params,
+                         fine_tune_params=fine_tune_params, trainer_kwargs=trainer_kwargs)
+            out = inference(sub_out + 'best_model.ckpt', data, subject, mvtec_inference=True,
+                            patch_localization=patch_localization)
+        if patch_localization:
+            out.anomaly_maps = upsample(out.anomaly_maps, int(out.ground_truths.shape[-1]), verbose=False).cpu()
+        ev = Evaluator(evaluation_metrics=[m for m in metrics if (m != 'f1-score') == patch_localization or m == 'auroc'])
+        ev.evaluate(out, subject, sub_out, patch_level=patch_localization)
+        rows[subject] = {k: v for k, v in vars(ev.scores).items() if v is not None}
+    if world > 1:
+        import torch.distributed as dist
+        parts = [None] * world
+        dist.all_gather_object(parts, rows)
+        rows = {k: v for part in parts for k, v in part.items()}
+    cols = sorted({k for r in rows.values() for k in r})
+    table = {c: [float(rows[s].get(c, float('nan'))) for s in categories] for c in cols}
+    for c in cols:
+        table[c].append(float(np.nanmean(table[c])))
+    df = mtr.metrics_to_dataframe(table, list(categories) + ['average'])
+    if tables_output and rank == 0:
+        name = 'patch_all_scores' if patch_localization else 'image_all_scores'
+        mtr.export_dataframe(df, tables_output + 'csv/', name + '.csv')
+        try:
+            mtr.export_dataframe(df, tables_output + 'markdown/', name + '.md', mode='markdown')
+        except ImportError:
+            pass
+    return df

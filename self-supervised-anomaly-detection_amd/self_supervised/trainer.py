@@ -66,8 +66,7 @@ class Trainer:
         self.check_val_every_n_epoch = check_val_every_n_epoch
         self.limit_train_batches, self.limit_val_batches = limit_train_batches, limit_val_batches
         self.logged_metrics, self.current_epoch, self.global_step, self.model = {}, 0, 0, None
-        self.world = dist.get_world_size() if dist.is_initialized() else 1
-        self.global_rank = dist.get_rank() if dist.is_initialized() else 0
+        self.global_rank, self.world = world_info()
         if not torch.cuda.is_available():
             raise RuntimeError("Trainer drives the MI355X HIP kernels: no GPU visible (there is no CPU fallback)")
         self.device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
@@ -201,9 +200,26 @@ class Trainer:
 # ---------------------------------------------------------------------------------------------
 # multi-GPU scoring helpers (one process per GPU; units = images, round-robin over ranks)
 # ---------------------------------------------------------------------------------------------
+_LOCAL_ONLY = 0
+
+
+class local_only:
+    """Context manager: inside it this process behaves as a single-GPU job (Trainer, tools.inference) even though
+    torch.distributed is initialised -- a rank working on its own category of a category-parallel sweep."""
+
+    def __enter__(self):
+        global _LOCAL_ONLY
+        _LOCAL_ONLY += 1
+
+    def __exit__(self, *exc):
+        global _LOCAL_ONLY
+        _LOCAL_ONLY -= 1
+
+
 def world_info():
-    """(rank, world) of the default process group, (0, 1) when torch.distributed is not initialised."""
-    if dist.is_available() and dist.is_initialized():
+    """(rank, world) of the default process group; (0, 1) when torch.distributed is not initialised or inside
+    `local_only()`."""
+    if not _LOCAL_ONLY and dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
 

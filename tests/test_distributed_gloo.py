@@ -91,6 +91,10 @@ def _score_worker(rank, world, port, q):
           and tuple(full.embedding_vectors.shape) == (21, 4))
     bank = broadcast_bank((torch.arange(6.0).view(2, 3), 0.25) if rank == 0 else None)
     ok = ok and torch.equal(bank[0], torch.arange(6.0).view(2, 3)) and bank[1] == 0.25
+    from self_supervised.trainer import local_only       # a rank inside a category-parallel sweep is a one-GPU job
+    with local_only():
+        ok = ok and world_info() == (0, 1)
+    ok = ok and world_info() == (rank, world)
     q.put((rank, ok))
     dist.destroy_process_group()
 

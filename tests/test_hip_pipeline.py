@@ -93,6 +93,25 @@ def test_predict_groups_batches_without_changing_results(seeded_sd):
     assert tuple(grouped[4].embedding_vectors.shape) == (2 * 25, 512)       # 64x64 image: 5x5 windows
 
 
+def test_category_sweep(tmp_path):
+    """tools.sweep over two synthetic categories: per-category training -> inference -> upsample -> Evaluator, one row of
+    scores each plus the average row, csv export (BASELINE configs[4] shape of work, tiny)."""
+    from self_supervised import tools, datasets
+    datasets._DataModule.num_workers = 0
+    root = make_tree(str(tmp_path / "data"), n_train=8, n_test_good=2, n_test_bad=2, size=96)
+    out = str(tmp_path / "out") + "/"
+    np.random.seed(0)
+    df = tools.sweep(root, out, ["bottle", "carpet"], imsize=(64, 64), batch_size=4, seed=0,
+                     projection_training_params=(1, 0.03), fine_tune_params=(1, 0.005),
+                     trainer_kwargs={"limit_train_batches": 2, "limit_val_batches": 1}, tables_output=out + "tables/")
+    assert list(df.index) == ["bottle", "carpet", "average"]
+    assert {"auroc", "aupro", "iou"} <= set(df.columns)
+    assert np.isfinite(df.loc["average"].values).all()
+    np.testing.assert_allclose(df.loc["average", "auroc"], df.loc[["bottle", "carpet"], "auroc"].mean())
+    assert os.path.exists(out + "tables/csv/patch_all_scores.csv")
+    assert os.path.exists(out + "bottle/best_model.ckpt") and os.path.exists(out + "carpet/best_model.ckpt")
+
+
 def test_gpu_auroc_matches_sklearn(golden):
     from sklearn.metrics import roc_auc_score
     from self_supervised import metrics as m
