@@ -583,6 +583,11 @@ int dispatch(const ConvParams& p, hipStream_t st) {
     }
     static const int big = getenv("SSAD_CONV128_VARIANT") ? atoi(getenv("SSAD_CONV128_VARIANT")) : 0;
     if (big == 1) return launch<256, 128, 2, 2, 32, TS, POS>(p, st);
+    // small problems (batch 32-96 on the 8x8 / 16x16 maps of layer3 / layer4): 128x128 tiles leave CUs idle -- fewer than
+    // ~1.5 workgroups per CU -- so the 128x64 tile doubles the grid (measured at batch 96 / 32: see DESIGN.md)
+    static const int small_min = getenv("SSAD_CONV_SMALL_GRID") ? atoi(getenv("SSAD_CONV_SMALL_GRID")) : 500;
+    if (!POS && TS == 1 && cdiv64(p.M, 128) * ((p.Cout + 127) / 128) < small_min)
+        return launch<128, 64, 1, 2, 32, TS, POS>(p, st);
     return launch<128, 128, 2, 2, 32, TS, POS>(p, st);
 }
 
