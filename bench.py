@@ -1,20 +1,25 @@
 #!/usr/bin/env python3
 """Headline benchmark (BASELINE.json): train images/sec + anomaly-maps/sec, ResNet-18, 256x256, batch 256.
 
-    python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N --steps K --warmup W          # any N: for N > 1 this process only starts the N ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W             # the same thing, launched by hand / by the driver
 
-One "step" = one pass of the hot path over one batch of 256 synthetic 256x256 images per GPU, inputs already
-resident in HBM: (a) one pretext training step (forward + backward + SGD update, + RCCL gradient all-reduce when
-N > 1) and (b) anomaly-map scoring of the same batch (841 sliding-window patches per image -> trunk -> 512-d
-embedding -> cosine 3-NN against a 588-row bank -> blur -> bilinear 256x256 map).  Both rates are reported;
-``value`` is the training rate (the first-named metric), ``anomaly_maps_per_sec`` the scoring rate.
-Weak scaling: every rank processes its own 256-image batch.  fp32 throughout (exact f32 MFMA).
+One "step" = one pass of the hot path over one batch of synthetic 256x256 images per GPU, inputs already resident in
+HBM: (a) one pretext training step (forward + backward + SGD update, + RCCL gradient all-reduce when N > 1) and (b)
+anomaly-map scoring of the same batch (841 sliding-window patches per image -> trunk -> 512-d embedding -> cosine
+3-NN against a 588-row bank -> blur -> bilinear 256x256 map).  Both rates are reported; ``value`` is the training rate
+(the first-named metric), ``anomaly_maps_per_sec`` the scoring rate.  fp32 throughout (exact f32 MFMA).
+
+Partition (SURVEY s.8e): the headline is WEAK scaling, 256 images per rank.  With N > 1 the same run also times the
+STRONG partition the survey names -- global batch 256 = 256/N images per rank -- and reports it under "strong"; with
+N = 1 it reports the per-rank work of that partition at N = 8 (batch 32) under "batch32".  ``--global-batch B`` makes
+the strong partition the headline instead (per-rank batch B / N, "scaling": "strong").
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -24,17 +29,51 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import torch
-import torch.distributed as dist
-
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBPS = 8000.0
+U_TRAIN_GFLOP = 14.22            # SURVEY s.8d: one 256x256 image through fwd + bwd + update
+U_MAP_GFLOP = 252.06             # SURVEY s.8d: one 256x256 image -> anomaly map
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step (weak scaling)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling as the headline: this many images per step over ALL ranks (SURVEY s.8e: 256)")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--phase", choices=["both", "train", "score"], default="both")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-partition-extra", action="store_true", help="skip the strong-partition / batch-32 extra line")
+    ap.add_argument("--no-graph", action="store_true", help="launch the training step eagerly instead of replaying hipGraphs")
+    ap.add_argument("--train-precision", choices=["32", "16", "bf16"], default="32",
+                    help="32: exact fp32 MFMA (headline); 16: fp16 operands + loss scaling (the reference's Trainer(precision=16)); "
+                         "bf16: bf16 operands")
+    ap.add_argument("--extras", default="", help="comma list of opt-in side measurements: precision16, bf16, bf16x3, bf16x6")
+    return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks as fresh child processes
+    (this parent never touches the GPU and never re-execs itself) and return their exit status."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def build_model(dev, seed=0):
+    import torch
     from self_supervised.models import PeraNet
     g = torch.Generator().manual_seed(seed)
-    m = PeraNet()
+    with torch.random.fork_rng():
+        torch.manual_seed(seed)
+        m = PeraNet()
     with torch.no_grad():        # random-init weights of the named architecture + non-trivial BN statistics
         for mod in m.modules():
             if isinstance(mod, (torch.nn.BatchNorm2d, torch.nn.BatchNorm1d)):
@@ -44,6 +83,7 @@ def build_model(dev, seed=0):
 
 
 def synth_images(n, size, seed, dev):
+    import torch
     g = torch.Generator().manual_seed(seed)
     u8 = torch.randint(0, 256, (n, 3, size, size), generator=g, dtype=torch.int32).float()
     k = torch.ones(3, 1, 3, 3) / 9.0
@@ -55,6 +95,7 @@ def synth_images(n, size, seed, dev):
 
 
 def score_batch(model, det, x, target=256):
+    import torch
     from self_supervised import tools
     with torch.no_grad():
         emb = model(x)["latent_space"]
@@ -76,61 +117,83 @@ def host_cores():
     return min(n, int(os.environ.get("SSAD_CPU_THREADS", "16")))
 
 
+def _timed_median(fn, budget_s, warmups=2, max_iters=5, min_iters=1):
+    """Median wall time of fn() over up to `max_iters` runs after `warmups` untimed ones, inside `budget_s` seconds:
+    the iteration counts shrink (never below one warm-up + `min_iters` timed) when a single run is slow."""
+    t0 = time.perf_counter()
+    fn()
+    first = time.perf_counter() - t0
+    warm_done = 1
+    while warm_done < warmups and (warm_done + 1 + min_iters) * first <= budget_s:
+        fn(); warm_done += 1
+    ts = []
+    while len(ts) < max_iters and (len(ts) < min_iters or time.perf_counter() - t0 + first <= budget_s):
+        t1 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t1)
+    ts.sort()
+    return ts[len(ts) // 2], warm_done, len(ts)
+
+
 def cpu_baseline(args):
-    """Oracle (torch-CPU fp32 restatement of the reference path) timed on the host cores: bounded sample."""
+    """Oracle (torch-CPU fp32 restatement of the reference path, SURVEY s.8d) timed on the host cores at N = all
+    granted cores and at 1 thread: a 256-image training step as 8 accumulated chunks of 32 (fwd + bwd per chunk, one SGD
+    update), and U_map for 8 images; 2 warm-ups and the median of 5 where the time budget allows (the sample shrinks, and
+    says so, where it does not)."""
+    import torch
     from oracle import weights as ow, scoring as osc
     from oracle.peranet import OraclePeraNet, train_step, make_optimizer
     cores = host_cores()
-    torch.set_num_threads(cores)
     sd = ow.seeded_state_dict(0)
-    m = OraclePeraNet(); m.load_state_dict(sd)
-    # training: batch 16 @ 256^2, fwd + bwd + SGD step
-    m.train()
-    opt, _ = make_optimizer(m, 0.03, 10, "projection_train")
-    xb, yb = ow.synthetic_images(16, 256, seed=1234), ow.synthetic_labels(16, seed=1235)
-    for it in range(3):
-        if it == 1:
-            t0 = time.perf_counter()
-        opt.zero_grad(); loss, _, _ = train_step(m, xb, yb); loss.backward(); opt.step()
-    t_train = (time.perf_counter() - t0) / 2
-    # scoring: 2 images -> 1682 patches -> kNN(588) -> blur -> bilinear
-    m.eval(); m.patch_level = True
     bank = ow.synthetic_bank(588, 512, seed=2).numpy()
-    xs = ow.synthetic_images(2, 256, seed=4321)
-    with torch.no_grad():
-        for it in range(2):
-            t0 = time.perf_counter()
-            emb = m(xs)["latent_space"].numpy()
-            s, _, _ = osc.cosine_knn_mean(bank, emb, 3)
-            osc.upsample(torch.from_numpy(s).reshape(2, 1, 29, 29), 256)
-            t_score = time.perf_counter() - t0
-    return {"value": round(16 / t_train, 2), "unit": "images/sec", "cores": cores, "kind": "port",
-            "anomaly_maps_per_sec": round(2 / t_score, 3),
-            "sample": "oracle on torch-CPU fp32: 2 timed train steps of batch 16 @256x256 (fwd+bwd+SGD); "
-                      "scoring of 2 images (1682 patches, 588-row bank, blur+bilinear)"}
+    out = {"unit": "images/sec", "kind": "port", "cores": cores}
+    notes = []
+    for threads, tag, n_train, n_img, budget in ((cores, "", 256, 8, 30.0), (1, "_1thread", 32, 1, 25.0)):
+        torch.set_num_threads(threads)
+        m = OraclePeraNet(); m.load_state_dict(sd)
+        m.train()
+        opt, _ = make_optimizer(m, 0.03, 10, "projection_train")
+        xb, yb = ow.synthetic_images(32, args.size, seed=1234), ow.synthetic_labels(32, seed=1235)
+        chunks = n_train // 32
+
+        def train_once():
+            opt.zero_grad()
+            for _ in range(chunks):
+                loss, _, _ = train_step(m, xb, yb)
+                (loss / chunks).backward()
+            opt.step()
+        t_train, w, k = _timed_median(train_once, budget)
+        notes.append(f"{threads} thread(s): train step of {n_train} images as {chunks} x 32 accumulated, {w} warm-up(s), median of {k}")
+        m.eval(); m.patch_level = True
+        xs = ow.synthetic_images(n_img, args.size, seed=4321)
+
+        def score_once():
+            with torch.no_grad():
+                emb = m(xs)["latent_space"].numpy()
+                s, _, _ = osc.cosine_knn_mean(bank, emb, 3)
+                osc.upsample(torch.from_numpy(s).reshape(n_img, 1, 29, 29), args.size)
+        t_score, w, k = _timed_median(score_once, budget)
+        notes.append(f"scoring of {n_img} image(s) ({n_img * 841} patches, 588-row bank, blur + bilinear), {w} warm-up(s), median of {k}")
+        out["value" + tag] = round(n_train / t_train, 2)
+        out["anomaly_maps_per_sec" + tag] = round(n_img / t_score, 3)
+    torch.set_num_threads(cores)
+    out["sample"] = "oracle on torch-CPU fp32, " + str(args.size) + "x" + str(args.size) + "; " + "; ".join(notes)
+    return out
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
-    ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--phase", choices=["both", "train", "score"], default="both")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--train-precision", choices=["32", "16"], default="32",
-                    help="32: exact fp32 MFMA (headline); 16: bf16-operand MFMA, the reference's Trainer(precision=16)")
-    ap.add_argument("--no-bf16-extra", action="store_true", help="skip the additional precision=16 training measurement")
-    ap.add_argument("--no-x3-extra", action="store_true",
-                    help="skip the additional split-bf16 (bf16x3: hi*hi + hi*lo + lo*hi, fp32-class accuracy) measurements")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     # one rank per GPU; SSAD_DIST_BACKEND=gloo + fewer GPUs than ranks is only for rehearsing the N>1 code path on a
     # one-GPU box (ranks then share device 0 and gloo stages the all-reduce through the host)
     backend = os.environ.get("SSAD_DIST_BACKEND", "nccl")
@@ -143,21 +206,29 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    from self_supervised import ops
+    from self_supervised import ops, training
     from self_supervised.models import AnomalyDetector
 
+    strong_headline = args.global_batch > 0
+    if strong_headline:
+        if args.global_batch % world:
+            raise SystemExit(f"--global-batch {args.global_batch} does not divide over {world} ranks")
+        per_rank = args.global_batch // world
+    else:
+        per_rank = args.batch
+    os.environ.setdefault("SSAD_ALLOW_RANDOM_BACKBONE", "1")      # synthetic benchmark: random-init weights by design
     model = build_model(dev)
-    x = synth_images(args.batch, args.size, 1234 + rank, dev)
-    y = torch.randint(0, 4, (args.batch,), generator=torch.Generator().manual_seed(1235 + rank)).to(dev)
+    x = synth_images(per_rank, args.size, 1234 + rank, dev)
+    y = torch.randint(0, 4, (per_rank,), generator=torch.Generator().manual_seed(1235 + rank)).to(dev)
     bank = torch.randn(588, 512, generator=torch.Generator().manual_seed(2)).to(dev)
+    use_graph = not args.no_graph
 
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()  # noqa
+            torch.cuda.synchronize()
 
     def timed(fn, steps, warmup):
         for _ in range(warmup):
@@ -174,99 +245,120 @@ def main():
             dt = t.item()
         return dt
 
-    res = {}
-    prof = {}
+    def optional(name, fn):
+        """Side measurements must never take the headline line down with them: on failure they are reported as skipped
+        (all ranks run the same code, so a deterministic failure is collective and nobody is left waiting)."""
+        try:
+            return fn()
+        except Exception as e:          # noqa: BLE001
+            print(f"[bench] optional measurement '{name}' skipped: {type(e).__name__}: {e}", file=sys.stderr)
+            return None
+
+    res, prof = {}, {}
+    extras = [e for e in args.extras.split(",") if e]
     if args.phase in ("both", "train"):
-        from self_supervised import training
         model.train()
         model.unfreeze()
-        trainer = training.DataParallelStep(model, lr=0.005, world_size=world, precision=int(args.train_precision))
+        prec = {"32": 32, "16": 16, "bf16": "bf16"}[args.train_precision]
+        trainer = training.DataParallelStep(model, lr=0.005, world_size=world, precision=prec, graph=use_graph)
         ops.PROFILE = None
-        for _ in range(args.warmup):
-            trainer.step(x, y)
+        res["train_s"] = timed(lambda: trainer.step(x, y), args.steps, max(args.warmup, 2))
+        res["train_graph_segments"] = sum(1 for p in trainer._plans.values() for o in p["ops"] if o[0] == "graph")
+        # per-kernel attribution: the same step launched eagerly with HIP events around every launch (a captured graph
+        # cannot carry them); not part of the timed region above
         ops.PROFILE = []
-        dt = timed(lambda: trainer.step(x, y), args.steps, 0)
+        for _ in range(2):
+            trainer.step(x, y)
         prof["train"] = ops.drain_profile()
-        res["train_s"] = dt
-        # extras, never the headline: the same step with bf16-operand MFMA (what the reference's precision=16 asks for) and
-        # with split-bf16 emulation of the fp32 product.  A failing extra must not take the headline line with it (on one
-        # GPU; with several ranks every rank runs the same code, an exception there is fatal either way).
-        extras = []
-        if args.train_precision == "32" and not args.no_bf16_extra:
-            extras.append(("train16_s", 16))
-        if args.train_precision == "32" and not args.no_x3_extra:
-            extras += [("train_x3_s", "bf16x3"), ("train_x6_s", "bf16x6")]
-        for key, prec in extras:
-            ops.PROFILE = None
-            try:
-                tx = training.DataParallelStep(model, lr=0.005, world_size=world, precision=prec)
-                for _ in range(max(args.warmup, 1)):
-                    tx.step(x, y)
-                res[key] = timed(lambda: tx.step(x, y), args.steps, 0)
-            except Exception as e:          # noqa: BLE001
-                if world > 1:
-                    raise
-                print(f"[bench] extra {key} skipped: {e}", file=sys.stderr)
-            trainer.eng.bf16 = False
+        prof_train_steps = 2
+        ops.PROFILE = None
+
+        def partition_extra():
+            nb = args.batch if strong_headline else (256 // world if world > 1 else 32)
+            if nb == per_rank or nb < 1:
+                return None
+            xs, ys = x[:nb].contiguous(), y[:nb].contiguous()
+            if xs.shape[0] < nb:
+                xs = synth_images(nb, args.size, 99 + rank, dev)
+                ys = torch.randint(0, 4, (nb,), generator=torch.Generator().manual_seed(98 + rank)).to(dev)
+            dt = timed(lambda: trainer.step(xs, ys), max(args.steps, 10), 3)
+            return {"images_per_gpu": nb, "global_batch": nb * world, "steps": max(args.steps, 10),
+                    "train_images_per_sec": round(world * nb * max(args.steps, 10) / dt, 2),
+                    "train_ms_per_step": round(1e3 * dt / max(args.steps, 10), 3)}
+        if not args.no_partition_extra:
+            r = optional("partition", partition_extra)
+            if r:
+                res["partition"] = r
+        for name in extras:
+            pmap = {"precision16": 16, "bf16": "bf16", "bf16x3": "bf16x3", "bf16x6": "bf16x6"}
+            if name not in pmap:
+                continue
+
+            def run_extra(p=pmap[name]):
+                tx = training.DataParallelStep(model, lr=0.005, world_size=world, precision=p, graph=use_graph)
+                return timed(lambda: tx.step(x, y), args.steps, 3)
+            dt = optional(name, run_extra)
+            if dt:
+                res["train_extra_" + name] = round(world * per_rank * args.steps / dt, 2)
+            trainer.eng.bf16 = training.precision_mode(prec)
+        del trainer
     torch.cuda.empty_cache()
     if args.phase in ("both", "score"):
         model.eval(); model.enable_patch_level_mode()
-        det = AnomalyDetector(patch_level=True, batch=args.batch, num_patches=841)
+        det = AnomalyDetector(patch_level=True, batch=per_rank, num_patches=841)
         det.fit_bank(bank)
         ops.PROFILE = None
-        for _ in range(args.warmup):
+        for _ in range(max(args.warmup, 1)):
             score_batch(model, det, x, args.size)
-        ops.PROFILE = []
-        dt = timed(lambda: score_batch(model, det, x, args.size), args.steps, 0)
+        ops.PROFILE = []           # scoring is ~270 launches of ~1.5 ms: the events ride inside the timed region
+        res["score_s"] = timed(lambda: score_batch(model, det, x, args.size), args.steps, 0)
         prof["score"] = ops.drain_profile()
-        res["score_s"] = dt
-        if not args.no_x3_extra:
-            # extra, not the headline: the same scoring pass with split-bf16 products on the bf16 matrix cores
-            ops.PROFILE = None
-            for tag in ("x3", "x6"):
-                os.environ["SSAD_MATH"] = "bf16" + tag
-                try:
-                    score_batch(model, det, x, args.size)
-                    ops.PROFILE = []
-                    res[f"score_{tag}_s"] = timed(lambda: score_batch(model, det, x, args.size), args.steps, 0)
-                    prof[f"score_{tag}"] = ops.drain_profile()
-                    ops.PROFILE = None
-                except Exception as e:      # noqa: BLE001
-                    if world > 1:
-                        raise
-                    print(f"[bench] extra score_{tag} skipped: {e}", file=sys.stderr)
-            os.environ["SSAD_MATH"] = "f32"
+        ops.PROFILE = None
+        for tag in ("bf16x3", "bf16x6"):
+            if tag in extras:
+                os.environ["SSAD_MATH"] = tag
+
+                def run_score_extra():
+                    return timed(lambda: score_batch(model, det, x, args.size), args.steps, 1)
+                dt = optional("score_" + tag, run_score_extra)
+                if dt:
+                    res["score_extra_" + tag] = round(world * per_rank * args.steps / dt, 3)
+                os.environ["SSAD_MATH"] = "f32"
         model.disable_patch_level_mode()
-    ops.PROFILE = None
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
+    mode = "strong" if strong_headline else "weak"
     out = {
         "metric": "train images/sec + anomaly-maps/sec, ResNet-18 256x256 bs256",
         "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"ResNet-18 {args.size}x{args.size} bs{args.batch} self-sup train + anomaly map, "
-                               f"{world}xMI355X, synthetic images (BASELINE configs[{1 if world == 1 else 2}])",
-                   "images_per_gpu": args.batch, "patches_per_image": 841, "bank_rows": 588,
-                   "parallelism": f"dp{world}"},
+        "higher_is_better": True, "scaling": mode, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"ResNet-18 {args.size}x{args.size} bs{per_rank * world if strong_headline else per_rank} self-sup train + "
+                               f"anomaly map, {world}xMI355X, synthetic images (BASELINE configs[{1 if world == 1 else 2}])",
+                   "images_per_gpu": per_rank, "global_batch": per_rank * world, "patches_per_image": 841, "bank_rows": 588,
+                   "parallelism": f"dp{world} ({mode}: {per_rank} images per rank, global batch {per_rank * world}; bucketed gradient "
+                                  f"all-reduce overlapped with backward)" if world > 1 else f"dp1 ({per_rank} images)",
+                   "train_step_launch": "hipGraph segments" if use_graph else "eager"},
     }
+    if args.train_precision != "32":
+        out["dtype"] = {"16": "f16 operands / f32 accumulate", "bf16": "bf16 operands / f32 accumulate"}[args.train_precision]
     tot_s = 0.0
     if "train_s" in res:
-        out["value"] = round(world * args.batch * args.steps / res["train_s"], 2)
+        out["value"] = round(world * per_rank * args.steps / res["train_s"], 2)
         out["train_ms_per_step"] = round(1e3 * res["train_s"] / args.steps, 3)
+        out["train_frac_of_f32_mfma_peak"] = round(out["value"] / world * U_TRAIN_GFLOP / 1e3 / PEAK_F32_MFMA_TFLOPS, 4)
+        out["config"]["train_graph_segments"] = res["train_graph_segments"]
         tot_s += res["train_s"]
-    if "train16_s" in res:
-        out["train_images_per_sec_precision16"] = round(world * args.batch * args.steps / res["train16_s"], 2)
-    for tag in ("x3", "x6"):       # extras: split-bf16 emulation of the fp32 product (x6: fp32-faithful; x3: 4.6e-6 vs fp64)
-        if f"train_{tag}_s" in res:
-            out[f"train_images_per_sec_bf16{tag}"] = round(world * args.batch * args.steps / res[f"train_{tag}_s"], 2)
-        if f"score_{tag}_s" in res:
-            out[f"anomaly_maps_per_sec_bf16{tag}"] = round(world * args.batch * args.steps / res[f"score_{tag}_s"], 3)
+    if "partition" in res:
+        out["strong" if world > 1 and not strong_headline else ("weak" if strong_headline else "batch32")] = res["partition"]
+    for k, v in res.items():
+        if k.startswith("train_extra_") or k.startswith("score_extra_"):
+            out.setdefault("extras", {})[k] = v
     if "score_s" in res:
-        out["anomaly_maps_per_sec"] = round(world * args.batch * args.steps / res["score_s"], 3)
+        out["anomaly_maps_per_sec"] = round(world * per_rank * args.steps / res["score_s"], 3)
         out["score_ms_per_step"] = round(1e3 * res["score_s"] / args.steps, 3)
         tot_s += res["score_s"]
         if "value" not in out:
@@ -276,41 +368,38 @@ def main():
 
     # roofline of the dominant kernel (conv_igemm_f32: every 3x3 / 1x1 conv and linear layer), live HIP events
     phase = "score" if "score" in prof else "train"
-    recs = [r for r in prof[phase] if r["kernel"].startswith("conv_igemm_f32")] or \
-           [r for r in prof[phase] if r["kernel"].startswith("conv_igemm")]
+    recs = [r for r in prof.get(phase, []) if r["kernel"].startswith("conv_igemm_f32")] or \
+           [r for r in prof.get(phase, []) if r["kernel"].startswith("conv_igemm")]
     if recs:
         t = sum(r["ms"] for r in recs) * 1e-3
         fl = sum(r["flops"] for r in recs)
+        xfl = sum(r["exec_flops"] for r in recs)
         allk = sum(r["ms"] for r in prof[phase]) * 1e-3
         ach = fl / t / 1e12
-        traffic = None          # HBM-side bytes per launch of this kernel from the committed PMC passes (same command line)
-        tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if phase == "score" and args.batch == 256 and args.size == 256 and os.path.exists(tj):
-            traffic = json.load(open(tj))["traffic_MB_per_launch"] * 1e6
+        traffic, tsrc = None, None       # HBM-side bytes per launch from the committed PMC passes of this command line
+        for name in ("r02_traffic.json", "r01_traffic.json"):
+            tj = os.path.join(ROOT, "profiles", name)
+            if phase == "score" and per_rank == 256 and args.size == 256 and os.path.exists(tj):
+                traffic, tsrc = json.load(open(tj))["traffic_MB_per_launch"] * 1e6, "profiles/" + name
+                break
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                           "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                           "executed": round(xfl / t / 1e12, 2), "executed_frac": round(xfl / t / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                           "traffic": traffic, "traffic_source": tsrc,
                            "kernel": "conv_igemm_f32_kernel", "phase": phase, "launches": len(recs),
                            "avg_launch_ms": round(1e3 * t / len(recs), 4),
                            "alg_gflop_per_launch": round(fl / len(recs) / 1e9, 3),
                            "alg_GBps": round(sum(r["bytes"] for r in recs) / t / 1e9, 1),
-                           "share_of_gpu_time": round(t / allk, 4)}
-        # the split-bf16 extras against the bf16 matrix-core peak: executed MFMA FLOPs = 3x / 6x the algorithmic ones
-        for tag, mult in (("x3", 3), ("x6", 6)):
-            rx = [r for r in prof.get(f"score_{tag}", []) if r["kernel"].startswith("conv_igemm_x")]
-            if rx:
-                tx = sum(r["ms"] for r in rx) * 1e-3
-                alg = sum(r["flops"] for r in rx) / tx / 1e12
-                out[f"roofline_bf16{tag}"] = {"bound": "mfma", "kernel": f"conv_igemm (bf16{tag})", "phase": "score",
-                                              "alg_TFLOPs": round(alg, 1), "achieved": round(mult * alg, 1), "peak": 2500.0,
-                                              "unit": "TFLOP/s (bf16 MFMA, executed)", "frac": round(mult * alg / 2500.0, 4)}
+                           "share_of_gpu_time": round(t / allk, 4),
+                           "note": "achieved = ALGORITHMIC FLOPs / kernel time; executed = MFMA FLOPs really issued (position-major "
+                                   "convs skip the filter taps that fall into the zero padding: exact, only x*0 products are dropped)"}
         out["kernel_ms"] = {}
         for ph in prof:
-            if ph.startswith("score_x"):
-                continue
+            nst = prof_train_steps if ph == "train" else args.steps
             by = {}
             for r in prof[ph]:
                 e = by.setdefault(r["kernel"], [0.0, 0, 0.0]); e[0] += r["ms"]; e[1] += 1; e[2] += r["flops"]
-            out["kernel_ms"][ph] = {k: [round(v[0] / args.steps, 3), v[1] // args.steps,
+            out["kernel_ms"][ph] = {k: [round(v[0] / nst, 3), v[1] // nst,
                                         round(v[2] / max(v[0], 1e-9) / 1e9, 1)] for k, v in sorted(by.items())}
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args)

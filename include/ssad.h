@@ -164,6 +164,16 @@ int ssad_conv_igemm_dgrad_bf16(const float* dy, const float* w_flipT, float* dx,
                                int Wy, int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride, int pad, void* stream);
 int ssad_conv_wgrad_bf16(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin, int Cout,
                          int KH, int KW, int stride, int pad, void* stream);
+/* fp16-operand forms: the reference trains under fp16 autocast (pl.Trainer(precision=16), src/self_supervised/tools.py:263,
+ * :296), i.e. its Conv2d / Linear products take fp16 operands and accumulate in fp32.  Same contract as the _bf16 forms
+ * with v_mfma_f32_32x32x16_f16 (11-bit significands); the slab of ssad_conv_wgrad_f16 is sized by ssad_wgrad_splits_bf16. */
+int ssad_conv_igemm_fwd_f16(const float* in, const float* w_ohwi, float* out, const float* scale, const float* shift,
+                            const float* residual, int relu, int64_t N, int H, int W, int Cin, int Cout, int KH, int KW,
+                            int stride, int pad, void* stream);
+int ssad_conv_igemm_dgrad_f16(const float* dy, const float* w_flipT, float* dx, const float* residual, int64_t N, int Hy,
+                              int Wy, int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride, int pad, void* stream);
+int ssad_conv_wgrad_f16(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin, int Cout,
+                        int KH, int KW, int stride, int pad, void* stream);
 /* Stem in training: im2col rows of 160 floats (147 taps + zero pad, nearest resize fused) so that conv1 forward and
  * its weight gradient run on the generic MFMA kernels.  Replaces conv1 of torchvision resnet18 under autograd. */
 int ssad_stem_im2col(const float* img, float* col, int64_t B, int H, int W, int Hv, int Wv, void* stream);
@@ -186,7 +196,7 @@ int ssad_bn_stats(const float* z, int64_t R, int C, float eps, float momentum, f
  * train-mode BatchNorm2d that follows it (models.py:224-243 under trainer.fit) in one pass: the conv kernel leaves
  * per-workgroup double-precision column sums in `workspace` (ssad_conv_stats_workspace(N, Ho, Wo, Cout) doubles), a
  * finalize launch produces mean / invstd and updates the running statistics exactly as ssad_bn_stats does.
- * `out` receives the raw convolution z (NHWC).  bf16 != 0 selects the bf16-operand kernel. */
+ * `out` receives the raw convolution z (NHWC).  bf16: operand mode, 0 fp32, 1 bf16, 2 fp16, 3 / 6 split-bf16. */
 int64_t ssad_conv_stats_workspace(int64_t N, int Ho, int Wo, int Cout);
 int ssad_conv_igemm_fwd_stats(const float* in, const float* w_ohwi, float* out, int64_t N, int H, int W, int Cin, int Cout,
                               int KH, int KW, int stride, int pad, int bf16, float eps, float momentum, float* mean,
@@ -234,6 +244,17 @@ int ssad_softmax_ce(const float* logits, const int64_t* labels, int B, int C, fl
  * m = momentum*m + (g*grad_scale + weight_decay*p); p -= lr*m. */
 int ssad_sgd_step(float* p, const float* g, float* m, int64_t n, float lr, float momentum, float weight_decay,
                   float grad_scale, void* stream);
+/* The same update with its hyper-parameters in device memory -- hyper = [lr, momentum, weight_decay, grad_scale] -- so a
+ * captured step (hipGraph) never bakes a learning rate in; `scaler` = NULL or the loss-scaler state below. */
+int ssad_sgd_step_dev(float* p, const float* g, float* m, int64_t n, const float* hyper, const float* scaler, void* stream);
+/* Dynamic loss scaling for the fp16-operand path: what torch.cuda.amp.GradScaler does for the reference under
+ * pl.Trainer(precision=16) (tools.py:263).  scaler = 3 device floats [loss_scale, growth_tracker, found_inf]:
+ * ssad_scale_by_loss_scale multiplies the loss gradient by loss_scale, ssad_check_finite sets found_inf when a gradient is
+ * inf / nan, ssad_sgd_step_dev unscales (and skips the update while found_inf is set), ssad_loss_scaler_update applies
+ * backoff / growth and clears found_inf. */
+int ssad_scale_by_loss_scale(float* x, int64_t n, const float* scaler, void* stream);
+int ssad_check_finite(const float* g, int64_t n, float* scaler, void* stream);
+int ssad_loss_scaler_update(float* scaler, float growth_factor, float backoff_factor, int growth_interval, void* stream);
 
 /* ---- synthetic-defect augmentation (batched, GPU resident) ---- */
 /* One record per sample, drawn on the host in the reference's order (datasets.py:209-394): the GPU does the pixels.

@@ -52,7 +52,9 @@ struct ConvParams {
 // DB   : double-buffered LDS stages (one barrier per K-step) or a single stage (two barriers, half the LDS:
 //        more workgroups per CU).
 // BF   : 1 = operands are rounded to bf16 while staging (fp32 in HBM, fp32 accumulate): v_mfma_f32_32x32x16_bf16 runs
-//        16x the fp32 rate, the kernel becomes load-bound.  Used by Trainer(precision=16), mirroring the reference's AMP.
+//        16x the fp32 rate, the kernel becomes load-bound.  Trainer(precision="bf16").
+//        2 = the same with fp16 operands (v_mfma_f32_32x32x16_f16, same rate): what the reference's fp16 autocast
+//        (pl.Trainer(precision=16), tools.py:263) feeds its convolutions -- 11-bit significands, fp32 accumulation.
 //        3 = split-bf16 emulation of the fp32 product: every operand x is staged as hi = bf16(x), lo = bf16(x - hi)
 //        (16 significant bits together; a row keeps its fp32 footprint: [BK hi | BK lo] bf16) and each 32x32x16 tile
 //        takes three MFMAs, lo*hi + hi*lo + hi*hi, accumulated in fp32: per-product relative error ~2^-17 instead of
@@ -277,6 +279,21 @@ void conv_igemm_f32_kernel(ConvParams p) {
             for (int i = 0; i < BR; ++i) split(rb[i], Bs + (sr + RPP * i) * LDK);
             return;
         }
+        if (BF == 2) {
+            _Float16* As = (_Float16*)buf;
+            _Float16* Bs = As + BM * LDK;
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                f16x4 v = {(_Float16)ra[i][0], (_Float16)ra[i][1], (_Float16)ra[i][2], (_Float16)ra[i][3]};
+                *(f16x4*)(As + (sr + RPP * i) * LDK + sc * 4) = v;
+            }
+#pragma unroll
+            for (int i = 0; i < BR; ++i) {
+                f16x4 v = {(_Float16)rb[i][0], (_Float16)rb[i][1], (_Float16)rb[i][2], (_Float16)rb[i][3]};
+                *(f16x4*)(Bs + (sr + RPP * i) * LDK + sc * 4) = v;
+            }
+            return;
+        }
         if (BF) {
             __bf16* As = (__bf16*)buf;
             __bf16* Bs = As + BM * LDK;
@@ -360,6 +377,23 @@ void conv_igemm_f32_kernel(ConvParams p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                     }
+            }
+        } else if (BF == 2) {
+            // v_mfma_f32_32x32x16_f16: same fragment layout as the bf16 form
+            const _Float16* Ab = (const _Float16*)cur + (wm * 32 * TM + r) * LDK + h * 8;
+            const _Float16* Bb = (const _Float16*)cur + BM * LDK + (wn * 32 * TN + r) * LDK + h * 8;
+#pragma unroll
+            for (int k16 = 0; k16 < BK / 16; ++k16) {
+                f16x8 a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = *(const f16x8*)(Ab + i * 32 * LDK + k16 * 16);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = *(const f16x8*)(Bb + j * 32 * LDK + k16 * 16);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
             }
         } else if (BF) {
             // v_mfma_f32_32x32x16_bf16: lane (r, h) feeds A[row r][k = 8h .. 8h+7] and B[k = 8h .. 8h+7][col r]: 16 bytes each
@@ -540,10 +574,10 @@ int launch(const ConvParams& p, hipStream_t st) {
 }
 
 // every dispatch returns the number of row workgroups launched (= rows of the statistics partials)
-template <int TS>
+template <int TS, int BF = 1>
 int dispatch_bf16(const ConvParams& p, hipStream_t st) {
-    if (p.Cout <= 64) return launch<256, 64, 2, 2, 32, TS, false, true, 1>(p, st);
-    return launch<128, 128, 2, 2, 32, TS, false, true, 1>(p, st);
+    if (p.Cout <= 64) return launch<256, 64, 2, 2, 32, TS, false, true, BF>(p, st);
+    return launch<128, 128, 2, 2, 32, TS, false, true, BF>(p, st);
 }
 
 // three-way split ("bf16x6"): rows are 1.5x the fp32 bytes.  Measured: one LDS stage with BK = 32 (53 KB, three
@@ -615,14 +649,15 @@ int conv_fwd_impl(const float* in, const float* w_ohwi, float* out, const float*
     SSAD_CHECK_ARG(cdiv64(p.M, 128) + 32 * p.Ho * p.Wo < (int64_t)2147483647, "M too large for one launch");
     hipStream_t st = (hipStream_t)stream;
     int rows;
-    SSAD_CHECK_ARG(bf16 == 0 || bf16 == 1 || bf16 == 3 || bf16 == 6, "operand mode: 0 (fp32), 1 (bf16), 3 (bf16x3), 6 (bf16x6)");
+    SSAD_CHECK_ARG(bf16 == 0 || bf16 == 1 || bf16 == 2 || bf16 == 3 || bf16 == 6,
+                   "operand mode: 0 (fp32), 1 (bf16), 2 (fp16), 3 (bf16x3), 6 (bf16x6)");
     if (bf16 == 6) {
         rows = posmajor ? dispatch_x6<1, true>(p, st) : dispatch_x6<1, false>(p, st);
     } else if (bf16 == 3) {
         rows = posmajor ? dispatch_x3<1, true>(p, st) : dispatch_x3<1, false>(p, st);
     } else if (bf16) {
-        SSAD_CHECK_ARG(!hwnc, "bf16 operands: NHWC only");
-        rows = dispatch_bf16<1>(p, st);
+        SSAD_CHECK_ARG(!hwnc, "16-bit operands: NHWC only");
+        rows = bf16 == 2 ? dispatch_bf16<1, 2>(p, st) : dispatch_bf16<1, 1>(p, st);
     } else if (posmajor) rows = dispatch<1, true>(p, st);
     else rows = dispatch<1, false>(p, st);
     if (stat_rows) *stat_rows = rows;
@@ -639,6 +674,15 @@ extern "C" int ssad_conv_igemm_fwd_bf16(const float* in, const float* w_ohwi, fl
                                         const float* shift, const float* residual, int relu, int64_t N, int H, int W,
                                         int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream) {
     return conv_fwd_impl(in, w_ohwi, out, scale, shift, residual, relu, N, H, W, Cin, Cout, KH, KW, stride, pad, 0, stream, 1);
+}
+
+// fp16-operand form: the arithmetic of the reference's own training precision (fp16 autocast under
+// pl.Trainer(precision=16), src/self_supervised/tools.py:263, :296): operands rounded to fp16 (11-bit significand) while
+// staging, v_mfma_f32_32x32x16_f16, fp32 accumulate; tensors stay fp32 in HBM.
+extern "C" int ssad_conv_igemm_fwd_f16(const float* in, const float* w_ohwi, float* out, const float* scale,
+                                       const float* shift, const float* residual, int relu, int64_t N, int H, int W,
+                                       int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream) {
+    return conv_fwd_impl(in, w_ohwi, out, scale, shift, residual, relu, N, H, W, Cin, Cout, KH, KW, stride, pad, 0, stream, 2);
 }
 
 // Split-bf16 ("bf16x3") form: fp32 tensors in and out, every product formed from (hi, lo) bf16 pairs on the bf16 matrix
@@ -721,6 +765,9 @@ static int dgrad_impl(const float* dy, const float* w_flipT, float* dx, const fl
     } else if (bf16 == 3) {
         if (stride == 1) dispatch_x3<1, false>(p, st);
         else dispatch_x3<2, false>(p, st);
+    } else if (bf16 == 2) {
+        if (stride == 1) dispatch_bf16<1, 2>(p, st);
+        else dispatch_bf16<2, 2>(p, st);
     } else if (bf16) {
         if (stride == 1) dispatch_bf16<1>(p, st);
         else dispatch_bf16<2>(p, st);
@@ -740,6 +787,12 @@ extern "C" int ssad_conv_igemm_dgrad_bf16(const float* dy, const float* w_flipT,
                                           int Hy, int Wy, int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride,
                                           int pad, void* stream) {
     return dgrad_impl(dy, w_flipT, dx, residual, N, Hy, Wy, Cout, Hx, Wx, Cin, KH, KW, stride, pad, stream, 1);
+}
+
+extern "C" int ssad_conv_igemm_dgrad_f16(const float* dy, const float* w_flipT, float* dx, const float* residual, int64_t N,
+                                         int Hy, int Wy, int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride,
+                                         int pad, void* stream) {
+    return dgrad_impl(dy, w_flipT, dx, residual, N, Hy, Wy, Cout, Hx, Wx, Cin, KH, KW, stride, pad, stream, 2);
 }
 
 extern "C" int ssad_conv_igemm_dgrad_x6(const float* dy, const float* w_flipT, float* dx, const float* residual, int64_t N,

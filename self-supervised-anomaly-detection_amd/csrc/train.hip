@@ -481,6 +481,51 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
     }
 }
 
+// ---- device-resident optimiser state (so that a captured step, a hipGraph, never bakes in a learning rate or a loss
+// scale): hyper = [lr, momentum, weight_decay, grad_scale]; scaler = [loss_scale, growth_tracker, found_inf] ----
+// The fp16-operand path (Trainer(precision=16)) follows torch.cuda.amp.GradScaler as PL drives it for the reference
+// (tools.py:263): loss * scale before backward, gradients unscaled in the update, the update skipped and the scale
+// halved when a gradient is not finite, the scale doubled after `interval` clean steps.
+__global__ void check_finite_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ scaler) {
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = g[i];
+        bad = bad || !(fabsf(v) <= 3.402823466e38f);       // inf or nan
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) scaler[2] = 1.f;   // benign race: every writer stores the same value
+}
+
+__global__ void sgd_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, int64_t n,
+                               const float* __restrict__ hyper, const float* __restrict__ scaler) {
+    if (scaler && scaler[2] != 0.f) return;                // non-finite gradients: GradScaler skips optimizer.step()
+    const float lr = hyper[0], mu = hyper[1], wd = hyper[2];
+    const float gscale = scaler ? hyper[3] / scaler[0] : hyper[3];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float pv = p[i];
+        const float d = g[i] * gscale + wd * pv;
+        const float mv = mu * m[i] + d;
+        m[i] = mv;
+        p[i] = pv - lr * mv;
+    }
+}
+
+__global__ void scaler_update_kernel(float* __restrict__ scaler, float growth, float backoff, float interval) {
+    if (threadIdx.x || blockIdx.x) return;
+    if (scaler[2] != 0.f) {
+        scaler[0] *= backoff;
+        scaler[1] = 0.f;
+    } else if (++scaler[1] >= interval) {
+        scaler[0] *= growth;
+        scaler[1] = 0.f;
+    }
+    scaler[2] = 0.f;
+}
+
+__global__ void scale_by_dev_kernel(float* __restrict__ x, int64_t n, const float* __restrict__ scaler) {
+    const float s = scaler[0];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] *= s;
+}
+
 static inline unsigned ew_grid(int64_t n) {
     int64_t b = cdiv64(n, 256);
     return (unsigned)(b < 8192 ? (b < 1 ? 1 : b) : 8192);
@@ -698,6 +743,42 @@ extern "C" int ssad_sgd_step(float* p, const float* g, float* m, int64_t n, floa
     SSAD_CHECK_ARG(p && g && m && n > 0, "bad argument");
     hipLaunchKernelGGL(sgd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, n, lr, momentum, weight_decay,
                        grad_scale);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+// SGD with the hyper-parameters read from device memory: hyper = [lr, momentum, weight_decay, grad_scale] (4 floats);
+// scaler = NULL or the GradScaler state [loss_scale, growth_tracker, found_inf] (the update then uses grad_scale /
+// loss_scale and is skipped while found_inf is set).  Same arithmetic as ssad_sgd_step.
+extern "C" int ssad_sgd_step_dev(float* p, const float* g, float* m, int64_t n, const float* hyper, const float* scaler,
+                                 void* stream) {
+    SSAD_CHECK_ARG(p && g && m && hyper && n > 0, "bad argument");
+    hipLaunchKernelGGL(sgd_dev_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, n, hyper, scaler);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+// GradScaler pieces (see above): x *= scaler[0];  scaler[2] = 1 if any of g[0..n) is inf / nan;  the end-of-step update.
+extern "C" int ssad_scale_by_loss_scale(float* x, int64_t n, const float* scaler, void* stream) {
+    SSAD_CHECK_ARG(x && scaler && n > 0, "bad argument");
+    hipLaunchKernelGGL(scale_by_dev_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, n, scaler);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ssad_check_finite(const float* g, int64_t n, float* scaler, void* stream) {
+    SSAD_CHECK_ARG(g && scaler && n > 0, "bad argument");
+    hipLaunchKernelGGL(check_finite_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, g, n, scaler);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ssad_loss_scaler_update(float* scaler, float growth_factor, float backoff_factor, int growth_interval,
+                                       void* stream) {
+    SSAD_CHECK_ARG(scaler && growth_factor >= 1.f && backoff_factor > 0.f && backoff_factor <= 1.f && growth_interval > 0,
+                   "bad argument");
+    hipLaunchKernelGGL(scaler_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scaler, growth_factor, backoff_factor,
+                       (float)growth_interval);
     SSAD_CHECK_LAUNCH();
     return 0;
 }

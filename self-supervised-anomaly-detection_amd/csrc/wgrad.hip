@@ -184,6 +184,16 @@ __global__ __launch_bounds__(512, 4) void wgrad_f32_kernel(WgradParams p) {
     }
 }
 
+template <bool F16> struct OpType;
+template <> struct OpType<false> {
+    using t = __bf16; using v4 = bf16x4; using v8 = bf16x8;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c, int, int, int) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct OpType<true> {
+    using t = _Float16; using v4 = f16x4; using v8 = f16x8;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c, int, int, int) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
 // bf16-operand variant (Trainer(precision=16)): same contraction, operands rounded to bf16 while staging.
 // v_mfma_f32_32x32x16_bf16 wants 8 consecutive k (= pixels) per lane for a fixed channel, so the tiles are stored
 // TRANSPOSED in LDS, [channel][32 pixels + pad] bf16 (80-byte rows): each thread loads a 4-pixel x 4-channel block
@@ -195,8 +205,13 @@ __global__ __launch_bounds__(512, 4) void wgrad_f32_kernel(WgradParams p) {
 //        workgroups still fit a CU).
 // WS: wave-specialised like wgrad_f32_kernel (4 MFMA waves + 4 loader waves): with MFMAs 16x shorter than the fp32 ones
 // the loads, converts and transposed LDS stores dominate a 4-wave step.
-template <int BT, int NS = 1, bool WS = false>
+// F16: fp16 operands (v_mfma_f32_32x32x16_f16) instead of bf16 -- the reference's fp16 autocast (tools.py:263); NS = 1 only.
+template <int BT, int NS = 1, bool WS = false, bool F16 = false>
 __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void wgrad_bf16_kernel(WgradParams p) {
+    using op_t = typename OpType<F16>::t;
+    using op4 = typename OpType<F16>::v4;
+    using op8 = typename OpType<F16>::v8;
+    static_assert(!F16 || NS == 1, "fp16 operands: plain products only");
     constexpr bool X3 = NS >= 2;
     constexpr bool DBUF = NS < 3;                // bf16x6: single stage (53 KB at BT = 128)
     static_assert(!WS || DBUF, "wave specialisation needs the double-buffered stages");
@@ -204,7 +219,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void wgrad_bf16_kernel(
     constexpr int LDP = NS * PK + 8;             // bf16 elements per LDS row ([32 hi | 32 mid | 32 lo] + pad)
     constexpr int STAGE = DBUF ? 2 * BT * LDP : 0;      // bf16 elements between the two stages (dY^T tile + X^T tile each)
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __bf16* L = (__bf16*)lds;
+    op_t* L = (op_t*)lds;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
     const bool loader = WS && tid >= 256;
@@ -269,88 +284,88 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void wgrad_bf16_kernel(
         if (oy2 >= p.Ho) { oy2 -= p.Ho; ++n2; }
         rox = ox2; roy = oy2; rn = n2;
     };
-    auto store_step = [&](__bf16* buf) {
+    auto store_step = [&](op_t* buf) {
         if (!stager) return;
-        __bf16* Yt = buf;
-        __bf16* Xt = buf + BT * LDP;
+        op_t* Yt = buf;
+        op_t* Xt = buf + BT * LDP;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            bf16x4 vy = {(__bf16)ry[0][k], (__bf16)ry[1][k], (__bf16)ry[2][k], (__bf16)ry[3][k]};
-            bf16x4 vx = {(__bf16)rx[0][k], (__bf16)rx[1][k], (__bf16)rx[2][k], (__bf16)rx[3][k]};
-            *(bf16x4*)(Yt + (c4 * 4 + k) * LDP + pg * 4) = vy;
-            *(bf16x4*)(Xt + (c4 * 4 + k) * LDP + pg * 4) = vx;
+            op4 vy = {(op_t)ry[0][k], (op_t)ry[1][k], (op_t)ry[2][k], (op_t)ry[3][k]};
+            op4 vx = {(op_t)rx[0][k], (op_t)rx[1][k], (op_t)rx[2][k], (op_t)rx[3][k]};
+            *(op4*)(Yt + (c4 * 4 + k) * LDP + pg * 4) = vy;
+            *(op4*)(Xt + (c4 * 4 + k) * LDP + pg * 4) = vx;
             if (X3) {
-                bf16x4 ly = {(__bf16)(ry[0][k] - (float)vy[0]), (__bf16)(ry[1][k] - (float)vy[1]),
-                             (__bf16)(ry[2][k] - (float)vy[2]), (__bf16)(ry[3][k] - (float)vy[3])};
-                bf16x4 lx = {(__bf16)(rx[0][k] - (float)vx[0]), (__bf16)(rx[1][k] - (float)vx[1]),
-                             (__bf16)(rx[2][k] - (float)vx[2]), (__bf16)(rx[3][k] - (float)vx[3])};
-                *(bf16x4*)(Yt + (c4 * 4 + k) * LDP + PK + pg * 4) = ly;
-                *(bf16x4*)(Xt + (c4 * 4 + k) * LDP + PK + pg * 4) = lx;
+                op4 ly = {(op_t)(ry[0][k] - (float)vy[0]), (op_t)(ry[1][k] - (float)vy[1]),
+                             (op_t)(ry[2][k] - (float)vy[2]), (op_t)(ry[3][k] - (float)vy[3])};
+                op4 lx = {(op_t)(rx[0][k] - (float)vx[0]), (op_t)(rx[1][k] - (float)vx[1]),
+                             (op_t)(rx[2][k] - (float)vx[2]), (op_t)(rx[3][k] - (float)vx[3])};
+                *(op4*)(Yt + (c4 * 4 + k) * LDP + PK + pg * 4) = ly;
+                *(op4*)(Xt + (c4 * 4 + k) * LDP + PK + pg * 4) = lx;
                 if (NS == 3) {
-                    bf16x4 my, mx;
+                    op4 my, mx;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        my[q] = (__bf16)(ry[q][k] - (float)vy[q] - (float)ly[q]);
-                        mx[q] = (__bf16)(rx[q][k] - (float)vx[q] - (float)lx[q]);
+                        my[q] = (op_t)(ry[q][k] - (float)vy[q] - (float)ly[q]);
+                        mx[q] = (op_t)(rx[q][k] - (float)vx[q] - (float)lx[q]);
                     }
-                    *(bf16x4*)(Yt + (c4 * 4 + k) * LDP + 2 * PK + pg * 4) = my;
-                    *(bf16x4*)(Xt + (c4 * 4 + k) * LDP + 2 * PK + pg * 4) = mx;
+                    *(op4*)(Yt + (c4 * 4 + k) * LDP + 2 * PK + pg * 4) = my;
+                    *(op4*)(Xt + (c4 * 4 + k) * LDP + 2 * PK + pg * 4) = mx;
                 }
             }
         }
     };
 
     const int nsteps = (int)((m_end - m_begin + PK - 1) / PK);
-    auto compute_step = [&](const __bf16* cur) {
-        const __bf16* ya = cur + (wm * 32 * T + r) * LDP + h * 8;
-        const __bf16* xb = cur + BT * LDP + (wn * 32 * T + r) * LDP + h * 8;
+    auto compute_step = [&](const op_t* cur) {
+        const op_t* ya = cur + (wm * 32 * T + r) * LDP + h * 8;
+        const op_t* xb = cur + BT * LDP + (wn * 32 * T + r) * LDP + h * 8;
 #pragma unroll
         for (int k16 = 0; k16 < PK / 16; ++k16) {
-            bf16x8 a[T], b[T];
+            op8 a[T], b[T];
 #pragma unroll
-            for (int i = 0; i < T; ++i) a[i] = *(const bf16x8*)(ya + i * 32 * LDP + k16 * 16);
+            for (int i = 0; i < T; ++i) a[i] = *(const op8*)(ya + i * 32 * LDP + k16 * 16);
 #pragma unroll
-            for (int j = 0; j < T; ++j) b[j] = *(const bf16x8*)(xb + j * 32 * LDP + k16 * 16);
+            for (int j = 0; j < T; ++j) b[j] = *(const op8*)(xb + j * 32 * LDP + k16 * 16);
             if (NS == 3) {                      // parts: a / al / am = hi / mid / lo  (x = hi + mid + lo)
-                bf16x8 al[T], bl[T], am[T], bm[T];
+                op8 al[T], bl[T], am[T], bm[T];
 #pragma unroll
                 for (int i = 0; i < T; ++i) {
-                    al[i] = *(const bf16x8*)(ya + i * 32 * LDP + PK + k16 * 16);
-                    am[i] = *(const bf16x8*)(ya + i * 32 * LDP + 2 * PK + k16 * 16);
+                    al[i] = *(const op8*)(ya + i * 32 * LDP + PK + k16 * 16);
+                    am[i] = *(const op8*)(ya + i * 32 * LDP + 2 * PK + k16 * 16);
                 }
 #pragma unroll
                 for (int j = 0; j < T; ++j) {
-                    bl[j] = *(const bf16x8*)(xb + j * 32 * LDP + PK + k16 * 16);
-                    bm[j] = *(const bf16x8*)(xb + j * 32 * LDP + 2 * PK + k16 * 16);
+                    bl[j] = *(const op8*)(xb + j * 32 * LDP + PK + k16 * 16);
+                    bm[j] = *(const op8*)(xb + j * 32 * LDP + 2 * PK + k16 * 16);
                 }
 #pragma unroll
                 for (int i = 0; i < T; ++i)
 #pragma unroll
                     for (int j = 0; j < T; ++j) {          // smallest terms first; hi*hi is added by the common tail below
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bl[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], b[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bm[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], b[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = OpType<F16>::mfma(al[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = OpType<F16>::mfma(am[i], b[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = OpType<F16>::mfma(a[i], bm[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = OpType<F16>::mfma(al[i], b[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = OpType<F16>::mfma(a[i], bl[j], acc[i][j], 0, 0, 0);
                     }
             } else if (X3) {
-                bf16x8 al[T], bl[T];
+                op8 al[T], bl[T];
 #pragma unroll
-                for (int i = 0; i < T; ++i) al[i] = *(const bf16x8*)(ya + i * 32 * LDP + PK + k16 * 16);
+                for (int i = 0; i < T; ++i) al[i] = *(const op8*)(ya + i * 32 * LDP + PK + k16 * 16);
 #pragma unroll
-                for (int j = 0; j < T; ++j) bl[j] = *(const bf16x8*)(xb + j * 32 * LDP + PK + k16 * 16);
+                for (int j = 0; j < T; ++j) bl[j] = *(const op8*)(xb + j * 32 * LDP + PK + k16 * 16);
 #pragma unroll
                 for (int i = 0; i < T; ++i)
 #pragma unroll
                     for (int j = 0; j < T; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], b[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = OpType<F16>::mfma(al[i], b[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = OpType<F16>::mfma(a[i], bl[j], acc[i][j], 0, 0, 0);
                     }
             }
 #pragma unroll
             for (int i = 0; i < T; ++i)
 #pragma unroll
-                for (int j = 0; j < T; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < T; ++j) acc[i][j] = OpType<F16>::mfma(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     };
     if (WS) {
@@ -380,7 +395,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void wgrad_bf16_kernel(
     }
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
-        const __bf16* cur = L + (DBUF ? (s & 1) * STAGE : 0);
+        const op_t* cur = L + (DBUF ? (s & 1) * STAGE : 0);
         const bool more = s + 1 < nsteps;
         if (more) load_step();
         compute_step(cur);
@@ -532,6 +547,9 @@ static int wgrad_impl(const float* dy, const float* x, float* slab, int splits, 
             }
             hipLaunchKernelGGL((wgrad_bf16_kernel<128, 2, true>), grid, dim3(512), 2 * 2 * 128 * (2 * PK + 8) * 2, st, p);
         }
+    } else if (bf16 == 2) {
+        if (BT == 64) hipLaunchKernelGGL((wgrad_bf16_kernel<64, 1, true, true>), grid, dim3(512), 2 * 2 * 64 * (PK + 8) * 2, st, p);
+        else hipLaunchKernelGGL((wgrad_bf16_kernel<128, 1, true, true>), grid, dim3(512), 2 * 2 * 128 * (PK + 8) * 2, st, p);
     } else if (bf16) {
         if (BT == 64) hipLaunchKernelGGL((wgrad_bf16_kernel<64, 1, true>), grid, dim3(512), 2 * 2 * 64 * (PK + 8) * 2, st, p);
         else hipLaunchKernelGGL((wgrad_bf16_kernel<128, 1, true>), grid, dim3(512), 2 * 2 * 128 * (PK + 8) * 2, st, p);
@@ -559,6 +577,12 @@ extern "C" int ssad_conv_wgrad(const float* dy, const float* x, float* slab, int
 extern "C" int ssad_conv_wgrad_bf16(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin,
                                     int Cout, int KH, int KW, int stride, int pad, void* stream) {
     return wgrad_impl(dy, x, slab, splits, N, H, W, Cin, Cout, KH, KW, stride, pad, stream, 1);
+}
+
+// fp16-operand form (the reference's fp16 autocast, tools.py:263); slab sizing as for the bf16 kernel (ssad_wgrad_splits_bf16).
+extern "C" int ssad_conv_wgrad_f16(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin,
+                                   int Cout, int KH, int KW, int stride, int pad, void* stream) {
+    return wgrad_impl(dy, x, slab, splits, N, H, W, Cin, Cout, KH, KW, stride, pad, stream, 2);
 }
 
 // split-bf16 ("bf16x3") form: fp32-class accuracy from the bf16 matrix cores (use ssad_wgrad_splits_bf16 for the slab).

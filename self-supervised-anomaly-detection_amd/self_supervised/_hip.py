@@ -17,7 +17,7 @@ _c_i = ctypes.c_int
 _c_l = ctypes.c_int64
 _c_f = ctypes.c_float
 
-# name -> argtypes; mirrors include/ssad.h one to one (tests/test_capi_symbols.py checks the header too)
+# name -> argtypes; mirrors include/ssad.h one to one (tests/test_host_cpu.py::test_library_builds_and_exports_every_declared_symbol checks the header too)
 SIGNATURES = {
     "ssad_repack_oihw_to_ohwi": [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp],
     "ssad_repack_ohwi_to_oihw": [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp],
@@ -55,6 +55,15 @@ SIGNATURES = {
     "ssad_conv_igemm_dgrad_bf16": [_c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
                                    _c_i, _c_fp],
     "ssad_conv_wgrad_bf16": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_conv_igemm_fwd_f16": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
+                                _c_i, _c_i, _c_fp],
+    "ssad_conv_igemm_dgrad_f16": [_c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
+                                  _c_i, _c_fp],
+    "ssad_conv_wgrad_f16": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_sgd_step_dev": [_c_fp, _c_fp, _c_fp, _c_l, _c_fp, _c_fp, _c_fp],
+    "ssad_scale_by_loss_scale": [_c_fp, _c_l, _c_fp, _c_fp],
+    "ssad_check_finite": [_c_fp, _c_l, _c_fp, _c_fp],
+    "ssad_loss_scaler_update": [_c_fp, _c_f, _c_f, _c_i, _c_fp],
     "ssad_conv_wgrad_x3": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
     "ssad_conv_wgrad_x6": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
     "ssad_wgrad_reduce": [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],

@@ -5,6 +5,7 @@ same constructor arguments, method names, return types and state_dict keys.  Num
 libssad_hip.so (see engine.py / ops.py); there is no CPU fallback -- inputs must live on the GPU.
 """
 import os
+import warnings
 from collections import OrderedDict
 
 import numpy as np
@@ -36,6 +37,19 @@ except Exception:                       # PL is absent in the build image; train
         def log_dict(self, metrics, **kw):
             for k, v in metrics.items():
                 self.logged.setdefault(k, []).append(float(v))
+
+
+_WARNED_RANDOM_BACKBONE = False
+
+
+def _warn_random_backbone():
+    global _WARNED_RANDOM_BACKBONE
+    if not _WARNED_RANDOM_BACKBONE:
+        _WARNED_RANDOM_BACKBONE = True
+        warnings.warn("PeraNet: no ImageNet resnet18 weights found ($SSAD_RESNET18_WEIGHTS or torch hub cache "
+                      "resnet18-f37072fd.pth); the backbone is RANDOMLY initialised.  The reference loads "
+                      "IMAGENET1K_V1 (models.py:59): load a checkpoint / call load_backbone() before training.",
+                      RuntimeWarning, stacklevel=3)
 
 
 class PeraNet(_Base):
@@ -79,13 +93,19 @@ class PeraNet(_Base):
         self.max_samples_per_pass = 16384      # patches pushed through the trunk per kernel sequence
         self._plan = None
         self._frozen = set()
-        # models.py:59 asks torchvision for IMAGENET1K_V1; there is no hub here, so the same file is taken from
-        # $SSAD_RESNET18_WEIGHTS or torch's hub cache when it exists (random init otherwise)
+        # models.py:59 asks torchvision for IMAGENET1K_V1 (and fails loudly without it); there is no hub here, so the
+        # same file is taken from $SSAD_RESNET18_WEIGHTS or torch's hub cache.  Without it the trunk keeps its random
+        # init -- fine when a checkpoint / state dict is loaded next, useless for stage 1 of tools.training (frozen
+        # backbone) -- so that case warns once per process (SSAD_ALLOW_RANDOM_BACKBONE=1 silences it).
+        self.pretrained_backbone = False
         for cand in (os.environ.get("SSAD_RESNET18_WEIGHTS"),
                      os.path.expanduser("~/.cache/torch/hub/checkpoints/resnet18-f37072fd.pth")):
             if cand and os.path.isfile(cand):
                 self.load_backbone(cand)
+                self.pretrained_backbone = True
                 break
+        if not self.pretrained_backbone and os.environ.get("SSAD_ALLOW_RANDOM_BACKBONE") != "1":
+            _warn_random_backbone()
 
     def load_backbone(self, weights) -> None:
         """Load a torchvision ``resnet18`` state dict (or a path to one, e.g. resnet18-f37072fd.pth) into the trunk:

@@ -11,8 +11,10 @@ def _new(shape, like):
     return torch.empty(shape, device=like.device, dtype=torch.float32)
 
 
-def _run(kernel, flops, nbytes, rc_fn):
-    """Launch through the C ABI; when PROFILE is on, bracket the launch with events on the launch stream."""
+def _run(kernel, flops, nbytes, rc_fn, exec_flops=None):
+    """Launch through the C ABI; when PROFILE is on, bracket the launch with events on the launch stream.
+    flops = ALGORITHMIC FLOPs of the op; exec_flops = the FLOPs the kernel really issues to the matrix cores when that
+    is fewer (position-major convs skip the taps that fall into the zero padding)."""
     if PROFILE is None:
         _hip.check(rc_fn())
         return
@@ -20,17 +22,30 @@ def _run(kernel, flops, nbytes, rc_fn):
     e0.record()
     _hip.check(rc_fn())
     e1.record()
-    PROFILE.append((kernel, flops, nbytes, e0, e1))
+    PROFILE.append((kernel, flops, nbytes, e0, e1, flops if exec_flops is None else exec_flops))
 
 
 def drain_profile():
-    """-> [{kernel, flops, bytes, ms}] for every launch recorded since PROFILE was set."""
+    """-> [{kernel, flops, exec_flops, bytes, ms}] for every launch recorded since PROFILE was set."""
     global PROFILE
     recs = PROFILE or []
     torch.cuda.synchronize()
-    out = [{"kernel": k, "flops": f, "bytes": b, "ms": e0.elapsed_time(e1)} for k, f, b, e0, e1 in recs]
+    out = [{"kernel": k, "flops": f, "bytes": b, "ms": e0.elapsed_time(e1), "exec_flops": x} for k, f, b, e0, e1, x in recs]
     PROFILE = [] if PROFILE is not None else None
     return out
+
+
+def _inbounds_taps(h, w, kh, kw, stride, pad):
+    """Sum over output positions of the filter taps that land inside the image (what a position-major conv executes)."""
+    ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+    ny = sum(sum(1 for ky in range(kh) if 0 <= oy * stride - pad + ky < h) for oy in range(ho))
+    nx = sum(sum(1 for kx in range(kw) if 0 <= ox * stride - pad + kx < w) for ox in range(wo))
+    return ny * nx
+
+
+def _kname(base, mode):
+    """Profile label of an MFMA kernel by operand mode (False/0 fp32, True/1 bf16, 2 fp16, 3 / 6 split-bf16)."""
+    return base + {0: "_f32", 1: "_bf16", 2: "_f16", 3: "_x3", 6: "_x6"}[int(mode)]
 
 
 def repack_oihw_to_ohwi(w):
@@ -132,7 +147,8 @@ def conv_fwd_hwnc(x, w_ohwi, scale=None, shift=None, residual=None, relu=False, 
     _run("conv_igemm_f32", 2.0 * out.numel() * kh * kw * cin, nb,
          lambda: _hip.lib().ssad_conv_igemm_fwd_hwnc(_hip.ptr(x), _hip.ptr(w_ohwi), _hip.ptr(out), _hip.ptr(scale, True),
                                                      _hip.ptr(shift, True), _hip.ptr(residual, True), int(relu), n, h, w,
-                                                     cin, cout, kh, kw, stride, pad, _hip.stream()))
+                                                     cin, cout, kh, kw, stride, pad, _hip.stream()),
+         exec_flops=2.0 * n * cout * cin * _inbounds_taps(h, w, kh, kw, stride, pad) if PROFILE is not None else None)
     return out
 
 
@@ -173,8 +189,9 @@ def conv_fwd(x, w_ohwi, scale=None, shift=None, residual=None, relu=False, strid
                                       _hip.ptr(shift, True), _hip.ptr(residual, True), int(relu), n, h, w,
                                       cin, cout, kh, kw, stride, pad, 0, _hip.stream()))
         return out
-    fn = _hip.lib().ssad_conv_igemm_fwd_bf16 if bf16 else _hip.lib().ssad_conv_igemm_fwd
-    _run("conv_igemm_bf16" if bf16 else "conv_igemm_f32", 2.0 * out.numel() * kh * kw * cin, nb,
+    fn = (_hip.lib().ssad_conv_igemm_fwd_f16 if bf16 == 2 else _hip.lib().ssad_conv_igemm_fwd_bf16 if bf16 else
+          _hip.lib().ssad_conv_igemm_fwd)
+    _run(_kname("conv_igemm", bf16), 2.0 * out.numel() * kh * kw * cin, nb,
          lambda: fn(_hip.ptr(x), _hip.ptr(w_ohwi), _hip.ptr(out), _hip.ptr(scale, True), _hip.ptr(shift, True),
                     _hip.ptr(residual, True), int(relu), n, h, w, cin, cout, kh, kw, stride, pad, _hip.stream()))
     return out
@@ -191,8 +208,7 @@ def conv_fwd_stats(x, w_ohwi, eps, momentum, running_mean, running_var, stride=1
     lib = _hip.lib()
     ws = torch.empty(lib.ssad_conv_stats_workspace(n, ho, wo, cout), device=x.device, dtype=torch.float64)
     nb = 4.0 * (x.numel() + out.numel() + w_ohwi.numel())
-    _run("conv_igemm_x6" if bf16 == 6 else "conv_igemm_x3" if bf16 == 3 else "conv_igemm_bf16" if bf16 else "conv_igemm_f32",
-         2.0 * out.numel() * kh * kw * cin, nb,
+    _run(_kname("conv_igemm", bf16), 2.0 * out.numel() * kh * kw * cin, nb,
          lambda: lib.ssad_conv_igemm_fwd_stats(_hip.ptr(x), _hip.ptr(w_ohwi), _hip.ptr(out), n, h, w, cin, cout, kh, kw,
                                                stride, pad, int(bf16), eps, momentum, _hip.ptr(mean), _hip.ptr(invstd),
                                                _hip.ptr(running_mean, True), _hip.ptr(running_var, True), ws.data_ptr(),
@@ -278,8 +294,9 @@ def conv_dgrad(dy, w_flipT, x_shape, stride, pad, residual=None, bf16=False):
     cin, kh, kw, _ = w_flipT.shape
     dx = _new(tuple(x_shape), dy)
     fn = (_hip.lib().ssad_conv_igemm_dgrad_x6 if bf16 == 6 else _hip.lib().ssad_conv_igemm_dgrad_x3 if bf16 == 3 else
+          _hip.lib().ssad_conv_igemm_dgrad_f16 if bf16 == 2 else
           _hip.lib().ssad_conv_igemm_dgrad_bf16 if bf16 else _hip.lib().ssad_conv_igemm_dgrad)
-    _run("conv_igemm_x6" if bf16 == 6 else "conv_igemm_x3" if bf16 == 3 else "conv_igemm_bf16" if bf16 else "conv_igemm_f32",
+    _run(_kname("conv_igemm", bf16),
          2.0 * dx.numel() * kh * kw * cout / (stride * stride),
          4.0 * (dy.numel() + dx.numel() * (2 if residual is not None else 1) + w_flipT.numel()),
          lambda: fn(_hip.ptr(dy), _hip.ptr(w_flipT), _hip.ptr(dx), _hip.ptr(residual, True), n, hy, wy, cout, x_shape[1],
@@ -300,8 +317,9 @@ def conv_wgrad(dy, x, dw_out, kh, kw, stride, pad, kreal=None, to_oihw=False, ac
     splits = (_hip.lib().ssad_wgrad_splits_bf16 if bf16 else _hip.lib().ssad_wgrad_splits)(m, cin, cout, kh, kw)
     slab = _new((splits, cout, kh * kw * cin), dy)
     fn = (_hip.lib().ssad_conv_wgrad_x6 if bf16 == 6 else _hip.lib().ssad_conv_wgrad_x3 if bf16 == 3 else
+          _hip.lib().ssad_conv_wgrad_f16 if bf16 == 2 else
           _hip.lib().ssad_conv_wgrad_bf16 if bf16 else _hip.lib().ssad_conv_wgrad)
-    _run("wgrad_x6" if bf16 == 6 else "wgrad_x3" if bf16 == 3 else "wgrad_bf16" if bf16 else "wgrad_f32", 2.0 * m * cout * kh * kw * cin,
+    _run(_kname("wgrad", bf16), 2.0 * m * cout * kh * kw * cin,
          4.0 * (dy.numel() * kh * kw + x.numel() * kh * kw + slab.numel()),
          lambda: fn(_hip.ptr(dy), _hip.ptr(x), _hip.ptr(slab), splits, n, h, w, cin, cout, kh, kw, stride, pad, _hip.stream()))
     rkh, rkw, rcin = kreal if kreal else (kh, kw, cin)
@@ -474,3 +492,24 @@ def sgd_step(p, g, m, lr, momentum, weight_decay, grad_scale=1.0):
     _run("sgd", 0.0, 20.0 * p.numel(),
          lambda: _hip.lib().ssad_sgd_step(_hip.ptr(p), _hip.ptr(g), _hip.ptr(m), p.numel(), lr, momentum, weight_decay,
                                           grad_scale, _hip.stream()))
+
+
+def sgd_step_dev(p, g, m, hyper, scaler=None):
+    """SGD with [lr, momentum, weight_decay, grad_scale] (and the optional loss-scaler state) read from device memory."""
+    _run("sgd", 0.0, 20.0 * p.numel(),
+         lambda: _hip.lib().ssad_sgd_step_dev(_hip.ptr(p), _hip.ptr(g), _hip.ptr(m), p.numel(), _hip.ptr(hyper),
+                                              _hip.ptr(scaler, True), _hip.stream()))
+
+
+def scale_by_loss_scale(x, scaler):
+    _hip.check(_hip.lib().ssad_scale_by_loss_scale(_hip.ptr(x), x.numel(), _hip.ptr(scaler), _hip.stream()))
+
+
+def check_finite(g, scaler):
+    _run("check_finite", 0.0, 4.0 * g.numel(),
+         lambda: _hip.lib().ssad_check_finite(_hip.ptr(g), g.numel(), _hip.ptr(scaler), _hip.stream()))
+
+
+def loss_scaler_update(scaler, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+    _hip.check(_hip.lib().ssad_loss_scaler_update(_hip.ptr(scaler), growth_factor, backoff_factor, growth_interval,
+                                                  _hip.stream()))

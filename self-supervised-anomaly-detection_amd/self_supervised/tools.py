@@ -18,7 +18,7 @@ from . import ops
 from .constants import METRICS, EvaluationOutputContainer, ModelOutputsContainer
 from .datasets import MVTecDatamodule, PretextTaskDatamodule
 from .models import AnomalyDetector, PeraNet
-from .trainer import MetricTracker, ModelCheckpoint, Trainer, broadcast_bank, gather_in_order, local_only, world_info
+from .trainer import MetricTracker, ModelCheckpoint, Trainer, barrier, broadcast_bank, gather_in_order, local_only, world_info
 
 
 class Evaluator:
@@ -89,15 +89,23 @@ def training(dataset_dir: str, outputs_dir: str, subject: str, imsize: tuple = (
     checkpoint_name = 'best_model.ckpt'
     proj_epochs, proj_lr = projection_training_params
     fine_tune_epochs, fine_tune_lr = fine_tune_params
-    os.makedirs(outputs_dir, exist_ok=True)
-    if os.path.exists(outputs_dir + 'logs/'):
-        shutil.rmtree(outputs_dir + 'logs/')
+    # under torch.distributed (one process per GPU; the reference is single-device) the filesystem side belongs to rank 0
+    # and every hand-over through a file is fenced by a barrier
+    rank, _ = world_info()
+    if rank == 0:
+        os.makedirs(outputs_dir, exist_ok=True)
+        if os.path.exists(outputs_dir + 'logs/'):
+            shutil.rmtree(outputs_dir + 'logs/')
+    barrier()
     print('>>> setting seeds')
     _seed_everything(seed)
     print('>>> preparing datamodule')
     datamodule = PretextTaskDatamodule(subject, dataset_dir, imsize=imsize, batch_size=batch_size, seed=seed,
                                        patch_localization=patch_localization, patch_size=patchsize, gpu_pipeline=gpu_pipeline)
     datamodule.setup()
+    if world_info()[1] > 1:      # SURVEY s.8e: each rank draws its own augmentations (rank-offset seed); the split above is shared
+        random.seed(seed + rank)
+        np.random.seed(seed + rank)
     tk = dict(trainer_kwargs or {})
     print('>>> preparing model')
     pretext_model = PeraNet(learning_rate=proj_lr, epochs=proj_epochs)
@@ -109,7 +117,8 @@ def training(dataset_dir: str, outputs_dir: str, subject: str, imsize: tuple = (
     trainer.fit(pretext_model, datamodule=datamodule)
     history = {'projection_train': cb.log_metrics}
     pretext_model.clear_memory_bank()
-    trainer.save_checkpoint(outputs_dir + checkpoint_name, weights_only=True)
+    trainer.save_checkpoint(outputs_dir + checkpoint_name, weights_only=True)     # rank 0 writes ...
+    barrier()                                                                      # ... before anybody reads
 
     print('>>> setting up the model (fine tune whole net)')
     pretext_model = PeraNet.load_from_checkpoint(outputs_dir + checkpoint_name, learning_rate=fine_tune_lr,
@@ -124,8 +133,10 @@ def training(dataset_dir: str, outputs_dir: str, subject: str, imsize: tuple = (
     trainer.fit(pretext_model, datamodule=datamodule)
     trainer.save_checkpoint(outputs_dir + checkpoint_name)
     history['fine_tune'] = cb.log_metrics
-    with open(outputs_dir + 'history.json', 'w') as f:
-        json.dump(history, f)
+    if rank == 0:
+        with open(outputs_dir + 'history.json', 'w') as f:
+            json.dump(history, f)
+    barrier()
     return history
 
 

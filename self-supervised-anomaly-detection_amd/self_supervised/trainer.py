@@ -62,14 +62,17 @@ class Trainer:
                  devices=1, max_epochs=1, check_val_every_n_epoch=1, limit_train_batches=None, limit_val_batches=None,
                  enable_progress=False):
         self.default_root_dir, self.callbacks, self.max_epochs = default_root_dir, list(callbacks or []), max_epochs
-        self.precision = precision          # 32: exact fp32 MFMA; 16 (what the reference passes): bf16-operand MFMA
+        # 32: exact fp32 MFMA; 16 (what the reference passes = fp16 autocast): fp16-operand MFMA + dynamic loss scaling;
+        # 'bf16': bf16-operand MFMA (explicit opt-in); see training.precision_mode
+        self.precision = precision
         self.check_val_every_n_epoch = check_val_every_n_epoch
         self.limit_train_batches, self.limit_val_batches = limit_train_batches, limit_val_batches
         self.logged_metrics, self.current_epoch, self.global_step, self.model = {}, 0, 0, None
         self.global_rank, self.world = world_info()
         if not torch.cuda.is_available():
             raise RuntimeError("Trainer drives the MI355X HIP kernels: no GPU visible (there is no CPU fallback)")
-        self.device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+        # one rank per GPU; more ranks than GPUs (rehearsing N ranks on a one-GPU box over gloo) share device 0, 1, ...
+        self.device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1))
 
     def _shard(self, loader, epoch):
         if hasattr(loader, "shard"):                    # GPU-resident loader: shards / reshuffles itself
@@ -109,7 +112,8 @@ class Trainer:
                 if epoch > int(self.max_epochs / 2):    # memory bank of well-classified normal samples (models.py:270-275)
                     y_hat = torch.max(step.last_logits, 1).indices
                     mask = (y == 0) & (y_hat == 0)
-                    model.memory_bank = torch.cat([model.memory_bank, step.last_embeddings[mask].detach().to('cpu')])
+                    rows = gather_bank_rows(step.last_embeddings, mask)      # every rank's rows, in rank order
+                    model.memory_bank = torch.cat([model.memory_bank, rows.to('cpu')])
                 self.global_step += 1
             model.on_train_epoch_end()
             if self.world > 1:
@@ -222,6 +226,29 @@ def world_info():
     if not _LOCAL_ONLY and dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
+
+
+def barrier():
+    """dist.barrier() under torch.distributed, nothing otherwise (or inside `local_only()`)."""
+    if world_info()[1] > 1:
+        dist.barrier()
+
+
+def gather_bank_rows(embeddings, mask):
+    """Rows of `embeddings` [B][D] selected by `mask` [B] from EVERY rank, concatenated in rank order (SURVEY s.8e: the
+    memory bank of models.py:270-275 under data parallelism).  Variable row counts travel as one padded all_gather of
+    [B][D] + a count, so the exchange has a fixed shape; with one rank this is plain boolean indexing."""
+    rank, world = world_info()
+    sel = embeddings[mask].detach()
+    if world == 1:
+        return sel
+    b, d = embeddings.shape
+    pad = torch.zeros((b + 1, d), device=embeddings.device, dtype=embeddings.dtype)
+    pad[:sel.shape[0]] = sel
+    pad[b, 0] = float(sel.shape[0])
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    return torch.cat([p[:int(p[b, 0].item())] for p in parts])
 
 
 def gather_in_order(local_items, total):

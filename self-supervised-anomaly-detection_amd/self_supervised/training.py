@@ -510,6 +510,7 @@ class FusedSGD:
         lr = self.param_groups[0]["lr"]
         for s, e in a.trainable_ranges():
             ops.sgd_step(a.p[s:e], a.g[s:e], a.m[s:e], lr, self.momentum, self.weight_decay, self.grad_scale)
+        self.model._plan = None       # the raw-pointer update does not bump tensor versions: drop folded eval weights
 
     def state_dict(self):
         return {"param_groups": self.param_groups, "momentum": get_engine(self.model).arena.m.cpu()}
@@ -535,17 +536,39 @@ class CosineWarmRestarts:
         return [self.opt.param_groups[0]["lr"]]
 
 
+def precision_mode(precision):
+    """Trainer(precision=...) -> operand mode of the conv / linear kernels.
+    32: exact fp32 MFMA.  16 / "16-mixed" (what the reference passes, tools.py:263 = fp16 autocast): fp16 operands,
+    fp32 accumulate, dynamic loss scaling.  "bf16" / "bf16-mixed": bf16 operands (explicit opt-in; narrower mantissa than
+    the reference's).  "bf16x6" / "bf16x3": split-bf16 emulation of the fp32 product (x6: fp32-faithful, forward + dgrad,
+    wgrad stays exact; x3: 4.6e-6, all three contractions)."""
+    s = str(precision)
+    if s in ("bf16x6", "32x6"):
+        return 6
+    if s in ("bf16x3", "32x3"):
+        return 3
+    if s in ("bf16", "bf16-mixed"):
+        return True
+    if s in ("16", "16-mixed", "fp16"):
+        return 2
+    if s in ("32", "32-true", "fp32"):
+        return False
+    raise ValueError(f"unknown precision {precision!r}")
+
+
 class GradBucketer:
     """Bucketed, overlapped gradient all-reduce over contiguous ranges of a flat gradient arena.
 
     ``notify(end)`` is called by backward whenever the arena prefix [0, end) has become final.  Trainable ranges
     inside the not-yet-reduced part of that prefix are all-reduced (sum, async) once at least ``min_bucket``
     floats are pending, or when ``final`` is set.  Pure torch.distributed: works over RCCL on GPUs and over gloo
-    on CPU tensors (tests/test_distributed_gloo.py)."""
+    on CPU tensors (tests/test_distributed_gloo.py).  ``recorder`` (graph capture): an object with ``bucket(lo, hi)``
+    and ``wait()`` that is told about the buckets instead of torch.distributed -- the bucket arithmetic stays in one place."""
 
     def __init__(self, grad_arena, ranges, process_group=None, min_bucket=1 << 20):
         self.g, self.ranges, self.pg, self.min_bucket = grad_arena, list(ranges), process_group, min_bucket
         self.works, self.done, self.launched = [], 0, []
+        self.recorder = None
 
     def reset(self, ranges=None):
         if ranges is not None:
@@ -558,14 +581,46 @@ class GradBucketer:
         for s, e in self.ranges:
             lo, hi = max(s, self.done), min(e, end)
             if hi > lo:
-                self.works.append(dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                if self.recorder is not None:
+                    self.recorder.bucket(lo, hi)
+                else:
+                    self.works.append(dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
                 self.launched.append((lo, hi))
         self.done = end
 
     def wait(self):
+        if self.recorder is not None:
+            self.recorder.wait()
+            return
         for w in self.works:
             w.wait()
         self.works = []
+
+
+def broadcast_replica_state(model, arena, process_group=None, src=0):
+    """Make every rank start from rank `src`'s replica: parameters, momentum and the BatchNorm buffers (running
+    statistics, num_batches_tracked) -- what DistributedDataParallel does at construction (parameters + buffers) plus
+    the optimizer state this engine owns.  The reference is single-device (tools.py:266); replicas that merely seeded
+    alike would drift apart silently the first time one of them is built differently."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
+        return
+    with torch.no_grad():
+        dist.broadcast(arena.p, src=src, group=process_group)
+        dist.broadcast(arena.m, src=src, group=process_group)
+        for b in model.buffers():
+            dist.broadcast(b, src=src, group=process_group)
+
+
+class LossScaler:
+    """torch.cuda.amp.GradScaler's state machine (what PL runs for the reference's precision=16, tools.py:263) kept in
+    three device floats [scale, growth_tracker, found_inf] so that no step needs a host round trip."""
+
+    def __init__(self, device, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        self.state = torch.tensor([init_scale, 0.0, 0.0], device=device, dtype=torch.float32)
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+
+    def get_scale(self):
+        return float(self.state[0])
 
 
 class DataParallelStep:
@@ -574,37 +629,157 @@ class DataParallelStep:
     Buckets are the arena prefixes that become final after the head, after each ResNet stage's first block, and
     after the stem; each is all-reduced (sum) as soon as it is final, on RCCL's stream, while the compute stream
     continues with the next stage.  The 1/world factor is applied inside the SGD kernel.  BatchNorm statistics
-    stay per rank (the reference has no SyncBN; DDP-default semantics)."""
+    stay per rank during training (the reference has no SyncBN); rank 0's replica (parameters, momentum, BatchNorm
+    buffers) is broadcast once at construction, as DistributedDataParallel does.
 
-    def __init__(self, model, lr, momentum=0.9, weight_decay=0.0005, world_size=None, process_group=None, precision=32):
+    hipGraph replay (``graph=True``, the default; SSAD_GRAPH=0 turns it off): the ~300 launches of a step are captured
+    once per input shape into graph SEGMENTS that end wherever a gradient bucket becomes final; a step is then
+    segment, all-reduce(bucket), segment, ... , wait, SGD segment.  The collectives themselves are never captured (they
+    are issued eagerly between the segment launches, on RCCL's own stream), so the same plan serves 1 and N ranks.
+    Learning rate and loss scale live in device memory: a captured step never bakes them in."""
+
+    def __init__(self, model, lr, momentum=0.9, weight_decay=0.0005, world_size=None, process_group=None, precision=32,
+                 graph=None):
         self.model = model
         self.eng = get_engine(model)
-        # 32: exact fp32 MFMA; 16: bf16 operands (the reference's AMP setting); "bf16x6" / "bf16x3": split-bf16 emulation of
-        # the fp32 product (x6: fp32-faithful, forward + dgrad, wgrad stays exact; x3: 4.6e-6, all three contractions)
-        self.eng.bf16 = (6 if str(precision) in ("bf16x6", "32x6") else 3 if str(precision) in ("bf16x3", "32x3") else
-                         str(precision) in ("16", "bf16", "16-mixed", "bf16-mixed"))
+        self.eng.bf16 = precision_mode(precision)
         self.opt = FusedSGD(model, lr, momentum, weight_decay)
         self.world = world_size if world_size is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
         self.opt.grad_scale = 1.0 / self.world
-        self.bucketer = GradBucketer(self.eng.arena.g, self.eng.arena.trainable_ranges(), process_group)
+        self.pg = process_group
+        a = self.eng.arena
+        self.bucketer = GradBucketer(a.g, a.trainable_ranges(), process_group)
+        if self.world > 1 and dist.is_available() and dist.is_initialized():
+            broadcast_replica_state(model, a, process_group)
+        self.scaler = LossScaler(a.p.device) if self.eng.bf16 == 2 else None      # fp16 operands: dynamic loss scaling
+        self.hyper = torch.zeros(4, device=a.p.device, dtype=torch.float32)
+        self._hyper_host = None
+        import os
+        self.use_graph = (os.environ.get("SSAD_GRAPH", "1") != "0") if graph is None else bool(graph)
+        self._plans, self._seen = {}, {}
+
+    # ---- pieces ----
+    def _sync_hyper(self):
+        h = (float(self.opt.param_groups[0]["lr"]), float(self.opt.momentum), float(self.opt.weight_decay),
+             float(self.opt.grad_scale))
+        if h != self._hyper_host:
+            self.hyper.copy_(torch.tensor(h, dtype=torch.float32), non_blocking=False)
+            self._hyper_host = h
 
     def _notify(self, end):
         a = self.eng.arena
         final = end == a.total or (not self.eng.trunk_grad and end == a.head_end)
         self.bucketer.notify(end, final)
 
-    def step(self, x, y):
+    def _body(self, x, y):
+        """The launches of one step, in order.  Returns (loss/acc, logits, embeddings)."""
         eng = self.eng
         a = eng.arena
-        eng.bucket_hooks = self._notify if self.world > 1 else None
-        self.bucketer.reset(a.trainable_ranges())
         logits, emb = eng.forward(x)
         dlogits = torch.empty_like(logits)
         la = ops.softmax_ce(logits, y, dlogits, 1.0 / x.shape[0])
+        sc = self.scaler.state if self.scaler is not None else None
+        if sc is not None:
+            ops.scale_by_loss_scale(dlogits, sc)
         eng.backward(dlogits)
         self.bucketer.wait()
-        for s, e in a.trainable_ranges():
-            ops.sgd_step(a.p[s:e], a.g[s:e], a.m[s:e], self.opt.param_groups[0]["lr"], self.opt.momentum,
-                         self.opt.weight_decay, self.opt.grad_scale)
+        rng = a.trainable_ranges()
+        if sc is not None:
+            for s, e in rng:
+                ops.check_finite(a.g[s:e], sc)
+        for s, e in rng:
+            ops.sgd_step_dev(a.p[s:e], a.g[s:e], a.m[s:e], self.hyper, sc)
+        if sc is not None:
+            ops.loss_scaler_update(sc, self.scaler.growth_factor, self.scaler.backoff_factor, self.scaler.growth_interval)
+        return la, logits, emb
+
+    # ---- eager ----
+    def _step_eager(self, x, y):
+        self.eng.bucket_hooks = self._notify if self.world > 1 else None
+        self.bucketer.reset(self.eng.arena.trainable_ranges())
+        return self._body(x, y)
+
+    # ---- captured ----
+    def _capture(self, x, y, key):
+        """Record the step for this input shape as graph segments cut at the gradient-bucket boundaries."""
+        plan = {"x": torch.empty_like(x).copy_(x), "y": torch.empty_like(y).copy_(y), "ops": []}
+        pool = torch.cuda.graph_pool_handle()
+        stream = torch.cuda.Stream()
+        multi = self.world > 1
+        seg = {"g": None}
+
+        def begin():
+            seg["g"] = torch.cuda.CUDAGraph()
+            seg["g"].capture_begin(pool=pool)
+
+        def end():
+            seg["g"].capture_end()
+            plan["ops"].append(("graph", seg["g"]))
+
+        class _Recorder:          # a final bucket / the wait before SGD ends the current segment
+            def bucket(_, lo, hi):
+                end()
+                plan["ops"].append(("allreduce", lo, hi))
+                begin()
+
+            def wait(_):
+                if multi:
+                    end()
+                    plan["ops"].append(("wait",))
+                    begin()
+
+        self.eng.bucket_hooks = self._notify if multi else None
+        self.bucketer.reset(self.eng.arena.trainable_ranges())
+        self.bucketer.recorder = _Recorder()
+        stream.wait_stream(torch.cuda.current_stream())
+        try:
+            with torch.cuda.stream(stream):
+                begin()
+                try:
+                    plan["out"] = self._body(plan["x"], plan["y"])
+                finally:
+                    end()
+        finally:
+            self.bucketer.recorder = None
+        torch.cuda.current_stream().wait_stream(stream)
+        self._plans[key] = plan
+        return plan
+
+    def _replay(self, plan, x, y):
+        if x.data_ptr() != plan["x"].data_ptr():
+            plan["x"].copy_(x, non_blocking=True)
+        if y.data_ptr() != plan["y"].data_ptr():
+            plan["y"].copy_(y, non_blocking=True)
+        works = []
+        g = self.eng.arena.g
+        for op in plan["ops"]:
+            if op[0] == "graph":
+                op[1].replay()
+            elif op[0] == "allreduce":
+                works.append(dist.all_reduce(g[op[1]:op[2]], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            else:
+                for w in works:
+                    w.wait()
+                works = []
+        return plan["out"]
+
+    def step(self, x, y):
+        self._sync_hyper()
+        key = (tuple(x.shape), tuple(y.shape), self.eng.bf16, tuple(self.eng.arena.trainable_ranges()),
+               tuple(bool(m.training) for m in self.model.modules() if isinstance(m, BN_TYPES)))
+        if self.use_graph and ops.PROFILE is None:
+            plan = self._plans.get(key)
+            if plan is None:
+                n = self._seen.get(key, 0)
+                self._seen[key] = n + 1
+                if n >= 1:              # first step of a shape runs eagerly (lazy kernel attributes, communicators)
+                    plan = self._capture(x, y, key)
+            if plan is not None:
+                la, logits, emb = self._replay(plan, x, y)
+                self.model._plan = None
+                self.last_logits, self.last_embeddings = logits, emb
+                return la
+        la, logits, emb = self._step_eager(x, y)
+        self.model._plan = None       # folded eval-mode weights are stale now (the kernels do not bump tensor versions)
         self.last_logits, self.last_embeddings = logits, emb
         return la

@@ -10,6 +10,8 @@ for p in (ROOT, PKG):
         sys.path.insert(0, p)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# tests build PeraNet from seeded state dicts: the "no ImageNet weights" warning (models.py) is checked by its own test
+os.environ.setdefault("SSAD_ALLOW_RANDOM_BACKBONE", "1")
 
 
 def pytest_configure(config):

@@ -112,3 +112,57 @@ def test_sharded_scoring_gather_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res), res
+
+
+def _replica_worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "self-supervised-anomaly-detection_amd"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from self_supervised.training import broadcast_replica_state
+    from self_supervised.trainer import gather_bank_rows, barrier
+    torch.manual_seed(100 + rank)                       # replicas built DIFFERENTLY on purpose
+
+    class _Arena:
+        p = torch.randn(50)
+        m = torch.randn(50)
+    bn = torch.nn.BatchNorm1d(6)
+    with torch.no_grad():
+        bn.running_mean.copy_(torch.randn(6)); bn.running_var.copy_(torch.rand(6) + 0.5); bn.num_batches_tracked += rank + 3
+    arena = _Arena()
+    broadcast_replica_state(bn, arena)
+    state = torch.cat([arena.p, arena.m, bn.running_mean, bn.running_var, bn.num_batches_tracked.float().view(1)])
+    parts = [torch.empty_like(state) for _ in range(world)]
+    dist.all_gather(parts, state)
+    ok = all(torch.equal(parts[0], p) for p in parts)
+    torch.manual_seed(100)                              # what rank 0 drew
+    ok = ok and torch.equal(arena.p, torch.randn(50)) and int(bn.num_batches_tracked) == 3
+    # memory-bank rows: ragged counts per rank (rank 0 keeps rows 0 and 2, rank 1 keeps row 1 only), rank order
+    emb = torch.arange(12, dtype=torch.float32).view(4, 3) + 100 * rank
+    mask = torch.tensor([True, False, True, False]) if rank == 0 else torch.tensor([False, True, False, False])
+    rows = gather_bank_rows(emb, mask)
+    want = torch.cat([(torch.arange(12, dtype=torch.float32).view(4, 3))[[0, 2]],
+                      (torch.arange(12, dtype=torch.float32).view(4, 3) + 100)[[1]]])
+    ok = ok and torch.equal(rows, want)
+    none = gather_bank_rows(emb, torch.zeros(4, dtype=torch.bool))
+    ok = ok and tuple(none.shape) == (0, 3)
+    barrier()
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_replica_broadcast_and_bank_gather_world2():
+    """Rank 0's parameters / momentum / BatchNorm buffers reach every rank (replicas are built with different seeds on
+    purpose), and the memory-bank rows of models.py:270-275 are collected from all ranks in rank order."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_replica_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res

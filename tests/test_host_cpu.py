@@ -166,3 +166,28 @@ def test_load_torchvision_backbone(tmp_path, monkeypatch):
     import pytest
     with pytest.raises(KeyError):
         m.load_backbone({"conv1.weight": torch.zeros(64, 3, 7, 7)})
+
+
+def test_random_backbone_warns(monkeypatch):
+    """The reference builds resnet18(weights='IMAGENET1K_V1') and fails loudly without it (models.py:59); here a missing
+    weight file leaves a random trunk, which must not pass silently."""
+    import warnings
+    from self_supervised import models
+    monkeypatch.delenv("SSAD_ALLOW_RANDOM_BACKBONE", raising=False)
+    monkeypatch.delenv("SSAD_RESNET18_WEIGHTS", raising=False)
+    monkeypatch.setattr(models, "_WARNED_RANDOM_BACKBONE", False)
+    monkeypatch.setattr(models.os.path, "isfile", lambda p: False)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        m = models.PeraNet()
+    assert not m.pretrained_backbone
+    assert any("RANDOMLY initialised" in str(x.message) for x in w)
+
+
+def test_precision_modes():
+    from self_supervised.training import precision_mode
+    assert precision_mode(32) is False and precision_mode(16) == 2 and precision_mode("16-mixed") == 2
+    assert precision_mode("bf16") is True and precision_mode("bf16x6") == 6 and precision_mode("bf16x3") == 3
+    import pytest
+    with pytest.raises(ValueError):
+        precision_mode("fp8")
