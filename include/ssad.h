@@ -164,6 +164,18 @@ int ssad_conv_igemm_dgrad_bf16(const float* dy, const float* w_flipT, float* dx,
                                int Wy, int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride, int pad, void* stream);
 int ssad_conv_wgrad_bf16(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin, int Cout,
                          int KH, int KW, int stride, int pad, void* stream);
+/* Halo-tile direct convolution for the 64 -> 64 channel 3x3 / stride 1 / pad 1 layers (torchvision BasicBlock conv3x3 of
+ * ResNet-18 layer1, models.py:224 of the reference under trainer.fit, and their input gradients -- call it with
+ * ssad_flip_transpose_weight(w) and dy): out = conv(T(in)) (+ residual), NHWC fp32, OHWI weights, exact fp32 MFMA.
+ * T = identity, or relu((x - tr_mean) * tr_invstd * tr_gamma + tr_beta) per input channel (the train-mode BatchNorm + ReLU of
+ * the producing layer, applied while the input tile is staged); `emit` (optional) receives T(in).  stats_ws != NULL: also
+ * the train-mode BatchNorm statistics of the output (ssad_conv3x3_c64_stats_rows(N, H, W) * 128 doubles of workspace),
+ * mean / invstd / running statistics as ssad_conv_igemm_fwd_stats produces them. */
+int64_t ssad_conv3x3_c64_stats_rows(int64_t N, int H, int W);
+int ssad_conv3x3_c64(const float* in, const float* w_ohwi, float* out, const float* residual, const float* tr_mean,
+                     const float* tr_invstd, const float* tr_gamma, const float* tr_beta, float* emit, int64_t N, int H, int W,
+                     double* stats_ws, float eps, float momentum, float* mean, float* invstd, float* running_mean,
+                     float* running_var, void* stream);
 /* fp16-operand forms: the reference trains under fp16 autocast (pl.Trainer(precision=16), src/self_supervised/tools.py:263,
  * :296), i.e. its Conv2d / Linear products take fp16 operands and accumulate in fp32.  Same contract as the _bf16 forms
  * with v_mfma_f32_32x32x16_f16 (11-bit significands); the slab of ssad_conv_wgrad_f16 is sized by ssad_wgrad_splits_bf16. */

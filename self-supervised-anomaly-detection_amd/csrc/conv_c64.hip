@@ -1,0 +1,254 @@
+// 3x3 / stride 1 / pad 1 convolution with 64 input and 64 output channels (ResNet-18 layer1: four forward convs and
+// four input-gradient convs per training step at 64x64 maps, one third of the step's FLOPs) on the fp32 matrix cores,
+// as a HALO-TILE direct convolution.
+//
+// The implicit-GEMM kernel (conv_igemm.hip) re-stages every activation row once per filter tap: per 32 MFMAs a thread
+// issues 5 global loads + 5 LDS stores (Cout = 64 tile), and the wave's in-order stream cannot hide them: 85-100 TFLOP/s
+// on this shape against 125-132 on the wide layers.  Here a workgroup owns an 8 x 16 patch of output pixels of ONE image
+// and all 64 output channels:
+//   * the 10 x 18 x 64 input halo is loaded ONCE into LDS (46 KB; zero padding written as zeros, so there are no tap
+//     masks), optionally through a per-channel affine + ReLU (the train-mode BatchNorm + ReLU of the producing layer:
+//     the normalised activation never makes a round trip through HBM) and optionally emitted for the weight-gradient
+//     kernel that needs it later;
+//   * the A fragment of tap (ky, kx) is the same LDS image read at a constant byte offset (an instruction immediate);
+//   * only the 64 x 64 weight slice of a tap (16 KB) is staged per step: 4 loads + 4 LDS stores per 64 MFMAs.
+// Train-mode BatchNorm statistics of the output are taken from the accumulators in registers (fp64, fixed order).
+//
+// Replaces the same autograd nodes as conv_igemm.hip for this shape: torchvision BasicBlock conv3x3 (models.py:224 of
+// the reference, under trainer.fit) and its input gradient.
+#include "common.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 16;              // output pixels per workgroup
+constexpr int HH = TH + 2, HW = TW + 2;     // halo
+constexpr int C = 64;                       // channels in and out
+constexpr int LDP = C + 4;                  // LDS row pitch in floats (272 B: conflict-free ds_read_b128 over rows)
+constexpr int HALO_F = HH * HW * LDP;       // floats
+constexpr int WT_F = C * LDP;               // one tap's [co][ci] slice
+constexpr int LDS_BYTES = (HALO_F + WT_F) * 4;
+
+struct C64Params {
+    const float* in;          // [N][H][W][64]
+    const float* wt;          // [64][3][3][64]  (OHWI)
+    float* out;               // [N][H][W][64]
+    const float* residual;    // optional, added to the output
+    const float* tr_mean;     // optional input transform: x <- relu((x - mean) * invstd * gamma + beta)
+    const float* tr_invstd;
+    const float* tr_gamma;
+    const float* tr_beta;
+    float* emit;              // optional: the transformed input, written for the interior pixels
+    double* stats;            // optional [workgroups][2][64] column sums / sums of squares of the raw output
+    int N, H, W, tiles_y, tiles_x;
+};
+
+__global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* halo = lds;
+    float* Bs = lds + HALO_F;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    // XCD-aware tile order: workgroups b, b+8, ... share an L2; give each XCD a contiguous run of tiles (neighbouring
+    // tiles of an image share halo rows and every tile re-reads the same 147 KB of weights)
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+    const int tx = bid % p.tiles_x;
+    const int ty = (bid / p.tiles_x) % p.tiles_y;
+    const int n = bid / (p.tiles_x * p.tiles_y);
+    const int y0 = ty * TH, x0 = tx * TW;
+    const float* img = p.in + (int64_t)n * p.H * p.W * C;
+
+    // ---- halo fill: thread -> channel quad c4, pixels q*16 + (tid >> 4) ----
+    const int c4 = tid & 15, p0 = tid >> 4;
+    constexpr int NPASS = (HH * HW + 15) / 16;     // 12
+    f32x4 hv[NPASS];
+    bool hin[NPASS];
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) {
+        const int hp = q * 16 + p0;
+        const int hy = hp / HW, hx = hp - hy * HW;
+        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+        hin[q] = hp < HH * HW && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (hin[q]) v = *(const f32x4*)(img + ((int64_t)y * p.W + x) * C + c4 * 4);
+        hv[q] = v;
+    }
+    // first weight slice while the halo loads are in flight: thread -> rows (tid >> 4) + 16 i, chunk c4
+    f32x4 wv[4];
+    const float* wrow = p.wt + (int64_t)(tid >> 4) * 9 * C + c4 * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wv[i] = *(const f32x4*)(wrow + (int64_t)i * 16 * 9 * C);
+    if (p.tr_mean) {
+        const f32x4 mu = *(const f32x4*)(p.tr_mean + c4 * 4), is = *(const f32x4*)(p.tr_invstd + c4 * 4);
+        const f32x4 ga = *(const f32x4*)(p.tr_gamma + c4 * 4), be = *(const f32x4*)(p.tr_beta + c4 * 4);
+#pragma unroll
+        for (int q = 0; q < NPASS; ++q) {
+            if (!hin[q]) continue;                 // padding stays exactly zero (it pads the TRANSFORMED activation)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) hv[q][k] = fmaxf((hv[q][k] - mu[k]) * is[k] * ga[k] + be[k], 0.f);   // bn_apply_fwd's expression
+            if (p.emit) {
+                const int hp = q * 16 + p0;
+                const int hy = hp / HW, hx = hp - hy * HW;
+                if (hy >= 1 && hy <= TH && hx >= 1 && hx <= TW)
+                    *(f32x4*)(p.emit + ((int64_t)n * p.H * p.W + (int64_t)(y0 - 1 + hy) * p.W + (x0 - 1 + hx)) * C + c4 * 4) = hv[q];
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) {
+        const int hp = q * 16 + p0;
+        if (hp < HH * HW) *(f32x4*)(halo + hp * LDP + c4 * 4) = hv[q];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *(f32x4*)(Bs + ((tid >> 4) + 16 * i) * LDP + c4 * 4) = wv[i];
+    __syncthreads();
+
+    // ---- main loop: 9 taps x 64 channels; wave w owns tile rows 2w, 2w+1 (32 pixels) x 64 output channels ----
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    const float* Ab = halo + ((2 * wave + (r >> 4)) * HW + (r & 15)) * LDP + h * 4;      // tap (0,0) of this lane's pixel
+    const float* Bb = Bs + r * LDP + h * 4;
+
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int ky = t / 3, kx = t - 3 * ky;
+        if (t < 8) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wv[i] = *(const f32x4*)(wrow + (int64_t)i * 16 * 9 * C + (t + 1) * C);
+        }
+        const float* At = Ab + (ky * HW + kx) * LDP;
+        f32x4 a[2], b[2][2];
+        a[0] = *(const f32x4*)(At);
+        b[0][0] = *(const f32x4*)(Bb);
+        b[0][1] = *(const f32x4*)(Bb + 32 * LDP);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const int cu = kk & 1, nx = cu ^ 1;
+            if (kk + 1 < 8) {
+                a[nx] = *(const f32x4*)(At + (kk + 1) * 8);
+                b[nx][0] = *(const f32x4*)(Bb + (kk + 1) * 8);
+                b[nx][1] = *(const f32x4*)(Bb + 32 * LDP + (kk + 1) * 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);       // keep the fragment reads one chunk ahead of the MFMAs
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0] = mfma32(a[cu][e], b[cu][0][e], acc[0]);
+                acc[1] = mfma32(a[cu][e], b[cu][1][e], acc[1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();                             // every wave is done with this tap's weights
+        if (t < 8) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *(f32x4*)(Bs + ((tid >> 4) + 16 * i) * LDP + c4 * 4) = wv[i];
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: statistics straight from the accumulators (pixel = register, channel = lane); the tile goes through
+    // LDS (the halo is dead after the last barrier) so that every thread stores -- and reads the residual as -- 16-byte
+    // pieces of contiguous NHWC rows, all residual loads in flight at once ----
+    // reg e of lane (r, h): pixel row index m = (e & 3) + 8 (e >> 2) + 4 h of the wave's 32, channel j*32 + r
+    float* Ct = halo;                               // [128 pixels][LDP]
+    double s0[2] = {0.0, 0.0}, s1[2] = {0.0, 0.0};
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int m = (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int y = y0 + 2 * wave + (m >> 4), x = x0 + (m & 15);
+        const bool ok = y < p.H && x < p.W;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float v = acc[j][e];
+            if (p.stats && ok) { s0[j] += (double)v; s1[j] += (double)v * (double)v; }
+            Ct[(wave * 32 + m) * LDP + j * 32 + r] = v;
+        }
+    }
+    __syncthreads();
+    {
+        // thread -> channel quad c4, tile pixels (tid >> 4) + 16 q
+        int64_t o[8];
+        f32x4 rs[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int tp = (tid >> 4) + 16 * q;
+            const int y = y0 + (tp >> 4), x = x0 + (tp & 15);
+            const bool ok = y < p.H && x < p.W;
+            o[q] = ok ? (((int64_t)n * p.H + y) * p.W + x) * C + c4 * 4 : -1;
+            f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            rs[q] = (ok && p.residual) ? *(const f32x4*)(p.residual + o[q]) : z4;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int tp = (tid >> 4) + 16 * q;
+            f32x4 v = *(const f32x4*)(Ct + tp * LDP + c4 * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] += rs[q][k];
+            if (o[q] >= 0) *(f32x4*)(p.out + o[q]) = v;
+        }
+    }
+    if (p.stats) {
+        // lane halves -> one value per channel per wave, then the four waves in a fixed order through LDS
+        double* S = (double*)Bs;                     // [4 waves][2][64]; the weight buffer is free (barrier above)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            s0[j] += __shfl_xor(s0[j], 32);
+            s1[j] += __shfl_xor(s1[j], 32);
+            if (h == 0) {
+                S[(wave * 2 + 0) * C + j * 32 + r] = s0[j];
+                S[(wave * 2 + 1) * C + j * 32 + r] = s1[j];
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * C) {
+            const int which = tid / C, cc = tid % C;
+            const double t = ((S[(0 * 2 + which) * C + cc] + S[(1 * 2 + which) * C + cc]) + S[(2 * 2 + which) * C + cc]) +
+                             S[(3 * 2 + which) * C + cc];
+            p.stats[((int64_t)blockIdx.x * 2 + which) * C + cc] = t;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t ssad_conv3x3_c64_stats_rows(int64_t N, int H, int W) {
+    return N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+}
+
+// out = conv3x3(pad 1, stride 1)(T(in)) (+ residual), 64 -> 64 channels, NHWC fp32, OHWI weights.
+// T = identity, or relu((x - tr_mean) * tr_invstd * tr_gamma + tr_beta) per input channel when tr_mean != NULL (then
+// `emit`, if given, receives T(in): the activation the weight-gradient kernel of this layer needs).
+// stats_ws != NULL: train-mode BatchNorm statistics of the output (ssad_conv3x3_c64_stats_rows(N, H, W) * 2 * 64 doubles
+// of workspace), finalised exactly as ssad_conv_igemm_fwd_stats does.
+extern "C" int ssad_conv3x3_c64(const float* in, const float* w_ohwi, float* out, const float* residual, const float* tr_mean,
+                                const float* tr_invstd, const float* tr_gamma, const float* tr_beta, float* emit, int64_t N,
+                                int H, int W, double* stats_ws, float eps, float momentum, float* mean, float* invstd,
+                                float* running_mean, float* running_var, void* stream) {
+    SSAD_CHECK_ARG(in && w_ohwi && out && N > 0 && H > 0 && W > 0, "bad argument");
+    SSAD_CHECK_ARG(!tr_mean || (tr_invstd && tr_gamma && tr_beta), "input transform needs mean, invstd, gamma, beta");
+    SSAD_CHECK_ARG(!emit || tr_mean, "emit without an input transform");
+    SSAD_CHECK_ARG(!stats_ws || (mean && invstd), "statistics need mean / invstd outputs");
+    C64Params p;
+    p.in = in; p.wt = w_ohwi; p.out = out; p.residual = residual;
+    p.tr_mean = tr_mean; p.tr_invstd = tr_invstd; p.tr_gamma = tr_gamma; p.tr_beta = tr_beta; p.emit = emit;
+    p.stats = stats_ws;
+    p.N = (int)N; p.H = H; p.W = W;
+    p.tiles_y = (H + TH - 1) / TH; p.tiles_x = (W + TW - 1) / TW;
+    const int64_t nwg = N * p.tiles_y * p.tiles_x;
+    SSAD_CHECK_ARG(nwg < (int64_t)2147483647, "too many tiles for one launch");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_c64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv3x3_c64_kernel, dim3((unsigned)nwg), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
+    SSAD_CHECK_LAUNCH();
+    if (stats_ws)
+        return ssad_bn_finalize_partials(stats_ws, (int)nwg, N * H * W, C, eps, momentum, mean, invstd, running_mean,
+                                         running_var, stream);
+    return 0;
+}

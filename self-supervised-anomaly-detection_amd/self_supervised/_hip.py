@@ -55,6 +55,9 @@ SIGNATURES = {
     "ssad_conv_igemm_dgrad_bf16": [_c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
                                    _c_i, _c_fp],
     "ssad_conv_wgrad_bf16": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_conv3x3_c64_stats_rows": [_c_l, _c_i, _c_i],
+    "ssad_conv3x3_c64": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp, _c_f, _c_f,
+                         _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
     "ssad_conv_igemm_fwd_f16": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
                                 _c_i, _c_i, _c_fp],
     "ssad_conv_igemm_dgrad_f16": [_c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
@@ -98,7 +101,7 @@ SIGNATURES = {
                               ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _c_fp],
     "ssad_u8hwc_to_f32chw": [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_fp],
 }
-RESTYPES = {"ssad_colreduce_workspace": _c_l, "ssad_conv_stats_workspace": _c_l, "ssad_stem_wgrad_workspace": _c_l, "ssad_auroc_workspace": _c_l}
+RESTYPES = {"ssad_conv3x3_c64_stats_rows": _c_l, "ssad_colreduce_workspace": _c_l, "ssad_conv_stats_workspace": _c_l, "ssad_stem_wgrad_workspace": _c_l, "ssad_auroc_workspace": _c_l}
 
 _lib = None
 

@@ -216,6 +216,38 @@ def conv_fwd_stats(x, w_ohwi, eps, momentum, running_mean, running_var, stride=1
     return out, mean, invstd
 
 
+def conv3x3_c64(x, w_ohwi, residual=None, transform=None, emit=False, stats=None):
+    """Halo-tile 3x3 / stride 1 / pad 1 convolution, 64 -> 64 channels (layer1 forward and input-gradient convs).
+    x NHWC [N][H][W][64], w OHWI [64][3][3][64].  transform = (mean, invstd, gamma, beta): the input is taken through
+    relu(bn(x)) while it is staged (emit=True also returns that activation).  stats = (eps, momentum, running_mean,
+    running_var): also the train-mode BatchNorm statistics of the output.  Returns out[, emitted][, mean, invstd]."""
+    n, h, w, c = x.shape
+    assert c == 64 and tuple(w_ohwi.shape) == (64, 3, 3, 64)
+    lib = _hip.lib()
+    out = _new((n, h, w, 64), x)
+    em = torch.empty_like(x) if emit else None
+    tr = transform if transform is not None else (None, None, None, None)
+    mean = invstd = ws = None
+    eps = mom = 0.0
+    rm = rv = None
+    if stats is not None:
+        eps, mom, rm, rv = stats
+        mean, invstd = _new((64,), x), _new((64,), x)
+        ws = torch.empty(lib.ssad_conv3x3_c64_stats_rows(n, h, w) * 128, device=x.device, dtype=torch.float64)
+    nb = 4.0 * (x.numel() + out.numel() * (2 if residual is not None else 1) + (out.numel() if emit else 0) + w_ohwi.numel())
+    _run("conv_c64_f32", 2.0 * out.numel() * 9 * 64, nb,
+         lambda: lib.ssad_conv3x3_c64(_hip.ptr(x), _hip.ptr(w_ohwi), _hip.ptr(out), _hip.ptr(residual, True), _hip.ptr(tr[0], True),
+                                      _hip.ptr(tr[1], True), _hip.ptr(tr[2], True), _hip.ptr(tr[3], True), _hip.ptr(em, True),
+                                      n, h, w, ws.data_ptr() if ws is not None else None, eps, mom, _hip.ptr(mean, True),
+                                      _hip.ptr(invstd, True), _hip.ptr(rm, True), _hip.ptr(rv, True), _hip.stream()))
+    res = [out]
+    if emit:
+        res.append(em)
+    if stats is not None:
+        res += [mean, invstd]
+    return res[0] if len(res) == 1 else tuple(res)
+
+
 def linear_fwd(x, w, scale=None, shift=None, relu=False, x3=False):
     """x [N][Cin], w [Cout][Cin] -> [N][Cout] (the same MFMA kernel with H=W=KH=KW=1)."""
     n, cin = x.shape

@@ -12,6 +12,7 @@ names and shapes while the kernels read them without repacking.  Bucketed all-re
 ranges; SGD = one launch per trainable range.
 """
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -189,6 +190,47 @@ class _Affine:
             ops.stem_wgrad(self.x, dz, a.grad(self.lin.weight))
         self.x = self.z = self.y = None
 
+    # ---- 64 -> 64 channel 3x3 / stride 1 layers (ResNet-18 layer1): halo-tile kernel, BatchNorm + ReLU of the first conv
+    # of a block applied inside the second conv's input staging (csrc/conv_c64.hip) ----
+    def c64_ok(self):
+        l, bn = self.lin, self.bn
+        return (self.is_conv and not self.stem and l.kernel_size == (3, 3) and self.stride == 1 and self.pad == 1
+                and l.in_channels == 64 and l.out_channels == 64 and l.bias is None and bn is not None and bn.training
+                and not self.eng.bf16 and os.environ.get("SSAD_C64", "1") != "0")
+
+    def fwd_raw_c64(self, x, producer=None):
+        """conv + batch statistics only: returns the raw z of this layer and leaves its BatchNorm (+ ReLU) to the consumer.
+        producer: the _Affine whose raw output `x` is -- its BatchNorm + ReLU is applied while x is staged (and, when the
+        backward pass will need it, the normalised activation is emitted for the weight gradient)."""
+        a, bn = self.eng.arena, self.bn
+        mom = 0.1 if bn.momentum is None else bn.momentum
+        st = (bn.eps, mom, bn.running_mean, bn.running_var)
+        self.x_shape = tuple(x.shape)
+        if producer is None:
+            z, self.mean, self.invstd = ops.conv3x3_c64(x, a.w(self.lin.weight), stats=st)
+            self.x = x
+        else:
+            pb = producer.bn
+            tr = (producer.mean, producer.invstd, a.w(pb.weight), a.w(pb.bias))
+            need_x = self.lin.weight.requires_grad and self.eng.param_grads and torch.is_grad_enabled()
+            if need_x:
+                z, self.x, self.mean, self.invstd = ops.conv3x3_c64(x, a.w(self.lin.weight), transform=tr, emit=True, stats=st)
+            else:
+                z, self.mean, self.invstd = ops.conv3x3_c64(x, a.w(self.lin.weight), transform=tr, stats=st)
+                self.x = None
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+        self.z, self.y, self.res_used = z, None, False
+        return z
+
+    def apply_bn(self, residual=None):
+        """The BatchNorm (+ residual) (+ ReLU) of a layer whose raw output fwd_raw_c64 left in self.z."""
+        a, bn = self.eng.arena, self.bn
+        y = ops.bn_apply_fwd(self.z, self.mean, self.invstd, a.w(bn.weight), a.w(bn.bias), residual, self.relu)
+        self.res_used = residual is not None
+        self.y = y if self.relu else None
+        return y
+
     def fwd(self, x, residual=None):
         """x NHWC (4-D; the stem takes the NCHW image).  Returns y NHWC."""
         a, bn = self.eng.arena, self.bn
@@ -196,6 +238,7 @@ class _Affine:
         if self.stem:
             return self._stem_fwd(x, w)
         self.x, self.res_used = x, residual is not None
+        self.x_shape = tuple(x.shape)
         bias = getattr(self.lin, "bias", None)
         bf = self.eng.bf16
         if bn is None:
@@ -280,7 +323,10 @@ class _Affine:
                 dzz[..., :cout] = dz
                 wt = torch.zeros((padc,) + tuple(w.shape[1:]), device=dz.device)
                 wt[:cout] = w
-            dx = ops.conv_dgrad(dzz, ops.flip_transpose_weight(wt), self.x.shape, self.stride, self.pad, dx_residual, bf)
+            if self.c64_ok() and dz.dim() == 4:
+                dx = ops.conv3x3_c64(dzz, ops.flip_transpose_weight(wt), residual=dx_residual)
+            else:
+                dx = ops.conv_dgrad(dzz, ops.flip_transpose_weight(wt), self.x_shape, self.stride, self.pad, dx_residual, bf)
         self.x = self.z = self.y = None
         return dx, dres
 
@@ -338,8 +384,13 @@ class TrainEngine:
             idt = a
             if d["ds"] is not None:
                 idt = d["ds"].fwd(a)
-            t = d["c1"].fwd(a)
-            a = d["c2"].fwd(t, residual=idt)
+            if d["ds"] is None and d["c1"].c64_ok() and d["c2"].c64_ok():
+                z1 = d["c1"].fwd_raw_c64(a)                       # bn1 + ReLU happen inside conv2's input staging
+                d["c2"].fwd_raw_c64(z1, producer=d["c1"])
+                a = d["c2"].apply_bn(residual=idt)
+            else:
+                t = d["c1"].fwd(a)
+                a = d["c2"].fwd(t, residual=idt)
             if i % 2 == 1 and d["name"] in self.gap_off:
                 ops.gap_fwd(a, pooled, self.gap_off[d["name"]])
                 self.stage_shapes[d["name"]] = a.shape

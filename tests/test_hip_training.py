@@ -717,3 +717,42 @@ def test_f16_training_step_vs_autocast_oracle(dev, seeded_sd):
     for _ in range(8):
         last = step.step(x.to(dev), y.to(dev))[0].item()
     assert last < first
+
+
+def test_conv3x3_c64_halo_kernel(dev):
+    """Halo-tile 64 -> 64 conv (layer1 forward / input gradient): plain, with residual, with the fused BatchNorm + ReLU input
+    transform (+ emitted activation) and with the output statistics -- ragged tiles (maps that are not multiples of 8 x 16),
+    a single partial tile, and the 64 x 64 maps of the benchmark."""
+    from self_supervised import ops
+    for (n, h, w) in [(2, 8, 16), (3, 12, 20), (1, 5, 7), (2, 64, 64), (5, 24, 24)]:
+        g = torch.Generator().manual_seed(n * 100 + h)
+        x = torch.randn(n, 64, h, w, generator=g, requires_grad=True)
+        wt = (torch.randn(64, 64, 3, 3, generator=g) / 24.0).requires_grad_()
+        res = torch.randn(n, 64, h, w, generator=g)
+        nh = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().to(dev)
+        w_ohwi = ops.repack_oihw_to_ohwi(wt.detach().to(dev))
+        y = F.conv2d(x, wt, None, 1, 1)
+        got = ops.conv3x3_c64(nh(x), w_ohwi)
+        assert rel_err(got.permute(0, 3, 1, 2), y) < 2e-5
+        assert rel_err(got, ops.conv_fwd(nh(x), w_ohwi, None, None, None, False, 1, 1)) < 2e-6
+        got_r = ops.conv3x3_c64(nh(x), w_ohwi, residual=nh(res))
+        assert rel_err(got_r.permute(0, 3, 1, 2), y + res) < 2e-5
+        # as the input gradient of the same layer
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy)
+        dx = ops.conv3x3_c64(nh(dy), ops.flip_transpose_weight(w_ohwi), residual=nh(res))
+        assert rel_err(dx.permute(0, 3, 1, 2), x.grad + res) < 2e-5
+        # fused input transform relu(bn(x)) + emitted activation + output statistics
+        mean, invstd = (torch.randn(64, generator=g) * 0.2).to(dev), (torch.rand(64, generator=g) + 0.5).to(dev)
+        gamma, beta = (torch.rand(64, generator=g) + 0.5).to(dev), (torch.randn(64, generator=g) * 0.3).to(dev)
+        t_want = ops.bn_apply_fwd(nh(x), mean, invstd, gamma, beta, None, True)
+        rm1, rv1 = torch.zeros(64, device=dev), torch.ones(64, device=dev)
+        rm2, rv2 = rm1.clone(), rv1.clone()
+        z_want, m_want, i_want = ops.conv_fwd_stats(t_want, w_ohwi, 1e-5, 0.1, rm1, rv1, 1, 1)
+        z, t, m, i = ops.conv3x3_c64(nh(x), w_ohwi, transform=(mean, invstd, gamma, beta), emit=True, stats=(1e-5, 0.1, rm2, rv2))
+        assert torch.equal(t, t_want)                                  # same expression as bn_apply_fwd, bit for bit
+        assert rel_err(z, z_want) < 2e-6
+        assert rel_err(m, m_want) < 1e-5 and rel_err(i, i_want) < 1e-5
+        assert rel_err(rm2, rm1) < 1e-5 and rel_err(rv2, rv1) < 1e-5
+        z2 = ops.conv3x3_c64(nh(x), w_ohwi, transform=(mean, invstd, gamma, beta))
+        assert torch.equal(z2, z)                                      # deterministic; emit / stats do not change the result
