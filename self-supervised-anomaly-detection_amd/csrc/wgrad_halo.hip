@@ -1,0 +1,167 @@
+// Weight gradient of the 3x3 / stride 1 / pad 1 convolutions (13 of ResNet-18's 20 trunk convolutions, 3/4 of the
+// weight-gradient FLOPs) on the fp32 matrix cores, as a HALO-TILE kernel:
+//
+//   dW[co][ky][kx][ci] = sum over pixels p of  dZ[p][co] * X[p + (ky-1, kx-1)][ci]
+//
+// The split-over-pixels kernel (wgrad.hip) gives every workgroup ONE filter tap: dZ and X are re-read once per tap
+// and a 64-wide tile gets 16 MFMAs per wave between barriers.  Here a workgroup owns a 64 x 64 (co, ci) block for ALL
+// nine taps and walks over 64-pixel tiles (4 x 16 or 8 x 8): it stages the dZ tile and the halo of X once per tile
+// (zero padding written as zeros) and every pixel pair then feeds nine MFMAs -- one dZ fragment against nine shifted X
+// fragments, the shift being an LDS address immediate.  288 MFMAs per wave between barriers, the next tile's operands in
+// flight in registers meanwhile, operands read from HBM / L2 ~1.6x instead of 9x.  Each wave keeps nine 32 x 32 accumulators (144 registers) across all its tiles;
+// the per-workgroup blocks go to slab[split] and ssad_wgrad_reduce sums the splits in a fixed order (deterministic).
+//
+// Replaces the same autograd node as wgrad.hip (conv2d weight gradient under loss.backward(), tools.py:270, :303).
+#include "common.h"
+
+namespace {
+
+struct WgHaloParams {
+    const float* dz;     // [N][H][W][Cout]
+    const float* x;      // [N][H][W][Cin]
+    float* slab;         // [splits][Cout][9 * Cin]
+    int N, H, W, Cin, Cout;
+    int tiles_y, tiles_x, ci_tiles, npairs, splits;
+    int64_t ntiles, chunk;
+};
+
+template <int TH, int TW>
+__global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(WgHaloParams p) {
+    constexpr int P = TH * TW, HWp = TW + 2, NH = (TH + 2) * HWp;
+    constexpr int NDZ = P / 16;                 // 16-byte pieces of the dZ tile per thread
+    constexpr int NX = (NH + 15) / 16;          // ... of the X halo
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* dzt = lds;                           // [P][64]
+    float* halo = lds + P * 64;                 // [NH][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int cb = wave & 1, ib = wave >> 1;    // 32-wide co / ci block of this wave inside the 64 x 64 block
+
+    const int pair = blockIdx.x % p.npairs, split = blockIdx.x / p.npairs;
+    const int co0 = (pair / p.ci_tiles) * 64, ci0 = (pair % p.ci_tiles) * 64;
+    const int64_t t_begin = (int64_t)split * p.chunk;
+    const int64_t t_end = t_begin + p.chunk < p.ntiles ? t_begin + p.chunk : p.ntiles;
+    const int c4 = tid & 15, p0 = tid >> 4;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    const int tpi = p.tiles_y * p.tiles_x;
+    f32x4 dv[NDZ], xv[NX];
+    // the operands of tile `tile` -> registers (zero padding / ragged tiles read as zeros)
+    auto load_tile = [&](int64_t tile) {
+        const int64_t n = tile / tpi;
+        const int rem = (int)(tile - n * tpi);
+        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+        const int y0 = ty * TH, x0 = tx * TW;
+        const int64_t ibase = n * p.H * p.W;
+#pragma unroll
+        for (int q = 0; q < NDZ; ++q) {
+            const int tp = q * 16 + p0;
+            const int y = y0 + tp / TW, x = x0 + tp % TW;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (y < p.H && x < p.W) v = *(const f32x4*)(p.dz + (ibase + (int64_t)y * p.W + x) * p.Cout + co0 + c4 * 4);
+            dv[q] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < NX; ++q) {
+            const int hp = q * 16 + p0;
+            const int hy = hp / HWp, hx = hp - hy * HWp;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (hp < NH && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
+                v = *(const f32x4*)(p.x + (ibase + (int64_t)y * p.W + x) * p.Cin + ci0 + c4 * 4);
+            xv[q] = v;
+        }
+    };
+    if (t_begin < t_end) load_tile(t_begin);
+    for (int64_t tile = t_begin; tile < t_end; ++tile) {
+        __syncthreads();                        // the previous tile's fragments have all been read
+#pragma unroll
+        for (int q = 0; q < NDZ; ++q) *(f32x4*)(dzt + (q * 16 + p0) * 64 + c4 * 4) = dv[q];
+#pragma unroll
+        for (int q = 0; q < NX; ++q)
+            if (q * 16 + p0 < NH) *(f32x4*)(halo + (q * 16 + p0) * 64 + c4 * 4) = xv[q];
+        __syncthreads();
+        if (tile + 1 < t_end) load_tile(tile + 1);      // in flight under this tile's MFMAs
+
+        // lane (r, h): k slot h = pixel (py, 2 pp + h); A = dZ[pixel][co0 + 32 cb + r], B_tap = X[pixel + tap][ci0 + 32 ib + r]
+        const float* ap = dzt + h * 64 + cb * 32 + r;
+        const float* bp = halo + h * 64 + ib * 32 + r;
+#pragma unroll 1
+        for (int py = 0; py < TH; ++py) {
+#pragma unroll
+            for (int pp = 0; pp < TW / 2; ++pp) {
+                const float a = ap[(py * TW + 2 * pp) * 64];
+                float b[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) b[t] = bp[((py + t / 3) * HWp + 2 * pp + t % 3) * 64];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc[t] = mfma32(a, b[t], acc[t]);
+            }
+        }
+    }
+
+    // D[row = co][col = ci]: reg e of lane (r, h) = co (e & 3) + 8 (e >> 2) + 4 h, ci r
+    float* out = p.slab + (int64_t)split * p.Cout * 9 * p.Cin;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = co0 + cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            out[((int64_t)co * 9 + t) * p.Cin + ci0 + ib * 32 + r] = acc[t][e];
+        }
+}
+
+static int halo_splits(int64_t ntiles, int npairs) {
+    // 512 workgroups = two per CU in ONE round of equal work (no tail), at least 4 tiles per workgroup; every split adds one
+    // slab (written once, read once by the reduction: 75 MB per layer at 512 workgroups)
+    int64_t s = (512 + npairs - 1) / npairs;
+    if (s > ntiles / 4) s = ntiles / 4;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+}  // namespace
+
+// 1 when ssad_conv_wgrad3x3_halo handles the layer.
+extern "C" int ssad_wgrad3x3_halo_ok(int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    return KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin % 64 == 0 && Cout % 64 == 0;
+}
+
+extern "C" int ssad_wgrad3x3_halo_splits(int64_t N, int H, int W, int Cin, int Cout) {
+    const int TW = W > 8 ? 16 : 8, TH = W > 8 ? 4 : 8;
+    const int64_t ntiles = N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+    return halo_splits(ntiles, (Cin / 64) * (Cout / 64));
+}
+
+// dz NHWC [N][H][W][Cout], x NHWC [N][H][W][Cin] (3x3, stride 1, pad 1) -> slab[splits][Cout][9 * Cin] with splits =
+// ssad_wgrad3x3_halo_splits(...); follow with ssad_wgrad_reduce(slab, dw, splits, Cout, 9 * Cin, 3, 3, Cin, ...).
+extern "C" int ssad_conv_wgrad3x3_halo(const float* dz, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin,
+                                       int Cout, void* stream) {
+    SSAD_CHECK_ARG(dz && x && slab && N > 0 && H > 0 && W > 0, "bad argument");
+    SSAD_CHECK_ARG(Cin % 64 == 0 && Cout % 64 == 0, "channel counts must be multiples of 64");
+    const int TW = W > 8 ? 16 : 8, TH = W > 8 ? 4 : 8;     // 64-pixel tiles: 144 accumulator + 44 staging registers fit
+    WgHaloParams p;
+    p.dz = dz; p.x = x; p.slab = slab; p.N = (int)N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    p.tiles_y = (H + TH - 1) / TH; p.tiles_x = (W + TW - 1) / TW;
+    p.ci_tiles = Cin / 64; p.npairs = (Cin / 64) * (Cout / 64);
+    p.ntiles = N * p.tiles_y * p.tiles_x;
+    SSAD_CHECK_ARG(splits >= 1 && splits == halo_splits(p.ntiles, p.npairs), "splits must come from ssad_wgrad3x3_halo_splits");
+    p.splits = splits;
+    p.chunk = (p.ntiles + splits - 1) / splits;
+    const unsigned grid = (unsigned)(p.npairs * splits);
+    hipStream_t st = (hipStream_t)stream;
+    if (TW == 16) {
+        constexpr int bytes = (4 * 16 + 6 * 18) * 64 * 4;
+        hipLaunchKernelGGL((wgrad3x3_halo_kernel<4, 16>), dim3(grid), dim3(256), bytes, st, p);
+    } else {
+        constexpr int bytes = (8 * 8 + 10 * 10) * 64 * 4;
+        hipLaunchKernelGGL((wgrad3x3_halo_kernel<8, 8>), dim3(grid), dim3(256), bytes, st, p);
+    }
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,4 +1,6 @@
 """Tensor-level wrappers over the C ABI: allocate outputs with torch, launch on the current stream."""
+import os
+
 import torch
 
 from . import _hip
@@ -342,6 +344,21 @@ def conv_wgrad(dy, x, dw_out, kh, kw, stride, pad, kreal=None, to_oihw=False, ac
     n, h, w, cin = x.shape
     cout = dy.shape[-1]
     m = dy.numel() // cout
+    lib = _hip.lib()
+    if bf16 == 6 and not force_x6:
+        bf16 = False            # (see below)
+    if (not bf16 and kreal is None and x.shape[:3] == dy.shape[:3] and os.environ.get("SSAD_WGRAD_HALO", "1") != "0"
+            and lib.ssad_wgrad3x3_halo_ok(cin, cout, kh, kw, stride, pad)):
+        # 3x3 / stride 1 / pad 1 on the exact fp32 path: halo-tile kernel (one workgroup = a 64 x 64 block, all nine taps)
+        splits = lib.ssad_wgrad3x3_halo_splits(n, h, w, cin, cout)
+        slab = _new((splits, cout, 9 * cin), dy)
+        _run("wgrad_f32", 2.0 * m * cout * 9 * cin, 4.0 * (dy.numel() + x.numel() + slab.numel()),
+             lambda: lib.ssad_conv_wgrad3x3_halo(_hip.ptr(dy), _hip.ptr(x), _hip.ptr(slab), splits, n, h, w, cin, cout,
+                                                 _hip.stream()))
+        _run("wgrad_reduce", 0.0, 4.0 * slab.numel(),
+             lambda: lib.ssad_wgrad_reduce(_hip.ptr(slab), _hip.ptr(dw_out), splits, cout, 9 * cin, 3, 3, cin, int(to_oihw),
+                                           int(accumulate), _hip.stream()))
+        return dw_out
     if bf16 == 6 and not force_x6:
         # bf16x6 training keeps weight gradients on the exact fp32 kernel: the wave-specialised fp32 wgrad (110 TFLOP/s) is
         # as fast as the six-product bf16 form (measured), and exact; ssad_conv_wgrad_x6 stays available (tests)

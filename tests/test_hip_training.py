@@ -756,3 +756,33 @@ def test_conv3x3_c64_halo_kernel(dev):
         assert rel_err(rm2, rm1) < 1e-5 and rel_err(rv2, rv1) < 1e-5
         z2 = ops.conv3x3_c64(nh(x), w_ohwi, transform=(mean, invstd, gamma, beta))
         assert torch.equal(z2, z)                                      # deterministic; emit / stats do not change the result
+
+
+def test_wgrad3x3_halo_kernel(dev, monkeypatch):
+    """Halo-tile weight gradient (3x3 / stride 1 / pad 1, channels multiples of 64) against autograd and against the
+    split-over-pixels kernel it replaces: ragged tiles, maps narrower than a tile, several (co, ci) blocks, many splits."""
+    from self_supervised import ops
+    for (n, h, w, cin, cout) in [(3, 8, 8, 64, 64), (2, 12, 20, 64, 128), (5, 2, 2, 128, 256), (4, 16, 16, 128, 64),
+                                 (70, 9, 17, 64, 64), (16, 64, 64, 64, 64)]:
+        g = torch.Generator().manual_seed(n * 31 + h)
+        x = torch.randn(n, cin, h, w, generator=g)
+        wt = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).requires_grad_()
+        y = F.conv2d(x, wt, None, 1, 1)
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy)
+        nh = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().to(dev)
+        dw = torch.empty(cout * 9 * cin, device=dev)
+        monkeypatch.setenv("SSAD_WGRAD_HALO", "1")
+        ops.conv_wgrad(nh(dy), nh(x), dw, 3, 3, 1, 1)
+        assert rel_err(dw.view(cout, 3, 3, cin).permute(0, 3, 1, 2), wt.grad) < 2e-5, (n, h, w, cin, cout)
+        dw2 = torch.empty_like(dw)
+        ops.conv_wgrad(nh(dy), nh(x), dw2, 3, 3, 1, 1)
+        assert torch.equal(dw, dw2)                                   # deterministic
+        monkeypatch.setenv("SSAD_WGRAD_HALO", "0")
+        dw3 = torch.empty_like(dw)
+        ops.conv_wgrad(nh(dy), nh(x), dw3, 3, 3, 1, 1)
+        assert rel_err(dw, dw3) < 2e-5
+        dwo = torch.zeros(cout * 9 * cin, device=dev)
+        monkeypatch.setenv("SSAD_WGRAD_HALO", "1")
+        ops.conv_wgrad(nh(dy), nh(x), dwo, 3, 3, 1, 1, to_oihw=True)
+        assert torch.equal(dwo.view(cout, cin, 3, 3), dw.view(cout, 3, 3, cin).permute(0, 3, 1, 2))

@@ -43,6 +43,9 @@ for name, h, cin, cout, k, s, p, nf, nd in SHAPES:
     tf0 = timeit(lambda: ops.conv_fwd(x, w, None, None, None, False, s, p, BF))
     td = timeit(lambda: ops.conv_dgrad(dy, wft, x.shape, s, p, bf16=BF))
     tw = timeit(lambda: ops.conv_wgrad(dy, x, dw, k, k, s, p, bf16=BF))
+    os.environ["SSAD_WGRAD_HALO"] = "0"
+    tw0 = timeit(lambda: ops.conv_wgrad(dy, x, dw, k, k, s, p, bf16=BF))
+    os.environ["SSAD_WGRAD_HALO"] = "1"
     tot["fwd"] += nf * tf; tot["dgrad"] += nd * td; tot["wgrad"] += nf * tw
-    print(f"{name:10s} {tf:8.3f} {fl / tf / 1e9:6.1f} {td:9.3f} {fl / td / 1e9:6.1f} {tw:9.3f} {fl / tw / 1e9:6.1f}  {nf}  (fwd without stats {tf0:.3f})", flush=True)
+    print(f"{name:10s} {tf:8.3f} {fl / tf / 1e9:6.1f} {td:9.3f} {fl / td / 1e9:6.1f} {tw:9.3f} {fl / tw / 1e9:6.1f}  {nf}  (fwd without stats {tf0:.3f}; wgrad split-kernel {tw0:.3f})", flush=True)
 print("totals (ms, with multiplicity):", {k: round(v, 2) for k, v in tot.items()})
