@@ -18,6 +18,7 @@ from . import _hip, constants
 from .dataset_generator import (check_valid_coordinates_by_container, get_random_coordinate, polygon_points,
                                 sample_patch_box)
 from .datasets import CPP, IMAGENET_MEAN, IMAGENET_STD
+from .tv_transforms import RandomAffine, RandomCrop, inverse_affine_matrix
 
 AUG_DTYPE = np.dtype([
     ("label", "<i4"), ("crop_left", "<i4"), ("crop_top", "<i4"), ("aff", "<f4", 6),
@@ -78,10 +79,8 @@ def sample_defect(subject, img_u8, seg_mask, cuts_u8=None, patch_localization=Fa
     rec["cut_index"] = -1
     y = random.randint(0, 3)
     if not patch_localization and subject not in constants.NON_FIXED_OBJECTS():
-        ang = math.radians(float(torch.empty(1).uniform_(-3, 3)))
-        sc = float(torch.empty(1).uniform_(1.05, 1.1))
-        ca, sa, cx, cy = math.cos(ang) / sc, math.sin(ang) / sc, W * 0.5, H * 0.5
-        rec["aff"] = (ca, sa, cx - ca * cx - sa * cy, -sa, ca, cy + sa * cx - ca * cy)
+        ang, sc = RandomAffine(3, scale=(1.05, 1.1)).sample()
+        rec["aff"] = inverse_affine_matrix((W * 0.5, H * 0.5), ang, (0, 0), sc)
     cut_u8 = img_u8
     if subject in constants.TEXTURES() and cuts_u8 is not None and len(cuts_u8):
         ci = random.randrange(len(cuts_u8))
@@ -93,12 +92,13 @@ def sample_defect(subject, img_u8, seg_mask, cuts_u8=None, patch_localization=Fa
         left, top = random.randint(0, W - ps), random.randint(0, H - ps)
         rec["crop_left"], rec["crop_top"] = left, top
         seg = seg_mask[top:top + ps, left:left + ps]
-        ct, cl = int(torch.randint(0, H - ps + 1, (1,))), int(torch.randint(0, W - ps + 1, (1,)))
+        ct, cl = RandomCrop(ps).sample(W, H)
         rec["cut_left"], rec["cut_top"] = cl, ct
         cut_u8 = cut_u8[ct:ct + ps, cl:cl + ps]
         h = w = ps
         k_patch = k_scar = 1
-        if seg.sum() < int((ps * ps) / 2):
+        # the reference sums ToTensor() of the RGB mask crop (datasets.py:258): a white pixel counts three times
+        if 3 * int(seg.sum()) < int((ps * ps) / 2):
             y = 0
     x_mean = img_u8[rec["crop_top"]:rec["crop_top"] + h, rec["crop_left"]:rec["crop_left"] + w].reshape(-1, 3).mean(axis=0)
     area_p = CPP.rectangle_area_ratio_patch if patch_localization else CPP.rectangle_area_ratio

@@ -63,9 +63,8 @@ def obj_mask(image: Image.Image) -> Image.Image:
     m = ndimage.binary_closing(m, sq3)
     m = ndimage.binary_fill_holes(m, sq3)
     m = ndimage.binary_erosion(m, sq4)
-    lab, n = ndimage.label(m)
-    if n == 0:
-        return Image.fromarray(m).convert('RGB')
+    lab, _ = ndimage.label(m, structure=np.ones((3, 3), int))      # skimage.morphology.label: full (8-) connectivity by default
+    # no component at all: bincount = [0], argmax 0, `labels == 0` is everywhere true -- the reference's white mask
     sizes = np.bincount(lab.ravel(), weights=m.ravel().astype(np.float64))
     return Image.fromarray(lab == int(np.argmax(sizes))).convert('RGB')
 

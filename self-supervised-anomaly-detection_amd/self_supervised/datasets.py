@@ -10,7 +10,6 @@ The defect synthesis itself has two back-ends sharing one parameter sampler (``s
   * HIP (augment.py / csrc/augment.hip; whole batches resident on the GPU).
 Dataset root is injectable (``dataset_root``); the reference hard-codes ``'dataset/'`` (datasets.py:189-200).
 """
-import math
 import os
 import random
 
@@ -30,87 +29,8 @@ IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 
 
-# ---------------------------------------------------------------------------------------------
-# transforms (restated, third-party: torchvision.transforms on PIL images)
-# ---------------------------------------------------------------------------------------------
-def to_tensor(img):
-    """PIL -> float32 CHW in [0,1] (mode '1' -> {0,1})."""
-    a = np.array(img.convert('L') if img.mode == '1' else img, dtype=np.uint8)
-    if a.ndim == 2:
-        a = a[:, :, None]
-    return torch.from_numpy(a.transpose(2, 0, 1).copy()).float().div_(255.0)
-
-
-class ToTensor:
-    def __call__(self, img):
-        return to_tensor(img)
-
-
-class Normalize:
-    def __init__(self, mean, std):
-        self.mean = torch.tensor(mean).view(-1, 1, 1)
-        self.std = torch.tensor(std).view(-1, 1, 1)
-
-    def __call__(self, t):
-        return (t - self.mean) / self.std
-
-
-class Compose:
-    def __init__(self, ts):
-        self.ts = list(ts)
-
-    def __call__(self, x):
-        for t in self.ts:
-            x = t(x)
-        return x
-
-
-class ColorJitter:
-    """brightness / contrast / saturation factors ~ U(1-d, 1+d), applied in a random order."""
-
-    def __init__(self, brightness=0.0, contrast=0.0, saturation=0.0):
-        self.b, self.c, self.s = brightness, contrast, saturation
-
-    def sample(self):
-        order = torch.randperm(3).tolist()
-        f = [float(torch.empty(1).uniform_(max(0.0, 1 - d), 1 + d)) for d in (self.b, self.c, self.s)]
-        return order, f
-
-    def __call__(self, img):
-        order, f = self.sample()
-        for op in order:
-            enh = (ImageEnhance.Brightness, ImageEnhance.Contrast, ImageEnhance.Color)[op]
-            img = enh(img).enhance(f[op])
-        return img
-
-
-class RandomAffine:
-    """Rotation ~ U(-deg, deg) and zoom ~ U(scale) about the centre, nearest resampling, zero fill."""
-
-    def __init__(self, degrees, scale=(1.0, 1.0)):
-        self.deg, self.scale = float(degrees), scale
-
-    def __call__(self, img):
-        ang = float(torch.empty(1).uniform_(-self.deg, self.deg))
-        sc = float(torch.empty(1).uniform_(self.scale[0], self.scale[1]))
-        w, h = img.size
-        cx, cy = w * 0.5, h * 0.5
-        a = math.radians(ang)
-        # inverse map: output pixel -> input pixel (rotate by -ang, scale by 1/sc about the centre)
-        ca, sa = math.cos(a) / sc, math.sin(a) / sc
-        m = (ca, sa, cx - ca * cx - sa * cy, -sa, ca, cy + sa * cx - ca * cy)
-        return img.transform((w, h), Image.AFFINE, m, resample=Image.NEAREST)
-
-
-class RandomCrop:
-    def __init__(self, size):
-        self.size = size
-
-    def __call__(self, img):
-        w, h = img.size
-        top = int(torch.randint(0, h - self.size + 1, (1,)))
-        left = int(torch.randint(0, w - self.size + 1, (1,)))
-        return img.crop((left, top, left + self.size, top + self.size))
+# transforms: third-party restatements (torchvision.transforms on PIL images) live in tv_transforms.py
+from .tv_transforms import ColorJitter, Compose, Normalize, RandomAffine, RandomCrop, ToTensor, to_tensor  # noqa: E402,F401
 
 
 class CPP:

@@ -187,7 +187,8 @@ class _Affine:
         dgamma = a.grad(bn.weight) if (bn.weight.requires_grad and pg) else torch.empty(64, device=dpool.device)
         dz = ops.pool_bn_relu_bwd(idx, dpool, self.z, self.mean, self.invstd, a.w(bn.weight), a.w(bn.bias), dbeta, dgamma)
         if self.lin.weight.requires_grad and pg:
-            ops.stem_wgrad(self.x, dz, a.grad(self.lin.weight))
+            with self.eng.wgrad_stream(dz, self.x):
+                ops.stem_wgrad(self.x, dz, a.grad(self.lin.weight))
         self.x = self.z = self.y = None
 
     # ---- 64 -> 64 channel 3x3 / stride 1 layers (ResNet-18 layer1): halo-tile kernel, BatchNorm + ReLU of the first conv
@@ -306,13 +307,14 @@ class _Affine:
             ops.bn_bwd_reduce(dz, None, None, None, None, a.grad(bias), None, cout)
         bf = self.eng.bf16
         if self.lin.weight.requires_grad and self.eng.param_grads:
-            if self.stem:
-                ops.stem_wgrad(self.x, dz, a.grad(self.lin.weight))
-            elif self.is_conv:
-                k = self.lin.kernel_size[0]
-                ops.conv_wgrad(dz, self.x, a.grad(self.lin.weight), k, k, self.stride, self.pad, bf16=bf)
-            else:
-                ops.conv_wgrad(dz, self.x, a.grad(self.lin.weight), 1, 1, 1, 0, bf16=bf)
+            with self.eng.wgrad_stream(dz, self.x):       # weight gradients run beside the input-gradient chain
+                if self.stem:
+                    ops.stem_wgrad(self.x, dz, a.grad(self.lin.weight))
+                elif self.is_conv:
+                    k = self.lin.kernel_size[0]
+                    ops.conv_wgrad(dz, self.x, a.grad(self.lin.weight), k, k, self.stride, self.pad, bf16=bf)
+                else:
+                    ops.conv_wgrad(dz, self.x, a.grad(self.lin.weight), 1, 1, 1, 0, bf16=bf)
         dx = None
         if need_dx:
             w = self.weight()
@@ -367,6 +369,45 @@ class TrainEngine:
         self.gap_off["layer4"] = off
         self.pooled_dim = off + 512
         self.bucket_hooks = None      # set by DataParallelStep: callable(range_end) after each finished arena prefix
+        # Weight gradients only feed the optimiser (and the gradient all-reduce), the input-gradient chain never waits for
+        # them, so they CAN be launched on a second HIP stream (SSAD_WGRAD_STREAM=1) to fill the tails of the dgrad /
+        # BatchNorm kernels.  Measured (round 2, bs256 / bs32): 36.33 vs 36.07 ms and 8.05 vs 7.51 ms per step -- every big
+        # kernel already fills the chip, the second stream only adds dependencies -- so it is OFF by default.
+        self.side = None
+        self._side_keep = []
+        self._side_on = os.environ.get("SSAD_WGRAD_STREAM", "0") == "1"
+
+    # ---- second stream for the weight gradients ----
+    class _Side:
+        def __init__(self, eng, keep):
+            self.eng, self.keep, self.ctx = eng, keep, None
+
+        def __enter__(self):
+            eng = self.eng
+            if not eng._side_on or ops.PROFILE is not None:
+                return self
+            if eng.side is None:
+                eng.side = torch.cuda.Stream()
+            eng._side_keep.extend(t for t in self.keep if t is not None)   # operands stay allocated until the join
+            eng.side.wait_stream(torch.cuda.current_stream())
+            self.ctx = torch.cuda.stream(eng.side)
+            self.ctx.__enter__()
+            return self
+
+        def __exit__(self, *exc):
+            if self.ctx is not None:
+                self.ctx.__exit__(*exc)
+            return False
+
+    def wgrad_stream(self, *operands):
+        return TrainEngine._Side(self, operands)
+
+    def join_wgrad(self):
+        """The compute stream waits for every weight-gradient launch issued so far (before an all-reduce of those ranges /
+        before the optimiser); the operands kept alive for the side stream are released."""
+        if self.side is not None and self._side_keep:
+            torch.cuda.current_stream().wait_stream(self.side)
+        self._side_keep = []
 
     # ---- forward (models.py:210-253, train mode) ----
     def forward(self, x):
@@ -409,7 +450,12 @@ class TrainEngine:
     def backward(self, dlogits):
         """dlogits [B][num_classes] -> fills the gradient arena."""
         b = self.batch
-        notify = self.bucket_hooks or (lambda end: None)
+        hook = self.bucket_hooks
+
+        def notify(end):
+            if hook is not None:
+                self.join_wgrad()          # the bucket that may go out now must hold finished weight gradients
+                hook(end)
         a = self.arena
         head_dx = self.trunk_grad or any(p.requires_grad for l in self.head for p in l.lin.parameters())
         d, _ = self.cls.bwd(dlogits.view(b, 1, 1, -1), need_dx=head_dx)
@@ -420,6 +466,7 @@ class TrainEngine:
             d, _ = layer.bwd(d, need_dx=(self.trunk_grad if last else True))
         notify(a.head_end)
         if not self.trunk_grad:
+            self.join_wgrad()
             self._drop_tape()
             return
         dpooled = d.view(b, -1).contiguous()
@@ -443,6 +490,7 @@ class TrainEngine:
                        a.offset[id(blk["ds"].lin.weight)][0] + blk["ds"].lin.weight.numel())
         self.stem.bwd_pool(self.pool_idx, dy, self.a0_shape)
         notify(a.total)
+        self.join_wgrad()
         self._drop_tape()
 
     def head_input_grad(self, dlogits):

@@ -14,10 +14,21 @@ as-is; third-party packages that are missing here are replaced by throw-away
   skimage / torchvision.transforms  -> empty shells (only names are imported)
 
 Outputs are data only (inputs are regenerated from seeds by oracle.weights):
-  forward.npz, train_step.npz, detector.npz, patches.npz, upsample.npz, cutpaste.npz, auroc.npz, gradcam.npz
+  forward.npz, train_step.npz, detector.npz, patches.npz, upsample.npz, cutpaste.npz, auroc.npz, gradcam.npz,
+  getitem.npz
 
     python tests/golden/make_fixtures.py            # everything
     python tests/golden/make_fixtures.py gradcam    # one section
+    python tests/golden/make_fixtures.py getitem    # PretextTaskDataset.__getitem__ of the reference (datasets.py:209-394)
+
+The `getitem` section imports the reference's datasets.py / dataset_generator.py and runs ITS __getitem__ on the synthetic
+MVTec-shaped tree of tests/fake_mvtec.py under fixed python / numpy / torch seeds.  Third-party pieces that are absent here
+are stand-ins, flagged: torchvision.transforms := self_supervised/tv_transforms.py of this repo (restated from
+torchvision's public behaviour, RNG calls in torchvision's order); skimage.feature.canny := this repo's Canny restatement;
+skimage.morphology.square / label := numpy / scipy.ndimage equivalents (label with skimage's default full connectivity).
+Everything else -- label draw, affine / crop order, defect source choice, generate_patch, colour-similarity brightness
+jitter, container clamp, rect2poly, scar rotation and pasting, poly-line sampling + savgol + ImageDraw.line, jitter call
+order, obj_mask's morphology chain -- is the reference's own code running on PIL / numpy / scipy.
 """
 import os
 import random
@@ -61,7 +72,7 @@ def install_stubs():
         def __init__(self, *a, **k):
             pass
 
-    pl = _stub("pytorch_lightning", LightningModule=LightningModule, LightningDataModule=_Any,
+    pl = _stub("pytorch_lightning", LightningModule=LightningModule, LightningDataModule=type("LightningDataModule", (), {}),
                Trainer=_Any, Callback=_Any)
     _stub("pytorch_lightning.callbacks", ModelCheckpoint=_Any, Callback=_Any)
     pl.callbacks = sys.modules["pytorch_lightning.callbacks"]
@@ -110,10 +121,69 @@ def make_gradcam(rm, sd):
     np.savez_compressed(os.path.join(HERE, "gradcam.npz"), **out)
 
 
+GETITEM_CASES = [("bottle", False), ("bottle", True), ("carpet", False), ("carpet", True)]
+GETITEM_SAMPLES = 12            # seeds 0..11 per case; every label 0..3 and every defect-source branch occurs
+
+
+def make_getitem():
+    """(ix) PretextTaskDataset.__getitem__ of the reference on a synthetic tree (see the module docstring)."""
+    import importlib.util
+    import tempfile
+    from scipy import ndimage
+    pkg = os.path.join(ROOT, "self-supervised-anomaly-detection_amd", "self_supervised")
+
+    def load(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    tvt = load("torchvision.transforms", os.path.join(pkg, "tv_transforms.py"))
+    sys.modules["torchvision.transforms"] = tvt
+    sys.modules["torchvision"].transforms = tvt
+    own_gen = load("_own_dataset_generator", os.path.join(pkg, "dataset_generator.py"))       # only for its Canny restatement
+    sk = sys.modules["skimage"]
+    sk.feature.canny = lambda gray, sigma, low_threshold, high_threshold: own_gen._canny(gray, sigma, low_threshold, high_threshold)
+    sk.morphology.square = lambda n: np.ones((n, n), int)
+    sk.morphology.label = lambda a: ndimage.label(a, structure=np.ones((3, 3), int))[0]
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from fake_mvtec import make_tree
+    from self_supervised import datasets as rd, constants as rconst          # the REFERENCE's modules
+    assert rd.__file__.startswith(REF_SRC)
+    out = {"cases": np.array([f"{s}:{int(p)}" for s, p in GETITEM_CASES]), "n_samples": np.int64(GETITEM_SAMPLES)}
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        make_tree(os.path.join(tmp, "dataset"), categories=("bottle", "carpet"), n_train=4, n_test_good=1, n_test_bad=1, size=96)
+        os.chdir(tmp)                                    # the reference hard-codes 'dataset/' (datasets.py:189-200)
+        try:
+            for subject, patch in GETITEM_CASES:
+                names = np.array(sorted(os.path.join("dataset", subject, "train/good", f) for f in
+                                        os.listdir(os.path.join("dataset", subject, "train/good"))))
+                ds = rd.PretextTaskDataset(subject, names, imsize=(64, 64), transform=None, patch_localization=patch, patch_size=32)
+                key = f"{subject}_{int(patch)}"
+                out[key + "_seg"] = np.array(ds.fixed_segmentation.convert("1"))
+                xs, ys = [], []
+                for s in range(GETITEM_SAMPLES):
+                    random.seed(s); np.random.seed(s); torch.manual_seed(s)
+                    x, y, orig = ds[s % len(names)]
+                    xs.append(np.array(x)); ys.append(y)
+                    if s == 0:
+                        out[key + "_orig0"] = (orig * 255).round().byte().numpy()
+                out[key + "_x"], out[key + "_y"] = np.stack(xs), np.array(ys)
+                # the RNG streams after the last sample: any extra / missing draw anywhere shows up here
+                out[key + "_rng"] = np.array([random.random(), np.random.rand(), float(torch.rand(1))])
+        finally:
+            os.chdir(cwd)
+    np.savez_compressed(os.path.join(HERE, "getitem.npz"), **out)
+    print("getitem.npz: labels", {k: out[k].tolist() for k in out if k.endswith("_y")})
+
+
 def main():
     assert os.path.isdir(REF_SRC), "reference not present: fixtures can only be made in the build container"
     install_stubs()
     sys.path.insert(0, REF_SRC)
+    if sys.argv[1:] == ["getitem"]:
+        make_getitem()
+        return
     from self_supervised import models as rm                     # reference
     if sys.argv[1:] == ["gradcam"]:
         torch.manual_seed(0)
@@ -295,6 +365,7 @@ def main():
     fpr, tpr, _ = roc_curve(labels, scores)
     np.savez_compressed(os.path.join(HERE, "auroc.npz"), labels=labels, scores=scores, auroc=np.float64(auc(fpr, tpr)))
     make_gradcam(rm, sd)
+    make_getitem()
     print("fixtures written to", HERE)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

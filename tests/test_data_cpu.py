@@ -1,5 +1,6 @@
 """CPU tests of the host-side data path: cut-paste primitives against vectors from the reference, datasets on a
 synthetic MVTec-shaped tree, metrics."""
+import os
 import random
 
 import numpy as np
@@ -98,3 +99,71 @@ def test_metrics(golden):
     thr = m.best_f1_threshold(s, t)
     assert abs(thr - 0.35) < 1e-6 and abs(m.compute_f1(t, s, thr) - 0.8) < 1e-9
     assert abs(m.compute_iou(s, t, 0.5) - np.mean([2 / 3, 1 / 2])) < 1e-9
+
+
+def _getitem_tree(tmp_path):
+    from fake_mvtec import make_tree
+    return make_tree(str(tmp_path / "dataset"), categories=("bottle", "carpet"), n_train=4, n_test_good=1, n_test_bad=1, size=96)
+
+
+def test_pretext_getitem_matches_reference(golden, tmp_path):
+    """PretextTaskDataset.__getitem__ against the reference's own __getitem__ (src/self_supervised/datasets.py:209-394),
+    run by tests/golden/make_fixtures.py on the same synthetic tree under the same python / numpy / torch seeds:
+    bit-identical uint8 images and labels for object + texture categories, image- and patch-level, and identical RNG
+    streams afterwards (one extra or missing draw anywhere would shift them)."""
+    import random
+    from PIL import Image
+    from self_supervised import datasets
+    g = golden("getitem")
+    root = _getitem_tree(tmp_path)
+    n = int(g["n_samples"])
+    for case in g["cases"]:
+        subject, patch = str(case).split(":")
+        patch = bool(int(patch))
+        key = f"{subject}_{int(patch)}"
+        names = np.array(sorted(os.path.join(root, subject, "train/good", f) for f in os.listdir(os.path.join(root, subject, "train/good"))))
+        ds = datasets.PretextTaskDataset(subject, names, imsize=(64, 64), transform=None, patch_localization=patch, patch_size=32,
+                                         dataset_root=root)
+        assert np.array_equal(np.array(ds.fixed_segmentation.convert("1")), g[key + "_seg"]), key
+        for s in range(n):
+            random.seed(s); np.random.seed(s); torch.manual_seed(s)
+            x, y, orig = ds[s % len(names)]
+            assert y == int(g[key + "_y"][s]), (key, s)
+            assert np.array_equal(np.array(x), g[key + "_x"][s]), (key, s, y)
+            if s == 0:
+                assert np.array_equal((orig * 255).round().byte().numpy(), g[key + "_orig0"])
+        rng = np.array([random.random(), np.random.rand(), float(torch.rand(1))])
+        assert np.array_equal(rng, g[key + "_rng"]), key
+    assert set(np.concatenate([g[f"{c.split(':')[0]}_{c.split(':')[1]}_y"] for c in map(str, g["cases"])]).tolist()) == {0, 1, 2, 3}
+
+
+def test_sample_defect_draws_like_getitem(golden, tmp_path):
+    """The GPU pipeline's host-side sampler (augment.sample_defect) consumes the three RNG streams exactly as
+    __getitem__ does -- i.e. as the reference does, by the test above -- and draws the same label: after one call from the
+    same seeds the python / numpy / torch generators are in the same state as after the PIL path."""
+    import random
+    from PIL import Image
+    from self_supervised import augment, datasets
+    g = golden("getitem")
+    root = _getitem_tree(tmp_path)
+    checked = 0
+    for case in g["cases"]:
+        subject, patch = str(case).split(":")
+        patch = bool(int(patch))
+        names = np.array(sorted(os.path.join(root, subject, "train/good", f) for f in os.listdir(os.path.join(root, subject, "train/good"))))
+        ds = datasets.PretextTaskDataset(subject, names, imsize=(64, 64), transform=None, patch_localization=patch, patch_size=32,
+                                         dataset_root=root)
+        seg = np.asarray(ds.fixed_segmentation.convert("1"))
+        cuts = np.stack([np.asarray(c) for c in ds.images_for_cut]) if subject == "carpet" else None
+        for s in range(int(g["n_samples"])):
+            img = np.asarray(Image.open(names[s % len(names)]).resize((64, 64)).convert("RGB"))
+            random.seed(s); np.random.seed(s); torch.manual_seed(s)
+            _, y, _ = ds[s % len(names)]
+            want = (random.random(), np.random.rand(), float(torch.rand(1)))
+            random.seed(s); np.random.seed(s); torch.manual_seed(s)
+            rec, _ = augment.sample_defect(subject, img, seg, cuts, patch, 32)
+            got = (random.random(), np.random.rand(), float(torch.rand(1)))
+            assert int(rec["label"]) == y, (subject, patch, s)
+            assert got == want, (subject, patch, s, y)
+            checked += 1
+    assert checked == 48
