@@ -276,37 +276,47 @@ int ssad_check_finite(const float* g, int64_t n, float* scaler, void* stream);
 int ssad_loss_scaler_update(float* scaler, float growth_factor, float backoff_factor, int growth_interval, void* stream);
 
 /* ---- synthetic-defect augmentation (batched, GPU resident) ---- */
-/* One record per sample, drawn on the host in the reference's order (datasets.py:209-394): the GPU does the pixels.
- * All fields are 32-bit; the Python side mirrors this layout with a numpy structured dtype (augment.py) and checks
- * ssad_aug_params_size(). */
+/* One record per sample, drawn on the host in the reference's order (datasets.py:209-394): the GPU does the pixels,
+ * with Pillow's own integer / float32 rules (self_supervised/pil_exact.py) so that the result is byte-identical to the
+ * reference's PIL path.  All fields are 32-bit; the Python side mirrors this layout with a numpy structured dtype
+ * (augment.py) and checks ssad_aug_params_size(). */
+#define SSAD_AUG_MAX_LINE_POINTS 32
 typedef struct ssad_aug_params {
     int32_t label;                          /* 0 good, 1 polygon patch, 2 scars, 3 poly-line */
     int32_t crop_left, crop_top;            /* output window origin inside the (affine) source image */
-    float   aff[6];                         /* inverse affine output->input {a,b,c,d,e,f}: x' = a x + b y + c, y' = d x + e y + f */
-    int32_t cut_index, cut_left, cut_top;   /* cutting image: index into `cuts` (-1 = the sample's own image) + crop origin */
+    int32_t aff_on;                         /* 0: no RandomAffine; 1: Image.transform(AFFINE, NEAREST) with the coefficients below */
+    int32_t aff_fix[6];                     /* Pillow affine_fixed 16.16 integers: sx = (a2 + y a1 + x a0) >> 16, sy = (a5 + y a4 + x a3) >> 16 */
+    int32_t cut_index, cut_left, cut_top, cut_w, cut_h;   /* defect source: index into `cuts` (-1 = the sample's own image) + window */
     int32_t patch_src_left, patch_src_top, patch_w, patch_h, patch_dst_left, patch_dst_top, patch_flat;
-    float   patch_rgb[3];
-    float   patch_bright[2];                /* two successive ImageEnhance.Brightness factors (1,1 = none) */
+    int32_t patch_rgb[3];
+    float   patch_bright[2];                /* two successive ImageEnhance.Brightness factors ... */
+    int32_t patch_nbright;                  /* ... applied when this is 2 (0: none) */
     int32_t poly_n;
-    float   poly_xy[16];                    /* up to 8 vertices in patch coordinates */
+    int32_t poly_xy[16];                    /* up to 8 integer vertices in patch coordinates (ImageDraw.polygon) */
     int32_t scar_src_left, scar_src_top, scar_w, scar_h, scar_flat;
-    float   scar_rgb[3];
+    int32_t scar_rgb[3];
     float   scar_bright[2];
-    float   scar_cos, scar_sin;             /* inverse rotation */
+    int32_t scar_nbright;
+    int32_t scar_rot;                       /* 0: rotate() took the copy path (angle % 360 == 0); 1: affine_fixed coefficients below */
+    int32_t scar_fix[6];
     int32_t scar_rw, scar_rh, scar_n;       /* rotated (expanded) size, number of pasted copies (<= 5) */
     int32_t scar_dst[10];                   /* left, top per copy */
-    int32_t line_n;                         /* poly-line points (<= 32) */
-    float   line_xy[64];
-    float   line_rgb[3];
-    float   line_width;
-    int32_t jit_order[3];                   /* permutation of {0 brightness, 1 contrast, 2 saturation} */
+    int32_t line_n;                         /* poly-line points (<= SSAD_AUG_MAX_LINE_POINTS), already (int)-truncated */
+    int32_t line_xy[2 * SSAD_AUG_MAX_LINE_POINTS];
+    int32_t line_quad[8 * (SSAD_AUG_MAX_LINE_POINTS - 1)];   /* width > 1: ImagingDrawWideLine's four vertices per segment */
+    int32_t line_quad_ok[SSAD_AUG_MAX_LINE_POINTS - 1];      /* 0: degenerate segment (a single point) */
+    int32_t line_rgb[3];
+    int32_t line_width;
+    int32_t jit_n;                          /* enabled ColorJitter ops, in application order: */
+    int32_t jit_order[3];                   /* 0 brightness, 1 contrast, 2 saturation */
     float   jit_factor[3];                  /* indexed by op */
 } ssad_aug_params;
 
 int ssad_aug_params_size(void);
 /* Replaces the PIL pixel work of PretextTaskDataset.__getitem__ (src/self_supervised/datasets.py:209-394;
  * dataset_generator.py:42-101, :268-275) for a whole batch: imgs [B][H][W][3] uint8 (and cuts [NC][H][W][3]) ->
- * out [B][3][h][w] fp32 normalised with mean3/std3 (host pointers).  work: B*h*w*3 bytes, gray_mean: B floats. */
+ * out [B][3][h][w] fp32 normalised with mean3/std3 (host pointers) and, in `work` (B*h*w*3 bytes), the uint8 HWC image
+ * BEFORE ColorJitter.  gray_mean: B floats of scratch. */
 int ssad_cutpaste_augment(const uint8_t* imgs, const uint8_t* cuts, const ssad_aug_params* params, uint8_t* work,
                           float* gray_mean, float* out, int B, int H, int W, int h, int w, const float* mean3_host,
                           const float* std3_host, void* stream);

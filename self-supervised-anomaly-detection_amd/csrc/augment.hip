@@ -1,57 +1,119 @@
-// Batched synthetic-defect augmentation on the GPU: crop / affine, polygon cut-paste, rotated scars, poly-lines,
-// colour jitter, ToTensor + Normalize -- one uint8 HWC batch in, one fp32 NCHW batch out.
+// Batched synthetic-defect augmentation on the GPU: RandomAffine / crop, polygon cut-paste, rotated scars, poly-lines,
+// ColorJitter, ToTensor + Normalize -- one uint8 HWC batch in, one fp32 NCHW batch out, BYTE-IDENTICAL to the PIL path.
 //
 // Replaces the pixel work of PretextTaskDataset.__getitem__ (src/self_supervised/datasets.py:209-394) and of
 // dataset_generator.rect2poly / paste_patch (src/self_supervised/dataset_generator.py:42-101, :268-275), which the
 // reference runs with PIL inside 8 DataLoader worker processes.  The random *parameters* (label, boxes, polygon
 // vertices, angles, jitter factors) are drawn on the host in the reference's order (augment.py) and arrive as one
-// ssad_aug_params record per sample; everything per-pixel happens here.  HBM-bound byte work: one thread per
-// output pixel, three channels per thread, no LDS needed.
+// ssad_aug_params record per sample; everything per-pixel happens here, by Pillow's own rules (restated in
+// self_supervised/pil_exact.py and pinned against Pillow there):
+//   * Image.transform(AFFINE, NEAREST) / Image.rotate(expand=True): 16.16 fixed-point source coordinates (affine_fixed);
+//   * ImageDraw.polygon: scan-line intersections in float32, doubled lower end points, ROUND_UP / ROUND_DOWN spans;
+//   * ImageDraw.line: Bresenham for width 1, one polygon quadrilateral per segment for wider lines;
+//   * ImageEnhance: Image.blend in float32 (separate multiply and add, truncation, clamping only when extrapolating),
+//     integer luma (19595, 38470, 7471), the Contrast mean taken from the image as it is when Contrast runs.
+// HBM-bound byte work: one thread per output pixel (or per line segment), no LDS needed.
 #include "common.h"
 #include "../../include/ssad.h"
 
+// Pillow's C code rounds every float32 product and sum separately (x86-64 has no fused multiply-add in its baseline):
+// hipcc's default -ffp-contract=fast would fuse `a * b + c` below into one v_fma_f32 and move scan-line intersections /
+// blend results across a rounding boundary (seen as isolated pixels on long poly-lines).  No contraction in this file.
+#pragma clang fp contract(off)
+
 namespace {
 
-__device__ __forceinline__ float clamp255(float v) { return v <= 0.f ? 0.f : (v >= 255.f ? 255.f : floorf(v)); }
-
-// PIL ImageEnhance = Image.blend(degenerate, image, factor) with uint8 truncation
-__device__ __forceinline__ float blend_u8(float degenerate, float v, float f) {
-    return clamp255(degenerate + f * (v - degenerate));
+// (int)in1 + alpha * ((int)in2 - (int)in1) in float32 with separate roundings (no fma contraction), Blend.c
+__device__ __forceinline__ int blend_u8(int degenerate, int v, float alpha) {
+    const float t = __fadd_rn((float)degenerate, __fmul_rn(alpha, (float)(v - degenerate)));
+    if (alpha >= 0.f && alpha <= 1.f) return (int)t;                  // interpolation: plain truncation
+    return t <= 0.f ? 0 : (t >= 255.f ? 255 : (int)t);
 }
 
-__device__ __forceinline__ float gray_u8(float r, float g, float b) {
-    // PIL "L": (R*19595 + G*38470 + B*7471 + 0x8000) >> 16
-    return floorf((r * 19595.f + g * 38470.f + b * 7471.f + 32768.f) / 65536.f);
+__device__ __forceinline__ int luma(int r, int g, int b) { return (r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16; }
+
+__device__ __forceinline__ int round_up(float f) {
+    return f >= 0.f ? (int)floorf(__fadd_rn(f, 0.5f)) : -(int)floorf(__fadd_rn(fabsf(f), 0.5f));
+}
+__device__ __forceinline__ int round_down(float f) {
+    return f >= 0.f ? (int)ceilf(__fsub_rn(f, 0.5f)) : -(int)ceilf(__fsub_rn(fabsf(f), 0.5f));
 }
 
-__device__ bool in_polygon(const float* xy, int n, float px, float py) {
-    bool in = false;
-    for (int i = 0, j = n - 1; i < n; j = i++) {
-        const float xi = xy[2 * i], yi = xy[2 * i + 1], xj = xy[2 * j], yj = xy[2 * j + 1];
-        if (((yi > py) != (yj > py)) && (px < (xj - xi) * (py - yi) / (yj - yi) + xi)) in = !in;
+// Does ImageDraw.polygon(vertices, fill) paint pixel (px, py) of a W x H image?  (pil_exact.polygon_row_spans)
+__device__ bool polygon_covers(const int32_t* __restrict__ xy, int n, int W, int H, int px, int py) {
+    if ((unsigned)px >= (unsigned)W || (unsigned)py >= (unsigned)H) return false;
+    int pymin = H - 1, pymax = 0;
+    bool hit = false;
+    float xx[16];
+    for (int i = 0; i < n; ++i) {
+        const int y0 = xy[2 * i + 1], y1 = xy[2 * ((i + 1) % n) + 1];
+        pymin = min(pymin, min(y0, y1));
+        pymax = max(pymax, max(y0, y1));
     }
-    return in;
+    pymin = max(pymin, 0);
+    pymax = min(pymax, H);
+    int j = 0;
+    for (int i = 0; i < n; ++i) {
+        const int x0 = xy[2 * i], y0 = xy[2 * i + 1], x1 = xy[2 * ((i + 1) % n)], y1 = xy[2 * ((i + 1) % n) + 1];
+        if (y0 == y1) {                                   // horizontal edges are drawn as they are
+            if (y0 == py && px >= min(x0, x1) && px <= max(x0, x1)) hit = true;
+            continue;
+        }
+        const int ymin = min(y0, y1), ymax = max(y0, y1);
+        if (py < pymin || py > pymax || py < ymin || py > ymax) continue;
+        const float dx = __fdiv_rn((float)(x1 - x0), (float)(y1 - y0));
+        const float v = __fadd_rn(__fmul_rn((float)(py - y0), dx), (float)x0);
+        xx[j++] = v;
+        if (py == ymax && py < pymax) xx[j++] = v;        // "needed to draw consistent polygons"
+    }
+    if (hit) return true;
+    for (int a = 1; a < j; ++a) {                         // insertion sort (j <= 16)
+        const float key = xx[a];
+        int b = a - 1;
+        while (b >= 0 && xx[b] > key) { xx[b + 1] = xx[b]; --b; }
+        xx[b + 1] = key;
+    }
+    int x_pos = j ? (int)xx[0] : 0;
+    for (int i = 1; i < j; i += 2) {
+        const int x_end = round_down(xx[i]);
+        if (x_end < x_pos) continue;
+        int x_start = round_up(xx[i - 1]);
+        if (x_pos > x_start) {
+            x_start = x_pos;
+            if (x_end < x_start) continue;
+        }
+        if (px >= x_start && px <= x_end) return true;
+        x_pos = x_end + 1;
+    }
+    return false;
 }
 
-__device__ float seg_dist2(float px, float py, float ax, float ay, float bx, float by) {
-    const float vx = bx - ax, vy = by - ay, wx = px - ax, wy = py - ay;
-    const float l2 = vx * vx + vy * vy;
-    float t = l2 > 0.f ? (wx * vx + wy * vy) / l2 : 0.f;
-    t = fminf(fmaxf(t, 0.f), 1.f);
-    const float dx = wx - t * vx, dy = wy - t * vy;
-    return dx * dx + dy * dy;
-}
-
-__device__ __forceinline__ void fetch(const uint8_t* img, int H, int W, int y, int x, float* rgb) {
+__device__ __forceinline__ void fetch(const uint8_t* img, int H, int W, int y, int x, int* rgb) {
     if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
         const uint8_t* p = img + ((int64_t)y * W + x) * 3;
         rgb[0] = p[0]; rgb[1] = p[1]; rgb[2] = p[2];
     } else {
-        rgb[0] = rgb[1] = rgb[2] = 0.f;
+        rgb[0] = rgb[1] = rgb[2] = 0;
     }
 }
 
-// stage 1: compose the defect into a uint8 HWC work image of size h x w
+// a pixel of the defect source: a flat colour, or the crop [src_left + lx, src_top + ly] of the cutting window (Image.crop
+// pads with zeros outside the window), then the optional twofold Brightness enhancement
+__device__ __forceinline__ void source_pixel(const uint8_t* cut, const ssad_aug_params& p, int H, int W, int flat, const int32_t* frgb,
+                                             int src_left, int src_top, int lx, int ly, int nbright, const float* bright, int* s) {
+    if (flat) {
+        s[0] = frgb[0]; s[1] = frgb[1]; s[2] = frgb[2];
+    } else {
+        const int cx = src_left + lx, cy = src_top + ly;
+        if ((unsigned)cx < (unsigned)p.cut_w && (unsigned)cy < (unsigned)p.cut_h) fetch(cut, H, W, p.cut_top + cy, p.cut_left + cx, s);
+        else s[0] = s[1] = s[2] = 0;
+    }
+    for (int k = 0; k < nbright; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s[c] = blend_u8(0, s[c], bright[k]);
+}
+
+// stage 1: affine / crop, polygon patch or scars -> uint8 HWC work image of size h x w
 __global__ void compose_kernel(const uint8_t* __restrict__ imgs, const uint8_t* __restrict__ cuts,
                                const ssad_aug_params* __restrict__ params, uint8_t* __restrict__ work, int B, int H, int W,
                                int h, int w) {
@@ -61,66 +123,141 @@ __global__ void compose_kernel(const uint8_t* __restrict__ imgs, const uint8_t* 
     const ssad_aug_params& p = params[b];
     const uint8_t* img = imgs + (int64_t)b * H * W * 3;
     const uint8_t* cut = p.cut_index >= 0 ? cuts + (int64_t)p.cut_index * H * W * 3 : img;
-    float rgb[3];
-    {   // base pixel: crop window of the (nearest-resampled, zero-filled) affine image
-        const float fx = (float)(x + p.crop_left) + 0.5f, fy = (float)(y + p.crop_top) + 0.5f;
-        const int sx = (int)floorf(p.aff[0] * fx + p.aff[1] * fy + p.aff[2]);
-        const int sy = (int)floorf(p.aff[3] * fx + p.aff[4] * fy + p.aff[5]);
-        fetch(img, H, W, sy, sx, rgb);
+    int rgb[3];
+    {
+        const int ox = x + p.crop_left, oy = y + p.crop_top;
+        if (p.aff_on) {
+            const int sx = (p.aff_fix[2] + oy * p.aff_fix[1] + ox * p.aff_fix[0]) >> 16;
+            const int sy = (p.aff_fix[5] + oy * p.aff_fix[4] + ox * p.aff_fix[3]) >> 16;
+            fetch(img, H, W, sy, sx, rgb);
+        } else {
+            fetch(img, H, W, oy, ox, rgb);
+        }
     }
     if (p.label == 1 && p.patch_w > 0) {
         const int lx = x - p.patch_dst_left, ly = y - p.patch_dst_top;
         if ((unsigned)lx < (unsigned)p.patch_w && (unsigned)ly < (unsigned)p.patch_h &&
-            in_polygon(p.poly_xy, p.poly_n, (float)lx + 0.5f, (float)ly + 0.5f)) {
-            float s[3];
-            if (p.patch_flat) { s[0] = p.patch_rgb[0]; s[1] = p.patch_rgb[1]; s[2] = p.patch_rgb[2]; }
-            else fetch(cut, H, W, p.cut_top + p.patch_src_top + ly, p.cut_left + p.patch_src_left + lx, s);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) rgb[c] = blend_u8(0.f, blend_u8(0.f, s[c], p.patch_bright[0]), p.patch_bright[1]);
-        }
+            polygon_covers(p.poly_xy, p.poly_n, p.patch_w, p.patch_h, lx, ly))
+            source_pixel(cut, p, H, W, p.patch_flat, p.patch_rgb, p.patch_src_left, p.patch_src_top, lx, ly, p.patch_nbright,
+                         p.patch_bright, rgb);
     } else if (p.label == 2) {
-        for (int k = 0; k < p.scar_n; ++k) {
+        for (int k = 0; k < p.scar_n; ++k) {              // pasted in order: a later copy overwrites an earlier one
             const int lx = x - p.scar_dst[2 * k], ly = y - p.scar_dst[2 * k + 1];
             if ((unsigned)lx >= (unsigned)p.scar_rw || (unsigned)ly >= (unsigned)p.scar_rh) continue;
-            // inverse rotation about the centres (PIL rotate(angle, expand=True), nearest, transparent outside)
-            const float u = (float)lx + 0.5f - 0.5f * (float)p.scar_rw, v = (float)ly + 0.5f - 0.5f * (float)p.scar_rh;
-            const int sx = (int)floorf(p.scar_cos * u - p.scar_sin * v + 0.5f * (float)p.scar_w);
-            const int sy = (int)floorf(p.scar_sin * u + p.scar_cos * v + 0.5f * (float)p.scar_h);
-            if ((unsigned)sx >= (unsigned)p.scar_w || (unsigned)sy >= (unsigned)p.scar_h) continue;
-            float s[3];
-            if (p.scar_flat) { s[0] = p.scar_rgb[0]; s[1] = p.scar_rgb[1]; s[2] = p.scar_rgb[2]; }
-            else fetch(cut, H, W, p.cut_top + p.scar_src_top + sy, p.cut_left + p.scar_src_left + sx, s);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) rgb[c] = blend_u8(0.f, blend_u8(0.f, s[c], p.scar_bright[0]), p.scar_bright[1]);
-        }
-    } else if (p.label == 3 && p.line_n > 1) {
-        const float r2 = 0.25f * p.line_width * p.line_width;
-        const float px = (float)x + 0.5f, py = (float)y + 0.5f;
-        for (int k = 0; k + 1 < p.line_n; ++k) {
-            if (seg_dist2(px, py, p.line_xy[2 * k] + 0.5f, p.line_xy[2 * k + 1] + 0.5f, p.line_xy[2 * k + 2] + 0.5f,
-                          p.line_xy[2 * k + 3] + 0.5f) <= r2) {
-                rgb[0] = p.line_rgb[0]; rgb[1] = p.line_rgb[1]; rgb[2] = p.line_rgb[2];
-                break;
+            int sx = lx, sy = ly;
+            if (p.scar_rot) {                             // Image.rotate(angle, expand=True), NEAREST, transparent outside
+                sx = (p.scar_fix[2] + ly * p.scar_fix[1] + lx * p.scar_fix[0]) >> 16;
+                sy = (p.scar_fix[5] + ly * p.scar_fix[4] + lx * p.scar_fix[3]) >> 16;
             }
+            if ((unsigned)sx >= (unsigned)p.scar_w || (unsigned)sy >= (unsigned)p.scar_h) continue;
+            source_pixel(cut, p, H, W, p.scar_flat, p.scar_rgb, p.scar_src_left, p.scar_src_top, sx, sy, p.scar_nbright,
+                         p.scar_bright, rgb);
         }
     }
     uint8_t* o = work + i * 3;
     o[0] = (uint8_t)rgb[0]; o[1] = (uint8_t)rgb[1]; o[2] = (uint8_t)rgb[2];
 }
 
-// stage 2: per-sample mean of the L channel (ImageEnhance.Contrast's degenerate image), rounded like PIL
-__global__ void gray_mean_kernel(const uint8_t* __restrict__ work, float* __restrict__ mean, int hw) {
-    __shared__ double sh[256];
-    const uint8_t* p = work + (int64_t)blockIdx.x * hw * 3;
-    double s = 0;
-    for (int i = threadIdx.x; i < hw; i += blockDim.x) s += (double)gray_u8(p[3 * i], p[3 * i + 1], p[3 * i + 2]);
+// stage 1b: poly-lines, one thread per (sample, segment).  Every writer stores the same colour, so overlapping segments
+// need no ordering.
+__device__ __forceinline__ void put(uint8_t* img, int h, int w, int x, int y, const int32_t* rgb) {
+    if ((unsigned)x < (unsigned)w && (unsigned)y < (unsigned)h) {
+        uint8_t* o = img + ((int64_t)y * w + x) * 3;
+        o[0] = (uint8_t)rgb[0]; o[1] = (uint8_t)rgb[1]; o[2] = (uint8_t)rgb[2];
+    }
+}
+
+__global__ void line_kernel(const ssad_aug_params* __restrict__ params, uint8_t* __restrict__ work, int B, int h, int w) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = t / (SSAD_AUG_MAX_LINE_POINTS - 1), seg = t % (SSAD_AUG_MAX_LINE_POINTS - 1);
+    if (b >= B) return;
+    const ssad_aug_params& p = params[b];
+    if (p.label != 3 || seg + 1 >= p.line_n) return;
+    uint8_t* img = work + (int64_t)b * h * w * 3;
+    int x0 = p.line_xy[2 * seg], y0 = p.line_xy[2 * seg + 1];
+    const int x1 = p.line_xy[2 * seg + 2], y1 = p.line_xy[2 * seg + 3];
+    if (p.line_width <= 1) {                              // Draw.c line8 / line32: all pixels but the end point ...
+        int dx = x1 - x0, xs = 1, dy = y1 - y0, ys = 1;
+        if (dx < 0) { dx = -dx; xs = -1; }
+        if (dy < 0) { dy = -dy; ys = -1; }
+        if (dx == 0) {
+            for (int i = 0; i < dy; ++i) { put(img, h, w, x0, y0, p.line_rgb); y0 += ys; }
+        } else if (dy == 0) {
+            for (int i = 0; i < dx; ++i) { put(img, h, w, x0, y0, p.line_rgb); x0 += xs; }
+        } else if (dx > dy) {
+            const int n = dx;
+            dy += dy;
+            int e = dy - dx;
+            dx += dx;
+            for (int i = 0; i < n; ++i) {
+                put(img, h, w, x0, y0, p.line_rgb);
+                if (e >= 0) { y0 += ys; e -= dx; }
+                e += dy;
+                x0 += xs;
+            }
+        } else {
+            const int n = dy;
+            dx += dx;
+            int e = dx - dy;
+            dy += dy;
+            for (int i = 0; i < n; ++i) {
+                put(img, h, w, x0, y0, p.line_rgb);
+                if (e >= 0) { x0 += xs; e -= dy; }
+                e += dx;
+                y0 += ys;
+            }
+        }
+        if (seg + 2 == p.line_n) put(img, h, w, x1, y1, p.line_rgb);        // ... then ImagingDrawPoint on the last point
+        return;
+    }
+    if (!p.line_quad_ok[seg]) {                           // ImagingDrawWideLine on a zero-length segment: one point
+        put(img, h, w, x0, y0, p.line_rgb);
+        return;
+    }
+    const int32_t* q = p.line_quad + 8 * seg;
+    int bx0 = q[0], bx1 = q[0], by0 = q[1], by1 = q[1];
+    for (int k = 1; k < 4; ++k) {
+        bx0 = min(bx0, q[2 * k]); bx1 = max(bx1, q[2 * k]);
+        by0 = min(by0, q[2 * k + 1]); by1 = max(by1, q[2 * k + 1]);
+    }
+    bx0 = max(bx0, 0); by0 = max(by0, 0); bx1 = min(bx1, w - 1); by1 = min(by1, h - 1);
+    for (int yy = by0; yy <= by1; ++yy)
+        for (int xq = bx0; xq <= bx1; ++xq)
+            if (polygon_covers(q, 4, w, h, xq, yy)) put(img, h, w, xq, yy, p.line_rgb);
+}
+
+// ColorJitter op k of the sampled order on one pixel; `mean` = the Contrast degenerate level
+__device__ __forceinline__ void jitter_op(int op, float f, int mean, int& r, int& g, int& b) {
+    if (op == 0) {
+        r = blend_u8(0, r, f); g = blend_u8(0, g, f); b = blend_u8(0, b, f);
+    } else if (op == 1) {
+        r = blend_u8(mean, r, f); g = blend_u8(mean, g, f); b = blend_u8(mean, b, f);
+    } else {
+        const int l = luma(r, g, b);
+        r = blend_u8(l, r, f); g = blend_u8(l, g, f); b = blend_u8(l, b, f);
+    }
+}
+
+// stage 2: ImageEnhance.Contrast's degenerate level = int(mean of the L channel + 0.5) of the image AS IT IS when Contrast
+// runs, i.e. after the jitter ops sampled before it (re-applied per pixel inside the reduction)
+__global__ void gray_mean_kernel(const uint8_t* __restrict__ work, const ssad_aug_params* __restrict__ params,
+                                 float* __restrict__ mean, int hw) {
+    __shared__ unsigned long long sh[256];
+    const ssad_aug_params& p = params[blockIdx.x];
+    const uint8_t* px = work + (int64_t)blockIdx.x * hw * 3;
+    unsigned long long s = 0;
+    for (int i = threadIdx.x; i < hw; i += blockDim.x) {
+        int r = px[3 * i], g = px[3 * i + 1], b = px[3 * i + 2];
+        for (int k = 0; k < p.jit_n && p.jit_order[k] != 1; ++k) jitter_op(p.jit_order[k], p.jit_factor[p.jit_order[k]], 0, r, g, b);
+        s += (unsigned long long)luma(r, g, b);
+    }
     sh[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) mean[blockIdx.x] = floorf((float)(sh[0] / hw) + 0.5f);
+    if (threadIdx.x == 0) mean[blockIdx.x] = (float)(int)((double)sh[0] / (double)hw + 0.5);
 }
 
 // stage 3: colour jitter in the sampled order, then ToTensor + Normalize -> NCHW fp32
@@ -133,24 +270,13 @@ __global__ void jitter_normalize_kernel(const uint8_t* __restrict__ work, const 
     const int b = (int)(i / hw);
     const int64_t pix = i - (int64_t)b * hw;
     const ssad_aug_params& p = params[b];
-    float r = work[i * 3], g = work[i * 3 + 1], bl = work[i * 3 + 2];
-    float mean = gmean[b];
-    for (int k = 0; k < 3; ++k) {
-        const int op = p.jit_order[k];
-        const float f = p.jit_factor[op];
-        if (op == 0) {
-            r = blend_u8(0.f, r, f); g = blend_u8(0.f, g, f); bl = blend_u8(0.f, bl, f);
-            mean = clamp255(mean * f);          // the grey mean seen by a later contrast step scales with it
-        } else if (op == 1) {
-            r = blend_u8(mean, r, f); g = blend_u8(mean, g, f); bl = blend_u8(mean, bl, f);
-        } else {
-            const float l = gray_u8(r, g, bl);
-            r = blend_u8(l, r, f); g = blend_u8(l, g, f); bl = blend_u8(l, bl, f);
-        }
-    }
-    out[((int64_t)b * 3 + 0) * hw + pix] = (r / 255.f - m0) / s0;
-    out[((int64_t)b * 3 + 1) * hw + pix] = (g / 255.f - m1) / s1;
-    out[((int64_t)b * 3 + 2) * hw + pix] = (bl / 255.f - m2) / s2;
+    int r = work[i * 3], g = work[i * 3 + 1], bl = work[i * 3 + 2];
+    const int mean = (int)gmean[b];
+    for (int k = 0; k < p.jit_n; ++k) jitter_op(p.jit_order[k], p.jit_factor[p.jit_order[k]], mean, r, g, bl);
+    // ToTensor (u8 / 255) then Normalize ((t - mean) / std): IEEE single operations, as torch evaluates them
+    out[((int64_t)b * 3 + 0) * hw + pix] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)r, 255.f), m0), s0);
+    out[((int64_t)b * 3 + 1) * hw + pix] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)g, 255.f), m1), s1);
+    out[((int64_t)b * 3 + 2) * hw + pix] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)bl, 255.f), m2), s2);
 }
 
 // uint8 HWC -> fp32 CHW in [0,1] (the "original" the Dataset returns as third element)
@@ -160,7 +286,7 @@ __global__ void u8_to_f32_kernel(const uint8_t* __restrict__ img, float* __restr
     const int b = (int)(i / hw);
     const int64_t pix = i - (int64_t)b * hw;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) out[((int64_t)b * 3 + c) * hw + pix] = (float)img[i * 3 + c] / 255.f;
+    for (int c = 0; c < 3; ++c) out[((int64_t)b * 3 + c) * hw + pix] = __fdiv_rn((float)img[i * 3 + c], 255.f);
 }
 
 }  // namespace
@@ -176,7 +302,9 @@ extern "C" int ssad_cutpaste_augment(const uint8_t* imgs, const uint8_t* cuts, c
     const int64_t total = (int64_t)B * h * w;
     hipLaunchKernelGGL(compose_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, imgs, cuts ? cuts : imgs, params,
                        work, B, H, W, h, w);
-    hipLaunchKernelGGL(gray_mean_kernel, dim3(B), dim3(256), 0, st, work, gray_mean, h * w);
+    hipLaunchKernelGGL(line_kernel, dim3((unsigned)cdiv64((int64_t)B * (SSAD_AUG_MAX_LINE_POINTS - 1), 64)), dim3(64), 0, st, params,
+                       work, B, h, w);
+    hipLaunchKernelGGL(gray_mean_kernel, dim3(B), dim3(256), 0, st, work, params, gray_mean, h * w);
     hipLaunchKernelGGL(jitter_normalize_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, work, params, gray_mean, out, B,
                        h, w, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2]);
     SSAD_CHECK_LAUNCH();

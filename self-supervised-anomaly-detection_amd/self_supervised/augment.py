@@ -7,7 +7,6 @@ helpers (dataset_generator) and the same distributions.  It only produces number
 one record per sample to csrc/augment.hip, which does every per-pixel operation for the whole batch.
 """
 import ctypes
-import math
 import random
 
 import numpy as np
@@ -18,74 +17,87 @@ from . import _hip, constants
 from .dataset_generator import (check_valid_coordinates_by_container, get_random_coordinate, polygon_points,
                                 sample_patch_box)
 from .datasets import CPP, IMAGENET_MEAN, IMAGENET_STD
+from . import pil_exact as px
 from .tv_transforms import RandomAffine, RandomCrop, inverse_affine_matrix
 
+MAX_LINE_POINTS = 32
 AUG_DTYPE = np.dtype([
-    ("label", "<i4"), ("crop_left", "<i4"), ("crop_top", "<i4"), ("aff", "<f4", 6),
-    ("cut_index", "<i4"), ("cut_left", "<i4"), ("cut_top", "<i4"),
+    ("label", "<i4"), ("crop_left", "<i4"), ("crop_top", "<i4"), ("aff_on", "<i4"), ("aff_fix", "<i4", 6),
+    ("cut_index", "<i4"), ("cut_left", "<i4"), ("cut_top", "<i4"), ("cut_w", "<i4"), ("cut_h", "<i4"),
     ("patch_src_left", "<i4"), ("patch_src_top", "<i4"), ("patch_w", "<i4"), ("patch_h", "<i4"),
     ("patch_dst_left", "<i4"), ("patch_dst_top", "<i4"), ("patch_flat", "<i4"),
-    ("patch_rgb", "<f4", 3), ("patch_bright", "<f4", 2), ("poly_n", "<i4"), ("poly_xy", "<f4", 16),
+    ("patch_rgb", "<i4", 3), ("patch_bright", "<f4", 2), ("patch_nbright", "<i4"), ("poly_n", "<i4"), ("poly_xy", "<i4", 16),
     ("scar_src_left", "<i4"), ("scar_src_top", "<i4"), ("scar_w", "<i4"), ("scar_h", "<i4"), ("scar_flat", "<i4"),
-    ("scar_rgb", "<f4", 3), ("scar_bright", "<f4", 2), ("scar_cos", "<f4"), ("scar_sin", "<f4"),
+    ("scar_rgb", "<i4", 3), ("scar_bright", "<f4", 2), ("scar_nbright", "<i4"), ("scar_rot", "<i4"), ("scar_fix", "<i4", 6),
     ("scar_rw", "<i4"), ("scar_rh", "<i4"), ("scar_n", "<i4"), ("scar_dst", "<i4", 10),
-    ("line_n", "<i4"), ("line_xy", "<f4", 64), ("line_rgb", "<f4", 3), ("line_width", "<f4"),
-    ("jit_order", "<i4", 3), ("jit_factor", "<f4", 3)])
+    ("line_n", "<i4"), ("line_xy", "<i4", 2 * MAX_LINE_POINTS), ("line_quad", "<i4", 8 * (MAX_LINE_POINTS - 1)),
+    ("line_quad_ok", "<i4", MAX_LINE_POINTS - 1), ("line_rgb", "<i4", 3), ("line_width", "<i4"),
+    ("jit_n", "<i4"), ("jit_order", "<i4", 3), ("jit_factor", "<f4", 3)])
 
 _NAMED = {"black": (0, 0, 0), "white": (255, 255, 255), "silver": (192, 192, 192), "gray": (128, 128, 128)}
 
 
-def _mean_rgb(img_u8, box):
+def _crop_mean_rgb(img_u8, box):
+    """np.array(img.crop(box)).mean(axis=(0, 1)) -- Image.crop pads with zeros where the box leaves the image."""
     l, t, w, h = box
-    return img_u8[t:t + h, l:l + w].reshape(-1, 3).mean(axis=0)
+    H, W = img_u8.shape[:2]
+    inside = img_u8[max(t, 0):min(t + h, H), max(l, 0):min(l + w, W)].reshape(-1, 3).astype(np.float64)
+    return inside.sum(axis=0) / float(w * h)
 
 
 def _cos(a, b):
-    a, b = np.asarray(a, float) / 255.0, np.asarray(b, float) / 255.0
-    return float(np.dot(a, b) / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-12))
+    """dataset_generator.check_color_similarity on two mean colours."""
+    a, b = np.asarray(a, float)[:3] / 255.0, np.asarray(b, float)[:3] / 255.0
+    return float(np.dot(a, b) / (np.linalg.norm(a) * np.linalg.norm(b)))
 
 
 def _source(rec, prefix, cut_u8, area_ratio, aspect_ratio):
-    """crop / average colour / random colour choice + box, as generate_patch draws them."""
+    """crop / average colour / random colour choice + box, as generate_patch draws them.  Returns (w, h, mean colour of
+    the patch image) -- the mean check_color_similarity sees."""
     t = np.random.choice([0, 1, 2], p=[0.7, 0.15, 0.15])
     l, tp, w, h = sample_patch_box((cut_u8.shape[1], cut_u8.shape[0]), area_ratio, aspect_ratio)
     rec[prefix + "_src_left"], rec[prefix + "_src_top"], rec[prefix + "_w"], rec[prefix + "_h"] = l, tp, w, h
-    mean = _mean_rgb(cut_u8, (l, tp, w, h))
     if t == 2:
         rgb = (random.randint(0, 255), random.randint(0, 255), random.randint(0, 255))
     elif t == 1:
-        rgb = tuple(int(c) for c in mean)
+        mean = _crop_mean_rgb(cut_u8, (l, tp, w, h))
+        rgb = (int(mean[0]), int(mean[1]), int(mean[2]))
     else:
         rgb = None
     rec[prefix + "_flat"] = int(rgb is not None)
     if rgb is not None:
         rec[prefix + "_rgb"] = rgb
-        mean = np.asarray(rgb, float)
-    return w, h, mean
+        return w, h, np.asarray(rgb, float)
+    return w, h, _crop_mean_rgb(cut_u8, (l, tp, w, h))
 
 
 def _decorrelate(rec, prefix, x_mean, src_mean):
-    rec[prefix + "_bright"] = (1.0, 1.0)
+    rec[prefix + "_bright"], rec[prefix + "_nbright"] = (1.0, 1.0), 0
     if _cos(x_mean, src_mean) > 0.99:
         low, high = np.random.uniform(0.75, 0.9), np.random.uniform(1.1, 1.15)
-        rec[prefix + "_bright"] = (random.choice([low, high]), random.choice([low, high]))
+        rec[prefix + "_bright"], rec[prefix + "_nbright"] = (random.choice([low, high]), random.choice([low, high])), 2
 
 
 def sample_defect(subject, img_u8, seg_mask, cuts_u8=None, patch_localization=False, patch_size=64):
-    """One ssad_aug_params record (numpy void) for an H x W uint8 image and its boolean object mask."""
+    """One ssad_aug_params record (numpy void) for an H x W uint8 image and its boolean object mask: every random draw of
+    PretextTaskDataset.__getitem__ in its order (pinned by tests/test_data_cpu.py), every geometric quantity as Pillow
+    computes it (pil_exact)."""
     H, W = img_u8.shape[:2]
     rec = np.zeros((), AUG_DTYPE)
-    rec["aff"] = (1, 0, 0, 0, 1, 0)
     rec["cut_index"] = -1
     y = random.randint(0, 3)
+    aff = None
     if not patch_localization and subject not in constants.NON_FIXED_OBJECTS():
         ang, sc = RandomAffine(3, scale=(1.05, 1.1)).sample()
-        rec["aff"] = inverse_affine_matrix((W * 0.5, H * 0.5), ang, (0, 0), sc)
+        aff = inverse_affine_matrix((W * 0.5, H * 0.5), ang, (0, 0), sc)
+        assert not px.affine_is_scale_only(aff), "a rotation of exactly 0 degrees takes another Pillow code path"
+        rec["aff_on"], rec["aff_fix"] = 1, px.affine_fix_coeffs(aff)
     cut_u8 = img_u8
     if subject in constants.TEXTURES() and cuts_u8 is not None and len(cuts_u8):
         ci = random.randrange(len(cuts_u8))
         rec["cut_index"], cut_u8 = ci, cuts_u8[ci]
     h, w, k_patch, k_scar = H, W, 1.75, 2
+    rec["cut_w"], rec["cut_h"] = W, H
     seg = seg_mask
     if patch_localization:
         ps = patch_size
@@ -93,38 +105,41 @@ def sample_defect(subject, img_u8, seg_mask, cuts_u8=None, patch_localization=Fa
         rec["crop_left"], rec["crop_top"] = left, top
         seg = seg_mask[top:top + ps, left:left + ps]
         ct, cl = RandomCrop(ps).sample(W, H)
-        rec["cut_left"], rec["cut_top"] = cl, ct
+        rec["cut_left"], rec["cut_top"], rec["cut_w"], rec["cut_h"] = cl, ct, ps, ps
         cut_u8 = cut_u8[ct:ct + ps, cl:cl + ps]
         h = w = ps
         k_patch = k_scar = 1
         # the reference sums ToTensor() of the RGB mask crop (datasets.py:258): a white pixel counts three times
         if 3 * int(seg.sum()) < int((ps * ps) / 2):
             y = 0
-    x_mean = img_u8[rec["crop_top"]:rec["crop_top"] + h, rec["crop_left"]:rec["crop_left"] + w].reshape(-1, 3).mean(axis=0)
     area_p = CPP.rectangle_area_ratio_patch if patch_localization else CPP.rectangle_area_ratio
     area_s = CPP.scar_area_ratio_patch if patch_localization else CPP.scar_area_ratio
     if y > 0:
         coords_map = np.flip(np.column_stack(np.where(seg)), axis=1)
-        if len(coords_map) == 0:
-            y = 0
+
+    def x_mean():
+        """Mean colour of the image the defect is pasted into (after RandomAffine / crop), for the similarity test."""
+        cur = px.affine_nearest(img_u8, (W, H), aff) if aff is not None else img_u8
+        cur = cur[rec["crop_top"]:rec["crop_top"] + h, rec["crop_left"]:rec["crop_left"] + w]
+        return cur.reshape(-1, 3).astype(np.float64).mean(axis=0)
     if y == 1:
         centre = get_random_coordinate(coords_map)
         pw, ph, mean = _source(rec, "patch", cut_u8, area_p, CPP.rectangle_aspect_ratio)
-        _decorrelate(rec, "patch", x_mean, mean)
+        _decorrelate(rec, "patch", x_mean(), mean)
         at = check_valid_coordinates_by_container((w, h), (pw, ph), current_coords=centre, container_scaling_factor=k_patch)
         rec["patch_dst_left"], rec["patch_dst_top"] = at
         pts = polygon_points((pw, ph), sides=8)
         rec["poly_n"] = len(pts)
-        rec["poly_xy"][:2 * len(pts)] = np.asarray(pts, np.float32).ravel()
+        rec["poly_xy"][:2 * len(pts)] = np.asarray(pts, np.int32).ravel()
     elif y == 2:
         sw, sh, mean = _source(rec, "scar", cut_u8, area_s, CPP.scar_aspect_ratio)
-        _decorrelate(rec, "scar", x_mean, mean)
+        _decorrelate(rec, "scar", x_mean(), mean)
         copies, angle = random.randint(2, 5), random.randint(-45, 45)
-        a = math.radians(angle)
-        c, s = math.cos(a), math.sin(a)
-        rw = int(math.ceil(abs(sw * c) + abs(sh * s)))
-        rh = int(math.ceil(abs(sw * s) + abs(sh * c)))
-        rec["scar_cos"], rec["scar_sin"], rec["scar_rw"], rec["scar_rh"], rec["scar_n"] = c, s, rw, rh, copies
+        rw, rh, m = px.rotate_params(sw, sh, angle)
+        rec["scar_rw"], rec["scar_rh"], rec["scar_n"] = rw, rh, copies
+        if m is not None:
+            assert not px.affine_is_scale_only(m)
+            rec["scar_rot"], rec["scar_fix"] = 1, px.affine_fix_coeffs(m)
         for k in range(copies):
             centre = get_random_coordinate(coords_map)
             at = check_valid_coordinates_by_container((w, h), (rw, rh), current_coords=centre, container_scaling_factor=k_scar)
@@ -143,13 +158,23 @@ def sample_defect(subject, img_u8, seg_mask, cuts_u8=None, patch_localization=Fa
         pts = savgol_filter(pts, 10, 2, axis=0)
         if not patch_localization:
             pts = np.array_split(pts, 10)[random.randint(0, 9)]
-        pts = np.asarray(pts, np.float32)[:32]
-        rec["line_n"] = len(pts)
-        rec["line_xy"][:2 * len(pts)] = pts.ravel()
-        rec["line_rgb"], rec["line_width"] = rgb, (1.0 if patch_localization else 3.0)
+        width = 1 if patch_localization else 3
+        ip = px.line_points_int([tuple(p) for p in pts])
+        assert len(ip) <= MAX_LINE_POINTS, "poly-line longer than the kernel's record"
+        rec["line_n"] = len(ip)
+        rec["line_xy"][:2 * len(ip)] = np.asarray(ip, np.int32).ravel()
+        rec["line_rgb"], rec["line_width"] = rgb, width
+        if width > 1:
+            for k, ((x0, y0), (x1, y1)) in enumerate(zip(ip[:-1], ip[1:])):
+                q = px.wide_line_quad(x0, y0, x1, y1, width)
+                if q is not None:
+                    rec["line_quad_ok"][k] = 1
+                    rec["line_quad"][8 * k:8 * k + 8] = np.asarray(q, np.int32).ravel()
     rec["label"] = y
     order, f = CPP.jitter_transforms.sample()
-    rec["jit_order"], rec["jit_factor"] = order, f
+    rec["jit_n"] = len(order)
+    rec["jit_order"][:len(order)] = order
+    rec["jit_factor"] = f
     return rec, (h, w)
 
 
