@@ -177,3 +177,90 @@ def paste_patch(image: Image.Image, patch: Image.Image, coords: tuple, mask: Ima
     out = image.copy()
     out.paste(patch, (coords[0], coords[1]), mask=mask)
     return out
+
+
+# ---- 'cable' pre-segmentation: SLIC super-pixels + per-segment mean colour (datasets.py:201-206) ----
+# THIRD-PARTY RESTATEMENT, unpinned: the reference calls skimage.segmentation.slic(image, n_segments=5, sigma=2,
+# convert2lab=True) and skimage.color.label2rgb(segments, image, kind='avg'); scikit-image is not installed, so the
+# published algorithm (Achanta et al., "SLIC Superpixels", as scikit-image documents its implementation: Gaussian
+# pre-smoothing, CIELAB, k-means in (L, a, b, y, x) restricted to 2S x 2S windows with compactness 10, 10 iterations,
+# connectivity enforcement with min / max size factors 0.5 / 3, labels from 1) is written out here.  It yields the same kind
+# of result -- a handful of compact colour regions -- not scikit-image's exact label image.
+def _rgb2lab(rgb):
+    x = rgb.astype(np.float64) / 255.0
+    lin = np.where(x > 0.04045, ((x + 0.055) / 1.055) ** 2.4, x / 12.92)
+    m = np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]])
+    xyz = lin @ m.T / np.array([0.95047, 1.0, 1.08883])
+    f = np.where(xyz > 0.008856, np.cbrt(xyz), 7.787 * xyz + 16.0 / 116.0)
+    return np.stack([116.0 * f[..., 1] - 16.0, 500.0 * (f[..., 0] - f[..., 1]), 200.0 * (f[..., 1] - f[..., 2])], axis=-1)
+
+
+def slic_superpixels(image_array, n_segments=5, sigma=2, compactness=10.0, max_num_iter=10):
+    """Label image (int, starting at 1) of ~n_segments SLIC super-pixels of an H x W x 3 uint8 array."""
+    h, w = image_array.shape[:2]
+    lab = _rgb2lab(image_array)
+    lab = np.stack([ndimage.gaussian_filter(lab[..., c], sigma, mode="nearest") for c in range(3)], axis=-1)
+    # regular grid of initial centres: ~n_segments cells of equal area
+    step = max(int(round(np.sqrt(h * w / float(n_segments)))), 1)
+    gy = np.arange(step // 2, h, step)
+    gx = np.arange(step // 2, w, step)
+    if len(gy) == 0:
+        gy = np.array([h // 2])
+    if len(gx) == 0:
+        gx = np.array([w // 2])
+    cy, cx = [a.ravel().astype(np.float64) for a in np.meshgrid(gy, gx, indexing="ij")]
+    centres = np.concatenate([lab[cy.astype(int), cx.astype(int)], cy[:, None], cx[:, None]], axis=1)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    ratio = (compactness / float(step)) ** 2                        # spatial weight of D^2 = d_lab^2 + ratio * d_xy^2
+    labels = np.zeros((h, w), np.int64)
+    for _ in range(max_num_iter):
+        best = np.full((h, w), np.inf)
+        for k, (l, a, b, y0, x0) in enumerate(centres):
+            ya, yb = max(int(y0 - 2 * step), 0), min(int(y0 + 2 * step) + 1, h)
+            xa, xb = max(int(x0 - 2 * step), 0), min(int(x0 + 2 * step) + 1, w)
+            win = lab[ya:yb, xa:xb]
+            d = ((win - np.array([l, a, b])) ** 2).sum(-1) + ratio * ((yy[ya:yb, xa:xb] - y0) ** 2 + (xx[ya:yb, xa:xb] - x0) ** 2)
+            sub = best[ya:yb, xa:xb]
+            better = d < sub
+            sub[better] = d[better]
+            labels[ya:yb, xa:xb][better] = k
+        moved = False
+        for k in range(len(centres)):
+            msk = labels == k
+            if msk.any():
+                new = np.concatenate([lab[msk].mean(0), [yy[msk].mean(), xx[msk].mean()]])
+                moved = moved or not np.allclose(new, centres[k])
+                centres[k] = new
+        if not moved:
+            break
+    # connectivity: every 4-connected component smaller than half the nominal segment joins its most frequent neighbour
+    out = np.zeros((h, w), np.int64)
+    nxt = 0
+    for k in range(len(centres)):
+        c, m = ndimage.label(labels == k)
+        out[c > 0] = c[c > 0] + nxt
+        nxt += m
+    min_size = int(0.5 * h * w / max(len(centres), 1))
+    sizes = np.bincount(out.ravel(), minlength=nxt + 1)
+    order = [lab_id for lab_id in range(1, nxt + 1) if 0 < sizes[lab_id] < min_size]
+    for lab_id in sorted(order, key=lambda i: sizes[i]):
+        msk = out == lab_id
+        ring = ndimage.binary_dilation(msk) & ~msk
+        neigh = out[ring]
+        neigh = neigh[neigh != lab_id]
+        if len(neigh):
+            target = np.bincount(neigh).argmax()
+            out[msk] = target
+            sizes[target] += sizes[lab_id]
+            sizes[lab_id] = 0
+    _, dense = np.unique(out, return_inverse=True)
+    return dense.reshape(h, w) + 1
+
+
+def label_mean_rgb(segments, image_array):
+    """skimage.color.label2rgb(segments, image, kind='avg'): every pixel takes the mean colour of its segment (uint8)."""
+    out = np.zeros_like(image_array)
+    for s in np.unique(segments):
+        msk = segments == s
+        out[msk] = image_array[msk].mean(axis=0).astype(image_array.dtype)
+    return out

@@ -21,7 +21,7 @@ from torch.utils.data import DataLoader, Dataset
 
 from . import constants
 from .dataset_generator import (check_color_similarity, check_valid_coordinates_by_container, generate_patch,
-                                get_random_coordinate, obj_mask, paste_patch, rect2poly)
+                                get_random_coordinate, label_mean_rgb, obj_mask, paste_patch, rect2poly, slic_superpixels)
 from .functional import (duplicate_filenames, get_all_subject_experiments, get_filenames, get_ground_truth,
                          get_ground_truth_filename, get_test_data_filenames)
 
@@ -124,9 +124,13 @@ class PretextTaskDataset(Dataset):
         if self.subject in constants.TEXTURES():
             self.fixed_segmentation = Image.new(size=self.imsize, mode='RGB', color='white')
         else:
-            # the reference pre-segments 'cable' with skimage SLIC super-pixels first (datasets.py:201-206); SLIC is
-            # not available here, the Canny-based mask is taken from the raw image instead
-            self.fixed_segmentation = obj_mask(first(self.subject))
+            temp = first(self.subject)
+            if self.subject == 'cable':
+                # datasets.py:201-206: SLIC super-pixels (5 segments, sigma 2, Lab) painted with their mean colours first
+                # (scikit-image is absent: dataset_generator.slic_superpixels restates the published algorithm, unpinned)
+                arr = np.array(temp)
+                temp = Image.fromarray(label_mean_rgb(slic_superpixels(arr, n_segments=5, sigma=2), arr)).convert('RGB')
+            self.fixed_segmentation = obj_mask(temp)
 
     # -- one synthetic defect, PIL back-end --
     def _defect_source(self, cutting, area_ratio, aspect_ratio):

@@ -167,3 +167,31 @@ def test_sample_defect_draws_like_getitem(golden, tmp_path):
             assert got == want, (subject, patch, s, y)
             checked += 1
     assert checked == 48
+
+
+def test_cable_slic_presegmentation(tmp_path):
+    """'cable' (datasets.py:201-206): SLIC super-pixels + mean colours before the object mask.  scikit-image is absent, so the
+    restated SLIC is held to the algorithm's properties: a handful of labels starting at 1, every label 4-connected, two
+    flat colour halves separated exactly, determinism; and the dataset builds its fixed mask through it."""
+    from scipy import ndimage
+    from self_supervised import dataset_generator as dg, datasets
+    img = np.zeros((64, 64, 3), np.uint8)
+    img[:, :32] = (200, 40, 40)
+    img[:, 32:] = (30, 60, 210)
+    seg = dg.slic_superpixels(img, n_segments=5, sigma=2)
+    assert seg.min() == 1 and 2 <= seg.max() <= 12
+    for s in np.unique(seg):
+        assert ndimage.label(seg == s)[1] == 1, "a super-pixel must be connected"
+    left, right = set(np.unique(seg[:, :28]).tolist()), set(np.unique(seg[:, 36:]).tolist())
+    assert not (left & right), "super-pixels must not straddle the colour edge"
+    assert np.array_equal(seg, dg.slic_superpixels(img, n_segments=5, sigma=2))
+    avg = dg.label_mean_rgb(seg, img)
+    assert avg.shape == img.shape and np.abs(avg[:, :24].astype(int) - (200, 40, 40)).max() <= 12
+    root = make_tree(str(tmp_path / "data"), categories=("cable", "carpet"), n_train=3, n_test_good=1, n_test_bad=1, size=96)
+    names = np.array(sorted(os.path.join(root, "cable", "train/good", f) for f in os.listdir(os.path.join(root, "cable", "train/good"))))
+    ds = datasets.PretextTaskDataset("cable", names, imsize=(64, 64), transform=None, dataset_root=root)
+    m = np.array(ds.fixed_segmentation.convert("1"))
+    assert m.shape == (64, 64) and 0 < m.sum() < 64 * 64
+    random.seed(0); np.random.seed(0); torch.manual_seed(0)
+    x, y, o = ds[0]
+    assert x.size == (64, 64) and y in (0, 1, 2, 3)
