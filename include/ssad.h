@@ -167,12 +167,13 @@ int ssad_conv_wgrad_bf16(const float* dy, const float* x, float* slab, int split
 /* Halo-tile direct convolution for the 64 -> 64 channel 3x3 / stride 1 / pad 1 layers (torchvision BasicBlock conv3x3 of
  * ResNet-18 layer1, models.py:224 of the reference under trainer.fit, and their input gradients -- call it with
  * ssad_flip_transpose_weight(w) and dy): out = conv(T(in)) (+ residual), NHWC fp32, OHWI weights, exact fp32 MFMA.
+ * res_mask (optional, with residual): nibble mask of ssad_bn_apply_fwd_mask -- only the masked elements of the residual are added.
  * T = identity, or relu((x - tr_mean) * tr_invstd * tr_gamma + tr_beta) per input channel (the train-mode BatchNorm + ReLU of
  * the producing layer, applied while the input tile is staged); `emit` (optional) receives T(in).  stats_ws != NULL: also
  * the train-mode BatchNorm statistics of the output (ssad_conv3x3_c64_stats_rows(N, H, W) * 128 doubles of workspace),
  * mean / invstd / running statistics as ssad_conv_igemm_fwd_stats produces them. */
 int64_t ssad_conv3x3_c64_stats_rows(int64_t N, int H, int W);
-int ssad_conv3x3_c64(const float* in, const float* w_ohwi, float* out, const float* residual, const float* tr_mean,
+int ssad_conv3x3_c64(const float* in, const float* w_ohwi, float* out, const float* residual, const uint8_t* res_mask, const float* tr_mean,
                      const float* tr_invstd, const float* tr_gamma, const float* tr_beta, float* emit, int64_t N, int H, int W,
                      double* stats_ws, float eps, float momentum, float* mean, float* invstd, float* running_mean,
                      float* running_var, void* stream);
@@ -227,6 +228,20 @@ int ssad_bn_bwd_reduce(const float* dy, const float* yact, const float* z, const
 int ssad_bn_apply_bwd(const float* dy, const float* yact, const float* z, const float* mean, const float* invstd,
                       const float* gamma, const float* dbeta, const float* dgamma, float* dz, float* dres, int64_t R, int C,
                       int eval_mode, void* stream);
+/* Residual blocks without the saved-activation reads: ssad_bn_apply_fwd_mask also writes the final ReLU's active set as a
+ * nibble mask (one byte per channel quad, bit k = channel 4q+k positive: 1/16 of the activation's bytes); the backward
+ * reductions / apply take g = dy * mask from it (mask4 NULL: no ReLU), and the gradient of the identity branch -- dy under the
+ * same mask -- is applied by the consumer (ssad_conv_igemm_dgrad_masked, ssad_conv3x3_c64 res_mask) instead of being stored.
+ * Replaces the same autograd nodes as ssad_bn_apply_fwd / _bwd_reduce / _apply_bwd (torchvision BasicBlock bn2 + add + relu). */
+int ssad_bn_apply_fwd_mask(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                           const float* residual, float* y, uint8_t* mask4, int64_t R, int C, int relu, void* stream);
+int ssad_bn_bwd_reduce_mask(const float* dy, const uint8_t* mask4, const float* z, const float* mean, const float* invstd,
+                            float* dbeta, float* dgamma, int64_t R, int C, double* workspace, void* stream);
+int ssad_bn_apply_bwd_mask(const float* dy, const uint8_t* mask4, const float* z, const float* mean, const float* invstd,
+                           const float* gamma, const float* dbeta, const float* dgamma, float* dz, int64_t R, int C, void* stream);
+int ssad_conv_igemm_dgrad_masked(const float* dy, const float* w_flipT, float* dx, const float* residual, const uint8_t* res_mask,
+                                 int64_t N, int Hy, int Wy, int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride, int pad,
+                                 void* stream);
 /* The same two calls for a BatchNorm + ReLU with NO residual in between (conv1 of a BasicBlock, the stem, the head's
  * Linear+BN+ReLU): the ReLU mask is recomputed as (z - mean) * invstd * gamma + beta > 0 -- the expression the forward
  * evaluated -- so the saved activation is not read again. */

@@ -32,7 +32,8 @@ struct C64Params {
     const float* in;          // [N][H][W][64]
     const float* wt;          // [64][3][3][64]  (OHWI)
     float* out;               // [N][H][W][64]
-    const float* residual;    // optional, added to the output
+    const float* residual;    // optional, added to the output ...
+    const uint8_t* res_mask;  // ... under this nibble mask when given (one byte per channel quad, bit k = keep channel 4q+k)
     const float* tr_mean;     // optional input transform: x <- relu((x - mean) * invstd * gamma + beta)
     const float* tr_invstd;
     const float* tr_gamma;
@@ -181,6 +182,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
             o[q] = ok ? (((int64_t)n * p.H + y) * p.W + x) * C + c4 * 4 : -1;
             f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
             rs[q] = (ok && p.residual) ? *(const f32x4*)(p.residual + o[q]) : z4;
+            if (ok && p.res_mask) {
+                const unsigned mk = p.res_mask[o[q] >> 2];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) rs[q][k] = (mk >> k) & 1u ? rs[q][k] : 0.f;
+            }
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -219,12 +225,14 @@ extern "C" int64_t ssad_conv3x3_c64_stats_rows(int64_t N, int H, int W) {
     return N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
 }
 
-// out = conv3x3(pad 1, stride 1)(T(in)) (+ residual), 64 -> 64 channels, NHWC fp32, OHWI weights.
+// out = conv3x3(pad 1, stride 1)(T(in)) (+ residual [* res_mask]), 64 -> 64 channels, NHWC fp32, OHWI weights.
+// res_mask (optional): nibble mask of ssad_bn_apply_fwd_mask -- the residual is the gradient of a ReLU output and only its
+// active elements flow into the identity branch (the masked copy is never materialised).
 // T = identity, or relu((x - tr_mean) * tr_invstd * tr_gamma + tr_beta) per input channel when tr_mean != NULL (then
 // `emit`, if given, receives T(in): the activation the weight-gradient kernel of this layer needs).
 // stats_ws != NULL: train-mode BatchNorm statistics of the output (ssad_conv3x3_c64_stats_rows(N, H, W) * 2 * 64 doubles
 // of workspace), finalised exactly as ssad_conv_igemm_fwd_stats does.
-extern "C" int ssad_conv3x3_c64(const float* in, const float* w_ohwi, float* out, const float* residual, const float* tr_mean,
+extern "C" int ssad_conv3x3_c64(const float* in, const float* w_ohwi, float* out, const float* residual, const uint8_t* res_mask, const float* tr_mean,
                                 const float* tr_invstd, const float* tr_gamma, const float* tr_beta, float* emit, int64_t N,
                                 int H, int W, double* stats_ws, float eps, float momentum, float* mean, float* invstd,
                                 float* running_mean, float* running_var, void* stream) {
@@ -233,7 +241,8 @@ extern "C" int ssad_conv3x3_c64(const float* in, const float* w_ohwi, float* out
     SSAD_CHECK_ARG(!emit || tr_mean, "emit without an input transform");
     SSAD_CHECK_ARG(!stats_ws || (mean && invstd), "statistics need mean / invstd outputs");
     C64Params p;
-    p.in = in; p.wt = w_ohwi; p.out = out; p.residual = residual;
+    SSAD_CHECK_ARG(!res_mask || residual, "residual mask without a residual");
+    p.in = in; p.wt = w_ohwi; p.out = out; p.residual = residual; p.res_mask = res_mask;
     p.tr_mean = tr_mean; p.tr_invstd = tr_invstd; p.tr_gamma = tr_gamma; p.tr_beta = tr_beta; p.emit = emit;
     p.stats = stats_ws;
     p.N = (int)N; p.H = H; p.W = W;

@@ -35,6 +35,7 @@ struct ConvParams {
     const float* scale;
     const float* shift;
     const float* residual;
+    const uint8_t* res_mask;   // optional nibble mask on the residual (one byte per channel quad of an output row)
     int64_t M;          // N*Ho*Wo
     int64_t N;          // samples
     int H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, relu;
@@ -505,6 +506,11 @@ void conv_igemm_f32_kernel(ConvParams p) {
             }
             o[q] = ok ? row * p.Cout + col : -1;
             res[q] = *(const f32x4*)((aligned && ok && p.residual) ? p.residual + o[q] : zero);
+            if (aligned && ok && p.res_mask) {
+                const unsigned mk = p.res_mask[o[q] >> 2];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) res[q][k] = (mk >> k) & 1u ? res[q][k] : 0.f;
+            }
         }
 #pragma unroll
         for (int q = 0; q < NPASS; ++q) {
@@ -633,7 +639,7 @@ int conv_fwd_impl(const float* in, const float* w_ohwi, float* out, const float*
     SSAD_CHECK_ARG(Cin % KALIGN == 0, "Cin must be a multiple of 32");
     SSAD_CHECK_ARG(KH > 0 && KW > 0 && stride > 0 && pad >= 0 && KH * KW <= 32, "bad filter geometry (<= 32 taps)");
     ConvParams p;
-    p.in = in; p.wt = w_ohwi; p.out = out; p.scale = scale; p.shift = shift; p.residual = residual;
+    p.in = in; p.wt = w_ohwi; p.out = out; p.scale = scale; p.shift = shift; p.residual = residual; p.res_mask = nullptr;
     p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.relu = relu;
     p.Ho = (H + 2 * pad - KH) / stride + 1;
     p.Wo = (W + 2 * pad - KW) / stride + 1;
@@ -742,7 +748,7 @@ extern "C" int ssad_conv_igemm_fwd_hwnc(const float* in, const float* w_ohwi, fl
 // same gather-GEMM with k = (ky', kx', co), numerator row = iy - (KH-1-pad) + ky'.
 static int dgrad_impl(const float* dy, const float* w_flipT, float* dx, const float* residual, int64_t N,
                                      int Hy, int Wy, int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride,
-                                     int pad, void* stream, int bf16) {
+                                     int pad, void* stream, int bf16, const uint8_t* res_mask = nullptr) {
     SSAD_CHECK_ARG(dy && w_flipT && dx, "null pointer");
     SSAD_CHECK_ARG(N > 0 && Hy > 0 && Wy > 0 && Hx > 0 && Wx > 0 && Cin > 0 && Cout > 0, "empty shape");
     SSAD_CHECK_ARG(Cout % KALIGN == 0, "Cout (the contraction) must be a multiple of 32");
@@ -751,7 +757,8 @@ static int dgrad_impl(const float* dy, const float* w_flipT, float* dx, const fl
     SSAD_CHECK_ARG((Hx + 2 * pad - KH) / stride + 1 == Hy && (Wx + 2 * pad - KW) / stride + 1 == Wy, "dy/dx sizes disagree");
     SSAD_CHECK_ARG(KH == KW && KH * KW <= 32, "square filters with at most 32 taps only");
     ConvParams p;
-    p.in = dy; p.wt = w_flipT; p.out = dx; p.scale = nullptr; p.shift = nullptr; p.residual = residual;
+    SSAD_CHECK_ARG(!res_mask || (residual && Cin % 4 == 0), "residual mask needs a residual and Cin % 4 == 0");
+    p.in = dy; p.wt = w_flipT; p.out = dx; p.scale = nullptr; p.shift = nullptr; p.residual = residual; p.res_mask = res_mask;
     p.H = Hy; p.W = Wy; p.Cin = Cout; p.Cout = Cin; p.KH = KH; p.KW = KW; p.relu = 0;
     p.stride = 1; p.pad = KH - 1 - pad; p.N = N; p.hwnc = 0;
     p.Ho = Hx; p.Wo = Wx; p.stats = nullptr;
@@ -781,6 +788,15 @@ extern "C" int ssad_conv_igemm_dgrad(const float* dy, const float* w_flipT, floa
                                      int Hy, int Wy, int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride,
                                      int pad, void* stream) {
     return dgrad_impl(dy, w_flipT, dx, residual, N, Hy, Wy, Cout, Hx, Wx, Cin, KH, KW, stride, pad, stream, 0);
+}
+
+// dgrad with the residual taken under a nibble mask (ssad_bn_apply_fwd_mask): dx = dgrad(dy) + residual * mask.  The
+// residual is the gradient of a residual block's output and the mask the active set of the block's final ReLU, so the masked
+// gradient of the identity branch is formed here instead of being written and re-read as a tensor of its own.
+extern "C" int ssad_conv_igemm_dgrad_masked(const float* dy, const float* w_flipT, float* dx, const float* residual,
+                                            const uint8_t* res_mask, int64_t N, int Hy, int Wy, int Cout, int Hx, int Wx, int Cin,
+                                            int KH, int KW, int stride, int pad, void* stream) {
+    return dgrad_impl(dy, w_flipT, dx, residual, N, Hy, Wy, Cout, Hx, Wx, Cin, KH, KW, stride, pad, stream, 0, res_mask);
 }
 
 extern "C" int ssad_conv_igemm_dgrad_bf16(const float* dy, const float* w_flipT, float* dx, const float* residual, int64_t N,

@@ -27,11 +27,14 @@ static inline ColReduce col_geom(int C) {
 // mode 1: g = dy * (yact > 0 if yact) ; s0 = sum g ; s1 = sum g * (z - mean) * invstd   (z may be null -> s1 = 0)
 //         mask source: yact (the saved activation) or, when zmask_gamma is given (no residual fed the ReLU), the
 //         sign of (z - mean) * invstd * gamma + beta recomputed from z -- one tensor less to read
+//         or mask4: one byte per channel quad, bit k = "the ReLU output of channel 4q+k was positive" (written by the forward
+//         BatchNorm apply: 1/16 of the bytes of the activation it stands for)
 template <int MODE>
 __global__ void col_reduce_kernel(const float* __restrict__ a, const float* __restrict__ yact, const float* __restrict__ z,
                                   const float* __restrict__ mean, const float* __restrict__ invstd,
                                   const float* __restrict__ zmask_gamma, const float* __restrict__ zmask_beta,
-                                  double* __restrict__ partial, int64_t R, int C, int TC, int RL, int rows_per_block) {
+                                  double* __restrict__ partial, int64_t R, int C, int TC, int RL, int rows_per_block,
+                                  const uint8_t* __restrict__ mask4 = nullptr) {
     __shared__ double sh[2][256][4];
     const int tid = threadIdx.x;
     const int tx = tid % TC, ty = tid / TC;
@@ -48,12 +51,14 @@ __global__ void col_reduce_kernel(const float* __restrict__ a, const float* __re
         constexpr int U = 4;
         for (int64_t row = rb + ty; row < re; row += (int64_t)U * RL) {
             f32x4 v[U], ya[U], zz[U];
+            unsigned mk[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t rw = row + (int64_t)u * RL;
                 const int64_t o = (rw < re ? rw : rb + ty) * C4 + cq;       // clamp: tail rows re-read a valid row ...
                 v[u] = ((const f32x4*)a)[o];
                 if (MODE == 1 && yact) ya[u] = ((const f32x4*)yact)[o];
+                if (MODE == 1 && mask4) mk[u] = mask4[o];
                 if (MODE == 1 && z) zz[u] = ((const f32x4*)z)[o];
             }
 #pragma unroll
@@ -66,6 +71,9 @@ __global__ void col_reduce_kernel(const float* __restrict__ a, const float* __re
                     if (yact) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) v[u][k] = ya[u][k] > 0.f ? v[u][k] : 0.f;
+                    } else if (mask4) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[u][k] = (mk[u] >> k) & 1u ? v[u][k] : 0.f;
                     } else if (zmask_gamma) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) v[u][k] = (zz[u][k] - mu[k]) * is[k] * mg[k] + mb[k] > 0.f ? v[u][k] : 0.f;
@@ -150,7 +158,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
 // y = (z - mean) * invstd * gamma + beta (+ res) (relu)
 __global__ void bn_apply_fwd_kernel(const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                    const float* __restrict__ res, float* __restrict__ y, int64_t total4, int C4, int relu) {
+                                    const float* __restrict__ res, float* __restrict__ y, int64_t total4, int C4, int relu,
+                                    uint8_t* __restrict__ mask4 = nullptr) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
         const int cq = (int)(i % C4);
         const f32x4 mu = ((const f32x4*)mean)[cq], is = ((const f32x4*)invstd)[cq];
@@ -163,6 +172,7 @@ __global__ void bn_apply_fwd_kernel(const float* __restrict__ z, const float* __
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] += rr[k];
         }
+        if (mask4) mask4[i] = (uint8_t)((v[0] > 0.f) | ((v[1] > 0.f) << 1) | ((v[2] > 0.f) << 2) | ((v[3] > 0.f) << 3));
         if (relu) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
@@ -177,7 +187,8 @@ __global__ void bn_apply_bwd_kernel(const float* __restrict__ dy, const float* _
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ gamma, const float* __restrict__ dbeta,
                                     const float* __restrict__ dgamma, float* __restrict__ dz, float* __restrict__ dres,
-                                    int64_t total4, int C4, float invR, int eval_mode, const float* __restrict__ zmask_beta) {
+                                    int64_t total4, int C4, float invR, int eval_mode, const float* __restrict__ zmask_beta,
+                                    const uint8_t* __restrict__ mask4 = nullptr) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
         const int cq = (int)(i % C4);
         const f32x4 mu = ((const f32x4*)mean)[cq], is = ((const f32x4*)invstd)[cq], ga = ((const f32x4*)gamma)[cq];
@@ -186,6 +197,10 @@ __global__ void bn_apply_bwd_kernel(const float* __restrict__ dy, const float* _
             const f32x4 ya = ((const f32x4*)yact)[i];
 #pragma unroll
             for (int k = 0; k < 4; ++k) g[k] = ya[k] > 0.f ? g[k] : 0.f;
+        } else if (mask4) {
+            const unsigned mk = mask4[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g[k] = (mk >> k) & 1u ? g[k] : 0.f;
         } else if (zmask_beta) {                 // ReLU mask recomputed from z (layer without residual)
             const f32x4 zb = ((const f32x4*)zmask_beta)[cq];
             const f32x4 zm = ((const f32x4*)z)[i];
@@ -544,7 +559,7 @@ extern "C" int64_t ssad_colreduce_workspace(int64_t R, int C) {
 
 static int launch_col_reduce(int mode, const float* a, const float* yact, const float* z, const float* mean,
                              const float* invstd, double* ws, int64_t R, int C, int* nblk_out, hipStream_t st,
-                             const float* zg = nullptr, const float* zb = nullptr) {
+                             const float* zg = nullptr, const float* zb = nullptr, const uint8_t* mask4 = nullptr) {
     ColReduce g = col_geom(C);
     int64_t nblk = cdiv64(R, (int64_t)g.RL * 32);
     if (nblk > 2048) nblk = 2048;
@@ -553,9 +568,11 @@ static int launch_col_reduce(int mode, const float* a, const float* yact, const 
     int gx = (C / 4 + g.TC - 1) / g.TC;
     dim3 grid(gx, (unsigned)nblk);
     if (mode == 0)
-        hipLaunchKernelGGL(col_reduce_kernel<0>, grid, dim3(256), 0, st, a, yact, z, mean, invstd, zg, zb, ws, R, C, g.TC, g.RL, rows_per_block);
+        hipLaunchKernelGGL(col_reduce_kernel<0>, grid, dim3(256), 0, st, a, yact, z, mean, invstd, zg, zb, ws, R, C, g.TC, g.RL, rows_per_block,
+                           (const uint8_t*)nullptr);
     else
-        hipLaunchKernelGGL(col_reduce_kernel<1>, grid, dim3(256), 0, st, a, yact, z, mean, invstd, zg, zb, ws, R, C, g.TC, g.RL, rows_per_block);
+        hipLaunchKernelGGL(col_reduce_kernel<1>, grid, dim3(256), 0, st, a, yact, z, mean, invstd, zg, zb, ws, R, C, g.TC, g.RL, rows_per_block,
+                           mask4);
     *nblk_out = (int)nblk;
     return 0;
 }
@@ -584,7 +601,19 @@ extern "C" int ssad_bn_apply_fwd(const float* z, const float* mean, const float*
     SSAD_CHECK_ARG(z && mean && invstd && gamma && beta && y && R > 0 && C > 0 && C % 4 == 0, "bad argument");
     const int64_t total4 = R * (C / 4);
     hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, z, mean, invstd, gamma,
-                       beta, residual, y, total4, C / 4, relu);
+                       beta, residual, y, total4, C / 4, relu, (uint8_t*)nullptr);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+// The same apply, also leaving the ReLU's active set as a nibble mask (one byte per channel quad, bit k = output of channel
+// 4q+k positive): the backward pass of a residual block reads 1/16 of the activation's bytes instead of the activation.
+extern "C" int ssad_bn_apply_fwd_mask(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                      const float* residual, float* y, uint8_t* mask4, int64_t R, int C, int relu, void* stream) {
+    SSAD_CHECK_ARG(z && mean && invstd && gamma && beta && y && mask4 && R > 0 && C > 0 && C % 4 == 0, "bad argument");
+    const int64_t total4 = R * (C / 4);
+    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, z, mean, invstd, gamma,
+                       beta, residual, y, total4, C / 4, relu, mask4);
     SSAD_CHECK_LAUNCH();
     return 0;
 }
@@ -592,12 +621,12 @@ extern "C" int ssad_bn_apply_fwd(const float* z, const float* mean, const float*
 // dbeta/dgamma over rows of g = dy*(yact>0); with z == NULL only dbeta (= column sums: Linear bias gradient).
 static int bn_bwd_reduce_impl(const float* dy, const float* yact, const float* z, const float* mean, const float* invstd,
                               float* dbeta, float* dgamma, int64_t R, int C, double* workspace, void* stream,
-                              const float* zg, const float* zb) {
+                              const float* zg, const float* zb, const uint8_t* mask4 = nullptr) {
     SSAD_CHECK_ARG(dy && workspace && R > 0 && C > 0 && C % 4 == 0, "bad argument");
     SSAD_CHECK_ARG(!z || (mean && invstd), "z needs mean/invstd");
     SSAD_CHECK_ARG(!zg || (z && zb && !yact), "mask-from-z needs z, gamma, beta and no yact");
     int nblk;
-    launch_col_reduce(1, dy, yact, z, mean, invstd, workspace, R, C, &nblk, (hipStream_t)stream, zg, zb);
+    launch_col_reduce(1, dy, yact, z, mean, invstd, workspace, R, C, &nblk, (hipStream_t)stream, zg, zb, mask4);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, workspace, nblk, C, dbeta,
                        z ? dgamma : nullptr);
     SSAD_CHECK_LAUNCH();
@@ -620,12 +649,13 @@ extern "C" int ssad_bn_bwd_reduce_zmask(const float* dy, const float* z, const f
 
 static int bn_apply_bwd_impl(const float* dy, const float* yact, const float* z, const float* mean, const float* invstd,
                                  const float* gamma, const float* dbeta, const float* dgamma, float* dz, float* dres,
-                                 int64_t R, int C, int eval_mode, void* stream, const float* zmask_beta) {
+                                 int64_t R, int C, int eval_mode, void* stream, const float* zmask_beta,
+                                 const uint8_t* mask4 = nullptr) {
     SSAD_CHECK_ARG(dy && mean && invstd && gamma && dz && R > 0 && C > 0 && C % 4 == 0, "bad argument");
     SSAD_CHECK_ARG(eval_mode || (z && dbeta && dgamma), "train-mode backward needs z, dbeta, dgamma");
     const int64_t total4 = R * (C / 4);
     hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, dy, yact, z, mean, invstd,
-                       gamma, dbeta, dgamma, dz, dres, total4, C / 4, 1.f / (float)R, eval_mode, zmask_beta);
+                       gamma, dbeta, dgamma, dz, dres, total4, C / 4, 1.f / (float)R, eval_mode, zmask_beta, mask4);
     SSAD_CHECK_LAUNCH();
     return 0;
 }
@@ -782,3 +812,20 @@ extern "C" int ssad_loss_scaler_update(float* scaler, float growth_factor, float
     SSAD_CHECK_LAUNCH();
     return 0;
 }
+
+// BatchNorm backward with g = dy * mask (mask4 from ssad_bn_apply_fwd_mask; NULL = no ReLU, g = dy): the two reductions,
+// then dz = gamma * invstd * (g - dbeta / R - xhat * dgamma / R).  The gradient of the identity branch is NOT written: it is
+// dy under the same mask, which the consumer applies itself (ssad_conv_igemm_dgrad_masked / ssad_conv3x3_c64).
+extern "C" int ssad_bn_bwd_reduce_mask(const float* dy, const uint8_t* mask4, const float* z, const float* mean,
+                                       const float* invstd, float* dbeta, float* dgamma, int64_t R, int C, double* workspace,
+                                       void* stream) {
+    SSAD_CHECK_ARG(z, "z required");
+    return bn_bwd_reduce_impl(dy, nullptr, z, mean, invstd, dbeta, dgamma, R, C, workspace, stream, nullptr, nullptr, mask4);
+}
+
+extern "C" int ssad_bn_apply_bwd_mask(const float* dy, const uint8_t* mask4, const float* z, const float* mean, const float* invstd,
+                                      const float* gamma, const float* dbeta, const float* dgamma, float* dz, int64_t R, int C,
+                                      void* stream) {
+    return bn_apply_bwd_impl(dy, nullptr, z, mean, invstd, gamma, dbeta, dgamma, dz, nullptr, R, C, 0, stream, nullptr, mask4);
+}
+

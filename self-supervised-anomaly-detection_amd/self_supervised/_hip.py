@@ -56,8 +56,13 @@ SIGNATURES = {
                                    _c_i, _c_fp],
     "ssad_conv_wgrad_bf16": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
     "ssad_conv3x3_c64_stats_rows": [_c_l, _c_i, _c_i],
-    "ssad_conv3x3_c64": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp, _c_f, _c_f,
+    "ssad_conv3x3_c64": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp, _c_f, _c_f,
                          _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
+    "ssad_bn_apply_fwd_mask": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp],
+    "ssad_bn_bwd_reduce_mask": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_fp, _c_fp],
+    "ssad_bn_apply_bwd_mask": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_fp],
+    "ssad_conv_igemm_dgrad_masked": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
+                                     _c_i, _c_fp],
     "ssad_wgrad3x3_halo_ok": [_c_i, _c_i, _c_i, _c_i, _c_i, _c_i],
     "ssad_wgrad3x3_halo_splits": [_c_l, _c_i, _c_i, _c_i, _c_i],
     "ssad_conv_wgrad3x3_halo": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_fp],

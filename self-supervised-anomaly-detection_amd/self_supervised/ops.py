@@ -218,7 +218,7 @@ def conv_fwd_stats(x, w_ohwi, eps, momentum, running_mean, running_var, stride=1
     return out, mean, invstd
 
 
-def conv3x3_c64(x, w_ohwi, residual=None, transform=None, emit=False, stats=None):
+def conv3x3_c64(x, w_ohwi, residual=None, transform=None, emit=False, stats=None, res_mask=None):
     """Halo-tile 3x3 / stride 1 / pad 1 convolution, 64 -> 64 channels (layer1 forward and input-gradient convs).
     x NHWC [N][H][W][64], w OHWI [64][3][3][64].  transform = (mean, invstd, gamma, beta): the input is taken through
     relu(bn(x)) while it is staged (emit=True also returns that activation).  stats = (eps, momentum, running_mean,
@@ -238,7 +238,8 @@ def conv3x3_c64(x, w_ohwi, residual=None, transform=None, emit=False, stats=None
         ws = torch.empty(lib.ssad_conv3x3_c64_stats_rows(n, h, w) * 128, device=x.device, dtype=torch.float64)
     nb = 4.0 * (x.numel() + out.numel() * (2 if residual is not None else 1) + (out.numel() if emit else 0) + w_ohwi.numel())
     _run("conv_c64_f32", 2.0 * out.numel() * 9 * 64, nb,
-         lambda: lib.ssad_conv3x3_c64(_hip.ptr(x), _hip.ptr(w_ohwi), _hip.ptr(out), _hip.ptr(residual, True), _hip.ptr(tr[0], True),
+         lambda: lib.ssad_conv3x3_c64(_hip.ptr(x), _hip.ptr(w_ohwi), _hip.ptr(out), _hip.ptr(residual, True),
+                                      res_mask.data_ptr() if res_mask is not None else None, _hip.ptr(tr[0], True),
                                       _hip.ptr(tr[1], True), _hip.ptr(tr[2], True), _hip.ptr(tr[3], True), _hip.ptr(em, True),
                                       n, h, w, ws.data_ptr() if ws is not None else None, eps, mom, _hip.ptr(mean, True),
                                       _hip.ptr(invstd, True), _hip.ptr(rm, True), _hip.ptr(rv, True), _hip.stream()))
@@ -322,11 +323,19 @@ def flip_transpose_weight(w_ohwi):
     return out
 
 
-def conv_dgrad(dy, w_flipT, x_shape, stride, pad, residual=None, bf16=False):
-    """dy NHWC [N][Hy][Wy][Cout]; w_flipT [Cin][KH][KW][Cout] -> dx NHWC of x_shape (+ residual)."""
+def conv_dgrad(dy, w_flipT, x_shape, stride, pad, residual=None, bf16=False, res_mask=None):
+    """dy NHWC [N][Hy][Wy][Cout]; w_flipT [Cin][KH][KW][Cout] -> dx NHWC of x_shape (+ residual [under res_mask])."""
     n, hy, wy, cout = dy.shape
     cin, kh, kw, _ = w_flipT.shape
     dx = _new(tuple(x_shape), dy)
+    if res_mask is not None:
+        assert not bf16 and residual is not None
+        _run("conv_igemm_f32", 2.0 * dx.numel() * kh * kw * cout / (stride * stride),
+             4.0 * (dy.numel() + dx.numel() * 2 + w_flipT.numel()),
+             lambda: _hip.lib().ssad_conv_igemm_dgrad_masked(_hip.ptr(dy), _hip.ptr(w_flipT), _hip.ptr(dx), _hip.ptr(residual),
+                                                             res_mask.data_ptr(), n, hy, wy, cout, x_shape[1], x_shape[2], cin, kh,
+                                                             kw, stride, pad, _hip.stream()))
+        return dx
     fn = (_hip.lib().ssad_conv_igemm_dgrad_x6 if bf16 == 6 else _hip.lib().ssad_conv_igemm_dgrad_x3 if bf16 == 3 else
           _hip.lib().ssad_conv_igemm_dgrad_f16 if bf16 == 2 else
           _hip.lib().ssad_conv_igemm_dgrad_bf16 if bf16 else _hip.lib().ssad_conv_igemm_dgrad)
@@ -562,3 +571,33 @@ def check_finite(g, scaler):
 def loss_scaler_update(scaler, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
     _hip.check(_hip.lib().ssad_loss_scaler_update(_hip.ptr(scaler), growth_factor, backoff_factor, growth_interval,
                                                   _hip.stream()))
+
+
+def bn_apply_fwd_mask(z, mean, invstd, gamma, beta, residual, relu):
+    """bn_apply_fwd that also returns the final ReLU's active set as a nibble mask (uint8 [R][C/4])."""
+    c = mean.numel()
+    y = torch.empty_like(z)
+    mask = torch.empty(z.numel() // 4, device=z.device, dtype=torch.uint8)
+    _run("bn_apply_fwd", 0.0, 4.0 * z.numel() * (3 if residual is not None else 2) + mask.numel(),
+         lambda: _hip.lib().ssad_bn_apply_fwd_mask(_hip.ptr(z), _hip.ptr(mean), _hip.ptr(invstd), _hip.ptr(gamma), _hip.ptr(beta),
+                                                   _hip.ptr(residual, True), _hip.ptr(y), mask.data_ptr(), z.numel() // c, c,
+                                                   int(relu), _hip.stream()))
+    return y, mask
+
+
+def bn_bwd_mask(dy, mask, z, mean, invstd, gamma, dbeta, dgamma):
+    """BatchNorm backward with g = dy * mask (mask None: g = dy): fills dbeta / dgamma, returns dz.  The identity-branch
+    gradient (g itself) is not materialised: consumers apply `mask` to dy (conv_dgrad / conv3x3_c64 res_mask)."""
+    c = mean.numel()
+    r = dy.numel() // c
+    ws = _colreduce_ws(r, c, dy)
+    lib = _hip.lib()
+    mp = mask.data_ptr() if mask is not None else None
+    _run("bn_bwd_reduce", 0.0, 8.0 * dy.numel() + (mask.numel() if mask is not None else 0),
+         lambda: lib.ssad_bn_bwd_reduce_mask(_hip.ptr(dy), mp, _hip.ptr(z), _hip.ptr(mean), _hip.ptr(invstd), _hip.ptr(dbeta),
+                                             _hip.ptr(dgamma), r, c, ws.data_ptr(), _hip.stream()))
+    dz = torch.empty_like(dy)
+    _run("bn_apply_bwd", 0.0, 12.0 * dy.numel() + (mask.numel() if mask is not None else 0),
+         lambda: lib.ssad_bn_apply_bwd_mask(_hip.ptr(dy), mp, _hip.ptr(z), _hip.ptr(mean), _hip.ptr(invstd), _hip.ptr(gamma),
+                                            _hip.ptr(dbeta), _hip.ptr(dgamma), _hip.ptr(dz), r, c, _hip.stream()))
+    return dz

@@ -221,12 +221,17 @@ class _Affine:
                 self.x = None
         with torch.no_grad():
             bn.num_batches_tracked += 1
-        self.z, self.y, self.res_used = z, None, False
+        self.z, self.y, self.res_used, self.mask = z, None, False, None
         return z
 
     def apply_bn(self, residual=None):
         """The BatchNorm (+ residual) (+ ReLU) of a layer whose raw output fwd_raw_c64 left in self.z."""
         a, bn = self.eng.arena, self.bn
+        if residual is not None and self.relu and self.eng.use_relu_mask():
+            # the block's final ReLU leaves its active set as a nibble mask: backward never re-reads the activation
+            y, self.mask = ops.bn_apply_fwd_mask(self.z, self.mean, self.invstd, a.w(bn.weight), a.w(bn.bias), residual, True)
+            self.res_used, self.y = True, None
+            return y
         y = ops.bn_apply_fwd(self.z, self.mean, self.invstd, a.w(bn.weight), a.w(bn.bias), residual, self.relu)
         self.res_used = residual is not None
         self.y = y if self.relu else None
@@ -240,6 +245,7 @@ class _Affine:
             return self._stem_fwd(x, w)
         self.x, self.res_used = x, residual is not None
         self.x_shape = tuple(x.shape)
+        self.mask = None
         bias = getattr(self.lin, "bias", None)
         bf = self.eng.bf16
         if bn is None:
@@ -258,8 +264,12 @@ class _Affine:
                 self.mean, self.invstd = ops.bn_stats(z, c, bn.eps, mom, bn.running_mean, bn.running_var)
             with torch.no_grad():
                 bn.num_batches_tracked += 1
-            y = ops.bn_apply_fwd(z, self.mean, self.invstd, a.w(bn.weight), a.w(bn.bias), residual, self.relu)
             self.z = z
+            if residual is not None and self.relu and self.eng.use_relu_mask():
+                y, self.mask = ops.bn_apply_fwd_mask(z, self.mean, self.invstd, a.w(bn.weight), a.w(bn.bias), residual, True)
+                self.y = None
+                return y
+            y = ops.bn_apply_fwd(z, self.mean, self.invstd, a.w(bn.weight), a.w(bn.bias), residual, self.relu)
         else:
             with torch.no_grad():
                 self.invstd = torch.rsqrt(bn.running_var + bn.eps)
@@ -273,11 +283,15 @@ class _Affine:
         self.y = y if self.relu else None
         return y
 
-    def bwd(self, dy, need_dx=True, dx_residual=None, want_dres=False):
-        """dy NHWC grad of the output.  Returns (dx or None, dres or None)."""
+    def bwd(self, dy, need_dx=True, dx_residual=None, want_dres=False, dy_mask=None, dx_res_mask=None):
+        """dy NHWC grad of the output.  Returns (dx or None, dres or None).
+        dres: the gradient of the identity branch -- a tensor, or the pair (dy, nibble mask) when the forward left the final
+        ReLU's active set as a mask (the consumer applies it: `dy_mask` of a downsample layer's bwd, `dx_res_mask` of the
+        first conv's dgrad); dy_mask: this layer's dy is to be taken under that mask."""
         a, bn = self.eng.arena, self.bn
         dres = None
         bias = getattr(self.lin, "bias", None)
+        mask = getattr(self, "mask", None)
         if bn is None:
             dz = dy
         else:
@@ -285,7 +299,15 @@ class _Affine:
             train_stats = self.z is not None
             pg = self.eng.param_grads
             wg, bg = bn.weight.requires_grad and pg, bn.bias.requires_grad and pg
-            if train_stats and self.relu and not self.res_used and not want_dres:
+            if train_stats and (dy_mask is not None or (mask is not None and want_dres)):
+                # residual block without re-reading activations: g = dy * mask inside the two BatchNorm passes
+                dbeta = a.grad(bn.bias) if bg else torch.empty(c, device=dy.device)
+                dgamma = a.grad(bn.weight) if wg else torch.empty(c, device=dy.device)
+                mk = dy_mask if dy_mask is not None else mask
+                dz = ops.bn_bwd_mask(dy, mk, self.z, self.mean, self.invstd, a.w(bn.weight), dbeta, dgamma)
+                if want_dres:
+                    dres = (dy, mk)
+            elif train_stats and self.relu and not self.res_used and not want_dres:
                 # y = relu(bn(z)) with nothing added in between: take the mask from z, skip re-reading y
                 dbeta = a.grad(bn.bias) if bg else torch.empty(c, device=dy.device)
                 dgamma = a.grad(bn.weight) if wg else torch.empty(c, device=dy.device)
@@ -326,10 +348,11 @@ class _Affine:
                 wt = torch.zeros((padc,) + tuple(w.shape[1:]), device=dz.device)
                 wt[:cout] = w
             if self.c64_ok() and dz.dim() == 4:
-                dx = ops.conv3x3_c64(dzz, ops.flip_transpose_weight(wt), residual=dx_residual)
+                dx = ops.conv3x3_c64(dzz, ops.flip_transpose_weight(wt), residual=dx_residual, res_mask=dx_res_mask)
             else:
-                dx = ops.conv_dgrad(dzz, ops.flip_transpose_weight(wt), self.x_shape, self.stride, self.pad, dx_residual, bf)
-        self.x = self.z = self.y = None
+                dx = ops.conv_dgrad(dzz, ops.flip_transpose_weight(wt), self.x_shape, self.stride, self.pad, dx_residual, bf,
+                                    res_mask=dx_res_mask)
+        self.x = self.z = self.y = self.mask = None
         return dx, dres
 
 
@@ -398,6 +421,10 @@ class TrainEngine:
             if self.ctx is not None:
                 self.ctx.__exit__(*exc)
             return False
+
+    def use_relu_mask(self):
+        """Residual blocks keep their final ReLU's active set as a nibble mask (exact fp32 path, gradients wanted)."""
+        return (not self.bf16 and self.trunk_grad and torch.is_grad_enabled() and os.environ.get("SSAD_RELU_MASK", "1") != "0")
 
     def wgrad_stream(self, *operands):
         return TrainEngine._Side(self, operands)
@@ -475,11 +502,15 @@ class TrainEngine:
         for i in range(len(self.blocks) - 1, -1, -1):
             blk = self.blocks[i]
             dz2_dx, dres = blk["c2"].bwd(dy, need_dx=True, want_dres=True)
+            masked = isinstance(dres, tuple)           # (dy, nibble mask): the identity-branch gradient, not materialised
+            rmask = None
             if blk["ds"] is not None:
-                dx_id, _ = blk["ds"].bwd(dres, need_dx=True)
+                dx_id, _ = blk["ds"].bwd(dres[0] if masked else dres, need_dx=True, dy_mask=dres[1] if masked else None)
+            elif masked:
+                dx_id, rmask = dres
             else:
                 dx_id = dres
-            dy, _ = blk["c1"].bwd(dz2_dx, need_dx=True, dx_residual=dx_id)
+            dy, _ = blk["c1"].bwd(dz2_dx, need_dx=True, dx_residual=dx_id, dx_res_mask=rmask)
             if i % 2 == 0 and i > 0:
                 prev = self.blocks[i - 1]["name"]
                 if prev in self.gap_off:
@@ -514,7 +545,7 @@ class TrainEngine:
         for d in self.blocks:
             for k in ("c1", "c2", "ds"):
                 if d[k] is not None:
-                    d[k].x = d[k].z = d[k].y = None
+                    d[k].x = d[k].z = d[k].y = d[k].mask = None
         self.stem.x = self.stem.z = self.stem.y = None
 
     def _drop_tape(self):

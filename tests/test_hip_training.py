@@ -786,3 +786,42 @@ def test_wgrad3x3_halo_kernel(dev, monkeypatch):
         monkeypatch.setenv("SSAD_WGRAD_HALO", "1")
         ops.conv_wgrad(nh(dy), nh(x), dwo, 3, 3, 1, 1, to_oihw=True)
         assert torch.equal(dwo.view(cout, cin, 3, 3), dw.view(cout, 3, 3, cin).permute(0, 3, 1, 2))
+
+
+def test_relu_mask_kernels(dev):
+    """Residual-block BatchNorm with the final ReLU's active set kept as a nibble mask: forward output and mask, the two
+    backward passes and the masked residual of both dgrad kernels equal the saved-activation path bit for bit."""
+    from self_supervised import ops
+    g = torch.Generator().manual_seed(3)
+    for (n, h, c) in [(3, 10, 64), (2, 7, 128), (40, 1, 512)]:
+        z = (torch.randn(n, h, h, c, generator=g) * 1.5 + 0.2).to(dev)
+        res = torch.randn(n, h, h, c, generator=g).to(dev)
+        gamma, beta = (torch.rand(c, generator=g) + 0.5).to(dev), (torch.randn(c, generator=g) * 0.3).to(dev)
+        mean, invstd = ops.bn_stats(z, c, 1e-5, 0.1, None, None)
+        y0 = ops.bn_apply_fwd(z, mean, invstd, gamma, beta, res, True)
+        y1, mask = ops.bn_apply_fwd_mask(z, mean, invstd, gamma, beta, res, True)
+        assert torch.equal(y0, y1)
+        bits = torch.stack([(mask.view(-1, 1) >> k) & 1 for k in range(4)], 1).view(-1).bool()
+        assert torch.equal(bits, (y0 > 0).view(-1))
+        dy = torch.randn(z.shape, generator=g).to(dev)
+        db0, dg0 = torch.empty(c, device=dev), torch.empty(c, device=dev)
+        ops.bn_bwd_reduce(dy, y0, z, mean, invstd, db0, dg0, c)
+        dz0, dres0 = ops.bn_apply_bwd(dy, y0, z, mean, invstd, gamma, db0, dg0, True)
+        db1, dg1 = torch.empty(c, device=dev), torch.empty(c, device=dev)
+        dz1 = ops.bn_bwd_mask(dy, mask, z, mean, invstd, gamma, db1, dg1)
+        assert torch.equal(db0, db1) and torch.equal(dg0, dg1) and torch.equal(dz0, dz1)
+        # no ReLU (downsample BatchNorm) fed by a masked gradient == the same fed by the materialised dres
+        db2, dg2 = torch.empty(c, device=dev), torch.empty(c, device=dev)
+        ops.bn_bwd_reduce(dres0, None, z, mean, invstd, db2, dg2, c)
+        dz2, _ = ops.bn_apply_bwd(dres0, None, z, mean, invstd, gamma, db2, dg2, False)
+        db3, dg3 = torch.empty(c, device=dev), torch.empty(c, device=dev)
+        dz3 = ops.bn_bwd_mask(dy, mask, z, mean, invstd, gamma, db3, dg3)
+        assert torch.equal(db2, db3) and torch.equal(dz2, dz3)
+        # masked residual in the input-gradient kernels
+        w = (torch.randn(c, 3, 3, c, generator=g) / (9 * c) ** 0.5).to(dev)
+        up = torch.randn(z.shape, generator=g).to(dev)
+        a = ops.conv_dgrad(up, w, z.shape, 1, 1, dres0)
+        b = ops.conv_dgrad(up, w, z.shape, 1, 1, dy, res_mask=mask)
+        assert torch.equal(a, b)
+        if c == 64:
+            assert torch.equal(ops.conv3x3_c64(up, w, residual=dres0), ops.conv3x3_c64(up, w, residual=dy, res_mask=mask))
