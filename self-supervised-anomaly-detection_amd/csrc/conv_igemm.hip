@@ -626,8 +626,14 @@ int dispatch(const ConvParams& p, hipStream_t st) {
     // small problems (batch 32-96 on the 8x8 / 16x16 maps of layer3 / layer4): 128x128 tiles leave CUs idle -- fewer than
     // ~1.5 workgroups per CU -- so the 128x64 tile doubles the grid (measured at batch 96 / 32: see DESIGN.md)
     static const int small_min = getenv("SSAD_CONV_SMALL_GRID") ? atoi(getenv("SSAD_CONV_SMALL_GRID")) : 500;
-    if (!POS && TS == 1 && cdiv64(p.M, 128) * ((p.Cout + 127) / 128) < small_min)
-        return launch<128, 64, 1, 2, 32, TS, POS>(p, st);
+    // ... and when even that leaves most CUs without a workgroup (batch 32 on the 8x8 maps of layer4: 128 workgroups of
+    // 144 K-steps each) the 64x64 tile doubles the grid again (measured at batch 32: layer4 3x3 0.204 -> see DESIGN.md)
+    static const int tiny_min = getenv("SSAD_CONV_TINY_GRID") ? atoi(getenv("SSAD_CONV_TINY_GRID")) : 200;
+    if (!POS) {
+        const int64_t g128 = cdiv64(p.M, 128) * ((p.Cout + 127) / 128);
+        if (cdiv64(p.M, 128) * ((p.Cout + 63) / 64) < tiny_min && p.M > 128) return launch<64, 64, 1, 1, 32, TS, POS>(p, st);
+        if (g128 < small_min) return launch<128, 64, 1, 2, 32, TS, POS>(p, st);
+    }
     return launch<128, 128, 2, 2, 32, TS, POS>(p, st);
 }
 
@@ -716,7 +722,7 @@ extern "C" int ssad_conv_igemm_fwd(const float* in, const float* w_ohwi, float* 
 // double-precision column sums of its tile in `workspace` (ssad_conv_stats_workspace doubles) and the finalize kernel of
 // ssad_bn_stats turns them into mean / invstd / running statistics.  Saves the separate read of z.
 extern "C" int64_t ssad_conv_stats_workspace(int64_t N, int Ho, int Wo, int Cout) {
-    return cdiv64(N * Ho * Wo, 128) * 2 * Cout;          // 128 = the smallest row tile any instantiation uses
+    return cdiv64(N * Ho * Wo, 64) * 2 * Cout;           // 64 = the smallest row tile any instantiation uses
 }
 
 extern "C" int ssad_conv_igemm_fwd_stats(const float* in, const float* w_ohwi, float* out, int64_t N, int H, int W, int Cin,

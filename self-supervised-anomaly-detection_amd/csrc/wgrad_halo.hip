@@ -119,7 +119,10 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(WgHaloParams p) {
 static int halo_splits(int64_t ntiles, int npairs) {
     // 512 workgroups = two per CU in ONE round of equal work (no tail), at least 4 tiles per workgroup; every split adds one
     // slab (written once, read once by the reduction: 75 MB per layer at 512 workgroups)
+    // (a workgroup with fewer than 16 tiles spends as long on its slab as on its MFMAs: small batches take one workgroup per
+    // CU instead -- a single wave per SIMD still keeps the fp32 matrix pipe ~85 % busy)
     int64_t s = (512 + npairs - 1) / npairs;
+    if (s * 16 > ntiles) s = (256 + npairs - 1) / npairs;
     if (s > ntiles / 4) s = ntiles / 4;
     if (s < 1) s = 1;
     return (int)s;

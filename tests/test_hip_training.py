@@ -436,6 +436,17 @@ def test_rccl_bucketed_allreduce_single_rank(dev, seeded_sd):
         w0 = dict(m0.named_parameters())["classifier.weight"].detach().flatten()
         w1 = dict(m1.named_parameters())["classifier.weight"].detach().flatten()
         assert torch.allclose((p_init - w1) * 2 - 0.03 * 0.0005 * p_init, (p_init - w0), atol=1e-7)
+        # hipGraph segments with REAL RCCL all-reduces issued between them (capture on step 2, replay on 3-4) == the same
+        # steps launched eagerly
+        m2 = PeraNet(); m2.load_state_dict(seeded_sd); m2.to(dev).train(); m2.unfreeze()
+        s2 = training.DataParallelStep(m2, lr=0.03, world_size=2, graph=False)
+        s2.step(x, y)
+        for _ in range(3):
+            s1.step(x, y); s2.step(x, y)
+        torch.cuda.synchronize()
+        plan = next(iter(s1._plans.values()))
+        assert sum(1 for o in plan["ops"] if o[0] == "allreduce") >= 2 and sum(1 for o in plan["ops"] if o[0] == "graph") >= 3
+        assert torch.equal(s1.eng.arena.p, s2.eng.arena.p) and torch.equal(s1.eng.arena.m, s2.eng.arena.m)
     finally:
         dist.destroy_process_group()
 
