@@ -137,7 +137,12 @@ def lib():
     return _lib
 
 
+LAUNCHES = 0          # C-ABI calls made so far (graph capture uses it to recognise segments that recorded nothing)
+
+
 def check(rc):
+    global LAUNCHES
+    LAUNCHES += 1
     if rc != 0:
         raise HipExtensionError(lib().ssad_last_error().decode())
 

@@ -18,7 +18,7 @@ import torch
 import torch.distributed as dist
 from torch import nn
 
-from . import engine, ops
+from . import _hip, engine, ops
 
 BN_TYPES = (nn.BatchNorm1d, nn.BatchNorm2d)
 
@@ -836,15 +836,20 @@ class DataParallelStep:
         pool = torch.cuda.graph_pool_handle()
         stream = torch.cuda.Stream()
         multi = self.world > 1
-        seg = {"g": None}
+        seg = {"g": None, "mark": 0}
 
         def begin():
             seg["g"] = torch.cuda.CUDAGraph()
+            seg["mark"] = _hip.LAUNCHES
             seg["g"].capture_begin(pool=pool)
 
         def end():
-            seg["g"].capture_end()
-            plan["ops"].append(("graph", seg["g"]))
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")            # an empty segment (two buckets back to back) is dropped below
+                seg["g"].capture_end()
+            if _hip.LAUNCHES != seg["mark"]:
+                plan["ops"].append(("graph", seg["g"]))
 
         class _Recorder:          # a final bucket / the wait before SGD ends the current segment
             def bucket(_, lo, hi):
