@@ -33,6 +33,7 @@ struct StemParams {
     int64_t total_tiles;
     int64_t Nsamp;
     int hwnc;             // write [Ho][Wo][Nsamp][64] instead of [Nsamp][Ho][Wo][64]
+    double* stats;        // optional [gridDim.x][2][64]: per-workgroup sums / sums of squares of the raw outputs it wrote
 };
 
 __global__ __launch_bounds__(256, 2) void stem_conv7x7_kernel(StemParams p) {
@@ -51,6 +52,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv7x7_kernel(StemParams p) {
         sh[j] = p.shift ? p.shift[j * 32 + r] : 0.f;
     }
 
+    double st0[2] = {0.0, 0.0}, st1[2] = {0.0, 0.0};      // train-mode BatchNorm statistics of this lane's channels
     const int tiles_per_sample = p.tiles_y * p.tiles_x;
     for (int64_t t = blockIdx.x; t < p.total_tiles; t += gridDim.x) {
         const int64_t n = t / tiles_per_sample;
@@ -117,6 +119,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv7x7_kernel(StemParams p) {
                 for (int e = 0; e < 16; ++e) {
                     int ox = tx0 + (e & 3) + 8 * (e >> 2) + 4 * h;
                     if (ox < p.Wo) {
+                        if (p.stats) { const double a = (double)acc[i][j][e]; st0[j] += a; st1[j] += a * a; }
                         float v = acc[i][j][e] * sc[j] + sh[j];
                         if (p.relu) v = fmaxf(v, 0.f);
                         const int64_t pix = p.hwnc ? ((int64_t)oy * p.Wo + ox) * p.Nsamp + n : (n * p.Ho + oy) * p.Wo + ox;
@@ -124,6 +127,26 @@ __global__ __launch_bounds__(256, 2) void stem_conv7x7_kernel(StemParams p) {
                     }
                 }
             }
+        }
+    }
+    if (p.stats) {
+        // lane halves -> one value per channel per wave, the four waves in a fixed order through LDS (the weights are dead)
+        __syncthreads();
+        double* S = (double*)lds;                    // [4 waves][2][64]
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            st0[j] += __shfl_xor(st0[j], 32);
+            st1[j] += __shfl_xor(st1[j], 32);
+            if (h == 0) {
+                S[(wave * 2 + 0) * 64 + j * 32 + r] = st0[j];
+                S[(wave * 2 + 1) * 64 + j * 32 + r] = st1[j];
+            }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int which = tid >> 6, cc = tid & 63;
+            p.stats[((int64_t)blockIdx.x * 2 + which) * 64 + cc] =
+                ((S[(0 * 2 + which) * 64 + cc] + S[(1 * 2 + which) * 64 + cc]) + S[(2 * 2 + which) * 64 + cc]) + S[(3 * 2 + which) * 64 + cc];
         }
     }
 }
@@ -329,9 +352,9 @@ extern "C" int ssad_pack_stem_weight(const float* w_oihw, float* wk, void* strea
     return 0;
 }
 
-extern "C" int ssad_stem_fwd(const float* img, int B, int H, int W, int patch_dim, int patch_stride, int Hv, int Wv,
-                             const float* wk, const float* scale, const float* shift, int relu, int hwnc, float* out,
-                             void* stream) {
+static int stem_fwd_impl(const float* img, int B, int H, int W, int patch_dim, int patch_stride, int Hv, int Wv,
+                         const float* wk, const float* scale, const float* shift, int relu, int hwnc, float* out,
+                         void* stream, double* stats, int* stat_rows) {
     SSAD_CHECK_ARG(img && wk && out, "null pointer");
     SSAD_CHECK_ARG(B > 0 && H > 0 && W > 0 && Hv > 0 && Wv > 0, "empty shape");
     StemParams p;
@@ -351,6 +374,7 @@ extern "C" int ssad_stem_fwd(const float* img, int B, int H, int W, int patch_di
     p.tiles_x = (p.Wo + TOW - 1) / TOW;
     p.Nsamp = (int64_t)B * p.prow * p.pcol;
     p.hwnc = hwnc;
+    p.stats = stats;
     p.total_tiles = p.Nsamp * p.tiles_y * p.tiles_x;
     constexpr int lds_bytes = (W_TILE + IN_TILE) * 4;
     static bool attr_set = false;
@@ -361,7 +385,29 @@ extern "C" int ssad_stem_fwd(const float* img, int B, int H, int W, int patch_di
     int64_t grid = p.total_tiles < 4096 ? p.total_tiles : 4096;   // 2 resident per CU x 256 CUs x 8 rounds
     hipLaunchKernelGGL(stem_conv7x7_kernel, dim3((unsigned)grid), dim3(256), lds_bytes, (hipStream_t)stream, p);
     SSAD_CHECK_LAUNCH();
+    if (stat_rows) *stat_rows = (int)grid;
     return 0;
+}
+
+extern "C" int ssad_stem_fwd(const float* img, int B, int H, int W, int patch_dim, int patch_stride, int Hv, int Wv,
+                             const float* wk, const float* scale, const float* shift, int relu, int hwnc, float* out,
+                             void* stream) {
+    return stem_fwd_impl(img, B, H, W, patch_dim, patch_stride, Hv, Wv, wk, scale, shift, relu, hwnc, out, stream, nullptr, nullptr);
+}
+
+// conv1 of the stem in training: the raw convolution z (NHWC) AND the train-mode BatchNorm statistics of bn1 in one pass
+// (resnet conv1 + bn1 under trainer.fit, models.py:224): per-workgroup fp64 partial sums from the accumulators, finalised as
+// ssad_bn_stats does.  workspace: 4096 * 128 doubles.
+extern "C" int ssad_stem_fwd_stats(const float* img, int B, int H, int W, int Hv, int Wv, const float* wk, float* out, float eps,
+                                   float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
+                                   double* workspace, void* stream) {
+    SSAD_CHECK_ARG(mean && invstd && workspace, "null pointer");
+    int rows = 0;
+    const int rc = stem_fwd_impl(img, B, H, W, 0, 0, Hv, Wv, wk, nullptr, nullptr, 0, 0, out, stream, workspace, &rows);
+    if (rc) return rc;
+    const int Ho = (Hv - 1) / 2 + 1, Wo = (Wv - 1) / 2 + 1;
+    return ssad_bn_finalize_partials(workspace, rows, (int64_t)B * Ho * Wo, 64, eps, momentum, mean, invstd, running_mean,
+                                     running_var, stream);
 }
 
 extern "C" int ssad_pack_stem_weight_folded(const float* w_oihw, float* wf, void* stream) {

@@ -96,6 +96,21 @@ def stem_fwd(img, wk, scale, shift, relu=True, patch_dim=0, patch_stride=0, hwnc
     return out
 
 
+def stem_fwd_stats(img, wk, eps, momentum, running_mean, running_var):
+    """Training stem conv: -> (z [B][Ho][Wo][64], mean, invstd) with the BatchNorm statistics taken from the accumulators."""
+    b, c, h, w = img.shape
+    assert c == 3
+    _, hv, wv, ho, wo = stem_geometry(h, w, 0, 0)
+    out = _new((b, ho, wo, 64), img)
+    mean, invstd = _new((64,), img), _new((64,), img)
+    ws = torch.empty(4096 * 128, device=img.device, dtype=torch.float64)
+    _run("stem_conv7x7", 2.0 * b * ho * wo * 64 * 147, 4.0 * (b * 3 * h * w + b * ho * wo * 64),
+         lambda: _hip.lib().ssad_stem_fwd_stats(_hip.ptr(img), b, h, w, hv, wv, _hip.ptr(wk), _hip.ptr(out), eps, momentum,
+                                                _hip.ptr(mean), _hip.ptr(invstd), _hip.ptr(running_mean, True),
+                                                _hip.ptr(running_var, True), ws.data_ptr(), _hip.stream()))
+    return out, mean, invstd
+
+
 def pack_stem_weight_folded(w):
     assert tuple(w.shape) == (64, 3, 7, 7)
     out = _new((24, 2, 64), w)

@@ -167,9 +167,8 @@ class _Affine:
         if not bn.training:
             return ops.maxpool3x3s2_fwd_idx(self._stem_fwd(img, self.weight()))
         self.x, self.res_used = img, False
-        z = ops.stem_fwd(img, self.weight(), None, None, relu=False)
         mom = 0.1 if bn.momentum is None else bn.momentum
-        self.mean, self.invstd = ops.bn_stats(z, 64, bn.eps, mom, bn.running_mean, bn.running_var)
+        z, self.mean, self.invstd = ops.stem_fwd_stats(img, self.weight(), bn.eps, mom, bn.running_mean, bn.running_var)
         with torch.no_grad():
             bn.num_batches_tracked += 1
         a = self.eng.arena

@@ -836,3 +836,21 @@ def test_relu_mask_kernels(dev):
         assert torch.equal(a, b)
         if c == 64:
             assert torch.equal(ops.conv3x3_c64(up, w, residual=dres0), ops.conv3x3_c64(up, w, residual=dy, res_mask=mask))
+
+
+def test_stem_conv_with_statistics(dev):
+    """conv1 + the train-mode statistics of bn1 from the accumulators == conv1 followed by the separate statistics pass."""
+    from self_supervised import ops
+    for (b, h, w) in [(3, 64, 64), (2, 70, 90), (5, 32, 32), (4, 256, 256)]:
+        g = torch.Generator().manual_seed(b + h)
+        img = torch.randn(b, 3, h, w, generator=g).to(dev)
+        wk = ops.pack_stem_weight((torch.randn(64, 3, 7, 7, generator=g) / 12).to(dev))
+        z0 = ops.stem_fwd(img, wk, None, None, relu=False)
+        rm0, rv0 = torch.zeros(64, device=dev), torch.ones(64, device=dev)
+        m0, i0 = ops.bn_stats(z0, 64, 1e-5, 0.1, rm0, rv0)
+        rm1, rv1 = torch.zeros(64, device=dev), torch.ones(64, device=dev)
+        z1, m1, i1 = ops.stem_fwd_stats(img, wk, 1e-5, 0.1, rm1, rv1)
+        assert torch.equal(z0, z1)
+        assert rel_err(m1, m0) < 1e-6 and rel_err(i1, i0) < 1e-6 and rel_err(rm1, rm0) < 1e-6 and rel_err(rv1, rv0) < 1e-6
+        z2, m2, i2 = ops.stem_fwd_stats(img, wk, 1e-5, 0.1, None, None)
+        assert torch.equal(m2, m1) and torch.equal(i2, i1)          # deterministic
