@@ -129,6 +129,8 @@ int ssad_auroc(const float* scores, const uint8_t* labels, int64_t n, void* work
 /* Replaces autograd's conv2d/linear input-gradient (loss.backward() inside pl.Trainer.fit, tools.py:270,:303).
  * w_flipT = ssad_flip_transpose_weight(w_ohwi).  dx = dgrad(dy) (+ residual).  Cout % 32 == 0. */
 int ssad_flip_transpose_weight(const float* w_ohwi, float* out, int O, int I, int KH, int KW, void* stream);
+/* ... for up to 32 filters of one arena in one launch: desc[k] = {src offset, dst offset, O, I, KH, KW} (host memory). */
+int ssad_flip_transpose_batch(const float* src, float* dst, const int64_t* desc, int n, void* stream);
 int ssad_conv_igemm_dgrad(const float* dy, const float* w_flipT, float* dx, const float* residual, int64_t N, int Hy, int Wy,
                           int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride, int pad, void* stream);
 /* Split-bf16 ("bf16x3") forms of the forward / position-major forward (hwnc != 0) and dgrad contractions: fp32 tensors in

@@ -446,6 +446,28 @@ __global__ void flip_transpose_kernel(const float* __restrict__ w, float* __rest
     out[idx] = w[(((int64_t)o * KH + (KH - 1 - ky)) * KW + (KW - 1 - kx)) * I + i];
 }
 
+// The same for up to 32 filters of one flat arena in ONE launch (a training step flips every conv weight once: 19 launches
+// of a few microseconds each otherwise).  tab[k] = {src offset, dst offset, O, I, KH, KW, first linear index}.
+struct FlipTable {
+    int n;
+    int64_t e[32][7];
+    int64_t total;
+};
+__global__ void flip_transpose_batch_kernel(const float* __restrict__ src, float* __restrict__ dst, FlipTable t) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= t.total) return;
+    int k = 0;
+    while (k + 1 < t.n && idx >= t.e[k + 1][6]) ++k;
+    const int64_t l = idx - t.e[k][6];
+    const int O = (int)t.e[k][2], I = (int)t.e[k][3], KH = (int)t.e[k][4], KW = (int)t.e[k][5];
+    const int o = (int)(l % O);
+    int64_t r = l / O;
+    const int kx = (int)(r % KW); r /= KW;
+    const int ky = (int)(r % KH);
+    const int i = (int)(r / KH);
+    dst[t.e[k][1] + l] = src[t.e[k][0] + (((int64_t)o * KH + (KH - 1 - ky)) * KW + (KW - 1 - kx)) * I + i];
+}
+
 // ---------------------------------------------------------------------------------------------
 // softmax cross-entropy (mean over the batch) + accuracy + dlogits; one workgroup, fixed reduction order
 // ---------------------------------------------------------------------------------------------
@@ -829,3 +851,22 @@ extern "C" int ssad_bn_apply_bwd_mask(const float* dy, const uint8_t* mask4, con
     return bn_apply_bwd_impl(dy, nullptr, z, mean, invstd, gamma, dbeta, dgamma, dz, nullptr, R, C, 0, stream, nullptr, mask4);
 }
 
+
+// ssad_flip_transpose_weight for n <= 32 filters at once: desc[k] = {src offset, dst offset, O, I, KH, KW} (floats, host
+// memory), sources inside `src`, results inside `dst`.
+extern "C" int ssad_flip_transpose_batch(const float* src, float* dst, const int64_t* desc, int n, void* stream) {
+    SSAD_CHECK_ARG(src && dst && desc && n > 0 && n <= 32, "bad argument");
+    FlipTable t;
+    t.n = n;
+    int64_t acc = 0;
+    for (int k = 0; k < n; ++k) {
+        for (int j = 0; j < 6; ++j) t.e[k][j] = desc[6 * k + j];
+        SSAD_CHECK_ARG(t.e[k][2] > 0 && t.e[k][3] > 0 && t.e[k][4] > 0 && t.e[k][5] > 0, "bad filter shape");
+        t.e[k][6] = acc;
+        acc += t.e[k][2] * t.e[k][3] * t.e[k][4] * t.e[k][5];
+    }
+    t.total = acc;
+    hipLaunchKernelGGL(flip_transpose_batch_kernel, dim3((unsigned)cdiv64(acc, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, t);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}

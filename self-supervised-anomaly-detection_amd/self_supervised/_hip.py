@@ -38,6 +38,7 @@ SIGNATURES = {
     "ssad_cosine_knn_mean": [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp],
     "ssad_blur_relu_bilinear": [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
     "ssad_flip_transpose_weight": [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_flip_transpose_batch": [_c_fp, _c_fp, ctypes.POINTER(ctypes.c_int64), _c_i, _c_fp],
     "ssad_conv_igemm_dgrad": [_c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
                               _c_fp],
     "ssad_wgrad_splits": [_c_l, _c_i, _c_i, _c_i, _c_i],

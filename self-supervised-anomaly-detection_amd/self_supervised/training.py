@@ -145,7 +145,7 @@ class _Affine:
             mom = 0.1 if bn.momentum is None else bn.momentum
             self.mean, self.invstd = ops.bn_stats(z, 64, bn.eps, mom, bn.running_mean, bn.running_var)
             with torch.no_grad():
-                bn.num_batches_tracked += 1
+                self.eng.count_batch(bn)
             a = self.eng.arena
             y = ops.bn_apply_fwd(z, self.mean, self.invstd, a.w(bn.weight), a.w(bn.bias), None, True)
             self.z = z
@@ -170,7 +170,7 @@ class _Affine:
         mom = 0.1 if bn.momentum is None else bn.momentum
         z, self.mean, self.invstd = ops.stem_fwd_stats(img, self.weight(), bn.eps, mom, bn.running_mean, bn.running_var)
         with torch.no_grad():
-            bn.num_batches_tracked += 1
+            self.eng.count_batch(bn)
         a = self.eng.arena
         self.z, self.y = z, None
         return ops.bn_relu_maxpool_fwd(z, self.mean, self.invstd, a.w(bn.weight), a.w(bn.bias))
@@ -219,7 +219,7 @@ class _Affine:
                 z, self.mean, self.invstd = ops.conv3x3_c64(x, a.w(self.lin.weight), transform=tr, stats=st)
                 self.x = None
         with torch.no_grad():
-            bn.num_batches_tracked += 1
+            self.eng.count_batch(bn)
         self.z, self.y, self.res_used, self.mask = z, None, False, None
         return z
 
@@ -262,7 +262,7 @@ class _Affine:
                 z = ops.conv_fwd(x, w, None, a.w(bias) if bias is not None else None, None, False, self.stride, self.pad, bf)
                 self.mean, self.invstd = ops.bn_stats(z, c, bn.eps, mom, bn.running_mean, bn.running_var)
             with torch.no_grad():
-                bn.num_batches_tracked += 1
+                self.eng.count_batch(bn)
             self.z = z
             if residual is not None and self.relu and self.eng.use_relu_mask():
                 y, self.mask = ops.bn_apply_fwd_mask(z, self.mean, self.invstd, a.w(bn.weight), a.w(bn.bias), residual, True)
@@ -347,10 +347,10 @@ class _Affine:
                 wt = torch.zeros((padc,) + tuple(w.shape[1:]), device=dz.device)
                 wt[:cout] = w
             if self.c64_ok() and dz.dim() == 4:
-                dx = ops.conv3x3_c64(dzz, ops.flip_transpose_weight(wt), residual=dx_residual, res_mask=dx_res_mask)
+                dx = ops.conv3x3_c64(dzz, self.eng.flipped(self.lin, wt), residual=dx_residual, res_mask=dx_res_mask)
             else:
-                dx = ops.conv_dgrad(dzz, ops.flip_transpose_weight(wt), self.x_shape, self.stride, self.pad, dx_residual, bf,
-                                    res_mask=dx_res_mask)
+                wf = self.eng.flipped(self.lin, wt) if (self.is_conv and wt is w) else ops.flip_transpose_weight(wt)
+                dx = ops.conv_dgrad(dzz, wf, self.x_shape, self.stride, self.pad, dx_residual, bf, res_mask=dx_res_mask)
         self.x = self.z = self.y = self.mask = None
         return dx, dres
 
@@ -395,6 +395,8 @@ class TrainEngine:
         # them, so they CAN be launched on a second HIP stream (SSAD_WGRAD_STREAM=1) to fill the tails of the dgrad /
         # BatchNorm kernels.  Measured (round 2, bs256 / bs32): 36.33 vs 36.07 ms and 8.05 vs 7.51 ms per step -- every big
         # kernel already fills the chip, the second stream only adds dependencies -- so it is OFF by default.
+        self._nbt = []
+        self._flip_view, self._flip_ready = {}, False
         self.side = None
         self._side_keep = []
         self._side_on = os.environ.get("SSAD_WGRAD_STREAM", "0") == "1"
@@ -421,6 +423,38 @@ class TrainEngine:
                 self.ctx.__exit__(*exc)
             return False
 
+    def count_batch(self, bn):
+        """num_batches_tracked += 1 for every train-mode BatchNorm of the step, in ONE multi-tensor launch (end of forward)."""
+        self._nbt.append(bn.num_batches_tracked)
+
+    def flipped(self, lin, w):
+        """dgrad operand of a conv layer (ssad_flip_transpose_weight of its OHWI weight).  All block convs are flipped by one
+        launch per step (the first request after a forward), not one launch per layer."""
+        key = id(lin.weight)
+        if self._flip_ready and key in self._flip_view:
+            return self._flip_view[key]
+        if not self._flip_view:                      # build the table once: every conv of the residual blocks, arena offsets
+            import ctypes
+            a, desc, off = self.arena, [], 0
+            for d in self.blocks:
+                for k in ("c1", "c2", "ds"):
+                    if d[k] is not None:
+                        p = d[k].lin.weight
+                        o, c, kh, kw = p.shape
+                        desc += [a.offset[id(p)][0], off, o, c, kh, kw]
+                        self._flip_view[id(p)] = (off, (c, kh, kw, o))
+                        off += p.numel()
+            self._flip_buf = torch.empty(off, device=a.p.device, dtype=torch.float32)
+            self._flip_desc = (ctypes.c_int64 * len(desc))(*desc)
+            self._flip_n = len(desc) // 6
+            self._flip_view = {k: self._flip_buf[o:o + s[0] * s[1] * s[2] * s[3]].view(s) for k, (o, s) in self._flip_view.items()}
+        if key not in self._flip_view:
+            return ops.flip_transpose_weight(w)
+        _hip.check(_hip.lib().ssad_flip_transpose_batch(_hip.ptr(self.arena.p), _hip.ptr(self._flip_buf), self._flip_desc, self._flip_n,
+                                                        _hip.stream()))
+        self._flip_ready = True
+        return self._flip_view[key]
+
     def use_relu_mask(self):
         """Residual blocks keep their final ReLU's active set as a nibble mask (exact fp32 path, gradients wanted)."""
         return (not self.bf16 and self.trunk_grad and torch.is_grad_enabled() and os.environ.get("SSAD_RELU_MASK", "1") != "0")
@@ -440,6 +474,7 @@ class TrainEngine:
         m = self.model
         b, _, h, w = x.shape
         self.trunk_grad = any(p.requires_grad for p in m.feature_extractor.parameters())
+        self._nbt, self._flip_ready = [], False
         a, self.pool_idx = self.stem.fwd_pool(x.contiguous())
         if not self.trunk_grad:
             self.stem.x = None
@@ -470,6 +505,10 @@ class TrainEngine:
             f = layer.fwd(f)
         logits = self.cls.fwd(f)
         self.batch = b
+        if self._nbt:
+            with torch.no_grad():
+                torch._foreach_add_(self._nbt, 1)
+            self._nbt = []
         return logits.view(b, -1), f.view(b, -1)
 
     # ---- backward ----
