@@ -13,6 +13,7 @@
 //
 // Replaces the same autograd node as wgrad.hip (conv2d weight gradient under loss.backward(), tools.py:270, :303).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -121,7 +122,8 @@ static int halo_splits(int64_t ntiles, int npairs) {
     // slab (written once, read once by the reduction: 75 MB per layer at 512 workgroups)
     // (a workgroup with fewer than 16 tiles spends as long on its slab as on its MFMAs: small batches take one workgroup per
     // CU instead -- a single wave per SIMD still keeps the fp32 matrix pipe ~85 % busy)
-    int64_t s = (512 + npairs - 1) / npairs;
+    static const int target = getenv("SSAD_WGRAD_HALO_WGS") ? atoi(getenv("SSAD_WGRAD_HALO_WGS")) : 512;
+    int64_t s = (target + npairs - 1) / npairs;
     if (s * 16 > ntiles) s = (256 + npairs - 1) / npairs;
     if (s > ntiles / 4) s = ntiles / 4;
     if (s < 1) s = 1;

@@ -879,7 +879,9 @@ class DataParallelStep:
         def begin():
             seg["g"] = torch.cuda.CUDAGraph()
             seg["mark"] = _hip.LAUNCHES
-            seg["g"].capture_begin(pool=pool)
+            # thread-local capture mode: RCCL's watchdog thread may query events while this thread captures (a "global" capture
+            # would be invalidated by any such call from another thread)
+            seg["g"].capture_begin(pool=pool, capture_error_mode="thread_local")
 
         def end():
             import warnings
