@@ -297,7 +297,7 @@ extern "C" int ssad_cutpaste_augment(const uint8_t* imgs, const uint8_t* cuts, c
                                      float* gray_mean, float* out, int B, int H, int W, int h, int w, const float* mean3_host,
                                      const float* std3_host, void* stream) {
     SSAD_CHECK_ARG(imgs && params && work && gray_mean && out && mean3_host && std3_host, "null pointer");
-    SSAD_CHECK_ARG(B > 0 && H > 0 && W > 0 && h > 0 && w > 0 && h <= H && w <= W, "bad shape");
+    SSAD_CHECK_ARG(B > 0 && H > 0 && W > 0 && h > 0 && w > 0, "bad shape");
     hipStream_t st = (hipStream_t)stream;
     const int64_t total = (int64_t)B * h * w;
     hipLaunchKernelGGL(compose_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, imgs, cuts ? cuts : imgs, params,

@@ -101,9 +101,16 @@ def sample_defect(subject, img_u8, seg_mask, cuts_u8=None, patch_localization=Fa
     seg = seg_mask
     if patch_localization:
         ps = patch_size
-        left, top = random.randint(0, W - ps), random.randint(0, H - ps)
+        # datasets.py:244-249: capsule and screw are first cut to a fixed window (Image.crop pads with zeros where the window
+        # leaves the image -- the kernel's out-of-image fetches and the mask crop below do the same)
+        ox, oy, ww, wh = {"capsule": (0, 50, 255, 150), "screw": (25, 25, 205, 205)}.get(subject, (0, 0, W, H))
+        left, top = random.randint(0, ww - ps), random.randint(0, wh - ps)
+        left, top = ox + left, oy + top
         rec["crop_left"], rec["crop_top"] = left, top
-        seg = seg_mask[top:top + ps, left:left + ps]
+        seg = np.zeros((ps, ps), bool)
+        ys, xs = slice(top, min(top + ps, H)), slice(left, min(left + ps, W))
+        if top < H and left < W:
+            seg[:ys.stop - ys.start, :xs.stop - xs.start] = seg_mask[ys, xs]
         ct, cl = RandomCrop(ps).sample(W, H)
         rec["cut_left"], rec["cut_top"], rec["cut_w"], rec["cut_h"] = cl, ct, ps, ps
         cut_u8 = cut_u8[ct:ct + ps, cl:cl + ps]
@@ -120,8 +127,9 @@ def sample_defect(subject, img_u8, seg_mask, cuts_u8=None, patch_localization=Fa
     def x_mean():
         """Mean colour of the image the defect is pasted into (after RandomAffine / crop), for the similarity test."""
         cur = px.affine_nearest(img_u8, (W, H), aff) if aff is not None else img_u8
-        cur = cur[rec["crop_top"]:rec["crop_top"] + h, rec["crop_left"]:rec["crop_left"] + w]
-        return cur.reshape(-1, 3).astype(np.float64).mean(axis=0)
+        t, l = int(rec["crop_top"]), int(rec["crop_left"])
+        inside = cur[t:min(t + h, H), l:min(l + w, W)]                  # zero padding outside the image counts in the mean
+        return inside.reshape(-1, 3).astype(np.float64).sum(axis=0) / float(h * w)
     if y == 1:
         centre = get_random_coordinate(coords_map)
         pw, ph, mean = _source(rec, "patch", cut_u8, area_p, CPP.rectangle_aspect_ratio)

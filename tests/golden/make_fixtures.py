@@ -121,7 +121,11 @@ def make_gradcam(rm, sd):
     np.savez_compressed(os.path.join(HERE, "gradcam.npz"), **out)
 
 
-GETITEM_CASES = [("bottle", False), ("bottle", True), ("carpet", False), ("carpet", True)]
+GETITEM_CASES = [("bottle", False), ("bottle", True), ("carpet", False), ("carpet", True), ("capsule", True), ("screw", True),
+                 ("screw", False)]
+GETITEM_SIZE = {("capsule", True): (256, 64), ("screw", True): (256, 64)}      # (imsize, patch_size); default (64, 32): the fixed
+                                                                                # pre-crops of datasets.py:244-249 presume 256 px
+GETITEM_TREE = ("bottle", "carpet", "capsule", "screw")
 GETITEM_SAMPLES = 12            # seeds 0..11 per case; every label 0..3 and every defect-source branch occurs
 
 
@@ -152,15 +156,18 @@ def make_getitem():
     out = {"cases": np.array([f"{s}:{int(p)}" for s, p in GETITEM_CASES]), "n_samples": np.int64(GETITEM_SAMPLES)}
     cwd = os.getcwd()
     with tempfile.TemporaryDirectory() as tmp:
-        make_tree(os.path.join(tmp, "dataset"), categories=("bottle", "carpet"), n_train=4, n_test_good=1, n_test_bad=1, size=96)
+        make_tree(os.path.join(tmp, "dataset"), categories=GETITEM_TREE, n_train=4, n_test_good=1, n_test_bad=1, size=96)
         os.chdir(tmp)                                    # the reference hard-codes 'dataset/' (datasets.py:189-200)
         try:
             for subject, patch in GETITEM_CASES:
                 names = np.array(sorted(os.path.join("dataset", subject, "train/good", f) for f in
                                         os.listdir(os.path.join("dataset", subject, "train/good"))))
-                ds = rd.PretextTaskDataset(subject, names, imsize=(64, 64), transform=None, patch_localization=patch, patch_size=32)
+                size, ps = GETITEM_SIZE.get((subject, patch), (64, 32))
+                ds = rd.PretextTaskDataset(subject, names, imsize=(size, size), transform=None, patch_localization=patch, patch_size=ps)
+                out[f"{subject}_{int(patch)}_size"] = np.array([size, ps])
                 key = f"{subject}_{int(patch)}"
                 out[key + "_seg"] = np.array(ds.fixed_segmentation.convert("1"))
+                out["tree"] = np.array(GETITEM_TREE)
                 xs, ys = [], []
                 for s in range(GETITEM_SAMPLES):
                     random.seed(s); np.random.seed(s); torch.manual_seed(s)

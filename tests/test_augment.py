@@ -69,17 +69,26 @@ def test_gpu_augmentation_is_byte_identical_to_pil(tmp_path):
     from fake_mvtec import make_tree
     from self_supervised import augment
     dev = torch.device("cuda:0")
-    root = make_tree(str(tmp_path / "dataset"), categories=("bottle", "carpet"), n_train=4, n_test_good=1, n_test_bad=1, size=160)
+    root = make_tree(str(tmp_path / "dataset"), categories=("bottle", "carpet", "capsule", "screw", "cable"), n_train=4, n_test_good=1,
+                     n_test_bad=1, size=160)
     labels = set()
     for subject, patch, size, ps, n in [("bottle", False, 64, 32, 40), ("bottle", True, 64, 32, 24), ("carpet", False, 64, 32, 40),
                                         ("carpet", True, 64, 32, 40), ("carpet", False, 128, 64, 24), ("carpet", True, 128, 64, 24),
-                                        ("bottle", False, 128, 64, 16)]:
+                                        ("bottle", False, 128, 64, 16),
+                                        # fixed pre-crops of datasets.py:244-249 (windows that leave a 256 / 128 px image: zero padding),
+                                        # per-sample object masks (screw is a non-fixed object), the SLIC pre-segmented cable
+                                        ("capsule", True, 256, 64, 12), ("capsule", True, 128, 32, 12), ("screw", True, 256, 64, 12),
+                                        ("screw", False, 128, 64, 8), ("cable", False, 128, 64, 8)]:
         names = np.array(sorted(os.path.join(root, subject, "train/good", f) for f in os.listdir(os.path.join(root, subject, "train/good"))))
         ds = _pil_reference(subject, names, size, patch, ps, root)
         imgs = np.stack([np.asarray(Image.open(nm).resize((size, size)).convert("RGB")) for nm in names])
-        seg = np.asarray(ds.fixed_segmentation.convert("1"))
+        if subject == "screw":                 # NON_FIXED_OBJECTS: a mask per image (datasets.py:232-233)
+            from self_supervised.dataset_generator import obj_mask
+            segs = np.stack([np.asarray(obj_mask(Image.fromarray(im)).convert("1")) for im in imgs])
+        else:
+            segs = np.broadcast_to(np.asarray(ds.fixed_segmentation.convert("1")), imgs.shape[:3])
         cuts = np.stack([np.asarray(c) for c in ds.images_for_cut]) if subject == "carpet" else None
-        aug = augment.GpuCutPaste(subject, imgs, np.broadcast_to(seg, imgs.shape[:3]), cuts, patch, ps, device=dev)
+        aug = augment.GpuCutPaste(subject, imgs, segs, cuts, patch, ps, device=dev)
         for s in range(n):
             i = s % len(names)
             random.seed(s); np.random.seed(s); torch.manual_seed(s)

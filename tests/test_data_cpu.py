@@ -101,9 +101,9 @@ def test_metrics(golden):
     assert abs(m.compute_iou(s, t, 0.5) - np.mean([2 / 3, 1 / 2])) < 1e-9
 
 
-def _getitem_tree(tmp_path):
+def _getitem_tree(tmp_path, g):
     from fake_mvtec import make_tree
-    return make_tree(str(tmp_path / "dataset"), categories=("bottle", "carpet"), n_train=4, n_test_good=1, n_test_bad=1, size=96)
+    return make_tree(str(tmp_path / "dataset"), categories=tuple(str(c) for c in g["tree"]), n_train=4, n_test_good=1, n_test_bad=1, size=96)
 
 
 def test_pretext_getitem_matches_reference(golden, tmp_path):
@@ -115,14 +115,15 @@ def test_pretext_getitem_matches_reference(golden, tmp_path):
     from PIL import Image
     from self_supervised import datasets
     g = golden("getitem")
-    root = _getitem_tree(tmp_path)
+    root = _getitem_tree(tmp_path, g)
     n = int(g["n_samples"])
     for case in g["cases"]:
         subject, patch = str(case).split(":")
         patch = bool(int(patch))
         key = f"{subject}_{int(patch)}"
         names = np.array(sorted(os.path.join(root, subject, "train/good", f) for f in os.listdir(os.path.join(root, subject, "train/good"))))
-        ds = datasets.PretextTaskDataset(subject, names, imsize=(64, 64), transform=None, patch_localization=patch, patch_size=32,
+        size, ps = (int(v) for v in g[key + "_size"])
+        ds = datasets.PretextTaskDataset(subject, names, imsize=(size, size), transform=None, patch_localization=patch, patch_size=ps,
                                          dataset_root=root)
         assert np.array_equal(np.array(ds.fixed_segmentation.convert("1")), g[key + "_seg"]), key
         for s in range(n):
@@ -145,28 +146,33 @@ def test_sample_defect_draws_like_getitem(golden, tmp_path):
     from PIL import Image
     from self_supervised import augment, datasets
     g = golden("getitem")
-    root = _getitem_tree(tmp_path)
+    root = _getitem_tree(tmp_path, g)
     checked = 0
     for case in g["cases"]:
         subject, patch = str(case).split(":")
         patch = bool(int(patch))
         names = np.array(sorted(os.path.join(root, subject, "train/good", f) for f in os.listdir(os.path.join(root, subject, "train/good"))))
-        ds = datasets.PretextTaskDataset(subject, names, imsize=(64, 64), transform=None, patch_localization=patch, patch_size=32,
+        size, ps = (int(v) for v in g[f"{subject}_{int(patch)}_size"])
+        ds = datasets.PretextTaskDataset(subject, names, imsize=(size, size), transform=None, patch_localization=patch, patch_size=ps,
                                          dataset_root=root)
-        seg = np.asarray(ds.fixed_segmentation.convert("1"))
         cuts = np.stack([np.asarray(c) for c in ds.images_for_cut]) if subject == "carpet" else None
         for s in range(int(g["n_samples"])):
-            img = np.asarray(Image.open(names[s % len(names)]).resize((64, 64)).convert("RGB"))
+            img = np.asarray(Image.open(names[s % len(names)]).resize((size, size)).convert("RGB"))
+            if subject == "screw":             # non-fixed object: the mask comes from the sample itself
+                from self_supervised.dataset_generator import obj_mask
+                seg = np.asarray(obj_mask(Image.fromarray(img)).convert("1"))
+            else:
+                seg = np.asarray(ds.fixed_segmentation.convert("1"))
             random.seed(s); np.random.seed(s); torch.manual_seed(s)
             _, y, _ = ds[s % len(names)]
             want = (random.random(), np.random.rand(), float(torch.rand(1)))
             random.seed(s); np.random.seed(s); torch.manual_seed(s)
-            rec, _ = augment.sample_defect(subject, img, seg, cuts, patch, 32)
+            rec, _ = augment.sample_defect(subject, img, seg, cuts, patch, ps)
             got = (random.random(), np.random.rand(), float(torch.rand(1)))
             assert int(rec["label"]) == y, (subject, patch, s)
             assert got == want, (subject, patch, s, y)
             checked += 1
-    assert checked == 48
+    assert checked == 12 * len(g["cases"])
 
 
 def test_cable_slic_presegmentation(tmp_path):
