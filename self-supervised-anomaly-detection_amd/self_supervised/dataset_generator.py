@@ -29,30 +29,56 @@ class Container:
 
 # ---- object mask: Canny -> dilate -> close -> fill -> erode -> largest component (dataset_generator.py:27-39) ----
 def _canny(gray, sigma, low, high):
-    """Canny edge map (restated, third-party: the reference calls skimage.feature.canny, not installed here):
-    Gaussian smoothing, Sobel gradients, non-maximum suppression along the quantised gradient direction,
-    hysteresis with absolute thresholds."""
-    g = ndimage.gaussian_filter(gray.astype(np.float64), sigma, mode="nearest")
-    gx = ndimage.sobel(g, axis=1, mode="nearest")
-    gy = ndimage.sobel(g, axis=0, mode="nearest")
-    mag = np.hypot(gx, gy)
-    ang = (np.rad2deg(np.arctan2(gy, gx)) + 180.0) % 180.0
-    q = (np.floor((ang + 22.5) / 45.0).astype(int)) % 4            # 0: E-W, 1: NE-SW, 2: N-S, 3: NW-SE
-    pad = np.pad(mag, 1, mode="constant")
+    """skimage.feature.canny(gray_uint8, sigma, low_threshold=low, high_threshold=high) -- THIRD-PARTY RESTATEMENT, unpinned
+    (scikit-image is not installed): its documented pipeline, step for step -- the image scaled to [0, 1] (thresholds divided
+    by 255 accordingly), Gaussian smoothing with zero ('constant') borders renormalised by the smoothed all-ones mask, Sobel
+    derivatives, non-maximum suppression by bilinear interpolation of the magnitude along the gradient direction on the
+    border-eroded mask, double threshold and hysteresis over 8-connected components."""
+    img = gray.astype(np.float64) / 255.0
+    low, high = low / 255.0, high / 255.0
+    bleed = ndimage.gaussian_filter(np.ones_like(img), sigma, mode="constant", cval=0.0) + np.finfo(np.float64).eps
+    sm = ndimage.gaussian_filter(img, sigma, mode="constant", cval=0.0) / bleed
+    js = ndimage.sobel(sm, axis=1)
+    is_ = ndimage.sobel(sm, axis=0)
+    mag = np.hypot(is_, js)
     h, w = mag.shape
-    offs = {0: ((0, 1), (0, -1)), 1: ((-1, 1), (1, -1)), 2: ((1, 0), (-1, 0)), 3: ((1, 1), (-1, -1))}
-    keep = np.zeros_like(mag, dtype=bool)
-    for k, ((dy1, dx1), (dy2, dx2)) in offs.items():
-        n1 = pad[1 + dy1:1 + dy1 + h, 1 + dx1:1 + dx1 + w]
-        n2 = pad[1 + dy2:1 + dy2 + h, 1 + dx2:1 + dx2 + w]
-        keep |= (q == k) & (mag >= n1) & (mag >= n2)
-    strong = keep & (mag >= high)
-    weak = keep & (mag >= low)
-    lab, n = ndimage.label(weak, structure=np.ones((3, 3), int))
+    out = np.zeros_like(mag)
+    if h < 3 or w < 3:
+        return np.zeros(mag.shape, bool)
+    c = (slice(1, -1), slice(1, -1))
+
+    def sh(dx, dy):                                  # magnitude at (row + dx, col + dy) for the interior pixels
+        return mag[1 + dx:h - 1 + dx, 1 + dy:w - 1 + dy]
+    i, j, m = is_[c], js[c], mag[c]
+    ai, aj = np.abs(i), np.abs(j)
+    ok = m >= low                                    # the eroded mask only removes the one-pixel border, i.e. the interior
+    up, down, left, right = i >= 0, i <= 0, j <= 0, j >= 0
+    c1 = (up & right) | (down & left)
+    c2 = ~c1 & ((down & right) | (up & left))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        w_ji, w_ij = np.where(ai > 0, aj / ai, 0.0), np.where(aj > 0, ai / aj, 0.0)
+    keep = np.zeros(m.shape, bool)
+
+    def test(sel, wgt, n11, n12, n21, n22):
+        plus = (n12 * wgt + n11 * (1.0 - wgt)) <= m
+        minus = (n22 * wgt + n21 * (1.0 - wgt)) <= m
+        keep[sel & plus & minus] = True
+    a = c1 & (ai > aj)
+    test(a, w_ji, sh(1, 0), sh(1, 1), sh(-1, 0), sh(-1, -1))
+    test(c1 & ~a, w_ij, sh(0, 1), sh(1, 1), sh(0, -1), sh(-1, -1))
+    b = c2 & (ai < aj)
+    test(b, w_ij, sh(0, 1), sh(-1, 1), sh(0, -1), sh(1, -1))
+    test(c2 & ~b, w_ji, sh(-1, 0), sh(-1, 1), sh(1, 0), sh(1, -1))
+    out[c] = np.where(keep & ok, m, 0.0)
+    low_mask = out > 0
+    lab, n = ndimage.label(low_mask, structure=np.ones((3, 3), int))
     if n == 0:
-        return np.zeros_like(weak)
-    good = np.unique(lab[strong])
-    return np.isin(lab, good[good > 0])
+        return low_mask
+    high_mask = low_mask & (out >= high)
+    sums = ndimage.sum_labels(high_mask, lab, np.arange(n + 1))
+    good = sums > 0
+    good[0] = False
+    return good[lab]
 
 
 def obj_mask(image: Image.Image) -> Image.Image:

@@ -153,6 +153,10 @@ def make_getitem():
     from fake_mvtec import make_tree
     from self_supervised import datasets as rd, constants as rconst          # the REFERENCE's modules
     assert rd.__file__.startswith(REF_SRC)
+    rgen = sys.modules["self_supervised.dataset_generator"]                 # may have been imported before the stubs were filled in
+    for name, fn in (("canny", sk.feature.canny), ("square", sk.morphology.square), ("label", sk.morphology.label)):
+        if hasattr(rgen, name):
+            setattr(rgen, name, fn)
     out = {"cases": np.array([f"{s}:{int(p)}" for s, p in GETITEM_CASES]), "n_samples": np.int64(GETITEM_SAMPLES)}
     cwd = os.getcwd()
     with tempfile.TemporaryDirectory() as tmp:

@@ -201,3 +201,28 @@ def test_cable_slic_presegmentation(tmp_path):
     random.seed(0); np.random.seed(0); torch.manual_seed(0)
     x, y, o = ds[0]
     assert x.size == (64, 64) and y in (0, 1, 2, 3)
+
+
+def test_canny_restatement_properties():
+    """dataset_generator._canny follows skimage's documented pipeline (third-party, unpinned): on a disc it returns a thin,
+    closed, one-component contour at the disc's radius, nothing on a flat image, and nothing on the one-pixel border."""
+    from self_supervised import dataset_generator as dg
+    from scipy import ndimage
+    yy, xx = np.mgrid[0:96, 0:96]
+    r = np.hypot(yy - 48, xx - 48)
+    img = np.where(r < 30, 200, 30).astype(np.uint8)
+    e = dg._canny(img, 1.5, 5, 15)
+    assert e.dtype == bool and e.any()
+    assert not e[0].any() and not e[-1].any() and not e[:, 0].any() and not e[:, -1].any()
+    assert np.abs(r[e] - 30).max() < 1.6                                   # on the contour
+    assert ndimage.label(e, structure=np.ones((3, 3), int))[1] == 1          # one closed curve ...
+    filled = ndimage.binary_fill_holes(e)
+    assert abs(int(filled.sum()) - np.pi * 30 ** 2) < 0.06 * np.pi * 30 ** 2  # ... that encloses the disc
+    assert e.sum() < 2.2 * 2 * np.pi * 30                                   # thin (non-maximum suppression)
+    assert not dg._canny(np.full((64, 64), 77, np.uint8), 1.5, 5, 15).any()
+    # hysteresis: a faint edge (below `high`) survives only when connected to a strong one
+    faint = np.full((64, 64), 100, np.uint8)
+    faint[:, 32:] = 105
+    assert not dg._canny(faint, 1.5, 5, 15).any()
+    faint[:, 32:] = (160 - 55 * np.arange(64) / 63).astype(np.uint8)[:, None]   # the same edge, fading from strong to faint
+    assert dg._canny(faint, 1.5, 5, 15)[56:62, 30:35].any()
