@@ -184,6 +184,14 @@ int ssad_conv3x3_c64(const float* in, const float* w_ohwi, float* out, const flo
                      const float* tr_invstd, const float* tr_gamma, const float* tr_beta, float* emit, int64_t N, int H, int W,
                      double* stats_ws, float eps, float momentum, float* mean, float* invstd, float* running_mean,
                      float* running_var, void* stream);
+/* Inference form of the halo-tile convolution (frozen BatchNorm folded into scale / shift):
+ * out = act(conv3x3(in) * scale[co] + shift[co] + residual), 64 -> 64 channels, stride 1, pad 1, exact fp32 MFMA.
+ * in_hwnc / out_hwnc / res_hwnc != 0: the input / the output / the residual is position-major [H][W][N][64] (the
+ * patch-scoring trunk's layout, see ssad_conv_igemm_fwd_hwnc), otherwise NHWC.  Replaces ssad_conv_igemm_fwd(_hwnc) for the four layer1
+ * convolutions of PeraNet.forward in eval mode (torchvision BasicBlock, models.py:224 of the reference). */
+int ssad_conv3x3_c64_eval(const float* in, const float* w_ohwi, float* out, const float* scale, const float* shift,
+                          const float* residual, int relu, int64_t N, int H, int W, int in_hwnc, int out_hwnc, int res_hwnc,
+                          void* stream);
 /* Weight gradient of the 3x3 / stride 1 / pad 1 convolutions (Cin, Cout multiples of 64) as a halo-tile kernel: a workgroup
  * owns a 64 x 64 (co, ci) block for all nine taps and walks over pixel tiles (csrc/wgrad_halo.hip).  Same contract as
  * ssad_conv_wgrad: slab[splits][Cout][9 * Cin] with splits = ssad_wgrad3x3_halo_splits(...), then ssad_wgrad_reduce. */

@@ -17,6 +17,19 @@
 // Replaces the same autograd nodes as conv_igemm.hip for this shape: torchvision BasicBlock conv3x3 (models.py:224 of
 // the reference, under trainer.fit) and its input gradient.
 #include "common.h"
+#include <stdlib.h>
+
+// Ablation switches for tools/micro/c64_ablate.hip (where the time goes); always 0 in the library build.
+#ifndef C64_ABL
+#define C64_ABL 0
+#endif
+
+#if C64_ABL & 16
+__device__ unsigned long long* g_c64_trace;      // [workgroups][8]: phase time stamps (tools/micro/c64_ablate.hip)
+#define C64_STAMP(i) do { if (threadIdx.x == 0 && g_c64_trace) g_c64_trace[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define C64_STAMP(i) do { } while (0)
+#endif
 
 namespace {
 
@@ -41,8 +54,16 @@ struct C64Params {
     float* emit;              // optional: the transformed input, written for the interior pixels
     double* stats;            // optional [workgroups][2][64] column sums / sums of squares of the raw output
     int N, H, W, tiles_y, tiles_x;
+    // EVAL instantiation (frozen-BatchNorm inference, the patch-scoring trunk): out = act(conv * scale + shift + residual),
+    // tensors addressed through (pixel, sample) strides in floats so that NHWC and the position-major [H][W][N][C] both fit
+    const float* scale;
+    const float* shift;
+    int relu;
+    int64_t in_ps, in_ss, out_ps, out_ss, res_ps, res_ss;
+    int stagger;              // start delay of the workgroups in the second wave slot of their CU, in units of s_sleep(127)
 };
 
+template <bool EVAL>
 __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* halo = lds;
@@ -50,6 +71,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
 
+    // Two workgroups share a CU.  They are started together, take the same time and are served round-robin, so they would
+    // stay in lockstep: both fill their halo (no MFMAs), both run their taps at half rate, both store (no MFMAs) -- measured:
+    // the fill and the epilogue of a tile are not hidden at all (tools/micro/c64_ablate.hip).  A phase offset, once there,
+    // persists (each workgroup is replaced when it ends), so the first-round workgroup in the second wave slot of its SIMDs
+    // (HW_ID.WAVE_ID odd: tools/micro/hwid_probe.hip) starts about half a tile late.  Placement only changes speed.
+    if (p.stagger > 0 && blockIdx.x < 512 && (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1)) {
+        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+
+    C64_STAMP(0);
+#if !(C64_ABL & 32)
+    __builtin_amdgcn_s_setprio(3);      // fill / epilogue instructions go ahead of the co-resident workgroup's MFMA stream
+#endif
+#if C64_ABL & 16
+    if (threadIdx.x == 0 && g_c64_trace) g_c64_trace[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
+#endif
     // XCD-aware tile order: workgroups b, b+8, ... share an L2; give each XCD a contiguous run of tiles (neighbouring
     // tiles of an image share halo rows and every tile re-reads the same 147 KB of weights)
     const int nwg = gridDim.x;
@@ -59,7 +96,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
     const int ty = (bid / p.tiles_x) % p.tiles_y;
     const int n = bid / (p.tiles_x * p.tiles_y);
     const int y0 = ty * TH, x0 = tx * TW;
-    const float* img = p.in + (int64_t)n * p.H * p.W * C;
+    const int64_t in_ps = EVAL ? p.in_ps : (int64_t)C;
+    const float* img = p.in + (EVAL ? (int64_t)n * p.in_ss : (int64_t)n * p.H * p.W * C);
 
     // ---- halo fill: thread -> channel quad c4, pixels q*16 + (tid >> 4) ----
     const int c4 = tid & 15, p0 = tid >> 4;
@@ -73,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
         const int y = y0 - 1 + hy, x = x0 - 1 + hx;
         hin[q] = hp < HH * HW && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (hin[q]) v = *(const f32x4*)(img + ((int64_t)y * p.W + x) * C + c4 * 4);
+        if (hin[q] && !(C64_ABL & 8)) v = *(const f32x4*)(img + ((int64_t)y * p.W + x) * in_ps + c4 * 4);
         hv[q] = v;
     }
     // first weight slice while the halo loads are in flight: thread -> rows (tid >> 4) + 16 i, chunk c4
@@ -81,7 +119,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
     const float* wrow = p.wt + (int64_t)(tid >> 4) * 9 * C + c4 * 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) wv[i] = *(const f32x4*)(wrow + (int64_t)i * 16 * 9 * C);
-    if (p.tr_mean) {
+    C64_STAMP(4);                                   // loads issued
+    if (!EVAL && p.tr_mean) {
         const f32x4 mu = *(const f32x4*)(p.tr_mean + c4 * 4), is = *(const f32x4*)(p.tr_invstd + c4 * 4);
         const f32x4 ga = *(const f32x4*)(p.tr_gamma + c4 * 4), be = *(const f32x4*)(p.tr_beta + c4 * 4);
 #pragma unroll
@@ -104,7 +143,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) *(f32x4*)(Bs + ((tid >> 4) + 16 * i) * LDP + c4 * 4) = wv[i];
+    C64_STAMP(5);                                   // loads landed, LDS writes done (the stamp waits for them)
     __syncthreads();
+    C64_STAMP(1);
+#if !(C64_ABL & 32)
+    __builtin_amdgcn_s_setprio(0);
+#endif
 
     // ---- main loop: 9 taps x 64 channels; wave w owns tile rows 2w, 2w+1 (32 pixels) x 64 output channels ----
     f32x16 acc[2];
@@ -118,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const int ky = t / 3, kx = t - 3 * ky;
-        if (t < 8) {
+        if (t < 8 && !(C64_ABL & 1)) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) wv[i] = *(const f32x4*)(wrow + (int64_t)i * 16 * 9 * C + (t + 1) * C);
         }
@@ -130,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
             const int cu = kk & 1, nx = cu ^ 1;
-            if (kk + 1 < 8) {
+            if (kk + 1 < 8 && !(C64_ABL & 2)) {
                 a[nx] = *(const f32x4*)(At + (kk + 1) * 8);
                 b[nx][0] = *(const f32x4*)(Bb + (kk + 1) * 8);
                 b[nx][1] = *(const f32x4*)(Bb + 32 * LDP + (kk + 1) * 8);
@@ -138,11 +182,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
             __builtin_amdgcn_sched_barrier(0);       // keep the fragment reads one chunk ahead of the MFMAs
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                acc[0] = mfma32(a[cu][e], b[cu][0][e], acc[0]);
-                acc[1] = mfma32(a[cu][e], b[cu][1][e], acc[1]);
+                acc[0] = mfma32(a[(C64_ABL & 2) ? 0 : cu][e], b[(C64_ABL & 2) ? 0 : cu][0][e], acc[0]);
+                acc[1] = mfma32(a[(C64_ABL & 2) ? 0 : cu][e], b[(C64_ABL & 2) ? 0 : cu][1][e], acc[1]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (C64_ABL & 1) continue;
         __syncthreads();                             // every wave is done with this tap's weights
         if (t < 8) {
 #pragma unroll
@@ -151,10 +196,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
         }
     }
 
+    C64_STAMP(2);
+#if !(C64_ABL & 32)
+    __builtin_amdgcn_s_setprio(3);
+#endif
     // ---- epilogue: statistics straight from the accumulators (pixel = register, channel = lane); the tile goes through
     // LDS (the halo is dead after the last barrier) so that every thread stores -- and reads the residual as -- 16-byte
     // pieces of contiguous NHWC rows, all residual loads in flight at once ----
     // reg e of lane (r, h): pixel row index m = (e & 3) + 8 (e >> 2) + 4 h of the wave's 32, channel j*32 + r
+    if (C64_ABL & 4) {
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sum += acc[0][e] + acc[1][e];
+        if (sum == 123.456f) p.out[0] = sum;
+        return;
+    }
     float* Ct = halo;                               // [128 pixels][LDP]
     double s0[2] = {0.0, 0.0}, s1[2] = {0.0, 0.0};
 #pragma unroll
@@ -165,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const float v = acc[j][e];
-            if (p.stats && ok) { s0[j] += (double)v; s1[j] += (double)v * (double)v; }
+            if (!EVAL && p.stats && ok) { s0[j] += (double)v; s1[j] += (double)v * (double)v; }
             Ct[(wave * 32 + m) * LDP + j * 32 + r] = v;
         }
     }
@@ -174,15 +230,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
         // thread -> channel quad c4, tile pixels (tid >> 4) + 16 q
         int64_t o[8];
         f32x4 rs[8];
+        f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+        if (EVAL && p.scale) sc4 = *(const f32x4*)(p.scale + c4 * 4);
+        if (EVAL && p.shift) sh4 = *(const f32x4*)(p.shift + c4 * 4);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int tp = (tid >> 4) + 16 * q;
             const int y = y0 + (tp >> 4), x = x0 + (tp & 15);
             const bool ok = y < p.H && x < p.W;
-            o[q] = ok ? (((int64_t)n * p.H + y) * p.W + x) * C + c4 * 4 : -1;
+            if (EVAL) o[q] = ok ? (int64_t)n * p.out_ss + ((int64_t)y * p.W + x) * p.out_ps + c4 * 4 : -1;
+            else o[q] = ok ? (((int64_t)n * p.H + y) * p.W + x) * C + c4 * 4 : -1;
             f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-            rs[q] = (ok && p.residual) ? *(const f32x4*)(p.residual + o[q]) : z4;
-            if (ok && p.res_mask) {
+            if (EVAL) rs[q] = (ok && p.residual) ? *(const f32x4*)(p.residual + (int64_t)n * p.res_ss + ((int64_t)y * p.W + x) * p.res_ps + c4 * 4) : z4;
+            else rs[q] = (ok && p.residual) ? *(const f32x4*)(p.residual + o[q]) : z4;
+            if (!EVAL && ok && p.res_mask) {
                 const unsigned mk = p.res_mask[o[q] >> 2];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) rs[q][k] = (mk >> k) & 1u ? rs[q][k] : 0.f;
@@ -193,11 +254,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
             const int tp = (tid >> 4) + 16 * q;
             f32x4 v = *(const f32x4*)(Ct + tp * LDP + c4 * 4);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] += rs[q][k];
+            for (int k = 0; k < 4; ++k) {
+                if (EVAL) {                         // the expression of conv_igemm's epilogue
+                    const float x = v[k] * sc4[k] + sh4[k] + rs[q][k];
+                    v[k] = p.relu ? fmaxf(x, 0.f) : x;
+                } else {
+                    v[k] += rs[q][k];
+                }
+            }
             if (o[q] >= 0) *(f32x4*)(p.out + o[q]) = v;
         }
     }
-    if (p.stats) {
+    C64_STAMP(3);
+    if (!EVAL && p.stats) {
         // lane halves -> one value per channel per wave, then the four waves in a fixed order through LDS
         double* S = (double*)Bs;                     // [4 waves][2][64]; the weight buffer is free (barrier above)
 #pragma unroll
@@ -217,6 +286,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
             p.stats[((int64_t)blockIdx.x * 2 + which) * C + cc] = t;
         }
     }
+}
+
+// start offset between the two workgroups of a CU (see the kernel), only when the launch has several rounds of them
+static int c64_stagger(int64_t nwg) {
+    static const int st = getenv("SSAD_C64_STAGGER") ? atoi(getenv("SSAD_C64_STAGGER")) : 0;
+    return nwg >= 4 * 512 ? st : 0;
 }
 
 }  // namespace
@@ -245,19 +320,53 @@ extern "C" int ssad_conv3x3_c64(const float* in, const float* w_ohwi, float* out
     p.in = in; p.wt = w_ohwi; p.out = out; p.residual = residual; p.res_mask = res_mask;
     p.tr_mean = tr_mean; p.tr_invstd = tr_invstd; p.tr_gamma = tr_gamma; p.tr_beta = tr_beta; p.emit = emit;
     p.stats = stats_ws;
+    p.scale = p.shift = nullptr; p.relu = 0; p.in_ps = p.out_ps = p.res_ps = C; p.in_ss = p.out_ss = p.res_ss = (int64_t)H * W * C;
     p.N = (int)N; p.H = H; p.W = W;
     p.tiles_y = (H + TH - 1) / TH; p.tiles_x = (W + TW - 1) / TW;
     const int64_t nwg = N * p.tiles_y * p.tiles_x;
     SSAD_CHECK_ARG(nwg < (int64_t)2147483647, "too many tiles for one launch");
+    p.stagger = c64_stagger(nwg);
+    static const int lds_bytes = LDS_BYTES + (getenv("SSAD_C64_LDS_PAD") ? atoi(getenv("SSAD_C64_LDS_PAD")) : 0);   // residency experiments
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_c64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv3x3_c64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv3x3_c64_kernel, dim3((unsigned)nwg), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(conv3x3_c64_kernel<false>, dim3((unsigned)nwg), dim3(256), lds_bytes, (hipStream_t)stream, p);
     SSAD_CHECK_LAUNCH();
     if (stats_ws)
         return ssad_bn_finalize_partials(stats_ws, (int)nwg, N * H * W, C, eps, momentum, mean, invstd, running_mean,
                                          running_var, stream);
+    return 0;
+}
+
+// Inference form (frozen BatchNorm folded into scale / shift): out = act(conv3x3(in) * scale[co] + shift[co] + residual),
+// 64 -> 64 channels, stride 1, pad 1.  in_hwnc / out_hwnc / res_hwnc select the position-major [H][W][N][64] layout of the
+// patch-scoring trunk for the input / the output / the residual (0 = NHWC).  Replaces ssad_conv_igemm_fwd(_hwnc) for
+// the four layer1 convolutions of a scoring pass (same call sites: torchvision BasicBlock under PeraNet.forward,
+// models.py:224 of the reference): one halo load per tile instead of one gather per filter tap.
+extern "C" int ssad_conv3x3_c64_eval(const float* in, const float* w_ohwi, float* out, const float* scale, const float* shift,
+                                     const float* residual, int relu, int64_t N, int H, int W, int in_hwnc, int out_hwnc,
+                                     int res_hwnc, void* stream) {
+    SSAD_CHECK_ARG(in && w_ohwi && out && N > 0 && H > 0 && W > 0, "bad argument");
+    C64Params p;
+    p.in = in; p.wt = w_ohwi; p.out = out; p.residual = residual; p.res_mask = nullptr;
+    p.tr_mean = p.tr_invstd = p.tr_gamma = p.tr_beta = nullptr; p.emit = nullptr; p.stats = nullptr;
+    p.scale = scale; p.shift = shift; p.relu = relu;
+    p.in_ps = in_hwnc ? N * C : C;   p.in_ss = in_hwnc ? C : (int64_t)H * W * C;
+    p.out_ps = out_hwnc ? N * C : C; p.out_ss = out_hwnc ? C : (int64_t)H * W * C;
+    p.res_ps = res_hwnc ? N * C : C; p.res_ss = res_hwnc ? C : (int64_t)H * W * C;
+    p.N = (int)N; p.H = H; p.W = W;
+    p.tiles_y = (H + TH - 1) / TH; p.tiles_x = (W + TW - 1) / TW;
+    const int64_t nwg = N * p.tiles_y * p.tiles_x;
+    SSAD_CHECK_ARG(nwg < (int64_t)2147483647, "too many tiles for one launch");
+    p.stagger = c64_stagger(nwg);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_c64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv3x3_c64_kernel<true>, dim3((unsigned)nwg), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
+    SSAD_CHECK_LAUNCH();
     return 0;
 }

@@ -43,6 +43,11 @@ struct ConvParams {
     int hwnc;           // activations (in, out, residual) laid out [H][W][N][C] instead of [N][H][W][C]
     int cls_start[5];   // TS == 2: first workgroup of each output-parity class (py, px) = (c >> 1, c & 1)
     double* stats;      // optional [gridDim.x][2][Cout]: per-workgroup column sums / sums of squares of the raw output
+    // POS, pos_lpt != 0: workgroups are numbered position-major with the positions sorted by their in-bounds tap count,
+    // heaviest first (pos_tab), sample groups fastest -- longest-processing-time-first for the in-order dispatcher
+    int pos_lpt;
+    int pos_sg;         // sample groups per position (workgroups along x = pos_sg * Ho * Wo)
+    unsigned char pos_tab[64];
 };
 
 // TS   : 1 = convolution; 2 = transposed gather (dgrad of a stride-2 conv): tap (ky,kx) reads in[(oy-pad+ky)/2]
@@ -101,11 +106,20 @@ void conv_igemm_f32_kernel(ConvParams p) {
         // pos = block % HoWo the heavy interior positions pin to the same engines and tap skipping buys nothing).
         // Positions differ in work (corner 4 taps .. interior 9), so every stream sweeps ALL positions of its own
         // sample groups (nb = 32*q + stream): equal work per engine, and a sample group's maps stay in one XCD's L2.
+        if (p.pos_lpt) {
+            // Positions differ in work (corner 4 taps .. interior 9) and workgroups are handed out in order: all the
+            // 9-tap positions first, the 4-tap corners last, every position over all sample groups (consecutive
+            // workgroups -> all XCDs / engines see the same mix), so the launch ends on its shortest workgroups.
+            const int pi = (int)(blockIdx.x / (unsigned)p.pos_sg);
+            pos = p.pos_tab[pi];
+            m0 = (int64_t)(blockIdx.x - (unsigned)pi * (unsigned)p.pos_sg) * BM;
+        } else {
         const int stream = blockIdx.x & 31;
         const int64_t j = blockIdx.x >> 5;
         const int64_t q = j / HoWo;
         pos = (int)(j - q * HoWo);
         m0 = (q * 32 + stream) * BM;
+        }
         if (m0 >= p.N) return;
         const int oy = pos / p.Wo, ox = pos - oy * p.Wo;
         tapmask = 0;
@@ -547,6 +561,31 @@ void conv_igemm_f32_kernel(ConvParams p) {
     }
 }
 
+// Position order for the position-major kernels: heaviest (most in-bounds taps) first, see the kernel.
+static void sort_positions(ConvParams& p, int sample_groups) {
+    static const int mode = getenv("SSAD_POS_LPT") ? atoi(getenv("SSAD_POS_LPT")) : 1;
+    const int HoWo = p.Ho * p.Wo;
+    p.pos_lpt = 0;
+    p.pos_sg = sample_groups;
+    if (!mode || HoWo > 64 || HoWo < 2) return;
+    int taps[64], order[64];
+    bool uniform = true;
+    for (int pos = 0; pos < HoWo; ++pos) {
+        const int oy = pos / p.Wo, ox = pos - oy * p.Wo;
+        int ny = 0, nx = 0;
+        for (int k = 0; k < p.KH; ++k) ny += (unsigned)(oy * p.stride - p.pad + k) < (unsigned)p.H;
+        for (int k = 0; k < p.KW; ++k) nx += (unsigned)(ox * p.stride - p.pad + k) < (unsigned)p.W;
+        taps[pos] = ny * nx;
+        order[pos] = pos;
+        uniform = uniform && taps[pos] == taps[0];
+    }
+    if (uniform) return;                                 // nothing to balance: keep the engine-stream mapping
+    for (int i = 1; i < HoWo; ++i)                       // stable insertion sort, heaviest first
+        for (int j = i; j > 0 && taps[order[j]] > taps[order[j - 1]]; --j) { int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+    for (int i = 0; i < HoWo; ++i) p.pos_tab[i] = (unsigned char)order[i];
+    p.pos_lpt = 1;
+}
+
 template <int BM, int BN, int TM, int TN, int BK, int TS, bool POS, bool DB = true, int BF = 0>
 int launch(const ConvParams& p, hipStream_t st) {
     constexpr int stage_bytes = (DB ? 2 : 1) * (BM + BN) *
@@ -563,8 +602,10 @@ int launch(const ConvParams& p, hipStream_t st) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         attr_set = true;
     }
-    int64_t gx = POS ? cdiv64(cdiv64(p.N, BM), 32) * 32 * p.Ho * p.Wo : cdiv64(p.M, BM);
     ConvParams q = p;
+    q.pos_lpt = 0;
+    if (POS) sort_positions(q, (int)cdiv64(p.N, BM));
+    int64_t gx = POS ? (q.pos_lpt ? (int64_t)q.pos_sg * p.Ho * p.Wo : cdiv64(cdiv64(p.N, BM), 32) * 32 * p.Ho * p.Wo) : cdiv64(p.M, BM);
     if (TS > 1) {
         gx = 0;
         for (int c = 0; c < 4; ++c) {
@@ -645,6 +686,7 @@ int conv_fwd_impl(const float* in, const float* w_ohwi, float* out, const float*
     SSAD_CHECK_ARG(Cin % KALIGN == 0, "Cin must be a multiple of 32");
     SSAD_CHECK_ARG(KH > 0 && KW > 0 && stride > 0 && pad >= 0 && KH * KW <= 32, "bad filter geometry (<= 32 taps)");
     ConvParams p;
+    p.pos_lpt = 0; p.pos_sg = 0;
     p.in = in; p.wt = w_ohwi; p.out = out; p.scale = scale; p.shift = shift; p.residual = residual; p.res_mask = nullptr;
     p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.relu = relu;
     p.Ho = (H + 2 * pad - KH) / stride + 1;
@@ -763,6 +805,7 @@ static int dgrad_impl(const float* dy, const float* w_flipT, float* dx, const fl
     SSAD_CHECK_ARG((Hx + 2 * pad - KH) / stride + 1 == Hy && (Wx + 2 * pad - KW) / stride + 1 == Wy, "dy/dx sizes disagree");
     SSAD_CHECK_ARG(KH == KW && KH * KW <= 32, "square filters with at most 32 taps only");
     ConvParams p;
+    p.pos_lpt = 0; p.pos_sg = 0;
     SSAD_CHECK_ARG(!res_mask || (residual && Cin % 4 == 0), "residual mask needs a residual and Cin % 4 == 0");
     p.in = dy; p.wt = w_flipT; p.out = dx; p.scale = nullptr; p.shift = nullptr; p.residual = residual; p.res_mask = res_mask;
     p.H = Hy; p.W = Wy; p.Cin = Cout; p.Cout = Cin; p.KH = KH; p.KW = KW; p.relu = 0;

@@ -15,6 +15,11 @@
 #include "common.h"
 #include <stdlib.h>
 
+// Ablation switches for tools/micro/wgh_ablate.hip; always 0 in the library build.
+#ifndef WGH_ABL
+#define WGH_ABL 0
+#endif
+
 namespace {
 
 struct WgHaloParams {
@@ -80,6 +85,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(WgHaloParams p) {
     };
     if (t_begin < t_end) load_tile(t_begin);
     for (int64_t tile = t_begin; tile < t_end; ++tile) {
+        if (!(WGH_ABL & 2) || tile == t_begin) {
         __syncthreads();                        // the previous tile's fragments have all been read
 #pragma unroll
         for (int q = 0; q < NDZ; ++q) *(f32x4*)(dzt + (q * 16 + p0) * 64 + c4 * 4) = dv[q];
@@ -87,7 +93,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(WgHaloParams p) {
         for (int q = 0; q < NX; ++q)
             if (q * 16 + p0 < NH) *(f32x4*)(halo + (q * 16 + p0) * 64 + c4 * 4) = xv[q];
         __syncthreads();
-        if (tile + 1 < t_end) load_tile(tile + 1);      // in flight under this tile's MFMAs
+        }
+        if (tile + 1 < t_end && !(WGH_ABL & 1)) load_tile(tile + 1);      // in flight under this tile's MFMAs
 
         // lane (r, h): k slot h = pixel (py, 2 pp + h); A = dZ[pixel][co0 + 32 cb + r], B_tap = X[pixel + tap][ci0 + 32 ib + r]
         const float* ap = dzt + h * 64 + cb * 32 + r;

@@ -128,13 +128,14 @@ def trunk_eval(plan, x, patch_dim, patch_stride, layer_outputs, pooled):
         conv = (lambda *a: ops.conv_fwd_hwnc(*a, x3=x3)) if x3 else ops.conv_fwd_hwnc
     else:
         conv = (lambda *a: ops.conv_fwd(*a, x3)) if x3 else ops.conv_fwd
+    c64 = not x3 and _os.environ.get("SSAD_C64_EVAL", "1") != "0"      # exact-fp32 layer1 through csrc/conv_c64.hip
     win = (patch_dim, patch_dim) if patch_dim else (h, w)
     if win == (32, 32):
         # exact 2x nearest upsample: folded 4x4 conv + BN + ReLU + max-pool fused, the conv map never reaches HBM
-        a = ops.stem_patch_pool_fwd(x, plan.stem_wf, plan.stem_s, plan.stem_t, patch_stride if patch_dim else 1, hwnc)
+        a = ops.stem_patch_pool_fwd(x, plan.stem_wf, plan.stem_s, plan.stem_t, patch_stride if patch_dim else 1, hwnc and not c64)
     else:
-        a = ops.stem_fwd(x, plan.stem_w, plan.stem_s, plan.stem_t, True, patch_dim, patch_stride, hwnc)
-        a = ops.maxpool3x3s2_fwd(a, hwnc)
+        a = ops.stem_fwd(x, plan.stem_w, plan.stem_s, plan.stem_t, True, patch_dim, patch_stride, hwnc and not c64)
+        a = ops.maxpool3x3s2_fwd(a, hwnc and not c64)
     offs, off = {}, 0
     for k in ("layer1", "layer2", "layer3"):
         if k in layer_outputs:
@@ -147,11 +148,19 @@ def trunk_eval(plan, x, patch_dim, patch_stride, layer_outputs, pooled):
         if "wd" in d:
             idt = conv(a, d["wd"], d["sd"], d["td"], None, False, s, 0)
         wino = hwnc and "u2" in d and hv == 64 and wv == 64
-        if wino and "u1" in d:
+        if c64 and name == "layer1":
+            # halo-tile kernel: one halo load per 8 x 16 pixel tile instead of one gather per filter tap
+            # (measured at 15 979 patches of 16 x 16: 2.39 ms against 2.53 position-major implicit GEMM; NHWC tensors are
+            # another 5 % faster than position-major ones, so layer1 stays NHWC and its last conv writes [H][W][N][C])
+            t = ops.conv3x3_c64_eval(a, d["w1"], d["s1"], d["t1"], None, True, False, False)
+            a = ops.conv3x3_c64_eval(t, d["w2"], d["s2"], d["t2"], idt, True, False, hwnc and i == 1, False)
+        elif wino and "u1" in d:
             t = ops.conv3x3_wino_hwnc(a, d["u1"], d["s1"], d["t1"], None, True)
         else:
             t = conv(a, d["w1"], d["s1"], d["t1"], None, True, s, 1)
-        if wino:
+        if c64 and name == "layer1":
+            pass
+        elif wino:
             a = ops.conv3x3_wino_hwnc(t, d["u2"], d["s2"], d["t2"], idt, True)
         else:
             a = conv(t, d["w2"], d["s2"], d["t2"], idt, True, 1, 1)

@@ -266,6 +266,27 @@ def conv3x3_c64(x, w_ohwi, residual=None, transform=None, emit=False, stats=None
     return res[0] if len(res) == 1 else tuple(res)
 
 
+def conv3x3_c64_eval(x, w_ohwi, scale=None, shift=None, residual=None, relu=False, in_hwnc=False, out_hwnc=False,
+                     res_hwnc=None):
+    """Halo-tile 3x3 / stride 1 / pad 1 convolution 64 -> 64 with the inference epilogue act(conv * scale + shift + residual).
+    x is NHWC [N][H][W][64] or, with in_hwnc, position-major [H][W][N][64]; the output likewise under out_hwnc and the
+    residual under res_hwnc (default: the output's layout)."""
+    res_hwnc = out_hwnc if res_hwnc is None else res_hwnc
+    if in_hwnc:
+        h, w, n, c = x.shape
+    else:
+        n, h, w, c = x.shape
+    assert c == 64 and tuple(w_ohwi.shape) == (64, 3, 3, 64)
+    out = _new((h, w, n, 64) if out_hwnc else (n, h, w, 64), x)
+    assert residual is None or tuple(residual.shape) == ((h, w, n, 64) if res_hwnc else (n, h, w, 64))
+    nb = 4.0 * (x.numel() + out.numel() * (2 if residual is not None else 1) + w_ohwi.numel())
+    _run("conv_c64_f32", 2.0 * out.numel() * 9 * 64, nb,
+         lambda: _hip.lib().ssad_conv3x3_c64_eval(_hip.ptr(x), _hip.ptr(w_ohwi), _hip.ptr(out), _hip.ptr(scale, True),
+                                                  _hip.ptr(shift, True), _hip.ptr(residual, True), int(relu), n, h, w,
+                                                  int(in_hwnc), int(out_hwnc), int(res_hwnc), _hip.stream()))
+    return out
+
+
 def linear_fwd(x, w, scale=None, shift=None, relu=False, x3=False):
     """x [N][Cin], w [Cout][Cin] -> [N][Cout] (the same MFMA kernel with H=W=KH=KW=1)."""
     n, cin = x.shape

@@ -769,6 +769,46 @@ def test_conv3x3_c64_halo_kernel(dev):
         assert torch.equal(z2, z)                                      # deterministic; emit / stats do not change the result
 
 
+def test_conv3x3_c64_eval_form(dev, monkeypatch):
+    """Inference form of the halo-tile conv (scale / shift / residual / ReLU epilogue) in both layouts and across them,
+    against torch and against the implicit-GEMM kernels it replaces in the scoring trunk; then a whole patch-scoring
+    forward with the kernel switched on and off."""
+    from self_supervised import ops
+    for (n, h, w) in [(130, 16, 16), (3, 12, 20), (1, 5, 7), (7, 8, 8), (2, 64, 64)]:
+        g = torch.Generator().manual_seed(n * 7 + h)
+        x = torch.randn(n, 64, h, w, generator=g)
+        wt = torch.randn(64, 64, 3, 3, generator=g) / 24.0
+        res = torch.randn(n, 64, h, w, generator=g)
+        sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+        nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev)
+        hw = lambda t: t.permute(2, 3, 0, 1).contiguous().to(dev)
+        w_ohwi = ops.repack_oihw_to_ohwi(wt.to(dev))
+        want = F.relu(F.conv2d(x, wt, None, 1, 1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + res)
+        scd, shd = sc.to(dev), sh.to(dev)
+        a = ops.conv3x3_c64_eval(nh(x), w_ohwi, scd, shd, nh(res), True)
+        assert rel_err(a.permute(0, 3, 1, 2), want) < 2e-5
+        assert rel_err(a, ops.conv_fwd(nh(x), w_ohwi, scd, shd, nh(res), True, 1, 1)) < 2e-6
+        b = ops.conv3x3_c64_eval(hw(x), w_ohwi, scd, shd, hw(res), True, True, True)
+        assert torch.equal(b.permute(2, 0, 1, 3), a)                      # the layout changes addresses, not arithmetic
+        assert rel_err(b, ops.conv_fwd_hwnc(hw(x), w_ohwi, scd, shd, hw(res), True, 1, 1)) < 2e-6
+        c = ops.conv3x3_c64_eval(nh(x), w_ohwi, scd, shd, hw(res), True, False, True)
+        assert torch.equal(c, b)
+        c = ops.conv3x3_c64_eval(nh(x), w_ohwi, scd, shd, nh(res), True, False, True, False)     # the scoring trunk's last layer1 conv
+        assert torch.equal(c, b)
+        d = ops.conv3x3_c64_eval(hw(x), w_ohwi, None, None, None, False, True, False)
+        assert rel_err(d.permute(0, 3, 1, 2), F.conv2d(x, wt, None, 1, 1)) < 2e-5
+    from self_supervised.models import PeraNet
+    torch.manual_seed(3)
+    m = PeraNet().to(dev).eval()
+    m.enable_patch_level_mode()
+    img = torch.rand(1, 3, 256, 256, device=dev)
+    monkeypatch.setenv("SSAD_C64_EVAL", "0")
+    ref = m(img)["latent_space"].clone()
+    monkeypatch.setenv("SSAD_C64_EVAL", "1")
+    got = m(img)["latent_space"]
+    assert got.shape == ref.shape and rel_err(got, ref) < 1e-5
+
+
 def test_wgrad3x3_halo_kernel(dev, monkeypatch):
     """Halo-tile weight gradient (3x3 / stride 1 / pad 1, channels multiples of 64) against autograd and against the
     split-over-pixels kernel it replaces: ragged tiles, maps narrower than a tile, several (co, ci) blocks, many splits."""

@@ -59,6 +59,11 @@ def main():
                 xh = x.permute(1, 2, 0, 3).contiguous()
                 t = timeit(lambda: ops.conv_fwd_hwnc(xh, wt, sc, sh, None, True, s, p), iters)
                 line += f" | hwnc {flops / t / 1e12:6.1f} ({t * 1e3:7.3f} ms)"
+                if k == 3 and s == 1 and cin == 64 and cout == 64:
+                    t = timeit(lambda: ops.conv3x3_c64_eval(xh, wt, sc, sh, None, True, True, True), iters)
+                    line += f" | c64 hwnc {flops / t / 1e12:6.1f} ({t * 1e3:7.3f} ms)"
+                    t = timeit(lambda: ops.conv3x3_c64_eval(x, wt, sc, sh, None, True, False, False), iters)
+                    line += f" | c64 nhwc {flops / t / 1e12:6.1f} ({t * 1e3:7.3f} ms)"
                 if k == 3 and s == 1 and h % 2 == 0:
                     u = ops.wino_weight_transform(wt)
                     t = timeit(lambda: ops.conv3x3_wino_hwnc(xh, u, sc, sh, None, True), iters)
