@@ -20,6 +20,13 @@
 #define WGH_ABL 0
 #endif
 
+#if WGH_ABL & 16
+__device__ unsigned long long* g_wgh_trace;      // [workgroups][72]: time stamps (tools/micro/wgh_ablate.hip)
+#define WGH_STAMP(i) do { if (threadIdx.x == 0 && g_wgh_trace && (i) < 64) g_wgh_trace[(size_t)blockIdx.x * 72 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WGH_STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 struct WgHaloParams {
@@ -57,35 +64,53 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(WgHaloParams p) {
 
     const int tpi = p.tiles_y * p.tiles_x;
     f32x4 dv[NDZ], xv[NX];
-    // the operands of tile `tile` -> registers (zero padding / ragged tiles read as zeros)
-    auto load_tile = [&](int64_t tile) {
-        const int64_t n = tile / tpi;
-        const int rem = (int)(tile - n * tpi);
+    // The operands of a tile -> registers, one 16-byte piece at a time (zero padding / ragged tiles read as zeros).
+    // A wave that streams fp32 MFMAs keeps its SIMD to itself (tools/micro/partner_starve.hip: the co-resident wave issues
+    // NOTHING meanwhile), so address arithmetic placed before or after the matrix loop is paid in full; placed BETWEEN the
+    // wave's own MFMAs it is free (the pipe is busy 64 cycles per instruction).  The pieces of the next tile are therefore
+    // issued one per MFMA group inside the loop below.
+    int y0n = 0, x0n = 0;                       // origin of the tile being fetched (workgroup-uniform)
+    const float *dzn = p.dz, *xn = p.x;         // its image (workgroup-uniform base pointers)
+    auto set_tile = [&](int tile) {
+        const int n = tile / tpi;
+        const int rem = tile - n * tpi;
         const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
-        const int y0 = ty * TH, x0 = tx * TW;
-        const int64_t ibase = n * p.H * p.W;
-#pragma unroll
-        for (int q = 0; q < NDZ; ++q) {
-            const int tp = q * 16 + p0;
-            const int y = y0 + tp / TW, x = x0 + tp % TW;
+        y0n = ty * TH;
+        x0n = tx * TW;
+        dzn = p.dz + (int64_t)n * p.H * p.W * p.Cout + co0;
+        xn = p.x + (int64_t)n * p.H * p.W * p.Cin + ci0;
+    };
+    auto load_piece = [&](int g) {              // g is a compile-time constant wherever this is called
+        if (g < NDZ) {
+            const int tp = g * 16 + p0;
+            const int y = y0n + tp / TW, x = x0n + tp % TW;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (y < p.H && x < p.W) v = *(const f32x4*)(p.dz + (ibase + (int64_t)y * p.W + x) * p.Cout + co0 + c4 * 4);
-            dv[q] = v;
-        }
-#pragma unroll
-        for (int q = 0; q < NX; ++q) {
+            if (y < p.H && x < p.W) v = *(const f32x4*)(dzn + (unsigned)((y * p.W + x) * p.Cout + c4 * 4));
+            dv[g] = v;
+        } else if (g < NDZ + NX) {
+            const int q = g - NDZ;
             const int hp = q * 16 + p0;
             const int hy = hp / HWp, hx = hp - hy * HWp;
-            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const int y = y0n - 1 + hy, x = x0n - 1 + hx;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (hp < NH && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
-                v = *(const f32x4*)(p.x + (ibase + (int64_t)y * p.W + x) * p.Cin + ci0 + c4 * 4);
+                v = *(const f32x4*)(xn + (unsigned)((y * p.W + x) * p.Cin + c4 * 4));
             xv[q] = v;
         }
     };
-    if (t_begin < t_end) load_tile(t_begin);
-    for (int64_t tile = t_begin; tile < t_end; ++tile) {
-        if (!(WGH_ABL & 2) || tile == t_begin) {
+    const int t_begin_i = (int)t_begin, t_end_i = (int)t_end;
+    if (t_begin_i < t_end_i) {
+        set_tile(t_begin_i);
+#pragma unroll
+        for (int g = 0; g < NDZ + NX; ++g) load_piece(g);
+    }
+    WGH_STAMP(0);
+#if WGH_ABL & 16
+    if (threadIdx.x == 0 && g_wgh_trace) { g_wgh_trace[(size_t)blockIdx.x * 72 + 64] = __builtin_amdgcn_s_memrealtime(); g_wgh_trace[(size_t)blockIdx.x * 72 + 66] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4); }
+#endif
+    for (int tile = t_begin_i; tile < t_end_i; ++tile) {
+        WGH_STAMP(1 + 2 * (tile - t_begin_i));
+        if (!(WGH_ABL & 2) || tile == t_begin_i) {
         __syncthreads();                        // the previous tile's fragments have all been read
 #pragma unroll
         for (int q = 0; q < NDZ; ++q) *(f32x4*)(dzt + (q * 16 + p0) * 64 + c4 * 4) = dv[q];
@@ -94,25 +119,34 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(WgHaloParams p) {
             if (q * 16 + p0 < NH) *(f32x4*)(halo + (q * 16 + p0) * 64 + c4 * 4) = xv[q];
         __syncthreads();
         }
-        if (tile + 1 < t_end && !(WGH_ABL & 1)) load_tile(tile + 1);      // in flight under this tile's MFMAs
+        WGH_STAMP(2 + 2 * (tile - t_begin_i));
+        // next tile (the last one re-fetches itself: no branch in the matrix loop, the data is simply not used)
+        set_tile(tile + 1 < t_end_i ? tile + 1 : tile);
 
         // lane (r, h): k slot h = pixel (py, 2 pp + h); A = dZ[pixel][co0 + 32 cb + r], B_tap = X[pixel + tap][ci0 + 32 ib + r]
         const float* ap = dzt + h * 64 + cb * 32 + r;
         const float* bp = halo + h * 64 + ib * 32 + r;
-#pragma unroll 1
-        for (int py = 0; py < TH; ++py) {
+        // fragments of group g + 1 are requested before the MFMAs of group g (LDS latency in the shadow as well)
+        constexpr int NG = TH * (TW / 2);
+        float a[2], b[2][9];
+        auto read_group = [&](int g, int slot) {
+            const int py = g / (TW / 2), pp = g % (TW / 2);
+            a[slot] = ap[(py * TW + 2 * pp) * 64];
 #pragma unroll
-            for (int pp = 0; pp < TW / 2; ++pp) {
-                const float a = ap[(py * TW + 2 * pp) * 64];
-                float b[9];
+            for (int t = 0; t < 9; ++t) b[slot][t] = bp[((py + t / 3) * HWp + 2 * pp + t % 3) * 64];
+        };
+        read_group(0, 0);
 #pragma unroll
-                for (int t = 0; t < 9; ++t) b[t] = bp[((py + t / 3) * HWp + 2 * pp + t % 3) * 64];
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) read_group(g + 1, (g + 1) & 1);
 #pragma unroll
-                for (int t = 0; t < 9; ++t) acc[t] = mfma32(a, b[t], acc[t]);
-            }
+            for (int t = 0; t < 9; ++t) acc[t] = mfma32(a[g & 1], b[g & 1][t], acc[t]);
+            if (!(WGH_ABL & 1)) load_piece(g);       // one piece of the next tile in this group's shadow
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
+    WGH_STAMP(62);
     // D[row = co][col = ci]: reg e of lane (r, h) = co (e & 3) + 8 (e >> 2) + 4 h, ci r
     float* out = p.slab + (int64_t)split * p.Cout * 9 * p.Cin;
 #pragma unroll
@@ -122,6 +156,10 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(WgHaloParams p) {
             const int co = co0 + cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
             out[((int64_t)co * 9 + t) * p.Cin + ci0 + ib * 32 + r] = acc[t][e];
         }
+    WGH_STAMP(63);
+#if WGH_ABL & 16
+    if (threadIdx.x == 0 && g_wgh_trace) g_wgh_trace[(size_t)blockIdx.x * 72 + 65] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 static int halo_splits(int64_t ntiles, int npairs) {
