@@ -366,9 +366,12 @@ def main():
             out["metric"] = "anomaly-maps/sec, ResNet-18 256x256 bs256 (scoring phase only)"
     out["ms_per_step"] = round(1e3 * tot_s / args.steps, 3)
 
-    # roofline of the dominant kernel (conv_igemm_f32: every 3x3 / 1x1 conv and linear layer), live HIP events
+    # roofline of the dominant kernel, live HIP events on the launch stream.  Scoring: the position-major instantiation of the
+    # implicit-GEMM conv (conv_igemm_f32_kernel<128,128,2,2,32,1,POS=true>, 30 launches per 128-image pass: layers 2-4);
+    # training-only runs: the NHWC instantiations of the same kernel (forward + input-gradient convs, linear layers).
     phase = "score" if "score" in prof else "train"
-    recs = [r for r in prof.get(phase, []) if r["kernel"].startswith("conv_igemm_f32")] or \
+    tag = "conv_igemm_pos_f32" if phase == "score" else "conv_igemm_f32"
+    recs = [r for r in prof.get(phase, []) if r["kernel"] == tag] or \
            [r for r in prof.get(phase, []) if r["kernel"].startswith("conv_igemm")]
     if recs:
         t = sum(r["ms"] for r in recs) * 1e-3
@@ -377,22 +380,26 @@ def main():
         allk = sum(r["ms"] for r in prof[phase]) * 1e-3
         ach = fl / t / 1e12
         traffic, tsrc = None, None       # HBM-side bytes per launch from the committed PMC passes of this command line
-        for name in ("r02_traffic.json", "r01_traffic.json"):
-            tj = os.path.join(ROOT, "profiles", name)
-            if phase == "score" and per_rank == 256 and args.size == 256 and os.path.exists(tj):
-                traffic, tsrc = json.load(open(tj))["traffic_MB_per_launch"] * 1e6, "profiles/" + name
-                break
+        tj = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        if phase == "score" and os.path.exists(tj):
+            tjd = json.load(open(tj))
+            if tjd.get("patches_per_launch") == getattr(model, "last_pass_samples", None):      # same launch geometry only
+                traffic, tsrc = tjd["traffic_MB_per_launch"] * 1e6, "profiles/r02_traffic.json"
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                            "executed": round(xfl / t / 1e12, 2), "executed_frac": round(xfl / t / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                            "traffic": traffic, "traffic_source": tsrc,
-                           "kernel": "conv_igemm_f32_kernel", "phase": phase, "launches": len(recs),
+                           "kernel": "conv_igemm_f32_kernel<128,128,2,2,32,1,POS=true>" if tag == "conv_igemm_pos_f32" else "conv_igemm_f32_kernel",
+                           "phase": phase, "launches": len(recs),
                            "avg_launch_ms": round(1e3 * t / len(recs), 4),
                            "alg_gflop_per_launch": round(fl / len(recs) / 1e9, 3),
+                           "alg_MB_per_launch": round(sum(r["bytes"] for r in recs) / len(recs) / 1e6, 1),
                            "alg_GBps": round(sum(r["bytes"] for r in recs) / t / 1e9, 1),
                            "share_of_gpu_time": round(t / allk, 4),
-                           "note": "achieved = ALGORITHMIC FLOPs / kernel time; executed = MFMA FLOPs really issued (position-major "
-                                   "convs skip the filter taps that fall into the zero padding: exact, only x*0 products are dropped)"}
+                           "note": "achieved / frac count ALGORITHMIC FLOPs (SURVEY 8d: 2 M K Cout per conv) over kernel time, so frac can "
+                                   "exceed 1: position-major convs skip the filter taps that fall into the zero padding (exact, only x*0 "
+                                   "products are dropped).  executed / executed_frac count the MFMA FLOPs really issued: that is the "
+                                   "kernel-quality figure."}
         out["kernel_ms"] = {}
         for ph in prof:
             nst = prof_train_steps if ph == "train" else args.steps

@@ -161,7 +161,7 @@ def conv_fwd_hwnc(x, w_ohwi, scale=None, shift=None, residual=None, relu=False, 
                                     _hip.ptr(shift, True), _hip.ptr(residual, True), int(relu), n, h, w,
                                     cin, cout, kh, kw, stride, pad, 1, _hip.stream()))
         return out
-    _run("conv_igemm_f32", 2.0 * out.numel() * kh * kw * cin, nb,
+    _run("conv_igemm_pos_f32", 2.0 * out.numel() * kh * kw * cin, nb,          # the position-major instantiations (POS = true)
          lambda: _hip.lib().ssad_conv_igemm_fwd_hwnc(_hip.ptr(x), _hip.ptr(w_ohwi), _hip.ptr(out), _hip.ptr(scale, True),
                                                      _hip.ptr(shift, True), _hip.ptr(residual, True), int(relu), n, h, w,
                                                      cin, cout, kh, kw, stride, pad, _hip.stream()),

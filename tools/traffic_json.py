@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/r02_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --phase score`.
-usage: traffic_json.py <dir_fetch> <dir_write> <out.json>   (MI355X_MICROARCH.md, HBM: FETCH_SIZE is doubled on gfx950)"""
+usage: traffic_json.py <dir_fetch> <dir_write> <out.json> <patches per launch>   (MI355X_MICROARCH.md, HBM: FETCH_SIZE is doubled on gfx950)"""
 import csv, glob, json, sys
 def total(d, counter):
     names = {}
@@ -22,6 +22,7 @@ out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separa
        "correction": "FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B for 16-B/lane streaming reads, MI355X_MICROARCH.md section HBM); WRITE_SIZE as read",
        "fetch_MB_per_launch": round(2 * fetch * 1024 / n / 1e6, 1), "write_MB_per_launch": round(write * 1024 / max(nw, 1) / 1e6, 1)}
 out["traffic_MB_per_launch"] = round(out["fetch_MB_per_launch"] + out["write_MB_per_launch"], 1)
+out["patches_per_launch"] = int(sys.argv[4])
 out["note"] = "fabric-side counters: Infinity-Cache hits are included, so this is an upper bound on HBM bytes"
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(out)
