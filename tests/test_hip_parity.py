@@ -78,9 +78,11 @@ def test_conv_igemm(dev, case):
 
 
 @pytest.mark.parametrize("case", [(130, 4, 4, 64, 64, 3, 1, 1), (200, 2, 2, 64, 128, 3, 1, 1), (150, 8, 8, 32, 96, 3, 2, 1),
-                                  (70, 16, 16, 32, 64, 3, 1, 1), (300, 8, 8, 64, 128, 1, 2, 0), (129, 1, 1, 32, 64, 3, 1, 1)])
+                                  (70, 16, 16, 32, 64, 3, 1, 1), (300, 8, 8, 64, 128, 1, 2, 0), (129, 1, 1, 32, 64, 3, 1, 1),
+                                  (4229, 4, 4, 32, 128, 3, 1, 1), (4229, 8, 8, 32, 64, 3, 2, 1), (8200, 2, 2, 32, 32, 3, 1, 1)])
 def test_conv_igemm_hwnc(dev, case):
-    """Position-major layout [H][W][N][C] with padding taps skipped: same numbers as conv2d."""
+    """Position-major layout [H][W][N][C] with padding taps skipped: same numbers as conv2d.  The last three cases have more
+    than 32 sample groups: the heaviest-first position order then runs chunk by chunk, with a ragged last chunk."""
     from self_supervised import ops
     n, h, w, cin, cout, k, s, p = case
     g = torch.Generator().manual_seed(sum(case))
