@@ -825,6 +825,7 @@ class DataParallelStep:
         import os
         self.use_graph = (os.environ.get("SSAD_GRAPH", "1") != "0") if graph is None else bool(graph)
         self._plans, self._seen = {}, {}
+        self._cap_stream = None
 
     # ---- pieces ----
     def _sync_hyper(self):
@@ -872,7 +873,9 @@ class DataParallelStep:
         """Record the step for this input shape as graph segments cut at the gradient-bucket boundaries."""
         plan = {"x": torch.empty_like(x).copy_(x), "y": torch.empty_like(y).copy_(y), "ops": []}
         pool = torch.cuda.graph_pool_handle()
-        stream = torch.cuda.Stream()
+        if self._cap_stream is None:               # ONE side stream for every capture of this object (streams are multiplexed
+            self._cap_stream = torch.cuda.Stream()  # onto a few hardware queues: a new one per input shape is not free)
+        stream = self._cap_stream
         multi = self.world > 1
         seg = {"g": None, "mark": 0}
 
