@@ -54,7 +54,13 @@ __global__ __launch_bounds__(256, 2) void stem_conv7x7_kernel(StemParams p) {
 
     double st0[2] = {0.0, 0.0}, st1[2] = {0.0, 0.0};      // train-mode BatchNorm statistics of this lane's channels
     const int tiles_per_sample = p.tiles_y * p.tiles_x;
-    for (int64_t t = blockIdx.x; t < p.total_tiles; t += gridDim.x) {
+    const bool direct = p.ph == p.Hv && p.pw == p.Wv;      // no nearest resize (windows of 64 pixels and more): no divisions
+    const int64_t plane = (int64_t)p.H * p.W;
+    // The (virtual, zero-padded) input tile of a workgroup's NEXT tile is fetched into registers while the current tile's MFMAs
+    // run (the loads are issued just before the matrix loop and land under it; they reach LDS after the next barrier)
+    constexpr int NIN = (TIH * TIW + 255) / 256;             // 6 pixels per thread
+    float pv[NIN][3];
+    auto fetch_tile = [&](int64_t t) {
         const int64_t n = t / tiles_per_sample;
         const int tt = (int)(t - n * tiles_per_sample);
         const int ty0 = (tt / p.tiles_x) * TOH, tx0 = (tt % p.tiles_x) * TOW;
@@ -62,24 +68,38 @@ __global__ __launch_bounds__(256, 2) void stem_conv7x7_kernel(StemParams p) {
         const int b = (int)(n / P);
         const int pi = (int)(n - (int64_t)b * P);
         const int y0 = (pi / p.pcol) * p.ps, x0 = (pi % p.pcol) * p.ps;
-        const float* src = p.img + (int64_t)b * 3 * p.H * p.W;
-
-        __syncthreads();   // previous tile's readers are done with tin (and wl is visible on first pass)
-        // ---- load the (virtual, zero-padded) input tile: rows 2*ty0-3 .., cols 2*tx0-3 .. ----
-        for (int i = tid; i < TIH * TIW; i += 256) {
-            int iy = i / TIW, ix = i - iy * TIW;
-            int vy = 2 * ty0 - 3 + iy, vx = 2 * tx0 - 3 + ix;
+        const float* src = p.img + (int64_t)b * 3 * plane;
+#pragma unroll
+        for (int q = 0; q < NIN; ++q) {
+            const int i = tid + 256 * q;
+            const int iy = i / TIW, ix = i - iy * TIW;
+            const int vy = 2 * ty0 - 3 + iy, vx = 2 * tx0 - 3 + ix;
             float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-            if ((unsigned)vy < (unsigned)p.Hv && (unsigned)vx < (unsigned)p.Wv) {
-                int sy = y0 + (vy * p.ph) / p.Hv, sx = x0 + (vx * p.pw) / p.Wv;
+            if (i < TIH * TIW && (unsigned)vy < (unsigned)p.Hv && (unsigned)vx < (unsigned)p.Wv) {
+                const int sy = y0 + (direct ? vy : (vy * p.ph) / p.Hv), sx = x0 + (direct ? vx : (vx * p.pw) / p.Wv);
                 const float* s = src + (int64_t)sy * p.W + sx;
-                int64_t plane = (int64_t)p.H * p.W;
                 v0 = s[0]; v1 = s[plane]; v2 = s[2 * plane];
             }
-            float* d = tin + i * 3;
-            d[0] = v0; d[1] = v1; d[2] = v2;
+            pv[q][0] = v0; pv[q][1] = v1; pv[q][2] = v2;
+        }
+    };
+    if ((int64_t)blockIdx.x < p.total_tiles) fetch_tile(blockIdx.x);
+    for (int64_t t = blockIdx.x; t < p.total_tiles; t += gridDim.x) {
+        const int64_t n = t / tiles_per_sample;
+        const int tt = (int)(t - n * tiles_per_sample);
+        const int ty0 = (tt / p.tiles_x) * TOH, tx0 = (tt % p.tiles_x) * TOW;
+
+        __syncthreads();   // previous tile's readers are done with tin (and wl is visible on first pass)
+#pragma unroll
+        for (int q = 0; q < NIN; ++q) {
+            const int i = tid + 256 * q;
+            if (i < TIH * TIW) {
+                float* d = tin + i * 3;
+                d[0] = pv[q][0]; d[1] = pv[q][1]; d[2] = pv[q][2];
+            }
         }
         __syncthreads();
+        if (t + gridDim.x < p.total_tiles) fetch_tile(t + gridDim.x);
 
         // wave w computes output rows ty0 + 2w, ty0 + 2w + 1 (32 pixels each) x 64 channels
         f32x16 acc[2][2];
@@ -187,23 +207,39 @@ __global__ __launch_bounds__(256, 2) void stem_patch_fused_kernel(StemPatchParam
     const int P = p.prow * p.pcol;
     const int64_t plane = (int64_t)p.H * p.W;
 
-    for (int64_t n = blockIdx.x; n < p.Nsamp; n += gridDim.x) {
+    // the source window of a workgroup's NEXT patch is fetched into registers while the current patch is computed
+    constexpr int NSRC = (SP_SH * SP_SW + 255) / 256;        // 6 pixels per thread
+    float pv[NSRC][3];
+    auto fetch_patch = [&](int64_t n) {
         const int b = (int)(n / P);
         const int pi = (int)(n - (int64_t)b * P);
         const int y0 = (pi / p.pcol) * p.ps, x0 = (pi % p.pcol) * p.ps;
         const float* im = p.img + (int64_t)b * 3 * plane;
-        __syncthreads();                                    // previous patch fully consumed
-        for (int i = tid; i < SP_SH * SP_SW; i += 256) {
+#pragma unroll
+        for (int q = 0; q < NSRC; ++q) {
+            const int i = tid + 256 * q;
             const int ty = i / SP_SW, tx = i - ty * SP_SW;
             const int sy = ty - 2, sx = tx - 2;
             float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-            if ((unsigned)sy < 32u && (unsigned)sx < 32u) {
+            if (i < SP_SH * SP_SW && (unsigned)sy < 32u && (unsigned)sx < 32u) {
                 const float* s = im + (int64_t)(y0 + sy) * p.W + x0 + sx;
                 v0 = s[0]; v1 = s[plane]; v2 = s[2 * plane];
             }
-            float* d = src + i * 3;
-            d[0] = v0; d[1] = v1; d[2] = v2;
+            pv[q][0] = v0; pv[q][1] = v1; pv[q][2] = v2;
         }
+    };
+    if ((int64_t)blockIdx.x < p.Nsamp) fetch_patch(blockIdx.x);
+    for (int64_t n = blockIdx.x; n < p.Nsamp; n += gridDim.x) {
+        __syncthreads();                                    // previous patch fully consumed
+#pragma unroll
+        for (int q = 0; q < NSRC; ++q) {
+            const int i = tid + 256 * q;
+            if (i < SP_SH * SP_SW) {
+                float* d = src + i * 3;
+                d[0] = pv[q][0]; d[1] = pv[q][1]; d[2] = pv[q][2];
+            }
+        }
+        if (n + gridDim.x < p.Nsamp) fetch_patch(n + gridDim.x);
         for (int pass = 0; pass < 2; ++pass) {
             const float sc = p.scale ? p.scale[pass * 32 + r] : 1.f;
             const float sh = p.shift ? p.shift[pass * 32 + r] : 0.f;

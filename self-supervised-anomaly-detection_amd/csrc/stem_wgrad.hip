@@ -52,35 +52,58 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemWgradParams p) {
 
     const int tiles_per_sample = p.tiles_y * p.tiles_x;
     const int64_t plane = (int64_t)p.H * p.W;
-    for (int64_t t = blockIdx.x; t < p.total_tiles; t += gridDim.x) {
+    const bool direct = p.Hv == p.H && p.Wv == p.W;      // no nearest resize (images of 64 pixels and more): no divisions
+    // The operands of a workgroup's NEXT tile are fetched into registers while the current tile's MFMAs run (issued just before
+    // the matrix loop, written to LDS after the next barrier)
+    constexpr int NDZ = DY_FLOATS / 4 / 256;                 // 8 16-byte pieces of dz per thread
+    constexpr int NIN = (IH * IW + 255) / 256;               // 4 input pixels per thread
+    f32x4 dzv[NDZ];
+    float pv[NIN][3];
+    auto fetch_tile = [&](int64_t t) {
         const int64_t n = t / tiles_per_sample;
         const int tt = (int)(t - n * tiles_per_sample);
         const int ty0 = (tt / p.tiles_x) * TH, tx0 = (tt % p.tiles_x) * TW;
         const float* src = p.img + n * 3 * plane;
-
-        __syncthreads();                 // the previous tile's readers are done
         // dz tile: TH rows of TW*64 contiguous floats; pixels outside the map contribute zeros
-        for (int i = tid; i < DY_FLOATS / 4; i += 256) {
-            const int px = i >> 4, q = i & 15;
+#pragma unroll
+        for (int q = 0; q < NDZ; ++q) {
+            const int i = tid + 256 * q;
+            const int px = i >> 4, c4 = i & 15;
             const int oy = ty0 + (px >> 5), ox = tx0 + (px & 31);
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (oy < p.Ho && ox < p.Wo) v = *(const f32x4*)(p.dz + ((n * p.Ho + oy) * p.Wo + ox) * 64 + q * 4);
-            ((f32x4*)dys)[i] = v;
+            if (oy < p.Ho && ox < p.Wo) v = *(const f32x4*)(p.dz + ((n * p.Ho + oy) * p.Wo + ox) * 64 + c4 * 4);
+            dzv[q] = v;
         }
         // input tile (virtual, i.e. after the nearest resize of models.py:217-219 when the image is below 64x64)
-        for (int i = tid; i < IH * IW; i += 256) {
+#pragma unroll
+        for (int q = 0; q < NIN; ++q) {
+            const int i = tid + 256 * q;
             const int iy = i / IW, ix = i - iy * IW;
             const int vy = 2 * ty0 - 3 + iy, vx = 2 * tx0 - 3 + ix;
             float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-            if ((unsigned)vy < (unsigned)p.Hv && (unsigned)vx < (unsigned)p.Wv) {
-                const int sy = (vy * p.H) / p.Hv, sx = (vx * p.W) / p.Wv;
+            if (i < IH * IW && (unsigned)vy < (unsigned)p.Hv && (unsigned)vx < (unsigned)p.Wv) {
+                const int sy = direct ? vy : (vy * p.H) / p.Hv, sx = direct ? vx : (vx * p.W) / p.Wv;
                 const float* s = src + (int64_t)sy * p.W + sx;
                 v0 = s[0]; v1 = s[plane]; v2 = s[2 * plane];
             }
-            float* d = tin + i * 3;
-            d[0] = v0; d[1] = v1; d[2] = v2;
+            pv[q][0] = v0; pv[q][1] = v1; pv[q][2] = v2;
+        }
+    };
+    if ((int64_t)blockIdx.x < p.total_tiles) fetch_tile(blockIdx.x);
+    for (int64_t t = blockIdx.x; t < p.total_tiles; t += gridDim.x) {
+        __syncthreads();                 // the previous tile's readers are done
+#pragma unroll
+        for (int q = 0; q < NDZ; ++q) ((f32x4*)dys)[tid + 256 * q] = dzv[q];
+#pragma unroll
+        for (int q = 0; q < NIN; ++q) {
+            const int i = tid + 256 * q;
+            if (i < IH * IW) {
+                float* d = tin + i * 3;
+                d[0] = pv[q][0]; d[1] = pv[q][1]; d[2] = pv[q][2];
+            }
         }
         __syncthreads();
+        if (t + gridDim.x < p.total_tiles) fetch_tile(t + gridDim.x);
 
         // wave w contracts pixel pairs w, w+4, ...: the lane halves hold the pair's two pixels
 #pragma unroll 2
