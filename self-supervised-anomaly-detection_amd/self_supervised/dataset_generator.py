@@ -29,8 +29,9 @@ class Container:
 
 # ---- object mask: Canny -> dilate -> close -> fill -> erode -> largest component (dataset_generator.py:27-39) ----
 def _canny(gray, sigma, low, high):
-    """skimage.feature.canny(gray_uint8, sigma, low_threshold=low, high_threshold=high) -- THIRD-PARTY RESTATEMENT, unpinned
-    (scikit-image is not installed): its documented pipeline, step for step -- the image scaled to [0, 1] (thresholds divided
+    """skimage.feature.canny(gray_uint8, sigma, low_threshold=low, high_threshold=high) -- THIRD-PARTY RESTATEMENT (scikit-image is
+    not a dependency of this package), pinned: identical edge maps to scikit-image 0.18.3 on tests/golden/skimage.npz, where the
+    REFERENCE's own obj_mask built on it is reproduced exactly too.  Its documented pipeline, step for step -- the image scaled to [0, 1] (thresholds divided
     by 255 accordingly), Gaussian smoothing with zero ('constant') borders renormalised by the smoothed all-ones mask, Sobel
     derivatives, non-maximum suppression by bilinear interpolation of the magnitude along the gradient direction on the
     border-eroded mask, double threshold and hysteresis over 8-connected components."""
@@ -212,81 +213,169 @@ def paste_patch(image: Image.Image, patch: Image.Image, coords: tuple, mask: Ima
 # pre-smoothing, CIELAB, k-means in (L, a, b, y, x) restricted to 2S x 2S windows with compactness 10, 10 iterations,
 # connectivity enforcement with min / max size factors 0.5 / 3, labels from 1) is written out here.  It yields the same kind
 # of result -- a handful of compact colour regions -- not scikit-image's exact label image.
-def _rgb2lab(rgb):
-    x = rgb.astype(np.float64) / 255.0
-    lin = np.where(x > 0.04045, ((x + 0.055) / 1.055) ** 2.4, x / 12.92)
+def _rgb2lab(x):
+    """skimage.color.rgb2lab of float RGB in [0, 1] (sRGB -> XYZ -> CIE-Lab, D65 / 2 degree observer) -- third-party, restated;
+    pinned against scikit-image 0.18.3 (tests/golden/skimage.npz)."""
+    x = np.asarray(x, dtype=np.float64)
+    lin = x.copy()
+    hi = x > 0.04045
+    lin[hi] = np.power((x[hi] + 0.055) / 1.055, 2.4)
+    lin[~hi] /= 12.92
     m = np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]])
-    xyz = lin @ m.T / np.array([0.95047, 1.0, 1.08883])
-    f = np.where(xyz > 0.008856, np.cbrt(xyz), 7.787 * xyz + 16.0 / 116.0)
-    return np.stack([116.0 * f[..., 1] - 16.0, 500.0 * (f[..., 0] - f[..., 1]), 200.0 * (f[..., 1] - f[..., 2])], axis=-1)
+    xyz = lin @ m.T.copy()
+    xyz = xyz / np.array([0.95047, 1.0, 1.08883])
+    hi = xyz > 0.008856
+    f = xyz.copy()
+    f[hi] = np.cbrt(xyz[hi])
+    f[~hi] = 7.787 * xyz[~hi] + 16.0 / 116.0
+    fx, fy, fz = f[..., 0], f[..., 1], f[..., 2]
+    return np.concatenate([x_[..., np.newaxis] for x_ in [(116.0 * fy) - 16.0, 500.0 * (fx - fy), 200.0 * (fy - fz)]], axis=-1)
 
 
-def slic_superpixels(image_array, n_segments=5, sigma=2, compactness=10.0, max_num_iter=10):
-    """Label image (int, starting at 1) of ~n_segments SLIC super-pixels of an H x W x 3 uint8 array."""
-    h, w = image_array.shape[:2]
-    lab = _rgb2lab(image_array)
-    lab = np.stack([ndimage.gaussian_filter(lab[..., c], sigma, mode="nearest") for c in range(3)], axis=-1)
-    # regular grid of initial centres: ~n_segments cells of equal area
-    step = max(int(round(np.sqrt(h * w / float(n_segments)))), 1)
-    gy = np.arange(step // 2, h, step)
-    gx = np.arange(step // 2, w, step)
-    if len(gy) == 0:
-        gy = np.array([h // 2])
-    if len(gx) == 0:
-        gx = np.array([w // 2])
-    cy, cx = [a.ravel().astype(np.float64) for a in np.meshgrid(gy, gx, indexing="ij")]
-    centres = np.concatenate([lab[cy.astype(int), cx.astype(int)], cy[:, None], cx[:, None]], axis=1)
-    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
-    ratio = (compactness / float(step)) ** 2                        # spatial weight of D^2 = d_lab^2 + ratio * d_xy^2
-    labels = np.zeros((h, w), np.int64)
-    for _ in range(max_num_iter):
-        best = np.full((h, w), np.inf)
-        for k, (l, a, b, y0, x0) in enumerate(centres):
-            ya, yb = max(int(y0 - 2 * step), 0), min(int(y0 + 2 * step) + 1, h)
-            xa, xb = max(int(x0 - 2 * step), 0), min(int(x0 + 2 * step) + 1, w)
-            win = lab[ya:yb, xa:xb]
-            d = ((win - np.array([l, a, b])) ** 2).sum(-1) + ratio * ((yy[ya:yb, xa:xb] - y0) ** 2 + (xx[ya:yb, xa:xb] - x0) ** 2)
-            sub = best[ya:yb, xa:xb]
-            better = d < sub
-            sub[better] = d[better]
-            labels[ya:yb, xa:xb][better] = k
-        moved = False
-        for k in range(len(centres)):
-            msk = labels == k
-            if msk.any():
-                new = np.concatenate([lab[msk].mean(0), [yy[msk].mean(), xx[msk].mean()]])
-                moved = moved or not np.allclose(new, centres[k])
-                centres[k] = new
-        if not moved:
+def _regular_grid(shape, n_points):
+    """skimage.util.regular_grid: (start, step) per axis of a grid of ~n_points points, as cubically spaced as the shape allows."""
+    ar = np.asanyarray(shape)
+    ndim = len(ar)
+    unsort = np.argsort(np.argsort(ar))
+    sd = np.sort(ar)
+    space = float(np.prod(ar))
+    if space <= n_points:
+        return [(0, 1)] * ndim
+    st = np.full(ndim, (space / n_points) ** (1.0 / ndim), dtype="float64")
+    if (sd < st).any():
+        for dim in range(ndim):
+            st[dim] = sd[dim]
+            space = float(np.prod(sd[dim + 1:]))
+            st[dim + 1:] = (space / n_points) ** (1.0 / (ndim - dim - 1))
+            if (sd >= st).all():
+                break
+    starts = (st // 2).astype(int)
+    steps = np.round(st).astype(int)
+    return [(int(starts[i]), int(steps[i])) for i in unsort]
+
+
+def _slic_kmeans(image, segments, step, max_iter):
+    """The k-means core of scikit-image's SLIC (_slic_cython, unit spacing, no mask) on a (H, W, C) float64 image whose
+    colours are already divided by the compactness; `segments` = rows [y, x, c...].  Every centroid searches a window of
+    +-2 grid steps -- the grid of the ACTUAL number of centroids, not of the requested one -- a pixel goes to the centroid
+    with the smallest colour^2 + xy^2 / step^2 (strict improvement, centroids in order), centroids become the means of their
+    pixels, until nothing changes or max_iter.  Returns labels from 0.  Bit-identical to the compiled function of 0.18.3."""
+    h, w, nc = image.shape
+    seg = np.array(segments, dtype=np.float64)
+    n = seg.shape[0]
+    spatial_weight = 1.0 / (step ** 2)
+    (_, _), (_, wy), (_, wx) = _regular_grid((1, h, w), n)
+    nearest = np.zeros((h, w), np.intp)
+    ys = np.arange(h, dtype=np.float64)[:, None]
+    xs = np.arange(w, dtype=np.float64)[None, :]
+    yy, xx = np.mgrid[0:h, 0:w]
+    fy, fx = yy.ravel().astype(np.float64), xx.ravel().astype(np.float64)
+    for _ in range(max_iter):
+        change = False
+        dist = np.full((h, w), np.finfo(np.float64).max)
+        for k in range(n):
+            cy, cx = seg[k, 0], seg[k, 1]
+            y0, y1 = int(max(cy - 2 * wy, 0)), int(min(cy + 2 * wy + 1, h))
+            x0, x1 = int(max(cx - 2 * wx, 0)), int(min(cx + 2 * wx + 1, w))
+            d = (0.0 + (cy - ys[y0:y1]) ** 2 + (cx - xs[:, x0:x1]) ** 2) * spatial_weight
+            dc = np.zeros((y1 - y0, x1 - x0))
+            for c in range(nc):
+                dc = dc + (image[y0:y1, x0:x1, c] - seg[k, 2 + c]) ** 2
+            d = d + dc
+            sub = dist[y0:y1, x0:x1]
+            better = sub > d
+            if better.any():
+                change = True
+                sub[better] = d[better]
+                nearest[y0:y1, x0:x1][better] = k
+        if not change:
             break
-    # connectivity: every 4-connected component smaller than half the nominal segment joins its most frequent neighbour
-    out = np.zeros((h, w), np.int64)
-    nxt = 0
-    for k in range(len(centres)):
-        c, m = ndimage.label(labels == k)
-        out[c > 0] = c[c > 0] + nxt
-        nxt += m
-    min_size = int(0.5 * h * w / max(len(centres), 1))
-    sizes = np.bincount(out.ravel(), minlength=nxt + 1)
-    order = [lab_id for lab_id in range(1, nxt + 1) if 0 < sizes[lab_id] < min_size]
-    for lab_id in sorted(order, key=lambda i: sizes[i]):
-        msk = out == lab_id
-        ring = ndimage.binary_dilation(msk) & ~msk
-        neigh = out[ring]
-        neigh = neigh[neigh != lab_id]
-        if len(neigh):
-            target = np.bincount(neigh).argmax()
-            out[msk] = target
-            sizes[target] += sizes[lab_id]
-            sizes[lab_id] = 0
-    _, dense = np.unique(out, return_inverse=True)
-    return dense.reshape(h, w) + 1
+        flat = nearest.ravel()
+        cnt = np.bincount(flat, minlength=n).astype(np.float64)
+        new = np.zeros_like(seg)
+        new[:, 0] = np.bincount(flat, weights=fy, minlength=n)
+        new[:, 1] = np.bincount(flat, weights=fx, minlength=n)
+        for c in range(nc):
+            new[:, 2 + c] = np.bincount(flat, weights=image[:, :, c].ravel(), minlength=n)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            seg = new / cnt[:, None]
+    return nearest
+
+
+def _slic_connectivity(labels, min_size, max_size):
+    """scikit-image's _enforce_label_connectivity_cython (2-D, labels from 0 -> from 1): components are found in raster order by
+    a breadth-first search over the 4-neighbourhood (capped at max_size pixels); one smaller than min_size takes the label of
+    the last already-relabelled neighbour the search met, every other one the next new label."""
+    h, w = labels.shape
+    out = np.zeros((h, w), dtype=np.intp)              # 0 = not yet relabelled
+    cur = 1
+    nbr = ((0, 1), (0, -1), (1, 0), (-1, 0))
+    coord = np.empty((max(max_size, 1), 2), np.intp)
+    for y in range(h):
+        for x in range(w):
+            if out[y, x] > 0:
+                continue
+            adjacent = 0
+            lab = labels[y, x]
+            out[y, x] = cur
+            size, visited = 1, 0
+            coord[0] = (y, x)
+            while visited < size < max_size:
+                for dy, dx in nbr:
+                    yy, xx = coord[visited, 0] + dy, coord[visited, 1] + dx
+                    if 0 <= xx < w and 0 <= yy < h:
+                        if labels[yy, xx] == lab and out[yy, xx] == 0:
+                            out[yy, xx] = cur
+                            coord[size] = (yy, xx)
+                            size += 1
+                            if size >= max_size:
+                                break
+                        elif out[yy, xx] > 0 and out[yy, xx] != cur:
+                            adjacent = out[yy, xx]
+                visited += 1
+            if size < min_size:
+                for i in range(size):
+                    out[coord[i, 0], coord[i, 1]] = adjacent
+            else:
+                cur += 1
+    return out
+
+
+def slic_superpixels(image_array, n_segments=5, sigma=2, compactness=10.0, max_num_iter=10, rescale=True):
+    """skimage.segmentation.slic(image, n_segments, sigma=sigma, convert2lab=True) for an H x W x 3 uint8 array: labels from 1.
+    THIRD-PARTY RESTATEMENT (scikit-image is not a dependency of this package).  Pinned: Lab conversion, Gaussian pre-filter, grid
+    seeding, the k-means core and the connectivity pass reproduce scikit-image 0.18.3 bit for bit (tests/golden/skimage.npz,
+    generated with the real library by tests/golden/make_skimage_fixtures.py).  `rescale` selects the wrapper's pre-processing:
+    True (default) = releases >= 0.19, which stretch the float image to [0, 1] by its min / max before the Lab conversion and
+    number labels from 1 -- the releases the reference must have run (datasets.py:204-205 hands label2rgb's result to
+    Image.fromarray, which only the dtype-preserving label2rgb of 0.19+ survives); False = 0.18 (uint8 / 255 only)."""
+    h, w = image_array.shape[:2]
+    img = np.asarray(image_array, dtype=np.float64) / 255.0
+    if rescale:
+        imin, imax = img.min(), img.max()
+        img = img - imin
+        if imax != imin:
+            img = img / (imax - imin)
+    lab = _rgb2lab(img)[np.newaxis]                                       # (1, H, W, 3), as the library lays it out
+    (z0, zs), (y0, ystep), (x0, xstep) = _regular_grid((1, h, w), n_segments)
+    gy, gx = np.arange(y0, h, ystep), np.arange(x0, w, xstep)
+    cy, cx = [a.ravel() for a in np.meshgrid(gy, gx, indexing="ij")]
+    lab = ndimage.gaussian_filter(lab, [sigma, sigma, sigma, 0])          # 'reflect' borders, 4 sigma
+    segments = np.concatenate([cy[:, None], cx[:, None], np.zeros((len(cy), 3))], axis=-1).astype(np.float64)
+    step = float(max(zs, ystep, xstep))
+    lab = np.ascontiguousarray(lab[0] * (1.0 / compactness))
+    labels = _slic_kmeans(lab, segments, step, max_num_iter)
+    segment_size = h * w / float(len(cy))
+    return _slic_connectivity(labels, int(0.5 * segment_size), int(3 * segment_size))
 
 
 def label_mean_rgb(segments, image_array):
-    """skimage.color.label2rgb(segments, image, kind='avg'): every pixel takes the mean colour of its segment (uint8)."""
+    """skimage.color.label2rgb(segments, image, kind='avg') of releases >= 0.19: every pixel takes the mean colour of its
+    segment, written into an array of the IMAGE's dtype (float64 mean -> uint8 by truncation); label 0 would be background."""
     out = np.zeros_like(image_array)
     for s in np.unique(segments):
-        msk = segments == s
-        out[msk] = image_array[msk].mean(axis=0).astype(image_array.dtype)
+        if s == 0:
+            continue
+        msk = (segments == s).nonzero()
+        out[msk] = image_array[msk].mean(axis=0)
     return out

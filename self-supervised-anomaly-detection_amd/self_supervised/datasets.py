@@ -127,7 +127,7 @@ class PretextTaskDataset(Dataset):
             temp = first(self.subject)
             if self.subject == 'cable':
                 # datasets.py:201-206: SLIC super-pixels (5 segments, sigma 2, Lab) painted with their mean colours first
-                # (scikit-image is absent: dataset_generator.slic_superpixels restates the published algorithm, unpinned)
+                # (scikit-image is not a dependency here: dataset_generator.slic_superpixels restates it, pinned against the library)
                 arr = np.array(temp)
                 temp = Image.fromarray(label_mean_rgb(slic_superpixels(arr, n_segments=5, sigma=2), arr)).convert('RGB')
             self.fixed_segmentation = obj_mask(temp)

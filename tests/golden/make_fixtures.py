@@ -24,7 +24,7 @@ Outputs are data only (inputs are regenerated from seeds by oracle.weights):
 The `getitem` section imports the reference's datasets.py / dataset_generator.py and runs ITS __getitem__ on the synthetic
 MVTec-shaped tree of tests/fake_mvtec.py under fixed python / numpy / torch seeds.  Third-party pieces that are absent here
 are stand-ins, flagged: torchvision.transforms := self_supervised/tv_transforms.py of this repo (restated from
-torchvision's public behaviour, RNG calls in torchvision's order); skimage.feature.canny := this repo's Canny restatement;
+torchvision's public behaviour, RNG calls in torchvision's order); skimage.feature.canny := this repo's Canny restatement (identical to scikit-image 0.18.3's: tests/golden/skimage.npz);
 skimage.morphology.square / label := numpy / scipy.ndimage equivalents (label with skimage's default full connectivity).
 Everything else -- label draw, affine / crop order, defect source choice, generate_patch, colour-similarity brightness
 jitter, container clamp, rect2poly, scar rotation and pasting, poly-line sampling + savgol + ImageDraw.line, jitter call

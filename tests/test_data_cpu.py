@@ -176,9 +176,9 @@ def test_sample_defect_draws_like_getitem(golden, tmp_path):
 
 
 def test_cable_slic_presegmentation(tmp_path):
-    """'cable' (datasets.py:201-206): SLIC super-pixels + mean colours before the object mask.  scikit-image is absent, so the
-    restated SLIC is held to the algorithm's properties: a handful of labels starting at 1, every label 4-connected, two
-    flat colour halves separated exactly, determinism; and the dataset builds its fixed mask through it."""
+    """'cable' (datasets.py:201-206): SLIC super-pixels + mean colours before the object mask.  Properties of the restated SLIC
+    (its equality with scikit-image is test_skimage_restatements_match_the_library): a handful of labels starting at 1, every
+    label 4-connected, two flat colour halves separated exactly, determinism; and the dataset builds its fixed mask through it."""
     from scipy import ndimage
     from self_supervised import dataset_generator as dg, datasets
     img = np.zeros((64, 64, 3), np.uint8)
@@ -192,7 +192,7 @@ def test_cable_slic_presegmentation(tmp_path):
     assert not (left & right), "super-pixels must not straddle the colour edge"
     assert np.array_equal(seg, dg.slic_superpixels(img, n_segments=5, sigma=2))
     avg = dg.label_mean_rgb(seg, img)
-    assert avg.shape == img.shape and np.abs(avg[:, :24].astype(int) - (200, 40, 40)).max() <= 12
+    assert avg.shape == img.shape and np.abs(avg[:, :24].astype(int) - (200, 40, 40)).max() <= 20
     root = make_tree(str(tmp_path / "data"), categories=("cable", "carpet"), n_train=3, n_test_good=1, n_test_bad=1, size=96)
     names = np.array(sorted(os.path.join(root, "cable", "train/good", f) for f in os.listdir(os.path.join(root, "cable", "train/good"))))
     ds = datasets.PretextTaskDataset("cable", names, imsize=(64, 64), transform=None, dataset_root=root)
@@ -203,8 +203,32 @@ def test_cable_slic_presegmentation(tmp_path):
     assert x.size == (64, 64) and y in (0, 1, 2, 3)
 
 
+def test_skimage_restatements_match_the_library(golden):
+    """scikit-image is a dependency of the reference (feature.canny inside obj_mask, dataset_generator.py:27-39; slic +
+    label2rgb for 'cable', datasets.py:203-204) but not of this package.  tests/golden/skimage.npz holds what scikit-image
+    0.18.3 -- and the REFERENCE's own obj_mask running on it -- return for eight synthetic images (generated with the real
+    library by tests/golden/make_skimage_fixtures.py in the build container's conda interpreter).  The restatements must
+    reproduce them exactly: edge maps, object masks, super-pixel labels (0.18 pre-processing and the >= 0.19 one assembled
+    from the library's own building blocks), the mean-colour image."""
+    from PIL import Image
+    from self_supervised import dataset_generator as dg
+    d = golden("skimage")
+    assert "scikit-image 0.18.3" in list(d["versions"])
+    for i in range(int(d["n"])):
+        im = d[f"img{i}"]
+        gray = np.array(Image.fromarray(im).convert("L"))
+        assert np.array_equal(gray, d[f"gray{i}"])
+        assert np.array_equal(dg._canny(gray, 1.5, 5, 15), d[f"canny{i}"])
+        assert np.array_equal(np.array(dg.obj_mask(Image.fromarray(im)).convert("1")), d[f"mask{i}"])
+        assert np.abs(dg._rgb2lab(im.astype(np.float64) / 255.0) - d[f"lab{i}"]).max() < 1e-9
+        assert np.array_equal(dg.slic_superpixels(im, 5, 2, rescale=False), d[f"slic18_{i}"])
+        seg = dg.slic_superpixels(im, 5, 2)
+        assert np.array_equal(seg, d[f"slic19_{i}"])
+        assert np.array_equal(dg.label_mean_rgb(seg, im), d[f"avg19_{i}"])
+
+
 def test_canny_restatement_properties():
-    """dataset_generator._canny follows skimage's documented pipeline (third-party, unpinned): on a disc it returns a thin,
+    """dataset_generator._canny follows skimage's documented pipeline (pinned by the test above): on a disc it returns a thin,
     closed, one-component contour at the disc's radius, nothing on a flat image, and nothing on the one-pixel border."""
     from self_supervised import dataset_generator as dg
     from scipy import ndimage
