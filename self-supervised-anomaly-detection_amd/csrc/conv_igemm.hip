@@ -22,6 +22,11 @@
 #include "common.h"
 #include <stdlib.h>
 
+// Ablation switch for tools/micro/igemm_ablate.hip; always 0 in the library build.
+#ifndef IGEMM_ABL
+#define IGEMM_ABL 0
+#endif
+
 namespace {
 
 constexpr int KALIGN = 32;   // Cin granularity every instantiation accepts
@@ -474,6 +479,19 @@ void conv_igemm_f32_kernel(ConvParams p) {
         }
     }
 
+#if IGEMM_ABL & 1      // ablation (tools/micro/igemm_ablate.hip): no epilogue at all
+    {
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sum += acc[i][j][e];
+        if (sum == 123.456f) p.out[0] = sum;
+        return;
+    }
+#endif
     // ---- epilogue: accumulators -> LDS tile [BM/TM][BN+4] -> 16-byte pieces of contiguous output rows; one pass per
     // accumulator row-tile so the tile never needs more LDS than the K-loop stages ----
     float* C = lds;
