@@ -238,6 +238,12 @@ def test_forward_golden_patch_level(dev, golden, seeded_sd):
         m.max_samples_per_pass = 841
         o2 = m(torch.cat([ow.synthetic_images(1, 256, seed=4321)] * 3).to(dev))
         assert torch.equal(o2["latent_space"][:841], o["latent_space"]) and torch.equal(o2["latent_space"][1682:], o["latent_space"])
+        assert m.last_pass_samples == 841
+        # ... nor the cap on elements per activation tensor (2 images per pass here), nor equalised passes (3 images: 2 + 1 -> 2 x 2 rounds down to 1 + ...)
+        m.max_samples_per_pass = 131072
+        m.max_elements_per_tensor = 2 * 841 * 16 * 16 * 64
+        o3 = m(torch.cat([ow.synthetic_images(1, 256, seed=4321)] * 3).to(dev))
+        assert m.last_pass_samples == 2 * 841 and torch.equal(o3["latent_space"], o2["latent_space"])
 
 
 def test_knn_golden(dev, golden):
