@@ -56,24 +56,36 @@ def compute_f1(targets, predictions, threshold) -> float:
 
 
 def best_f1_threshold(scores, targets):
-    """Threshold maximising F1 over the precision-recall curve (tools.py:141-146 of the reference)."""
-    from sklearn.metrics import precision_recall_curve
-    precision, recall, thr = precision_recall_curve(_np(targets).ravel() > 0, _np(scores).ravel())
+    """Threshold maximising F1 over the precision-recall curve (tools.py:141-146 of the reference: torchmetrics'
+    PrecisionRecallCurve(), then t[argmax(2PR / (P + R + 1e-10))]).  The curve is restated the way torchmetrics 0.8-0.10
+    builds it -- one point per distinct score, counts accumulated and divided in float32, cut at the first full-recall point,
+    ascending thresholds -- so that near-ties in F1 resolve as they do there."""
+    s = torch.as_tensor(_np(scores)).flatten().float()
+    t = (torch.as_tensor(_np(targets)).flatten() == 1).to(torch.long)
+    order = torch.argsort(s, descending=True)
+    s, t = s[order], t[order]
+    idx = torch.cat([torch.where(s[1:] - s[:-1])[0], torch.tensor([t.numel() - 1])])
+    tps = torch.cumsum(t * 1.0, dim=0)[idx]
+    fps = 1 + idx - tps
+    last = int(torch.where(tps == tps[-1])[0][0])
+    precision = torch.cat([torch.flip((tps / (tps + fps))[:last + 1], [0]), torch.ones(1)])
+    recall = torch.cat([torch.flip((tps / tps[-1])[:last + 1], [0]), torch.zeros(1)])
+    thr = torch.flip(s[idx][:last + 1], [0])
     f1 = (2 * precision * recall) / (precision + recall + 1e-10)
-    return float(thr[min(int(np.argmax(f1)), len(thr) - 1)])
+    return float(thr[int(np.argmax(f1.numpy()))])
 
 
 def compute_iou(scores, targets, threshold) -> float:
-    """Mean IoU over the two classes {normal, anomalous} of (scores >= threshold)."""
+    """tools.py:131-139: torchmetrics JaccardIndex(2, threshold=) -- mean over the classes {normal, anomalous} of
+    intersection / union of (scores >= threshold) against targets > 0; a class that occurs in neither scores 0."""
     t = _np(targets).ravel() > 0
     p = _np(scores).ravel() >= float(threshold)
     ious = []
     for cls in (False, True):
         inter = float(np.sum((p == cls) & (t == cls)))
         union = float(np.sum((p == cls) | (t == cls)))
-        if union:
-            ious.append(inter / union)
-    return float(np.mean(ious)) if ious else 0.0
+        ious.append(inter / union if union else 0.0)
+    return float(np.mean(ious))
 
 
 def compute_pro(anomaly_maps, ground_truth_maps):

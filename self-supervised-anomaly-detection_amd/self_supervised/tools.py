@@ -58,8 +58,8 @@ class Evaluator:
         if 'f1-score' in self.evaluation_metrics:
             self.scores.f1_score = mtr.compute_f1(targets, scores, threshold)
         if 'aupro' in self.evaluation_metrics:
-            fprs, pros = mtr.compute_pro(np.array(output_container.anomaly_maps.cpu().squeeze(1)),
-                                         np.array(output_container.ground_truths.cpu().squeeze(1)))
+            fprs, pros = mtr.compute_pro(output_container.anomaly_maps.detach().cpu().squeeze(1).numpy(),
+                                         output_container.ground_truths.detach().cpu().squeeze(1).numpy())
             self.scores.aupro = mtr.compute_aupro(fprs, pros, 0.3)
             self.curves['pro'] = (fprs, pros)
         if 'iou' in self.evaluation_metrics:

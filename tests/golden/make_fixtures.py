@@ -15,11 +15,12 @@ as-is; third-party packages that are missing here are replaced by throw-away
 
 Outputs are data only (inputs are regenerated from seeds by oracle.weights):
   forward.npz, train_step.npz, detector.npz, patches.npz, upsample.npz, cutpaste.npz, auroc.npz, gradcam.npz,
-  getitem.npz
+  getitem.npz, metrics.npz
 
     python tests/golden/make_fixtures.py            # everything
     python tests/golden/make_fixtures.py gradcam    # one section
     python tests/golden/make_fixtures.py getitem    # PretextTaskDataset.__getitem__ of the reference (datasets.py:209-394)
+    python tests/golden/make_fixtures.py metrics    # the reference's metrics.py + tools.Evaluator on seeded maps
 
 The `getitem` section imports the reference's datasets.py / dataset_generator.py and runs ITS __getitem__ on the synthetic
 MVTec-shaped tree of tests/fake_mvtec.py under fixed python / numpy / torch seeds.  Third-party pieces that are absent here
@@ -188,12 +189,158 @@ def make_getitem():
     print("getitem.npz: labels", {k: out[k].tolist() for k in out if k.endswith("_y")})
 
 
+def install_torchmetrics_spec_stub():
+    """torchmetrics is absent here.  The three classes the reference's Evaluator uses (tools.py:131-146, metrics.py:42-46) are
+    restated from the published torchmetrics 0.8-0.10 behaviour (the API the reference calls: PrecisionRecallCurve() without
+    `task`, JaccardIndex(2, threshold=), F1Score(threshold=)), in torch and in its dtypes: third-party arithmetic pinned to the
+    spec only; the reference's OWN code around them (F1 formula, argmax, indexing, flattening, target binarisation) runs for real."""
+    F = torch.nn.functional
+
+    class PrecisionRecallCurve:
+        def __call__(self, preds, target):
+            preds, target = preds.flatten(), target.flatten()
+            order = torch.argsort(preds, descending=True)
+            preds, target = preds[order], target[order]
+            distinct = torch.where(preds[1:] - preds[:-1])[0]
+            idx = F.pad(distinct, [0, 1], value=target.size(0) - 1)
+            target = (target == 1).to(torch.long)
+            tps = torch.cumsum(target * 1.0, dim=0)[idx]
+            fps = 1 + idx - tps
+            thr = preds[idx]
+            precision = tps / (tps + fps)
+            recall = tps / tps[-1]
+            last = torch.where(tps == tps[-1])[0][0]
+            sl = slice(0, last.item() + 1)
+            precision = torch.cat([reversed(precision[sl]), torch.ones(1, dtype=precision.dtype)])
+            recall = torch.cat([reversed(recall[sl]), torch.zeros(1, dtype=recall.dtype)])
+            return precision, recall, reversed(thr[sl]).detach().clone()
+
+    class JaccardIndex:
+        def __init__(self, num_classes, threshold=0.5):
+            self.n, self.t = num_classes, threshold
+
+        def __call__(self, preds, target):
+            p = (preds.flatten() >= self.t).long()
+            t = target.flatten().long()
+            conf = torch.bincount(t * self.n + p, minlength=self.n * self.n).reshape(self.n, self.n)
+            inter = torch.diag(conf)
+            union = conf.sum(0) + conf.sum(1) - inter
+            scores = inter.float() / union.float()
+            scores[union == 0] = 0.0                       # absent_score
+            return scores.mean()
+
+    class F1Score:
+        def __init__(self, threshold=0.5):
+            self.t = threshold
+
+        def __call__(self, preds, target):
+            if target.is_floating_point():
+                raise ValueError("The `target` has to be an integer tensor.")
+            p = (preds.flatten() >= self.t).int()
+            t = target.flatten().int()
+            tp = ((p == 1) & (t == 1)).sum()
+            fp = ((p == 1) & (t == 0)).sum()
+            fn = ((p == 0) & (t == 1)).sum()
+
+            def safe(a, b):
+                b = b.float().clone()
+                b[b == 0] = 1.0
+                return a.float() / b
+            prec, rec = safe(tp, tp + fp), safe(tp, tp + fn)
+            den = prec + rec
+            den = torch.where(den == 0, torch.ones_like(den), den)
+            return 2 * prec * rec / den
+
+    tm = sys.modules["torchmetrics"]
+    tm.PrecisionRecallCurve, tm.JaccardIndex, tm.F1Score = PrecisionRecallCurve, JaccardIndex, F1Score
+
+
+def metric_cases():
+    """Seeded (maps, ground truths) for the metric fixtures: blobs of several sizes, diagonal contacts (8-connectivity), a
+    defect-free image, quantised scores (ties: the keep-last-of-a-run rule) and continuous ones."""
+    g = torch.Generator().manual_seed(2024)
+    cases = {}
+    for name, n, hw, quant in (("ties", 5, 24, 32), ("smooth", 6, 32, 0)):
+        gt = torch.zeros(n, 1, hw, hw)
+        for i in range(n - 1):                          # the last image stays defect-free
+            for _ in range(1 + i % 3):
+                y, x = (int(v) for v in torch.randint(0, hw - 6, (2,), generator=g))
+                h, w = (int(v) for v in torch.randint(2, 7, (2,), generator=g))
+                gt[i, 0, y:y + h, x:x + w] = 1.0
+            gt[i, 0, 0, 0] = 1.0; gt[i, 0, 1, 1] = 1.0   # two pixels touching by a corner: ONE region under the 3x3 structure
+        maps = torch.rand(n, 1, hw, hw, generator=g) * 0.6 + 0.35 * gt * torch.rand(n, 1, hw, hw, generator=g)
+        if quant:
+            maps = torch.round(maps * quant) / quant
+        cases[name] = (maps.float(), gt)
+    return cases
+
+
+def make_metrics():
+    """(x) evaluation metrics: the reference's own metrics.py (compute_roc / compute_auc / compute_pro / compute_aupro /
+    trapezoid / compute_f1) and tools.Evaluator (evaluate, _get_threshold) on seeded maps (metrics.py:42-228, tools.py:52-146)."""
+    install_torchmetrics_spec_stub()
+    _stub("self_supervised.visualization", plot_curve=lambda *a, **k: None, plot_tsne=lambda *a, **k: None)
+    _stub("cv2"); _stub("seaborn")
+    import contextlib
+    import io
+    from self_supervised import metrics as rmtr                   # the REFERENCE's modules
+    from self_supervised import tools as rtools
+    from self_supervised.constants import ModelOutputsContainer
+    assert rmtr.__file__.startswith(REF_SRC) and rtools.__file__.startswith(REF_SRC)
+    out = {"cases": np.array(sorted(metric_cases()))}
+    for name, (maps, gt) in metric_cases().items():
+        with contextlib.redirect_stdout(io.StringIO()):
+            out[name + "_maps"], out[name + "_gts"] = t2n(maps), t2n(gt).astype(np.uint8)
+            fprs, pros = rmtr.compute_pro(maps.squeeze().numpy(), gt.squeeze().numpy())
+            out[name + "_fprs"], out[name + "_pros"] = fprs, pros
+            out[name + "_aupro03"] = np.float64(rmtr.compute_aupro(fprs, pros, 0.3))
+            out[name + "_aupro_full"] = np.float64(rmtr.compute_aupro(fprs, pros, 1.0))
+            x_in = float(fprs[len(fprs) // 3])                     # an x_max that IS a curve point / one that is not
+            out[name + "_trap_xs"] = np.array([x_in, 0.3, 0.123456])
+            out[name + "_trap"] = np.array([rmtr.trapezoid(fprs, pros, x_max=v) for v in out[name + "_trap_xs"]] +
+                                           [rmtr.trapezoid(fprs, pros)])
+            flat_s, flat_t = torch.flatten(maps, 0, -1), torch.flatten(gt, 0, -1)
+            fpr, tpr, thr = rmtr.compute_roc(flat_t, flat_s)
+            out[name + "_roc_fpr"], out[name + "_roc_tpr"] = fpr, tpr
+            out[name + "_auc"] = np.float64(rmtr.compute_auc(fpr, tpr))
+            ev = rtools.Evaluator(evaluation_metrics=['auroc', 'aupro', 'iou'])
+            thr_v = ev._get_threshold(flat_s, flat_t)
+            out[name + "_threshold"] = np.float64(float(thr_v))
+            out[name + "_f1"] = np.float64(rmtr.compute_f1(flat_t.long(), flat_s, thr_v))
+            box = ModelOutputsContainer()
+            box.anomaly_maps, box.ground_truths = maps.clone(), gt.clone()
+            box.y_true_binary_labels = (gt.flatten(1).sum(1) > 0).long()
+            ev.evaluate(box, name, None, patch_level=True)         # the reference's own call (test_patch_level_evaluation.py)
+            out[name + "_eval_pixel"] = np.array([ev.scores.auroc, ev.scores.aupro, ev.scores.iou], dtype=np.float64)
+    # image level (tools.py:87-98): one score and one label per image, auroc only (tools.py:101-104 exits on 'f1-score' when
+    # patch_level is False); threshold and F1 through the reference's _get_threshold / compute_f1 called directly
+    g = torch.Generator().manual_seed(77)
+    labels = (torch.rand(60, generator=g) > 0.6).long()
+    scores = (torch.rand(60, generator=g) * 0.5 + 0.25 * labels * torch.rand(60, generator=g)).float()
+    scores[::7] = scores[3]                                        # ties
+    with contextlib.redirect_stdout(io.StringIO()):
+        box2 = ModelOutputsContainer()
+        box2.anomaly_maps, box2.y_true_binary_labels = scores.clone(), labels.clone()
+        ev2 = rtools.Evaluator(evaluation_metrics=['auroc'])
+        ev2.evaluate(box2, "image", None)
+        out["image_scores"], out["image_labels"] = t2n(scores), t2n(labels)
+        out["image_auroc"] = np.float64(ev2.scores.auroc)
+        thr_v = ev2._get_threshold(scores, labels)
+        out["image_threshold"] = np.float64(float(thr_v))
+        out["image_f1"] = np.float64(rmtr.compute_f1(labels, scores, thr_v))
+    np.savez_compressed(os.path.join(HERE, "metrics.npz"), **out)
+    print("metrics.npz:", {k: (v.tolist() if v.size < 5 else v.shape) for k, v in out.items() if not k.endswith(("fprs", "pros", "fpr", "tpr"))})
+
+
 def main():
     assert os.path.isdir(REF_SRC), "reference not present: fixtures can only be made in the build container"
     install_stubs()
     sys.path.insert(0, REF_SRC)
     if sys.argv[1:] == ["getitem"]:
         make_getitem()
+        return
+    if sys.argv[1:] == ["metrics"]:
+        make_metrics()
         return
     from self_supervised import models as rm                     # reference
     if sys.argv[1:] == ["gradcam"]:
@@ -377,6 +524,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "auroc.npz"), labels=labels, scores=scores, auroc=np.float64(auc(fpr, tpr)))
     make_gradcam(rm, sd)
     make_getitem()
+    make_metrics()
     print("fixtures written to", HERE)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

@@ -92,13 +92,58 @@ def test_metrics(golden):
         assert abs(fprs[j] - fpr_t) < 1e-6 and abs(pros[j] - pro_t) < 1e-9
     assert fprs[0] == 0 and pros[-1] == 1
     x = np.array([0, 0.1, 0.2, 0.5, 1.0]); y = np.array([0, 0.5, 0.6, 0.8, 1.0])
-    assert abs(m.trapezoid(x, y) - np.trapz(y, x)) < 1e-12
+    assert abs(m.trapezoid(x, y) - np.trapezoid(y, x)) < 1e-12
     assert abs(m.trapezoid(x, y, x_max=0.3) - (0.025 + 0.055 + 0.5 * (0.6 + 0.6 + 0.2 / 3) * 0.1)) < 1e-12
     assert 0 < m.compute_aupro(fprs, pros, 0.3) <= 1
     s = torch.tensor([0.1, 0.4, 0.35, 0.8]); t = torch.tensor([0, 0, 1, 1])
     thr = m.best_f1_threshold(s, t)
     assert abs(thr - 0.35) < 1e-6 and abs(m.compute_f1(t, s, thr) - 0.8) < 1e-9
     assert abs(m.compute_iou(s, t, 0.5) - np.mean([2 / 3, 1 / 2])) < 1e-9
+
+
+def test_metrics_match_reference(golden):
+    """metrics.py / tools.Evaluator against the reference's own metrics.py:49-228 and tools.py:52-146 run on seeded maps
+    (tests/golden/make_fixtures.py metrics): PRO curve point for point, AUPRO at 0.3 and 1.0, the clipped trapezoid with x_max on
+    and off a curve point, ROC / AUC, the F1-optimal threshold, F1, IoU, and Evaluator.evaluate's pixel- and image-level scores."""
+    from self_supervised import metrics as m, tools
+    from self_supervised.constants import ModelOutputsContainer
+    g = golden("metrics")
+    for name in (str(c) for c in g["cases"]):
+        maps, gts = torch.from_numpy(g[name + "_maps"]), torch.from_numpy(g[name + "_gts"]).float()
+        fprs, pros = m.compute_pro(maps.squeeze(1).numpy(), gts.squeeze(1).numpy())
+        assert fprs.shape == g[name + "_fprs"].shape
+        assert np.abs(fprs - g[name + "_fprs"]).max() < 2e-7 and np.abs(pros - g[name + "_pros"]).max() < 1e-12
+        assert abs(m.compute_aupro(fprs, pros, 0.3) - float(g[name + "_aupro03"])) < 1e-7
+        assert abs(m.compute_aupro(fprs, pros, 1.0) - float(g[name + "_aupro_full"])) < 1e-7
+        rf, rp = g[name + "_fprs"], g[name + "_pros"]              # the integrator alone, on the reference's own curve: exact
+        want = g[name + "_trap"]
+        for v, w in zip(g[name + "_trap_xs"], want[:3]):
+            assert abs(m.trapezoid(rf, rp, x_max=float(v)) - w) < 1e-13
+        assert abs(m.trapezoid(rf, rp) - want[3]) < 1e-13
+        flat_s, flat_t = maps.flatten(), gts.flatten()
+        fpr, tpr, _ = m.compute_roc(flat_t, flat_s)
+        assert np.array_equal(fpr, g[name + "_roc_fpr"]) and np.array_equal(tpr, g[name + "_roc_tpr"])
+        assert abs(m.compute_auc(fpr, tpr) - float(g[name + "_auc"])) < 1e-15
+        thr = m.best_f1_threshold(flat_s, flat_t)
+        assert thr == float(g[name + "_threshold"])
+        assert abs(m.compute_f1(flat_t, flat_s, thr) - float(g[name + "_f1"])) < 2e-7
+        box = ModelOutputsContainer()
+        box.anomaly_maps, box.ground_truths = maps, gts
+        box.y_true_binary_labels = (gts.flatten(1).sum(1) > 0).long()
+        ev = tools.Evaluator(evaluation_metrics=['auroc', 'aupro', 'iou'])
+        ev.evaluate(box, name, None, patch_level=True)
+        got = np.array([ev.scores.auroc, ev.scores.aupro, ev.scores.iou])
+        assert np.abs(got - g[name + "_eval_pixel"]).max() < 2e-7, (got, g[name + "_eval_pixel"])
+    s, l = torch.from_numpy(g["image_scores"]), torch.from_numpy(g["image_labels"])
+    box = ModelOutputsContainer()
+    box.anomaly_maps, box.y_true_binary_labels = s, l
+    ev = tools.Evaluator(evaluation_metrics=['auroc', 'f1-score'])
+    ev.evaluate(box, "image", None)
+    assert abs(ev.scores.auroc - float(g["image_auroc"])) < 1e-15
+    assert ev._get_threshold(s, l) == float(g["image_threshold"])
+    assert abs(ev.scores.f1_score - float(g["image_f1"])) < 2e-7
+    # a class that occurs neither in the prediction nor in the target scores 0 (JaccardIndex's absent_score)
+    assert m.compute_iou(torch.zeros(4), torch.zeros(4), 0.5) == 0.5
 
 
 def _getitem_tree(tmp_path, g):
