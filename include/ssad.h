@@ -89,13 +89,6 @@ int ssad_conv_igemm_fwd_hwnc(const float* in, const float* w_ohwi, float* out, c
                              const float* residual, int relu, int64_t N, int H, int W, int Cin, int Cout, int KH, int KW,
                              int stride, int pad, void* stream);
 
-/* Winograd F(2x2,3x3) form of ssad_conv_igemm_fwd_hwnc for 3x3 stride-1 pad-1 convs on even-sized maps: same call sites
- * (BasicBlock convs, models.py:224), 4 multiplies per output instead of 9.  u = ssad_wino_weight_transform(w_ohwi):
- * [16][Cout][Cin] = G g G^T.  Activations [H][W][N][C]; result equals the direct convolution up to fp32 rounding. */
-int ssad_wino_weight_transform(const float* w_ohwi, float* u, int Cout, int Cin, void* stream);
-int ssad_conv3x3_wino_fwd_hwnc(const float* in, const float* u, float* out, const float* scale, const float* shift,
-                               const float* residual, int relu, int64_t N, int H, int W, int Cin, int Cout, void* stream);
-
 /* Replaces F.adaptive_avg_pool2d(., (1,1)) + flatten + torch.cat (models.py:227-245):
  * out[n*out_stride + out_offset + c] = mean over HW of in[n][hw][c]. */
 int ssad_gap_fwd(const float* in, float* out, int64_t N, int HW, int C, int out_stride, int out_offset, int hwnc,

@@ -9,14 +9,11 @@ beta' = beta - mean*alpha: the same two-constant form PyTorch's CPU kernel evalu
 import torch
 from torch import nn
 
+import os as _os
+
 from . import ops
 
 BLOCKS = [("layer1", 64, 64, 1), ("layer2", 64, 128, 2), ("layer3", 128, 256, 2), ("layer4", 256, 512, 2)]
-# Stages whose patch-scoring 3x3/1 convs run through Winograd F(2x2,3x3) (csrc/conv_wino.hip).  Measured in round 1:
-# 8-9 % faster than the tap-skipping direct kernel on 8x8 / 4x4 maps in isolation, +1 % end to end (622 -> 628 maps/s)
-# -- not enough to justify a second rounding path, so it is OFF by default; SSAD_WINOGRAD=1 enables layer2/layer3.
-import os as _os
-WINO_STAGES = ("layer2", "layer3") if _os.environ.get("SSAD_WINOGRAD") == "1" else ()
 
 
 def math_mode():
@@ -88,10 +85,6 @@ class EvalPlan:
                     d = {"stride": blk.stride,
                          "w1": ops.repack_oihw_to_ohwi(blk.conv1.weight.contiguous()),
                          "w2": ops.repack_oihw_to_ohwi(blk.conv2.weight.contiguous())}
-                    if name in WINO_STAGES:          # Winograd-transformed copies for the stride-1 3x3 convs
-                        d["u2"] = ops.wino_weight_transform(d["w2"])
-                        if blk.stride == 1:
-                            d["u1"] = ops.wino_weight_transform(d["w1"])
                     d["s1"], d["t1"] = _fold_bn(blk.bn1)
                     d["s2"], d["t2"] = _fold_bn(blk.bn2)
                     if blk.downsample is not None:
@@ -147,22 +140,15 @@ def trunk_eval(plan, x, patch_dim, patch_stride, layer_outputs, pooled):
         idt = a
         if "wd" in d:
             idt = conv(a, d["wd"], d["sd"], d["td"], None, False, s, 0)
-        wino = hwnc and "u2" in d and hv == 64 and wv == 64
         if c64 and name == "layer1":
             # halo-tile kernel: one halo load per 8 x 16 pixel tile instead of one gather per filter tap
             # (measured at 15 979 patches of 16 x 16: 2.39 ms against 2.53 position-major implicit GEMM; NHWC tensors are
             # another 5 % faster than position-major ones, so layer1 stays NHWC and its last conv writes [H][W][N][C])
             t = ops.conv3x3_c64_eval(a, d["w1"], d["s1"], d["t1"], None, True, False, False)
             a = ops.conv3x3_c64_eval(t, d["w2"], d["s2"], d["t2"], idt, True, False, hwnc and i == 1, False)
-        elif wino and "u1" in d:
-            t = ops.conv3x3_wino_hwnc(a, d["u1"], d["s1"], d["t1"], None, True)
         else:
             t = conv(a, d["w1"], d["s1"], d["t1"], None, True, s, 1)
-        if c64 and name == "layer1":
-            pass
-        elif wino:
-            a = ops.conv3x3_wino_hwnc(t, d["u2"], d["s2"], d["t2"], idt, True)
-        else:
+        if not (c64 and name == "layer1"):
             a = conv(t, d["w2"], d["s2"], d["t2"], idt, True, 1, 1)
         last_of_stage = (i % 2 == 1)
         if last_of_stage and name in offs:

@@ -169,27 +169,6 @@ def conv_fwd_hwnc(x, w_ohwi, scale=None, shift=None, residual=None, relu=False, 
     return out
 
 
-def wino_weight_transform(w_ohwi):
-    cout, kh, kw, cin = w_ohwi.shape
-    assert kh == 3 and kw == 3
-    u = _new((16, cout, cin), w_ohwi)
-    _hip.check(_hip.lib().ssad_wino_weight_transform(_hip.ptr(w_ohwi), _hip.ptr(u), cout, cin, _hip.stream()))
-    return u
-
-
-def conv3x3_wino_hwnc(x, u, scale=None, shift=None, residual=None, relu=False):
-    """Winograd F(2x2,3x3), stride 1, pad 1: x [H][W][N][Cin], u [16][Cout][Cin] -> [H][W][N][Cout]."""
-    h, w, n, cin = x.shape
-    cout = u.shape[1]
-    out = _new((h, w, n, cout), x)
-    nb = 4.0 * (x.numel() + out.numel() * (2 if residual is not None else 1) + u.numel())
-    _run("conv_wino_f32", 2.0 * out.numel() * 9 * cin, nb,
-         lambda: _hip.lib().ssad_conv3x3_wino_fwd_hwnc(_hip.ptr(x), _hip.ptr(u), _hip.ptr(out), _hip.ptr(scale, True),
-                                                       _hip.ptr(shift, True), _hip.ptr(residual, True), int(relu), n, h, w,
-                                                       cin, cout, _hip.stream()))
-    return out
-
-
 def conv_fwd(x, w_ohwi, scale=None, shift=None, residual=None, relu=False, stride=1, pad=0, bf16=False):
     """x NHWC [N][H][W][Cin]; w OHWI [Cout][KH][KW][Cin] -> NHWC [N][Ho][Wo][Cout].
     bf16=True: operands rounded to bf16 in the loader (fp32 storage / accumulate), the Trainer(precision=16) path;

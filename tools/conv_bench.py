@@ -64,10 +64,6 @@ def main():
                     line += f" | c64 hwnc {flops / t / 1e12:6.1f} ({t * 1e3:7.3f} ms)"
                     t = timeit(lambda: ops.conv3x3_c64_eval(x, wt, sc, sh, None, True, False, False), iters)
                     line += f" | c64 nhwc {flops / t / 1e12:6.1f} ({t * 1e3:7.3f} ms)"
-                if k == 3 and s == 1 and h % 2 == 0:
-                    u = ops.wino_weight_transform(wt)
-                    t = timeit(lambda: ops.conv3x3_wino_hwnc(xh, u, sc, sh, None, True), iters)
-                    line += f" | wino {flops / t / 1e12:6.1f} ({t * 1e3:7.3f} ms)"
             if tag == "train":
                 dy = torch.randn(n, ho, wo, cout, device=dev)
                 if cout % 32 == 0 and k > 0 and "im2col" not in name:
