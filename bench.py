@@ -11,10 +11,14 @@ anomaly-map scoring of the same batch (841 sliding-window patches per image -> t
 3-NN against a 588-row bank -> blur -> bilinear 256x256 map).  Both rates are reported; ``value`` is the training rate
 (the first-named metric), ``anomaly_maps_per_sec`` the scoring rate.  fp32 throughout (exact f32 MFMA).
 
-Partition (SURVEY s.8e): the headline is WEAK scaling, 256 images per rank.  With N > 1 the same run also times the
-STRONG partition the survey names -- global batch 256 = 256/N images per rank -- and reports it under "strong"; with
-N = 1 it reports the per-rank work of that partition at N = 8 (batch 32) under "batch32".  ``--global-batch B`` makes
-the strong partition the headline instead (per-rank batch B / N, "scaling": "strong").
+Partition (SURVEY s.8e): the headline is the STRONG partition the survey names -- global batch 256, 256 / N images per rank
+for training and for scoring, "scaling": "strong" -- so the N = 1 line is the 256-image step and an N = 8 run is the same
+job on eight ranks.  The same run also times WEAK scaling (256 images per rank) and reports it under "weak"; at N = 1 it
+reports the per-rank work of the N = 8 partition (batch 32) under "batch32".  ``--scaling weak`` makes weak scaling the
+headline instead (``--batch`` images per rank).
+
+Profiling: put rocprofv3 on a single-rank command (`rocprofv3 ... -- python3 bench.py --gpus 1 ...`); with --gpus N > 1 this
+process is only a launcher, so a profiler must wrap the per-rank command, never the launcher.
 """
 import argparse
 import json
@@ -40,9 +44,11 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step (weak scaling)")
-    ap.add_argument("--global-batch", type=int, default=0,
-                    help="strong scaling as the headline: this many images per step over ALL ranks (SURVEY s.8e: 256)")
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step under weak scaling")
+    ap.add_argument("--global-batch", type=int, default=256,
+                    help="images per step over ALL ranks under strong scaling (SURVEY s.8e: 256)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="which partition is the headline when N > 1 (the other one is reported as an extra)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--phase", choices=["both", "train", "score"], default="both")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -210,7 +216,7 @@ def main():
     from self_supervised import ops, training
     from self_supervised.models import AnomalyDetector
 
-    strong_headline = args.global_batch > 0
+    strong_headline = args.scaling == "strong"
     if strong_headline:
         if args.global_batch % world:
             raise SystemExit(f"--global-batch {args.global_batch} does not divide over {world} ranks")
@@ -274,7 +280,7 @@ def main():
         ops.PROFILE = None
 
         def partition_extra():
-            nb = args.batch if strong_headline else (256 // world if world > 1 else 32)
+            nb = 32 if world == 1 else (args.batch if strong_headline else args.global_batch // world)
             if nb == per_rank or nb < 1:
                 return None
             xs, ys = x[:nb].contiguous(), y[:nb].contiguous()
@@ -353,7 +359,7 @@ def main():
         out["config"]["train_graph_segments"] = res["train_graph_segments"]
         tot_s += res["train_s"]
     if "partition" in res:
-        out["strong" if world > 1 and not strong_headline else ("weak" if strong_headline else "batch32")] = res["partition"]
+        out["batch32" if world == 1 else ("weak" if strong_headline else "strong")] = res["partition"]
     for k, v in res.items():
         if k.startswith("train_extra_") or k.startswith("score_extra_"):
             out.setdefault("extras", {})[k] = v
@@ -379,27 +385,42 @@ def main():
         xfl = sum(r["exec_flops"] for r in recs)
         allk = sum(r["ms"] for r in prof[phase]) * 1e-3
         ach = fl / t / 1e12
-        traffic, tsrc = None, None       # HBM-side bytes per launch from the committed PMC passes of this command line
-        tj = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        kname = "conv_igemm_f32_kernel<128,128,2,2,32,1,POS=true>" if tag == "conv_igemm_pos_f32" else "conv_igemm_f32_kernel"
+        # `frac` prices the MFMA FLOPs the kernel really ISSUES against the dense fp32-MFMA peak: position-major convs skip the
+        # filter taps that fall into the zero padding (exact: only x * 0 products are dropped), so the algorithmic count of
+        # SURVEY s.8d (2 M K Cout per conv) over the kernel's time can exceed the peak; that figure is kept as alg_frac.
+        # `traffic` (HBM-side bytes per launch) needs rocprofv3 PMC passes, which cannot run inside this process: null here;
+        # the committed passes of this command line are named in traffic_profile.
+        tprof = None
+        tj = os.path.join(ROOT, "profiles", "r03_traffic.json")
         if phase == "score" and os.path.exists(tj):
             tjd = json.load(open(tj))
             if tjd.get("patches_per_launch") == getattr(model, "last_pass_samples", None):      # same launch geometry only
-                traffic, tsrc = tjd["traffic_MB_per_launch"] * 1e6, "profiles/r02_traffic.json"
-        out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                           "executed": round(xfl / t / 1e12, 2), "executed_frac": round(xfl / t / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                           "traffic": traffic, "traffic_source": tsrc,
-                           "kernel": "conv_igemm_f32_kernel<128,128,2,2,32,1,POS=true>" if tag == "conv_igemm_pos_f32" else "conv_igemm_f32_kernel",
-                           "phase": phase, "launches": len(recs),
+                tprof = {"file": "profiles/r03_traffic.json", "traffic_MB_per_launch": tjd["traffic_MB_per_launch"],
+                         "ratio_to_algorithmic": tjd.get("ratio_to_algorithmic")}
+        out["roofline"] = {"bound": "mfma", "achieved": round(xfl / t / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(xfl / t / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                           "alg_achieved": round(ach, 2), "alg_frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                           "skipped_tap_share": round(1.0 - xfl / fl, 4),
+                           "traffic": None, "traffic_profile": tprof,
+                           "kernel": kname, "phase": phase, "launches": len(recs),
                            "avg_launch_ms": round(1e3 * t / len(recs), 4),
                            "alg_gflop_per_launch": round(fl / len(recs) / 1e9, 3),
+                           "exec_gflop_per_launch": round(xfl / len(recs) / 1e9, 3),
                            "alg_MB_per_launch": round(sum(r["bytes"] for r in recs) / len(recs) / 1e6, 1),
                            "alg_GBps": round(sum(r["bytes"] for r in recs) / t / 1e9, 1),
                            "share_of_gpu_time": round(t / allk, 4),
-                           "note": "achieved / frac count ALGORITHMIC FLOPs (SURVEY 8d: 2 M K Cout per conv) over kernel time, so frac can "
-                                   "exceed 1: position-major convs skip the filter taps that fall into the zero padding (exact, only x*0 "
-                                   "products are dropped).  executed / executed_frac count the MFMA FLOPs really issued: that is the "
-                                   "kernel-quality figure."}
+                           "note": "achieved / frac = MFMA FLOPs issued per second of kernel time (HIP events on the launch stream) "
+                                   "over the dense fp32-MFMA peak; alg_* count SURVEY 8d's 2 M K Cout, which includes the taps in "
+                                   "the zero padding that the position-major kernel skips (skipped_tap_share)."}
+        # HBM-bound kernels: algorithmic bytes (each operand read once, each result written once) over their event time
+        hbm = {}
+        for ph in prof:
+            for r in prof[ph]:
+                if r["flops"] == 0.0 and r["bytes"] > 0:
+                    e = hbm.setdefault(ph + "." + r["kernel"], [0.0, 0.0, 0]); e[0] += r["bytes"]; e[1] += r["ms"]; e[2] += 1
+        out["hbm_kernels"] = {k: {"GBps": round(v[0] / max(v[1], 1e-9) / 1e6, 1), "frac_of_8TBps": round(v[0] / max(v[1], 1e-9) / 1e6 / PEAK_HBM_GBPS, 4),
+                                  "launches": v[2], "MB_per_launch": round(v[0] / v[2] / 1e6, 2)} for k, v in sorted(hbm.items())}
         out["kernel_ms"] = {}
         for ph in prof:
             nst = prof_train_steps if ph == "train" else args.steps

@@ -55,7 +55,8 @@ int ssad_pack_stem_weight(const float* w_oihw, float* wk, void* stream);
 int ssad_stem_fwd(const float* img, int B, int H, int W, int patch_dim, int patch_stride, int Hv, int Wv,
                   const float* wk, const float* scale, const float* shift, int relu, int hwnc, float* out, void* stream);
 /* The same conv1 in training (no patch window, no affine): raw z plus the train-mode statistics of bn1 in one pass
- * (models.py:224 under trainer.fit).  workspace: 4096 * 128 doubles. */
+ * (models.py:224 under trainer.fit).  workspace: ssad_stem_stats_rows() * 128 doubles (one [2][64] row per workgroup). */
+int ssad_stem_stats_rows(void);
 int ssad_stem_fwd_stats(const float* img, int B, int H, int W, int Hv, int Wv, const float* wk, float* out, float eps,
                         float momentum, float* mean, float* invstd, float* running_mean, float* running_var, double* workspace,
                         void* stream);

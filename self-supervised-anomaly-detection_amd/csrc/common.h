@@ -30,6 +30,18 @@ void ssad_set_error(const char* fmt, ...);
         }                                                             \
     } while (0)
 
+// Opt a kernel in to more than 64 KB of dynamic LDS; a refusal (a device that is not gfx950: 160 KB of LDS per CU) is an error
+// the caller sees, not a launch that fails later.
+#define SSAD_SET_DYN_LDS(kernel, bytes)                                                                      \
+    do {                                                                                                     \
+        hipError_t e_ = hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+        if (e_ != hipSuccess) {                                                                              \
+            ssad_set_error("%s: %d bytes of LDS per workgroup refused (%s); this library targets gfx950",    \
+                           __func__, (int)(bytes), hipGetErrorString(e_));                                   \
+            return 1;                                                                                        \
+        }                                                                                                    \
+    } while (0)
+
 // train.hip: mean / invstd / running statistics from `nblk` rows of [2][C] double partial sums over R samples
 int ssad_bn_finalize_partials(const double* partial, int nblk, int64_t R, int C, float eps, float momentum, float* mean,
                               float* invstd, float* running_mean, float* running_var, void* stream);

@@ -6,8 +6,9 @@
 // issues 5 global loads + 5 LDS stores (Cout = 64 tile), and the wave's in-order stream cannot hide them: 85-100 TFLOP/s
 // on this shape against 125-132 on the wide layers.  Here a workgroup owns an 8 x 16 patch of output pixels of ONE image
 // and all 64 output channels:
-//   * the 10 x 18 x 64 input halo is loaded ONCE into LDS (46 KB; zero padding written as zeros, so there are no tap
-//     masks), optionally through a per-channel affine + ReLU (the train-mode BatchNorm + ReLU of the producing layer:
+//   * the 10 x 18 x 64 input halo is loaded ONCE into LDS (48 960 B in 68-float rows, + the 17 408 B weight slice of a tap =
+//     66 368 B per workgroup; two workgroups per CU = 130 KB, which only gfx950's 160 KB of LDS per CU holds; zero padding
+//     written as zeros, so there are no tap masks), optionally through a per-channel affine + ReLU (the train-mode BatchNorm + ReLU of the producing layer:
 //     the normalised activation never makes a round trip through HBM) and optionally emitted for the weight-gradient
 //     kernel that needs it later;
 //   * the A fragment of tap (ky, kx) is the same LDS image read at a constant byte offset (an instruction immediate);
@@ -329,7 +330,7 @@ extern "C" int ssad_conv3x3_c64(const float* in, const float* w_ohwi, float* out
     static const int lds_bytes = LDS_BYTES + (getenv("SSAD_C64_LDS_PAD") ? atoi(getenv("SSAD_C64_LDS_PAD")) : 0);   // residency experiments
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_c64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        SSAD_SET_DYN_LDS(conv3x3_c64_kernel<false>, lds_bytes);
         attr_set = true;
     }
     hipLaunchKernelGGL(conv3x3_c64_kernel<false>, dim3((unsigned)nwg), dim3(256), lds_bytes, (hipStream_t)stream, p);
@@ -363,7 +364,7 @@ extern "C" int ssad_conv3x3_c64_eval(const float* in, const float* w_ohwi, float
     p.stagger = c64_stagger(nwg);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_c64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        SSAD_SET_DYN_LDS(conv3x3_c64_kernel<true>, LDS_BYTES);
         attr_set = true;
     }
     hipLaunchKernelGGL(conv3x3_c64_kernel<true>, dim3((unsigned)nwg), dim3(256), LDS_BYTES, (hipStream_t)stream, p);

@@ -13,6 +13,9 @@
 
 namespace {
 
+constexpr int STEM_MAX_GRID = 4096;   // persistent workgroups of the stem conv = rows of its statistics partials (ssad_stem_stats_rows)
+
+
 constexpr int TOH = 8, TOW = 32;             // output tile per workgroup iteration
 constexpr int TIH = TOH * 2 + 5;             // 21 input rows
 constexpr int TIW = 72;                      // >= TOW*2 + 5 + 1 (kx pad) = 70
@@ -415,10 +418,10 @@ static int stem_fwd_impl(const float* img, int B, int H, int W, int patch_dim, i
     constexpr int lds_bytes = (W_TILE + IN_TILE) * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)stem_conv7x7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        SSAD_SET_DYN_LDS(stem_conv7x7_kernel, lds_bytes);
         attr_set = true;
     }
-    int64_t grid = p.total_tiles < 4096 ? p.total_tiles : 4096;   // 2 resident per CU x 256 CUs x 8 rounds
+    int64_t grid = p.total_tiles < STEM_MAX_GRID ? p.total_tiles : STEM_MAX_GRID;   // 2 resident per CU x 256 CUs x 8 rounds
     hipLaunchKernelGGL(stem_conv7x7_kernel, dim3((unsigned)grid), dim3(256), lds_bytes, (hipStream_t)stream, p);
     SSAD_CHECK_LAUNCH();
     if (stat_rows) *stat_rows = (int)grid;
@@ -433,7 +436,9 @@ extern "C" int ssad_stem_fwd(const float* img, int B, int H, int W, int patch_di
 
 // conv1 of the stem in training: the raw convolution z (NHWC) AND the train-mode BatchNorm statistics of bn1 in one pass
 // (resnet conv1 + bn1 under trainer.fit, models.py:224): per-workgroup fp64 partial sums from the accumulators, finalised as
-// ssad_bn_stats does.  workspace: 4096 * 128 doubles.
+// ssad_bn_stats does.  workspace: ssad_stem_stats_rows() * 128 doubles.
+extern "C" int ssad_stem_stats_rows(void) { return STEM_MAX_GRID; }
+
 extern "C" int ssad_stem_fwd_stats(const float* img, int B, int H, int W, int Hv, int Wv, const float* wk, float* out, float eps,
                                    float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
                                    double* workspace, void* stream) {
@@ -466,7 +471,7 @@ extern "C" int ssad_stem_patch_pool_fwd(const float* img, int B, int H, int W, i
     constexpr int lds_bytes = (SP_WF + SP_SRC + SP_CB) * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)stem_patch_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        SSAD_SET_DYN_LDS(stem_patch_fused_kernel, lds_bytes);
         attr_set = true;
     }
     const int64_t grid = p.Nsamp < 2048 ? p.Nsamp : 2048;

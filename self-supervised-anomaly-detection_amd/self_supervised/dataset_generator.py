@@ -207,12 +207,12 @@ def paste_patch(image: Image.Image, patch: Image.Image, coords: tuple, mask: Ima
 
 
 # ---- 'cable' pre-segmentation: SLIC super-pixels + per-segment mean colour (datasets.py:201-206) ----
-# THIRD-PARTY RESTATEMENT, unpinned: the reference calls skimage.segmentation.slic(image, n_segments=5, sigma=2,
-# convert2lab=True) and skimage.color.label2rgb(segments, image, kind='avg'); scikit-image is not installed, so the
-# published algorithm (Achanta et al., "SLIC Superpixels", as scikit-image documents its implementation: Gaussian
-# pre-smoothing, CIELAB, k-means in (L, a, b, y, x) restricted to 2S x 2S windows with compactness 10, 10 iterations,
-# connectivity enforcement with min / max size factors 0.5 / 3, labels from 1) is written out here.  It yields the same kind
-# of result -- a handful of compact colour regions -- not scikit-image's exact label image.
+# THIRD-PARTY RESTATEMENT, pinned: the reference calls skimage.segmentation.slic(image, n_segments=5, sigma=2,
+# convert2lab=True) and skimage.color.label2rgb(segments, image, kind='avg'); scikit-image is not a dependency of this
+# package, so its algorithm (Achanta et al., "SLIC Superpixels": Gaussian pre-smoothing, CIELAB, k-means in (L, a, b, y, x)
+# restricted to 2S x 2S windows with compactness 10, 10 iterations, connectivity enforcement with min / max size factors
+# 0.5 / 3) is written out here and reproduces scikit-image 0.18.3's label image bit for bit (tests/golden/skimage.npz,
+# test_skimage_restatements_match_the_library).
 def _rgb2lab(x):
     """skimage.color.rgb2lab of float RGB in [0, 1] (sRGB -> XYZ -> CIE-Lab, D65 / 2 degree observer) -- third-party, restated;
     pinned against scikit-image 0.18.3 (tests/golden/skimage.npz)."""

@@ -90,11 +90,14 @@ class PeraNet(_Base):
         self.memory_bank = torch.tensor([], device='cpu')
         self.batch = None
         self.num_patches = None
-        # patches pushed through the trunk per kernel sequence: sized for 288 GB of HBM (26 GiB of activations at this value;
-        # measured 390.8 ms per 256 images at 16 384, 384.0 ms at 131 072, identical results) and kept below 2^31 elements
-        # per layer1 tensor (131 072 x 16 x 16 x 64)
+        # upper bound on the patches pushed through the trunk per kernel sequence; the bound actually used is derived per call
+        # from the free HBM (_samples_per_pass: ~4 live layer1-sized tensors per sample, 60 % of what is free) and halves on an
+        # out-of-memory error, so a smaller card, ranks sharing a device or a resident training graph pool get smaller passes
+        # instead of failing.  Measured on an idle 288 GB card: 390.8 ms per 256 images at 16 384, 384.0 ms at 131 072, identical
+        # results.  Every activation stays below 2^31 elements (131 072 x 16 x 16 x 64 would be exactly 2^31: hence the -1).
         self.max_samples_per_pass = 131072
         self.max_elements_per_tensor = 2 ** 31 - 1
+        self.hbm_fraction_per_pass = 0.6
         self._plan = None
         self._frozen = set()
         # models.py:59 asks torchvision for IMAGENET1K_V1 (and fails loudly without it); there is no hub here, so the
@@ -195,6 +198,20 @@ class PeraNet(_Base):
             self._plan = engine.EvalPlan(self)
         return self._plan
 
+    def _samples_per_pass(self, b, p, hv, wv, pd):
+        """Images per trunk pass: the configured cap, fewer than 2^31 elements in the largest activation (the stem map: 1/4 of the
+        network input's pixels x 64 channels per sample; the 32 x 32 patch path fuses stem + pool: 1/16), and what the free HBM
+        holds (free = the driver's free bytes + what torch's allocator has cached but not handed out)."""
+        shrink = 4 if pd == 32 else 2
+        act = max(1, (hv // shrink) * (wv // shrink) * 64)                       # floats of the largest activation per sample
+        cap = min(self.max_samples_per_pass, self.max_elements_per_tensor // act)
+        free, _ = torch.cuda.mem_get_info()
+        free += torch.cuda.memory_reserved() - torch.cuda.memory_allocated()
+        live = 4 if pd == 32 else 3                                              # tensors of that size alive at once (+ 25 % for the deeper stages)
+        cap = min(cap, int(self.hbm_fraction_per_pass * free / (act * 4 * live * 1.25)))
+        per_pass = max(1, cap // p)
+        return -(-b // -(-b // per_pass))               # equal passes (256 images: 2 x 128 rather than 155 + 101)
+
     def forward(self, x: Tensor) -> dict:
         if not x.is_cuda:
             raise RuntimeError("PeraNet.forward runs on the MI355X HIP kernels only: move the batch to the GPU")
@@ -210,16 +227,20 @@ class PeraNet(_Base):
         plan = self._eval_plan()
         dim_in = self.concatenator[0].in_features
         pooled = torch.empty((b * p, dim_in), device=x.device, dtype=torch.float32)
-        # samples per pass: the configured cap, and fewer than 2^31 elements in the largest activation (the stem map, 1/4 of
-        # the network input's pixels x 64 channels per sample; the 32 x 32 patch path fuses stem + pool: 1/16)
-        shrink = 4 if pd == 32 else 2
-        cap = min(self.max_samples_per_pass, self.max_elements_per_tensor // max(1, (hv // shrink) * (wv // shrink) * 64))
-        per_pass = max(1, cap // p)
-        per_pass = -(-b // -(-b // per_pass))           # equal passes (256 images: 2 x 128 rather than 155 + 101)
-        self.last_pass_samples = per_pass * p
-        for i0 in range(0, b, per_pass):
+        per_pass = self._samples_per_pass(b, p, hv, wv, pd)
+        i0 = 0
+        while i0 < b:
             i1 = min(b, i0 + per_pass)
-            engine.trunk_eval(plan, x[i0:i1], pd, ps, self.layer_outputs, pooled[i0 * p:i1 * p])
+            try:
+                engine.trunk_eval(plan, x[i0:i1], pd, ps, self.layer_outputs, pooled[i0 * p:i1 * p])
+            except torch.cuda.OutOfMemoryError:
+                if per_pass == 1:
+                    raise
+                torch.cuda.empty_cache()
+                per_pass = max(1, per_pass // 2)           # the estimate was too generous for what else lives on the card
+                continue
+            self.last_pass_samples = (i1 - i0) * p if i0 == 0 else self.last_pass_samples
+            i0 = i1
         logits, emb = engine.head_eval(plan, pooled)
         return {'classifier': logits, 'latent_space': emb}
 

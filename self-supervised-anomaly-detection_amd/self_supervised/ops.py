@@ -103,7 +103,7 @@ def stem_fwd_stats(img, wk, eps, momentum, running_mean, running_var):
     _, hv, wv, ho, wo = stem_geometry(h, w, 0, 0)
     out = _new((b, ho, wo, 64), img)
     mean, invstd = _new((64,), img), _new((64,), img)
-    ws = torch.empty(4096 * 128, device=img.device, dtype=torch.float64)
+    ws = torch.empty(_hip.lib().ssad_stem_stats_rows() * 128, device=img.device, dtype=torch.float64)
     _run("stem_conv7x7", 2.0 * b * ho * wo * 64 * 147, 4.0 * (b * 3 * h * w + b * ho * wo * 64),
          lambda: _hip.lib().ssad_stem_fwd_stats(_hip.ptr(img), b, h, w, hv, wv, _hip.ptr(wk), _hip.ptr(out), eps, momentum,
                                                 _hip.ptr(mean), _hip.ptr(invstd), _hip.ptr(running_mean, True),

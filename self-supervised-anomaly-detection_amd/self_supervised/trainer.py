@@ -236,19 +236,24 @@ def barrier():
 
 def gather_bank_rows(embeddings, mask):
     """Rows of `embeddings` [B][D] selected by `mask` [B] from EVERY rank, concatenated in rank order (SURVEY s.8e: the
-    memory bank of models.py:270-275 under data parallelism).  Variable row counts travel as one padded all_gather of
-    [B][D] + a count, so the exchange has a fixed shape; with one rank this is plain boolean indexing."""
+    memory bank of models.py:270-275 under data parallelism).  Two fixed-shape exchanges: the int64 (batch size, row count)
+    pair of every rank, then the rows padded to the largest batch size; ranks may hold different batch sizes (a ragged last
+    batch).  The result is assembled on the device with ONE host read (the counts); with one rank this is plain indexing."""
     rank, world = world_info()
     sel = embeddings[mask].detach()
     if world == 1:
         return sel
     b, d = embeddings.shape
-    pad = torch.zeros((b + 1, d), device=embeddings.device, dtype=embeddings.dtype)
+    mine = torch.tensor([b, sel.shape[0]], device=embeddings.device, dtype=torch.int64)
+    meta = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(meta, mine)
+    meta = torch.stack(meta).cpu()                       # the one synchronising read
+    bmax = int(meta[:, 0].max())
+    pad = torch.zeros((bmax, d), device=embeddings.device, dtype=embeddings.dtype)
     pad[:sel.shape[0]] = sel
-    pad[b, 0] = float(sel.shape[0])
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad)
-    return torch.cat([p[:int(p[b, 0].item())] for p in parts])
+    return torch.cat([p[:int(n)] for p, n in zip(parts, meta[:, 1])])
 
 
 def gather_in_order(local_items, total):

@@ -196,7 +196,7 @@ class _Affine:
         l, bn = self.lin, self.bn
         return (self.is_conv and not self.stem and l.kernel_size == (3, 3) and self.stride == 1 and self.pad == 1
                 and l.in_channels == 64 and l.out_channels == 64 and l.bias is None and bn is not None and bn.training
-                and not self.eng.bf16 and os.environ.get("SSAD_C64", "1") != "0")
+                and not self.eng.bf16 and self.eng.sw_c64)
 
     def fwd_raw_c64(self, x, producer=None):
         """conv + batch statistics only: returns the raw z of this layer and leaves its BatchNorm (+ ReLU) to the consumer.
@@ -399,7 +399,17 @@ class TrainEngine:
         self._flip_view, self._flip_ready = {}, False
         self.side = None
         self._side_keep = []
+        # environment switches are read ONCE here: a captured step (hipGraph plan) must never be replayed under a different
+        # setting than the one it was recorded with (they are part of the plan key as well)
         self._side_on = os.environ.get("SSAD_WGRAD_STREAM", "0") == "1"
+        self.sw_c64 = os.environ.get("SSAD_C64", "1") != "0"
+        self.sw_relu_mask = os.environ.get("SSAD_RELU_MASK", "1") != "0"
+        self.sw_wgrad_halo = os.environ.get("SSAD_WGRAD_HALO", "1") != "0"
+
+    def switches(self):
+        """Everything besides shapes that decides which launches a step consists of (hipGraph plan key)."""
+        return (self.bf16, self.param_grads, self.sw_c64, self.sw_relu_mask, self.sw_wgrad_halo, self._side_on,
+                os.environ.get("SSAD_WGRAD_HALO", "1") != "0", torch.is_grad_enabled())
 
     # ---- second stream for the weight gradients ----
     class _Side:
@@ -457,7 +467,7 @@ class TrainEngine:
 
     def use_relu_mask(self):
         """Residual blocks keep their final ReLU's active set as a nibble mask (exact fp32 path, gradients wanted)."""
-        return (not self.bf16 and self.trunk_grad and torch.is_grad_enabled() and os.environ.get("SSAD_RELU_MASK", "1") != "0")
+        return not self.bf16 and self.trunk_grad and torch.is_grad_enabled() and self.sw_relu_mask
 
     def wgrad_stream(self, *operands):
         return TrainEngine._Side(self, operands)
@@ -915,8 +925,13 @@ class DataParallelStep:
                 begin()
                 try:
                     plan["out"] = self._body(plan["x"], plan["y"])
-                finally:
-                    end()
+                except BaseException:
+                    try:                                   # leave capture mode, but let the ORIGINAL error propagate
+                        seg["g"].capture_end()
+                    except Exception:
+                        pass
+                    raise
+                end()
         finally:
             self.bucketer.recorder = None
         torch.cuda.current_stream().wait_stream(stream)
@@ -943,7 +958,7 @@ class DataParallelStep:
 
     def step(self, x, y):
         self._sync_hyper()
-        key = (tuple(x.shape), tuple(y.shape), self.eng.bf16, tuple(self.eng.arena.trainable_ranges()),
+        key = (tuple(x.shape), tuple(y.shape), x.dtype, y.dtype, self.eng.switches(), tuple(self.eng.arena.trainable_ranges()),
                tuple(bool(m.training) for m in self.model.modules() if isinstance(m, BN_TYPES)))
         if self.use_graph and ops.PROFILE is None:
             plan = self._plans.get(key)

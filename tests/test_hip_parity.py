@@ -224,6 +224,30 @@ def test_forward_golden_patch_level(dev, golden, seeded_sd):
         m.max_elements_per_tensor = 2 * 841 * 16 * 16 * 64
         o3 = m(torch.cat([ow.synthetic_images(1, 256, seed=4321)] * 3).to(dev))
         assert m.last_pass_samples == 2 * 841 and torch.equal(o3["latent_space"], o2["latent_space"])
+        # ... nor a pass size derived from (very little) free HBM
+        m.max_elements_per_tensor = 2 ** 31 - 1
+        m.hbm_fraction_per_pass = 1e-9
+        o4 = m(torch.cat([ow.synthetic_images(1, 256, seed=4321)] * 3).to(dev))
+        assert m.last_pass_samples == 841 and torch.equal(o4["latent_space"], o2["latent_space"])
+
+
+def test_scoring_pass_just_under_2_31_elements(dev, seeded_sd):
+    """One trunk pass whose layer1 tensors hold 155 x 841 x 16 x 16 x 64 = 2 135 736 320 elements (2^31 = 2 147 483 648): every
+    kernel's offsets must survive the largest pass forward() ever builds.  First and last image == the same image scored alone."""
+    from oracle import weights as ow
+    free, _ = torch.cuda.mem_get_info()
+    if free < 80 * 2 ** 30:
+        pytest.skip("needs ~40 GB of free HBM")
+    m = _model(seeded_sd, dev, True)
+    a, b = ow.synthetic_images(1, 256, seed=11).to(dev), ow.synthetic_images(1, 256, seed=12).to(dev)
+    x = torch.cat([a] + [b] * 154 + [a])                 # 156 images -> passes of 155 + 1 unless equalised: force ONE big pass
+    with torch.no_grad():
+        ra, rb = m(a)["latent_space"].clone(), m(b)["latent_space"].clone()
+        m._samples_per_pass = lambda *args: 155
+        o = m(x)["latent_space"]
+    assert m.last_pass_samples == 155 * 841
+    assert torch.equal(o[:841], ra) and torch.equal(o[154 * 841:155 * 841], rb) and torch.equal(o[155 * 841:], ra)
+    assert torch.equal(o[77 * 841:78 * 841], rb)
 
 
 def test_knn_golden(dev, golden):
