@@ -21,10 +21,33 @@
 // flight at once.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 // Ablation switch for tools/micro/igemm_ablate.hip; always 0 in the library build.
 #ifndef IGEMM_ABL
 #define IGEMM_ABL 0
+#endif
+// K-loop schedule of the exact-fp32 path: 0 = loads ahead of the first MFMA, next stage stored after the last MFMA of a K-step
+// (rounds 1-2); 3 = loads (chunk 0) AND stores (last chunk) between MFMAs; 4 = the same with two staging register sets: loads
+// two K-steps ahead, stores in chunk 1 of the following K-step
+#ifndef IGEMM_VAR
+#define IGEMM_VAR 4
+#endif
+// 1 = direct (LDS-free) epilogue where the output rows of a tile are equally spaced; 0 = always the LDS-transpose epilogue
+#ifndef IGEMM_EPI
+#define IGEMM_EPI 1
+#endif
+
+
+// Phase time stamps per workgroup for tools/micro/igemm_var.hip (-DIGEMM_TRACE=1); never set in the library build.
+#ifndef IGEMM_TRACE
+#define IGEMM_TRACE 0
+#endif
+#if IGEMM_TRACE
+__device__ unsigned long long* g_ig_trace;      // [workgroups][8]
+#define IG_STAMP(i) do { if (threadIdx.x == 0 && g_ig_trace) g_ig_trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define IG_STAMP(i) do { } while (0)
 #endif
 
 namespace {
@@ -75,7 +98,7 @@ struct ConvParams {
 //        of weight >= 2^-18 (hh, hm, mh, hl, lh, mm): what is dropped is ~2^-25 of the product, i.e. fp32-faithful
 //        products at 6/16 of the fp32-MFMA time ("bf16x6").
 template <int BM, int BN, int TM, int TN, int BK, int TS, bool POS, bool DB = true, int BF = 0>
-__global__ __launch_bounds__((BM / (32 * TM)) * (BN / (32 * TN)) * 64, (BM / (32 * TM)) * (BN / (32 * TN)) == 8 ? 2 : 2)
+__global__ __launch_bounds__((BM / (32 * TM)) * (BN / (32 * TN)) * 64, TM * TN >= 8 ? 1 : 2)
 void conv_igemm_f32_kernel(ConvParams p) {
     constexpr int NT = (BM / (32 * TM)) * (BN / (32 * TN)) * 64;   // threads: one wave per (32 TM) x (32 TN) sub-tile
     // LDS row stride in elements (f32: 144 / 80 bytes; bf16: 80 / 48 bytes; bf16x3: hi and lo halves, the f32 bytes)
@@ -95,6 +118,12 @@ void conv_igemm_f32_kernel(ConvParams p) {
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     const int n0 = blockIdx.y * BN;
+    IG_STAMP(0);
+#if IGEMM_TRACE
+    if (threadIdx.x == 0 && g_ig_trace)
+        g_ig_trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] =
+            ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
+#endif
     const int sc = tid % CPR, sr = tid / CPR;
     const int HoWo = p.Ho * p.Wo;
     const int ntaps = p.KH * p.KW;
@@ -223,7 +252,7 @@ void conv_igemm_f32_kernel(ConvParams p) {
                 }
             mk &= tapmask;
         }
-        a_mask[i] = mk;
+        a_mask[i] = (IGEMM_ABL & 2) ? 0u : mk;      // ablation 2: every activation piece comes from the zero page (no HBM latency)
         a_ptr[i] = TS > 1 ? p.in + n * in_sn + sc * 4 : p.in + n * in_sn + ((int64_t)iy0 * p.W + ix0) * in_sp + sc * 4;
     }
     const float* b_ptr[BR];
@@ -243,24 +272,20 @@ void conv_igemm_f32_kernel(ConvParams p) {
 
     const int cpt = p.Cin / BK;               // K-steps per filter tap
     const int nk = __builtin_popcount(tapmask) * cpt;
-    f32x4 ra[AR], rb[BR];
+    f32x4 ra2[2][AR], rb2[2][BR];          // two staging sets: the exact-fp32 pipeline prefetches two K-steps ahead
+    f32x4 (&ra)[AR] = ra2[0];
+    f32x4 (&rb)[BR] = rb2[0];
 
     // state of the next K-step to load: current tap (lowest set bit of ld_mask) and channel chunk -- all scalar
     unsigned ld_mask = tapmask;
     int ld_tap = tapmask ? __builtin_ctz(tapmask) : 0;
     int ld_ky = ld_tap / p.KW, ld_kx = ld_tap - ld_ky * p.KW, ld_cc = 0;
-    auto load_step = [&]() {
-        const int64_t koff = TS > 1 ? (int64_t)ld_cc * BK : ((int64_t)ld_ky * p.W + ld_kx) * in_sp + ld_cc * BK;
-        const int woff = (ld_tap * cpt + ld_cc) * BK;
-#pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            const bool ok = (a_mask[i] >> ld_tap) & 1u;
-            const float* src = a_ptr[i] + koff;
-            if (TS > 1) src += ((int64_t)((a_iy[i] + ld_ky) / TS) * p.W + (a_ix[i] + ld_kx) / TS) * in_sp;
-            ra[i] = *(const f32x4*)(ok ? src : zero);
-        }
-#pragma unroll
-        for (int i = 0; i < BR; ++i) rb[i] = *(const f32x4*)(b_ptr[i] ? b_ptr[i] + woff : zero);
+    int64_t ld_koff = 0;
+    int ld_woff = 0, ld_ptap = 0, ld_pky = 0, ld_pkx = 0;
+    auto load_begin = [&]() {              // scalar offsets of the K-step about to be loaded, then the tap / chunk state moves on
+        ld_koff = TS > 1 ? (int64_t)ld_cc * BK : ((int64_t)ld_ky * p.W + ld_kx) * in_sp + ld_cc * BK;
+        ld_woff = (ld_tap * cpt + ld_cc) * BK;
+        ld_ptap = ld_tap; ld_pky = ld_ky; ld_pkx = ld_kx;
         if (++ld_cc == cpt) {
             ld_cc = 0;
             ld_mask &= ld_mask - 1;
@@ -268,6 +293,21 @@ void conv_igemm_f32_kernel(ConvParams p) {
             ld_ky = ld_tap / p.KW;
             ld_kx = ld_tap - ld_ky * p.KW;
         }
+    };
+    auto load_piece = [&](int q, int set = 0) {         // one 16-byte piece: q < AR activation rows, then the BR weight rows
+        if (q < AR) {
+            const bool ok = (a_mask[q] >> ld_ptap) & 1u;
+            const float* src = a_ptr[q] + ld_koff;
+            if (TS > 1) src += ((int64_t)((a_iy[q] + ld_pky) / TS) * p.W + (a_ix[q] + ld_pkx) / TS) * in_sp;
+            ra2[set][q] = *(const f32x4*)(ok ? src : zero);
+        } else {
+            rb2[set][q - AR] = *(const f32x4*)(b_ptr[q - AR] ? b_ptr[q - AR] + ld_woff : zero);
+        }
+    };
+    auto load_step = [&]() {
+        load_begin();
+#pragma unroll
+        for (int q = 0; q < AR + BR; ++q) load_piece(q);
     };
     auto store_step = [&](float* buf) {
         if (BF == 6) {
@@ -346,13 +386,103 @@ void conv_igemm_f32_kernel(ConvParams p) {
         for (int i = 0; i < BR; ++i) *(f32x4*)(Bs + (sr + RPP * i) * LDK + sc * 4) = rb[i];
     };
 
+    // Exact-fp32, double-buffered instantiations: ONE basic block per K-step with everything that is not an MFMA placed between
+    // the wave's own MFMAs.  Measured (profiles/r03_igemm_phases.md): a workgroup ALONE on its CU and two workgroups sharing it
+    // take the same time per tile -- the co-resident wave does not fill the gaps of this wave's matrix stream -- so every cycle a
+    // wave spends outside MFMA issue is lost: ~60 VALU + 8 loads ahead of the first MFMA and 8 LDS stores behind the last one
+    // (the round-2 schedule), and the HBM / L2 latency of a stage that was requested only one K-step (4 096 cycles) before it
+    // is needed (~300 cycles per K-step in s_waitcnt vmcnt).  Per K-step of NCH fragment chunks x 4 TM TN MFMAs:
+    //   chunk 0    : global loads of the stage TWO K-steps ahead into register set (ks & 1), one 16-byte piece (address
+    //                arithmetic included) per MFMA group
+    //   chunk 1    : the other register set (requested a whole K-step ago) stored to the other LDS stage, one piece per
+    //                MFMA group -- complete long before the barrier that publishes it
+    //   all chunks : fragment reads one chunk ahead
+    // Loads and stores are unconditional: past the last K-step the loader has wrapped to the first tap (valid addresses or
+    // the zero page) and the pieces land in the stage nobody reads any more.
+    constexpr bool PIPE = IGEMM_VAR >= 3 && BF == 0 && DB && BK >= 16;
+    constexpr bool PIPE2 = PIPE && IGEMM_VAR >= 4;          // two register sets (IGEMM_VAR 3: one set, loads chunk 0, stores last chunk)
     if (nk > 0) {
         load_step();
         store_step(lds);
+        if (PIPE2) {                        // stage 1 goes into flight before the loop: set 1
+            load_begin();
+#pragma unroll
+            for (int q = 0; q < AR + BR; ++q) load_piece(q, 1);
+        }
     }
     __syncthreads();
+    IG_STAMP(1);
 
-    for (int ks = 0; ks < nk; ++ks) {
+    auto kstep = [&](int ks, auto set_c) {
+        constexpr int SET = decltype(set_c)::value;                              // register set the loads of this K-step fill
+        constexpr int NCH = BK / 8, NPIECE = AR + BR, NM = 4 * TM * TN;          // chunks, pieces, MFMAs per chunk
+        constexpr int EVERY = NM / NPIECE > 0 ? NM / NPIECE : 1;
+        constexpr int SCH = PIPE2 ? (NCH > 1 ? 1 : 0) : NCH - 1;                 // chunk that carries the LDS stores
+        constexpr int SSET = PIPE2 ? SET ^ 1 : 0;                                // ... of this register set
+        const float* cur = lds + (ks & 1) * STAGE;
+        const float* As = cur + (wm * 32 * TM + r) * LDK + h * 4;
+        const float* Bs = cur + BM * LDK + (wn * 32 * TN + r) * LDK + h * 4;
+        float* nAs = lds + ((ks + 1) & 1) * STAGE;
+        float* nBs = nAs + BM * LDK;
+        f32x4 a[2][TM], b[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[0][i] = *(const f32x4*)(As + i * 32 * LDK);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[0][j] = *(const f32x4*)(Bs + j * 32 * LDK);
+        load_begin();
+#pragma unroll
+        for (int kk = 0; kk < NCH; ++kk) {
+            const int cu = kk & 1, nx = cu ^ 1;
+            if (kk + 1 < NCH && !(IGEMM_ABL & 16)) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[nx][i] = *(const f32x4*)(As + i * 32 * LDK + (kk + 1) * 8);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[nx][j] = *(const f32x4*)(Bs + j * 32 * LDK + (kk + 1) * 8);
+            } else if (kk + 1 < NCH) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[nx][i] = a[cu][i];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[nx][j] = b[cu][j];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            int q = 0, m = 0, q2 = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = mfma32(a[cu][i][e], b[cu][j][e], acc[i][j]);
+                        ++m;
+                        if (m % EVERY == (EVERY > 1 ? 1 : 0)) {
+                            if (kk == 0 && q < NPIECE && !(IGEMM_ABL & 4)) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                load_piece(q, PIPE2 ? SET : 0);
+                                ++q;
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                            if (kk == SCH && q2 < NPIECE && !(IGEMM_ABL & 8)) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (q2 < AR) *(f32x4*)(nAs + (sr + RPP * q2) * LDK + sc * 4) = ra2[SSET][q2];
+                                else *(f32x4*)(nBs + (sr + RPP * (q2 - AR)) * LDK + sc * 4) = rb2[SSET][q2 - AR];
+                                ++q2;
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!(IGEMM_ABL & 32)) __syncthreads();
+    };
+    if (PIPE) {
+        int ks = 0;
+        for (; ks + 1 < nk; ks += 2) {
+            kstep(ks, std::integral_constant<int, 0>{});
+            kstep(ks + 1, std::integral_constant<int, 1>{});
+        }
+        if (ks < nk) kstep(ks, std::integral_constant<int, 0>{});
+    }
+    for (int ks = 0; !PIPE && ks < nk; ++ks) {
         float* cur = DB ? lds + (ks & 1) * STAGE : lds;
         const bool more = ks + 1 < nk;
         if (more) load_step();
@@ -479,6 +609,7 @@ void conv_igemm_f32_kernel(ConvParams p) {
         }
     }
 
+    IG_STAMP(2);
 #if IGEMM_ABL & 1      // ablation (tools/micro/igemm_ablate.hip): no epilogue at all
     {
         float sum = 0.f;
@@ -492,6 +623,102 @@ void conv_igemm_f32_kernel(ConvParams p) {
         return;
     }
 #endif
+    // ---- direct epilogue (stride-1 gathers, whole tiles): every accumulator register goes straight to HBM.  Register e
+    // of lane (r, h) is row (e & 3) + 8 (e >> 2) + 4 h, column r of its 32 x 32 tile, so one wave store instruction writes two
+    // rows x 128 contiguous bytes (whole lines).  No LDS transpose, no barrier, a quarter of the instructions of the LDS
+    // epilogue below -- and instruction ISSUE outside the K loop is what a tile pays for: while this workgroup is in its
+    // prologue / epilogue the co-resident one streams MFMAs and this one only advances in the gaps of that stream
+    // (profiles/r03_igemm_phases.md: 10 k cycles of epilogue alone, 33-40 k next to a streaming partner). ----
+    {
+    int64_t R0 = m0, RS = 1, limit = p.M - m0;  // output row of tile row lr = R0 + lr * RS; tile rows < limit exist
+    if (POS) {
+        limit = p.N - m0;
+        if (p.hwnc) { R0 = (int64_t)pos * p.N + m0; RS = 1; }
+        else { R0 = m0 * HoWo + pos; RS = HoWo; }
+    }
+    // whole tiles only (every row and column of the tile exists: all but the last row / column tile of a launch), so that the
+    // path is straight-line code without a single per-lane predicate; ragged tiles take the LDS epilogue below
+    if (IGEMM_EPI && TS == 1 && limit >= BM && n0 + BN <= p.Cout) {
+        const int64_t pitch = RS * p.Cout;          // floats between consecutive tile rows (workgroup-uniform)
+        const int lrow0 = wm * 32 * TM + 4 * h;     // this lane's tile row for e = 0, i = 0
+        const int colb = n0 + wn * 32 * TN + r;     // ... and its column for j = 0
+        const int64_t lane_off = (R0 + (int64_t)lrow0 * RS) * p.Cout + colb;
+        float* outp = p.out + lane_off;
+        float scl[TN], sft[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            scl[j] = p.scale ? p.scale[colb + 32 * j] : 1.f;
+            sft[j] = p.shift ? p.shift[colb + 32 * j] : 0.f;
+        }
+        double st0[TN], st1[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) st0[j] = st1[j] = 0.0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float res[16][TN];
+            if (p.residual) {                       // all residual loads of this row-tile in flight before any is used
+                const float* resp = p.residual + lane_off;
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) res[e][j] = resp[(i * 32 + (e & 3) + 8 * (e >> 2)) * pitch + 32 * j];
+                if (p.res_mask) {                   // one byte per channel quad of a row: bit (column & 3) = keep
+                    const uint8_t* mp = p.res_mask;
+                    unsigned mk[16][TN];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            mk[e][j] = mp[(lane_off + (i * 32 + (e & 3) + 8 * (e >> 2)) * pitch + 32 * j) >> 2];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) res[e][j] = (mk[e][j] >> (r & 3)) & 1u ? res[e][j] : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) res[e][j] = 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float a = acc[i][j][e];
+                    if (p.stats) { st0[j] += (double)a; st1[j] += (double)a * (double)a; }
+                    const float x = a * scl[j] + sft[j] + res[e][j];           // the LDS epilogue's expression
+                    outp[(i * 32 + (e & 3) + 8 * (e >> 2)) * pitch + 32 * j] = p.relu ? fmaxf(x, 0.f) : x;
+                }
+            }
+        }
+        if (p.stats) {
+            // column sums: the lane's 32 rows, its half-wave partner's 32 (fixed xor), then the row-waves in order through LDS
+            // (the stages are dead: the K loop ended on a barrier)
+            constexpr int WM = BM / (32 * TM);
+            double* S = (double*)lds;                       // [WM][2][BN]
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                st0[j] += __shfl_xor(st0[j], 32);
+                st1[j] += __shfl_xor(st1[j], 32);
+                if (h == 0) {
+                    S[(wm * 2 + 0) * BN + wn * 32 * TN + j * 32 + r] = st0[j];
+                    S[(wm * 2 + 1) * BN + wn * 32 * TN + j * 32 + r] = st1[j];
+                }
+            }
+            __syncthreads();
+            if (tid < 2 * BN) {
+                const int which = tid / BN, cc = tid % BN;
+                double t = 0.0;
+#pragma unroll
+                for (int q = 0; q < WM; ++q) t += S[(q * 2 + which) * BN + cc];
+                p.stats[((int64_t)blockIdx.x * 2 + which) * p.Cout + n0 + cc] = t;
+            }
+        }
+        IG_STAMP(3);
+        return;
+    }
+    }
     // ---- epilogue: accumulators -> LDS tile [BM/TM][BN+4] -> 16-byte pieces of contiguous output rows; one pass per
     // accumulator row-tile so the tile never needs more LDS than the K-loop stages ----
     float* C = lds;
@@ -586,6 +813,7 @@ void conv_igemm_f32_kernel(ConvParams p) {
             if (n0 + cc < p.Cout) p.stats[((int64_t)blockIdx.x * 2 + which) * p.Cout + n0 + cc] = t;
         }
     }
+    IG_STAMP(3);
 }
 
 // Position order for the position-major kernels: heaviest (most in-bounds taps) first, see the kernel.
@@ -696,6 +924,7 @@ int dispatch(const ConvParams& p, hipStream_t st) {
     }
     static const int big = getenv("SSAD_CONV128_VARIANT") ? atoi(getenv("SSAD_CONV128_VARIANT")) : 0;
     if (big == 1) return launch<256, 128, 2, 2, 32, TS, POS>(p, st);
+    if (big == 2) return launch<256, 128, 4, 2, 32, TS, POS>(p, st);      // one workgroup per CU, four waves of 128 x 64
     // small problems (batch 32-96 on the 8x8 / 16x16 maps of layer3 / layer4): 128x128 tiles leave CUs idle -- fewer than
     // ~1.5 workgroups per CU -- so the 128x64 tile doubles the grid (measured at batch 96 / 32: see DESIGN.md)
     static const int small_min = getenv("SSAD_CONV_SMALL_GRID") ? atoi(getenv("SSAD_CONV_SMALL_GRID")) : 500;
