@@ -52,6 +52,7 @@ def parse_args():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--phase", choices=["both", "train", "score"], default="both")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end tools.training measurement (N = 1 only)")
     ap.add_argument("--no-partition-extra", action="store_true", help="skip the strong-partition / batch-32 extra line")
     ap.add_argument("--no-graph", action="store_true", help="launch the training step eagerly instead of replaying hipGraphs")
     ap.add_argument("--train-precision", choices=["32", "16", "bf16"], default="32",
@@ -183,6 +184,35 @@ def cpu_baseline(args):
     torch.set_num_threads(cores)
     out["sample"] = "oracle on torch-CPU fp32, " + str(args.size) + "x" + str(args.size) + "; " + "; ".join(notes)
     return out
+
+
+def end_to_end(args):
+    """tools.training(gpu_pipeline=True) at the reference's own settings (tools.py:204-214: batch 96, image level, 256 x 256) on a
+    synthetic MVTec-shaped category: images per second of whole fine-tune epochs -- host-side sampling of the defect parameters
+    (8 forked sampler workers, as the reference's DataLoader has 8 workers), GPU synthesis of the batch, training step,
+    memory-bank gathering -- in fp32 and in the reference's Trainer(precision=16).  Median over the epochs after the first
+    (which records the hipGraph)."""
+    import contextlib
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from fake_mvtec import make_tree
+    from self_supervised import tools
+    res = {"workload": "tools.training(gpu_pipeline=True), bottle-shaped synthetic category, 256x256 image level, batch 96, "
+                       "1 + 5 epochs of ~10 steps; median fine-tune epoch after the first"}
+    with tempfile.TemporaryDirectory() as tmp:
+        root = make_tree(os.path.join(tmp, "data"), categories=("bottle",), n_train=40, n_test_good=2, n_test_bad=2, size=256)
+        for prec in (32, 16):
+            with contextlib.redirect_stdout(sys.stderr):
+                hist = tools.training(root + "bottle/", os.path.join(tmp, f"out{prec}") + "/", "bottle", imsize=(args.size, args.size),
+                                      batch_size=96, seed=0, projection_training_params=(1, 0.03), fine_tune_params=(5, 0.005),
+                                      trainer_kwargs={"precision": prec, "limit_val_batches": 1}, gpu_pipeline=True)
+            rates = sorted(n / t for n, t in hist["throughput"]["fine_tune"][1:])
+            res["fp32" if prec == 32 else "precision16"] = {
+                "end_to_end_train_images_per_sec": round(rates[len(rates) // 2], 1),
+                "epochs": [[n, round(t, 4)] for n, t in hist["throughput"]["fine_tune"]],
+                "projection_stage_images_per_sec": round(sum(n for n, _ in hist["throughput"]["projection_train"]) /
+                                                         sum(t for _, t in hist["throughput"]["projection_train"]), 1)}
+    return res
 
 
 def main():
@@ -429,6 +459,10 @@ def main():
                 e = by.setdefault(r["kernel"], [0.0, 0, 0.0]); e[0] += r["ms"]; e[1] += 1; e[2] += r["flops"]
             out["kernel_ms"][ph] = {k: [round(v[0] / nst, 3), v[1] // nst,
                                         round(v[2] / max(v[0], 1e-9) / 1e9, 1)] for k, v in sorted(by.items())}
+    if not args.no_e2e and world == 1 and args.phase in ("both", "train"):
+        r = optional("end_to_end", lambda: end_to_end(args))
+        if r:
+            out["end_to_end"] = r
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args)
     print(json.dumps(out))

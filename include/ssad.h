@@ -344,6 +344,12 @@ int ssad_aug_params_size(void);
 int ssad_cutpaste_augment(const uint8_t* imgs, const uint8_t* cuts, const ssad_aug_params* params, uint8_t* work,
                           float* gray_mean, float* out, int B, int H, int W, int h, int w, const float* mean3_host,
                           const float* std3_host, void* stream);
+/* HOST function (no GPU work): per-channel integer sums of the window [top, top + h) x [left, left + w) of the NEAREST affine
+ * transform of an H x W x 3 uint8 image (fix: the six 16.16 coefficients of ssad_aug_params.aff_fix; NULL: the image itself),
+ * zero outside the image.  The sampler's colour-similarity test (datasets.py:300-312) needs this mean between two random
+ * draws. */
+int ssad_affine_window_sum_u8(const uint8_t* img, int H, int W, const int32_t* fix, int left, int top, int w, int h,
+                              int64_t* sum3);
 /* transforms.ToTensor() on a uint8 HWC batch: -> [B][3][H][W] fp32 in [0,1] (the Dataset's third output). */
 int ssad_u8hwc_to_f32chw(const uint8_t* img, float* out, int B, int H, int W, void* stream);
 

@@ -311,6 +311,35 @@ extern "C" int ssad_cutpaste_augment(const uint8_t* imgs, const uint8_t* cuts, c
     return 0;
 }
 
+// HOST helper of the sampler (augment.sample_defect): channel sums of the window [top, top + h) x [left, left + w) of
+// Image.transform((W, H), AFFINE, NEAREST) of an H x W x 3 uint8 image (fix = Pillow's 16.16 coefficients; NULL = the image
+// itself), zero outside the image -- what np.array(img.transform(...).crop(...)).sum((0, 1)) gives, in integers (exact).  The
+// colour-similarity test of datasets.py:300-312 needs this mean BEFORE the next random draw, so it cannot wait for the GPU.
+extern "C" int ssad_affine_window_sum_u8(const uint8_t* img, int H, int W, const int32_t* fix, int left, int top, int w, int h,
+                                         int64_t* sum3) {
+    SSAD_CHECK_ARG(img && sum3 && H > 0 && W > 0 && w > 0 && h > 0 && left >= 0 && top >= 0, "bad argument");
+    int64_t s0 = 0, s1 = 0, s2 = 0;
+    const int y1 = top + h < H ? top + h : H, x1 = left + w < W ? left + w : W;
+    for (int y = top; y < y1; ++y) {
+        if (!fix) {
+            const uint8_t* row = img + ((int64_t)y * W + left) * 3;
+            for (int x = left; x < x1; ++x, row += 3) { s0 += row[0]; s1 += row[1]; s2 += row[2]; }
+            continue;
+        }
+        int64_t fx = (int64_t)fix[2] + (int64_t)y * fix[1] + (int64_t)left * fix[0];
+        int64_t fy = (int64_t)fix[5] + (int64_t)y * fix[4] + (int64_t)left * fix[3];
+        for (int x = left; x < x1; ++x, fx += fix[0], fy += fix[3]) {
+            const int64_t sx = fx >> 16, sy = fy >> 16;         // arithmetic shift = floor, as Pillow's affine_fixed
+            if (sx >= 0 && sx < W && sy >= 0 && sy < H) {
+                const uint8_t* px = img + (sy * W + sx) * 3;
+                s0 += px[0]; s1 += px[1]; s2 += px[2];
+            }
+        }
+    }
+    sum3[0] = s0; sum3[1] = s1; sum3[2] = s2;
+    return 0;
+}
+
 extern "C" int ssad_u8hwc_to_f32chw(const uint8_t* img, float* out, int B, int H, int W, void* stream) {
     SSAD_CHECK_ARG(img && out && B > 0 && H > 0 && W > 0, "bad argument");
     const int64_t total = (int64_t)B * H * W;

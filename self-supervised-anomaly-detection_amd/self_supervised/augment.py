@@ -78,10 +78,27 @@ def _decorrelate(rec, prefix, x_mean, src_mean):
         rec[prefix + "_bright"], rec[prefix + "_nbright"] = (random.choice([low, high]), random.choice([low, high])), 2
 
 
-def sample_defect(subject, img_u8, seg_mask, cuts_u8=None, patch_localization=False, patch_size=64):
+def _window_sum(img_u8, fix, left, top, w, h):
+    """Channel sums (exact integers) of a window of the NEAREST-affine-transformed image: the library's host helper (one C loop
+    over the window) instead of warping the whole image in numpy -- 4.5 ms -> 0.1 ms per call at 256 x 256, and it was 75 % of
+    the sampler's time."""
+    H, W = img_u8.shape[:2]
+    img = np.ascontiguousarray(img_u8)
+    out = (ctypes.c_int64 * 3)()
+    cf = None if fix is None else (ctypes.c_int32 * 6)(*[int(v) for v in fix])
+    _hip.check(_hip.lib().ssad_affine_window_sum_u8(img.ctypes.data, H, W, cf, int(left), int(top), int(w), int(h), out))
+    return np.array([out[0], out[1], out[2]], dtype=np.float64)
+
+
+def mask_coordinates(seg):
+    """(x, y) of the mask's pixels in row-major order: datasets.py:283's coords_map."""
+    return np.flip(np.column_stack(np.where(seg)), axis=1)
+
+
+def sample_defect(subject, img_u8, seg_mask, cuts_u8=None, patch_localization=False, patch_size=64, coords=None):
     """One ssad_aug_params record (numpy void) for an H x W uint8 image and its boolean object mask: every random draw of
     PretextTaskDataset.__getitem__ in its order (pinned by tests/test_data_cpu.py), every geometric quantity as Pillow
-    computes it (pil_exact)."""
+    computes it (pil_exact).  coords: mask_coordinates(seg_mask) when the caller keeps it (image level only)."""
     H, W = img_u8.shape[:2]
     rec = np.zeros((), AUG_DTYPE)
     rec["cut_index"] = -1
@@ -122,14 +139,13 @@ def sample_defect(subject, img_u8, seg_mask, cuts_u8=None, patch_localization=Fa
     area_p = CPP.rectangle_area_ratio_patch if patch_localization else CPP.rectangle_area_ratio
     area_s = CPP.scar_area_ratio_patch if patch_localization else CPP.scar_area_ratio
     if y > 0:
-        coords_map = np.flip(np.column_stack(np.where(seg)), axis=1)
+        coords_map = coords if (coords is not None and seg is seg_mask) else mask_coordinates(seg)
 
     def x_mean():
-        """Mean colour of the image the defect is pasted into (after RandomAffine / crop), for the similarity test."""
-        cur = px.affine_nearest(img_u8, (W, H), aff) if aff is not None else img_u8
-        t, l = int(rec["crop_top"]), int(rec["crop_left"])
-        inside = cur[t:min(t + h, H), l:min(l + w, W)]                  # zero padding outside the image counts in the mean
-        return inside.reshape(-1, 3).astype(np.float64).sum(axis=0) / float(h * w)
+        """Mean colour of the image the defect is pasted into (after RandomAffine / crop), for the similarity test; the zero
+        padding outside the image counts in the mean."""
+        fix = rec["aff_fix"] if aff is not None else None
+        return _window_sum(img_u8, fix, int(rec["crop_left"]), int(rec["crop_top"]), w, h) / float(h * w)
     if y == 1:
         centre = get_random_coordinate(coords_map)
         pw, ph, mean = _source(rec, "patch", cut_u8, area_p, CPP.rectangle_aspect_ratio)
@@ -202,15 +218,36 @@ class GpuCutPaste:
         self.cuts = None if self.cuts_cpu is None else torch.from_numpy(self.cuts_cpu).to(self.device)
         self._mean = (ctypes.c_float * 3)(*IMAGENET_MEAN)
         self._std = (ctypes.c_float * 3)(*IMAGENET_STD)
+        self._coords = {}
+
+    def sample(self, indices):
+        """Host half: one record per index, drawn from the process-global python / numpy / torch RNG streams in the order
+        PretextTaskDataset.__getitem__ draws.  -> (records [B] of AUG_DTYPE, (h, w) of the synthesised images)."""
+        recs, hw = [], None
+        for i in np.asarray(indices, dtype=np.int64):
+            r, hw = sample_defect(self.subject, self.images_cpu[i], self.masks[i], self.cuts_cpu, self.patch_localization,
+                                  self.patch_size, coords=self._coords_of(i))
+            recs.append(r)
+        return np.stack(recs), hw
+
+    def _coords_of(self, i):
+        """mask_coordinates of image i's object mask, computed once per distinct mask (fixed-object categories share one)."""
+        if self.patch_localization:
+            return None                      # the mask is cropped per sample there
+        m = self.masks[i]
+        key = m.__array_interface__["data"][0]
+        c = self._coords.get(key)
+        if c is None:
+            c = self._coords[key] = mask_coordinates(m)
+        return c
 
     def __call__(self, indices):
         idx = np.asarray(indices, dtype=np.int64)
-        recs, hw = [], None
-        for i in idx:
-            r, hw = sample_defect(self.subject, self.images_cpu[i], self.masks[i], self.cuts_cpu, self.patch_localization,
-                                  self.patch_size)
-            recs.append(r)
-        recs = np.stack(recs)
+        recs, hw = self.sample(idx)
+        return self.synthesise(idx, recs, hw)
+
+    def synthesise(self, idx, recs, hw):
+        """Device half: every per-pixel operation of the batch (csrc/augment.hip) from the records."""
         b, (h, w) = len(idx), hw
         _, H, W, _ = self.images.shape
         params = torch.from_numpy(recs.view(np.uint8).reshape(b, -1)).to(self.device)
@@ -228,14 +265,38 @@ class GpuCutPaste:
         return out, y, orig
 
 
+_POOL_STATE = {}      # key -> GpuCutPaste of the forking parent; read by the sampler workers (fork: no pickling of the images)
+
+
+def _batch_seed(base, epoch, batch_no, rank):
+    return (((int(base) * 1000003 + int(epoch)) * 1000003 + int(batch_no)) * 1000003 + int(rank)) % (2 ** 63)
+
+
+def _pool_sample(key, seed, idx):
+    """Runs in a sampler worker: the records of one batch under that batch's own seed."""
+    aug = _POOL_STATE[key]
+    random.seed(seed)
+    np.random.seed(seed % (2 ** 32))
+    torch.manual_seed(seed)
+    recs, hw = aug.sample(idx)
+    return recs.tobytes(), hw
+
+
 class GpuPretextLoader:
     """GPU-resident replacement for ``DataLoader(PretextTaskDataset)``: the category's images are decoded and resized
     once, kept on the GPU as uint8, and every batch is synthesised there (GpuCutPaste).  Yields the same triple the
-    Dataset does -- (x normalised fp32, y int64, original fp32 in [0,1]) -- already on the device, so the 8 PIL worker
-    processes of the reference's DataLoader (src/self_supervised/datasets.py:501-533) are not needed and host-side data
-    feeding stops limiting multi-GPU scaling (SURVEY s.8e)."""
+    Dataset does -- (x normalised fp32, y int64, original fp32 in [0,1]) -- already on the device.
 
-    def __init__(self, dataset, batch_size, shuffle=True, drop_last=True, device="cuda", rank=0, world=1):
+    Host side of a batch = drawing one parameter record per sample (0.4 ms each: label, boxes, polygon, scar, poly-line, jitter
+    -- numbers only).  ``num_workers = 0``: drawn in this process from the global RNG streams, sample after sample in the
+    order the reference's ``__getitem__`` draws (what the parity tests pin).  ``num_workers > 0`` (the counterpart of the
+    reference's ``DataLoader(num_workers=8)``, src/self_supervised/datasets.py:501-533): forked sampler processes draw whole
+    batches ahead of the training loop, batch b of epoch e under its own seed (base_seed, e, b, rank), so the stream does not
+    depend on the number of workers or on their timing; the device work of a batch is unchanged.  Measured: 2.4 k samples/s per
+    worker at 256 x 256 image level; 8 workers keep up with the 7.4 k img/s of the training step."""
+
+    def __init__(self, dataset, batch_size, shuffle=True, drop_last=True, device="cuda", rank=0, world=1, num_workers=0,
+                 base_seed=0, prefetch_batches=None):
         from PIL import Image
         from .dataset_generator import obj_mask
         self.dataset, self.batch_size, self.shuffle, self.drop_last = dataset, batch_size, shuffle, drop_last
@@ -251,7 +312,10 @@ class GpuPretextLoader:
         self.aug = GpuCutPaste(dataset.subject, np.stack(imgs), np.stack(masks), cuts, dataset.patch_localization,
                                dataset.patch_size, device)
         self.index = np.array([self.slot[n] for n in dataset.images_filenames])
-        self.num_workers = 0
+        self.num_workers = int(num_workers)
+        self.base_seed = int(base_seed)
+        self.prefetch_batches = prefetch_batches if prefetch_batches is not None else 2 * max(self.num_workers, 1)
+        self._pool, self._key = None, None
 
     def shard(self, world, rank, epoch):
         self.world, self.rank, self.epoch = world, rank, epoch
@@ -261,10 +325,55 @@ class GpuPretextLoader:
         n = len(self.index) // self.world
         return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
 
-    def __iter__(self):
+    def _batches(self):
         order = np.arange(len(self.index))
         if self.shuffle:
             order = np.random.RandomState(1234 + self.epoch).permutation(len(order))
         order = order[self.rank::self.world]
-        for i in range(len(self)):
-            yield self.aug(self.index[order[i * self.batch_size:(i + 1) * self.batch_size]])
+        return [self.index[order[i * self.batch_size:(i + 1) * self.batch_size]] for i in range(len(self))]
+
+    def _ensure_pool(self):
+        if self._pool is None:
+            import multiprocessing
+            from concurrent.futures import ProcessPoolExecutor
+            self._key = id(self)
+            _POOL_STATE[self._key] = self.aug            # visible to the children through fork
+            for i in range(len(self.aug.images_cpu)):    # fill the coordinate cache before forking: children inherit it
+                self.aug._coords_of(i)
+            self._pool = ProcessPoolExecutor(self.num_workers, mp_context=multiprocessing.get_context("fork"))
+        return self._pool
+
+    def close(self):
+        if self._pool is not None:
+            self._pool.shutdown(wait=False, cancel_futures=True)
+            _POOL_STATE.pop(self._key, None)
+            self._pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __iter__(self):
+        batches = self._batches()
+        if self.num_workers <= 0:
+            for idx in batches:
+                yield self.aug(idx)
+            return
+        pool = self._ensure_pool()
+        pending, nxt = [], 0
+
+        def submit():
+            nonlocal nxt
+            if nxt < len(batches):
+                pending.append((batches[nxt], pool.submit(_pool_sample, self._key,
+                                                          _batch_seed(self.base_seed, self.epoch, nxt, self.rank), batches[nxt])))
+                nxt += 1
+        for _ in range(self.prefetch_batches):
+            submit()
+        while pending:
+            idx, fut = pending.pop(0)
+            raw, hw = fut.result()
+            submit()
+            yield self.aug.synthesise(np.asarray(idx, dtype=np.int64), np.frombuffer(raw, dtype=AUG_DTYPE), hw)

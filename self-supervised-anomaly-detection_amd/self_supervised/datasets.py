@@ -255,13 +255,15 @@ class PretextTaskDatamodule(_DataModule):
     def train_dataloader(self):
         if self.gpu_pipeline:
             from .augment import GpuPretextLoader
-            return GpuPretextLoader(self.train_dataset, self.batch_size, shuffle=True, drop_last=True)
+            return GpuPretextLoader(self.train_dataset, self.batch_size, shuffle=True, drop_last=True,
+                                    num_workers=min(self.num_workers, os.cpu_count() or 1), base_seed=self.seed)
         return self._loader(self.train_dataset, True, drop_last=True)
 
     def val_dataloader(self):
         if self.gpu_pipeline:
             from .augment import GpuPretextLoader
-            return GpuPretextLoader(self.val_dataset, self.batch_size, shuffle=False, drop_last=True)
+            return GpuPretextLoader(self.val_dataset, self.batch_size, shuffle=False, drop_last=True,
+                                    num_workers=min(self.num_workers, os.cpu_count() or 1), base_seed=self.seed + 1)
         return self._loader(self.val_dataset, False, drop_last=True)
 
     def test_dataloader(self):

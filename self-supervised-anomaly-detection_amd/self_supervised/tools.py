@@ -111,11 +111,15 @@ def training(dataset_dir: str, outputs_dir: str, subject: str, imsize: tuple = (
     pretext_model = PeraNet(learning_rate=proj_lr, epochs=proj_epochs)
     pretext_model.freeze_net(['backbone'])
     cb = MetricTracker()
-    trainer = Trainer(default_root_dir=outputs_dir + 'logs/', callbacks=[cb], precision=16, benchmark=True,
-                      accelerator='auto', devices=1, max_epochs=proj_epochs, check_val_every_n_epoch=1, **tk)
+    # the reference's Trainer arguments (tools.py:260-267); trainer_kwargs may override them (e.g. precision=32)
+    targs = dict(default_root_dir=outputs_dir + 'logs/', precision=16, benchmark=True, accelerator='auto', devices=1,
+                 check_val_every_n_epoch=1)
+    targs.update(tk)
+    trainer = Trainer(callbacks=[cb], max_epochs=proj_epochs, **targs)
     print('>>> training projection head')
     trainer.fit(pretext_model, datamodule=datamodule)
     history = {'projection_train': cb.log_metrics}
+    throughput = {'projection_train': list(trainer.epoch_throughput)}
     pretext_model.clear_memory_bank()
     trainer.save_checkpoint(outputs_dir + checkpoint_name, weights_only=True)     # rank 0 writes ...
     barrier()                                                                      # ... before anybody reads
@@ -127,12 +131,13 @@ def training(dataset_dir: str, outputs_dir: str, subject: str, imsize: tuple = (
     mc = ModelCheckpoint(dirpath=outputs_dir + 'logs/', filename='best_model_so_far', save_top_k=1, monitor="val_loss",
                          mode='min', every_n_epochs=5)
     cb = MetricTracker()
-    trainer = Trainer(default_root_dir=outputs_dir + 'logs/', callbacks=[cb, mc], precision=16, benchmark=True,
-                      accelerator='auto', devices=1, max_epochs=fine_tune_epochs, check_val_every_n_epoch=1, **tk)
+    trainer = Trainer(callbacks=[cb, mc], max_epochs=fine_tune_epochs, **targs)
     print('>>> Fine tuning')
     trainer.fit(pretext_model, datamodule=datamodule)
     trainer.save_checkpoint(outputs_dir + checkpoint_name)
     history['fine_tune'] = cb.log_metrics
+    throughput['fine_tune'] = list(trainer.epoch_throughput)
+    history['throughput'] = throughput          # (images, seconds) per training epoch of this rank: data feeding included
     if rank == 0:
         with open(outputs_dir + 'history.json', 'w') as f:
             json.dump(history, f)

@@ -6,6 +6,7 @@ batch, ``on_train_epoch_end``, ``validation_step``, per-epoch scheduler step, ca
 One process per GPU: when ``torch.distributed`` is initialised the train set is sharded with a DistributedSampler
 and gradients are all-reduced by training.DataParallelStep (RCCL); the reference itself is single-device."""
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -99,23 +100,33 @@ class Trainer:
                                          weight_decay=opt.weight_decay, world_size=self.world, precision=self.precision)
         step.opt = opt
         opt.grad_scale = 1.0 / self.world
+        self.epoch_throughput = []                      # (images of this rank, seconds) per training epoch, validation excluded
         for epoch in range(self.max_epochs):
             self.current_epoch = model.current_epoch = epoch
             model.train()
             sums = torch.zeros(3, device=self.device)
+            torch.cuda.synchronize(self.device)
+            t_epoch, n_images = time.perf_counter(), 0
+            bank_steps = []
             for i, batch in enumerate(self._shard(train_dataloaders, epoch)):
                 if self.limit_train_batches is not None and i >= self.limit_train_batches:
                     break
                 x, y, _ = _to_device(batch, self.device)
                 la = step.step(x.contiguous().float(), y.contiguous())
+                n_images += int(x.shape[0])
                 sums += torch.stack([la[0], la[1], torch.ones_like(la[0])])
                 if epoch > int(self.max_epochs / 2):    # memory bank of well-classified normal samples (models.py:270-275)
+                    # the reference moves the selected rows to the CPU every step (a device-to-host sync per step); here the
+                    # step's embeddings and its selection mask stay on the device and the bank is brought up to date once, at
+                    # the end of the epoch, in the same row order (step after step, rank after rank inside a step)
                     y_hat = torch.max(step.last_logits, 1).indices
-                    mask = (y == 0) & (y_hat == 0)
-                    rows = gather_bank_rows(step.last_embeddings, mask)      # every rank's rows, in rank order
-                    model.memory_bank = torch.cat([model.memory_bank, rows.to('cpu')])
+                    bank_steps.append((step.last_embeddings.detach().clone(), (y == 0) & (y_hat == 0)))
                 self.global_step += 1
+            if bank_steps:
+                model.memory_bank = torch.cat([model.memory_bank, gather_bank_steps(bank_steps).to('cpu')])
             model.on_train_epoch_end()
+            torch.cuda.synchronize(self.device)
+            self.epoch_throughput.append((n_images, time.perf_counter() - t_epoch))
             if self.world > 1:
                 dist.all_reduce(sums)
             n = max(float(sums[2]), 1.0)
@@ -254,6 +265,23 @@ def gather_bank_rows(embeddings, mask):
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad)
     return torch.cat([p[:int(n)] for p, n in zip(parts, meta[:, 1])])
+
+
+def gather_bank_steps(steps):
+    """steps: [(embeddings [B][D], mask [B])] of this rank's training steps (equal B: the loaders drop the last batch).  Returns
+    the selected rows of every rank in the order per-step gathering gives -- step 0 of rank 0, step 0 of rank 1, ..., step 1 of
+    rank 0, ... -- with ONE exchange per epoch instead of one per step."""
+    rank, world = world_info()
+    emb = torch.stack([e for e, _ in steps])                     # [S][B][D]
+    msk = torch.stack([m for _, m in steps])                     # [S][B]
+    if world > 1:
+        es = [torch.empty_like(emb) for _ in range(world)]
+        ms = [torch.empty_like(msk) for _ in range(world)]
+        dist.all_gather(es, emb)
+        dist.all_gather(ms, msk)
+        emb = torch.stack(es, dim=1)                             # [S][W][B][D]
+        msk = torch.stack(ms, dim=1)
+    return emb.reshape(-1, emb.shape[-1])[msk.reshape(-1)]
 
 
 def gather_in_order(local_items, total):

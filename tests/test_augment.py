@@ -52,6 +52,54 @@ def test_sampler_records_are_well_formed():
     assert seen == {0, 1, 2, 3}
 
 
+def test_window_sum_helper_matches_the_numpy_warp():
+    """ssad_affine_window_sum_u8 (host C loop of the library) == summing the window of pil_exact.affine_nearest's warp, exactly:
+    rotations + scales as RandomAffine draws them, windows inside the image and hanging over its right / bottom edge, no affine."""
+    from self_supervised import augment, pil_exact as px
+    from self_supervised.tv_transforms import inverse_affine_matrix
+    rng = np.random.RandomState(5)
+    for size in (64, 96, 256):
+        img = _image(size, size)
+        for _ in range(12):
+            ang, sc = rng.uniform(-3, 3), rng.uniform(1.05, 1.1)
+            aff = inverse_affine_matrix((size * 0.5, size * 0.5), ang, (0, 0), sc)
+            fix = px.affine_fix_coeffs(aff)
+            warped = px.affine_nearest(img, (size, size), aff)
+            for left, top, w, h in ((0, 0, size, size), (5, 9, 32, 32), (size - 20, size - 10, 32, 32), (size - 1, 0, 64, 3)):
+                for cur, f in ((warped, fix), (img, None)):
+                    want = cur[top:min(top + h, size), left:min(left + w, size)].reshape(-1, 3).astype(np.float64).sum(0)
+                    got = augment._window_sum(img, f, left, top, w, h)
+                    assert np.array_equal(got, want), (size, left, top, w, h, f is None)
+
+
+def test_sampler_pool_is_deterministic_per_batch():
+    """Forked sampler workers: the records of batch b depend on (base seed, epoch, b, rank) only -- not on how many workers draw
+    them or in which order they finish -- and equal what the same seed gives in-process."""
+    import multiprocessing
+    from concurrent.futures import ProcessPoolExecutor
+    from self_supervised import augment
+    imgs = np.stack([_image(s, 64) for s in range(6)])
+    aug = augment.GpuCutPaste("bottle", imgs, np.broadcast_to(_mask(64), (6, 64, 64)), device="cpu")
+    key = "test-pool"
+    augment._POOL_STATE[key] = aug
+    batches = [np.array([0, 1, 2, 3]), np.array([4, 5, 0, 1]), np.array([2, 2, 3, 5])]
+    seeds = [augment._batch_seed(3, 1, b, 0) for b in range(3)]
+    try:
+        results = []
+        for nw in (1, 3):
+            with ProcessPoolExecutor(nw, mp_context=multiprocessing.get_context("fork")) as pool:
+                futs = [pool.submit(augment._pool_sample, key, s, b) for s, b in zip(seeds, batches)]
+                results.append([f.result() for f in reversed(futs)][::-1])
+        assert results[0] == results[1]
+        for (raw, hw), s, b in zip(results[0], seeds, batches):
+            random.seed(s); np.random.seed(s % 2 ** 32); torch.manual_seed(s)
+            recs, hw2 = aug.sample(b)
+            assert recs.tobytes() == raw and tuple(hw) == tuple(hw2)
+        assert len({r[0] for r in results[0]}) == 3 and augment._batch_seed(3, 1, 0, 0) != augment._batch_seed(3, 1, 0, 1)
+    finally:
+        augment._POOL_STATE.pop(key, None)
+
+
 def _pil_reference(subject, names, size, patch, ps, root):
     from self_supervised import datasets
     return datasets.PretextTaskDataset(subject, names, imsize=(size, size), transform=datasets._default_transform(),
@@ -212,3 +260,29 @@ def test_gpu_batches_feed_training(seeded_sd):
     for _ in range(5):
         l = step.step(x, y)[0].item()
     assert np.isfinite(l) and l < l0
+
+
+@pytest.mark.gpu
+def test_loader_with_sampler_workers(tmp_path):
+    """GpuPretextLoader(num_workers > 0): the batches of an epoch are the same tensors whatever the number of sampler workers,
+    differ between epochs, and come out in batch order."""
+    import os
+    from fake_mvtec import make_tree
+    from self_supervised import augment, datasets
+    root = make_tree(str(tmp_path / "dataset"), categories=("bottle",), n_train=10, n_test_good=1, n_test_bad=1, size=96)
+    names = np.array(sorted(os.path.join(root, "bottle", "train/good", f) for f in os.listdir(os.path.join(root, "bottle", "train/good"))))
+    ds = datasets.PretextTaskDataset("bottle", np.tile(names, 4), imsize=(64, 64), transform=datasets._default_transform(),
+                                     dataset_root=root)
+    out = {}
+    for nw in (1, 3):
+        ld = augment.GpuPretextLoader(ds, 8, shuffle=True, drop_last=True, num_workers=nw, base_seed=11)
+        assert len(ld) == 5
+        out[nw] = [[tuple(t.cpu() for t in b) for b in ld.shard(1, 0, e)] for e in (0, 1)]
+        ld.close()
+    for e in (0, 1):
+        assert len(out[1][e]) == 5
+        for a, b in zip(out[1][e], out[3][e]):
+            assert all(torch.equal(u, v) for u, v in zip(a, b))
+    assert not torch.equal(out[1][0][0][0], out[1][1][0][0])
+    x, y, orig = out[1][0][0]
+    assert tuple(x.shape) == (8, 3, 64, 64) and y.dtype == torch.int64 and tuple(orig.shape) == (8, 3, 64, 64)

@@ -121,7 +121,7 @@ def _replica_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from self_supervised.training import broadcast_replica_state
-    from self_supervised.trainer import gather_bank_rows, barrier
+    from self_supervised.trainer import gather_bank_rows, gather_bank_steps, barrier
     torch.manual_seed(100 + rank)                       # replicas built DIFFERENTLY on purpose
 
     class _Arena:
@@ -147,6 +147,10 @@ def _replica_worker(rank, world, port, q):
     ok = ok and torch.equal(rows, want)
     none = gather_bank_rows(emb, torch.zeros(4, dtype=torch.bool))
     ok = ok and tuple(none.shape) == (0, 3)
+    # the per-epoch form used by Trainer.fit: same row order as gathering step after step
+    steps = [(emb + 1000 * s, torch.roll(mask, s)) for s in range(3)]
+    per_step = torch.cat([gather_bank_rows(e, m) for e, m in steps])
+    ok = ok and torch.equal(gather_bank_steps(steps), per_step) and per_step.shape[0] > 0
     barrier()
     q.put((rank, ok))
     dist.destroy_process_group()
