@@ -51,6 +51,9 @@ def parse_args():
                     help="which partition is the headline when N > 1 (the other one is reported as an extra)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--phase", choices=["both", "train", "score"], default="both")
+    ap.add_argument("--config", choices=["resnet18", "wrn50"], default="resnet18",
+                    help="resnet18: BASELINE configs[1] / [2] (the headline); wrn50: configs[3], WideResNet-50-2 layer1-3 feature-distance "
+                         "maps at 512x512 batch 64 on one GPU (throughput only: the reference has no such model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end tools.training measurement (N = 1 only)")
     ap.add_argument("--no-partition-extra", action="store_true", help="skip the strong-partition / batch-32 extra line")
@@ -215,8 +218,78 @@ def end_to_end(args):
     return res
 
 
+def bench_wrn50(args):
+    """BASELINE configs[3]: 64 synthetic 512 x 512 images -> WideResNet-50-2 layer1-3 features -> per-scale cosine 3-NN maps against
+    588-row banks -> blur + bilinear 512 x 512, mean over the scales.  One GPU; throughput only (no reference counterpart)."""
+    import torch
+    from self_supervised import ops
+    from self_supervised.wrn50 import FeatureDistanceScorer, WideResNet50Features
+    from oracle import wrn50 as ow
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    dev = torch.device("cuda", 0)
+    size, batch = 512, 64
+    ref = ow.seeded_trunk(0)
+    m = WideResNet50Features()
+    m.load_state_dict(ref.state_dict())
+    m.to(dev).eval()
+    banks = ow.seeded_banks(588)
+    scorer = FeatureDistanceScorer([b.to(dev) for b in banks])
+    x = synth_images(batch, size, 1234, dev)
+
+    def step():
+        with torch.no_grad():
+            return scorer(m(x), size)
+    for _ in range(max(args.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+    ops.PROFILE = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = ops.drain_profile()
+    ops.PROFILE = None
+    out = {"metric": "anomaly-maps/sec, WideResNet-50-2 layer1-3 feature-distance maps 512x512 bs64", "unit": "anomaly-maps/sec",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "WideResNet-50 multi-scale (layer1-3) feature-distance maps, 512x512 bs64, 1 GPU (BASELINE configs[3]; "
+                                  "no reference counterpart: the reference hard-wires resnet18, models.py:58-62)",
+                      "images_per_gpu": batch, "bank_rows": 588, "scales": [[128, 256], [64, 512], [32, 1024]]},
+           "value": round(batch * args.steps / dt, 2), "ms_per_step": round(1e3 * dt / args.steps, 3)}
+    recs = [r for r in prof if r["kernel"].startswith("conv_igemm")]
+    t = sum(r["ms"] for r in recs) * 1e-3
+    fl = sum(r["flops"] for r in recs)
+    allk = sum(r["ms"] for r in prof) * 1e-3
+    out["roofline"] = {"bound": "mfma", "achieved": round(fl / t / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                       "frac": round(fl / t / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "kernel": "conv_igemm_f32_kernel (NHWC)",
+                       "launches": len(recs), "avg_launch_ms": round(1e3 * t / len(recs), 4),
+                       "alg_gflop_per_launch": round(fl / len(recs) / 1e9, 3), "share_of_gpu_time": round(t / allk, 4),
+                       "gflop_per_image": round(sum(r["flops"] for r in prof) / args.steps / batch / 1e9, 2)}
+    by = {}
+    for r in prof:
+        e = by.setdefault(r["kernel"], [0.0, 0, 0.0]); e[0] += r["ms"]; e[1] += 1; e[2] += r["flops"]
+    out["kernel_ms"] = {k: [round(v[0] / args.steps, 3), v[1] // args.steps, round(v[2] / max(v[0], 1e-9) / 1e9, 1)] for k, v in sorted(by.items())}
+    if not args.no_cpu_baseline:
+        cores = host_cores()
+        torch.set_num_threads(cores)
+        xc = x[:1].cpu()
+
+        def once():
+            with torch.no_grad():
+                ow.distance_maps(ref(xc), banks, size)
+        tt, w, k = _timed_median(once, 30.0)
+        out["cpu_baseline"] = {"value": round(1.0 / tt, 3), "unit": "anomaly-maps/sec", "cores": cores, "kind": "port",
+                               "sample": f"oracle/wrn50.py on torch-CPU fp32: 1 image 512x512 (trunk + three k-NN maps + blur / bilinear), "
+                                         f"{w} warm-up(s), median of {k}"}
+    print(json.dumps(out))
+
+
 def main():
     args = parse_args()
+    if args.config == "wrn50":
+        return bench_wrn50(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
 

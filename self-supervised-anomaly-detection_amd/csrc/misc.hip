@@ -196,6 +196,70 @@ __global__ void blur_relu_bilinear_kernel(const float* __restrict__ maps, float*
     }
 }
 
+// The same map -> map function for maps that do not fit one workgroup's LDS (WideResNet-50 scales: 128 x 128 -> 512 x 512): one
+// workgroup per TT x TT tile of the OUTPUT; it stages the source rows / columns its bilinear taps touch plus the blur halo (reflect
+// indices resolved while loading), blurs them in LDS and interpolates.  Same expressions, same summation order per pixel as the
+// single-workgroup kernel: identical results.
+constexpr int BLUR_TT = 64;
+__global__ void blur_relu_bilinear_tiled_kernel(const float* __restrict__ maps, float* __restrict__ out, int h, int w, int ks,
+                                                int target, int tiles, int rmax) {
+    extern __shared__ float sm[];
+    const int pad = ks / 2, sw = rmax + 2 * pad;
+    float* src = sm;                      // [rmax + 2 pad][rmax + 2 pad]
+    float* blr = sm + sw * sw;            // [rmax][rmax]
+    float* k1 = blr + rmax * rmax;        // ks
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const int ty0 = (blockIdx.x / tiles) * BLUR_TT, tx0 = (blockIdx.x % tiles) * BLUR_TT;
+    const int ty1 = min(ty0 + BLUR_TT, target) - 1, tx1 = min(tx0 + BLUR_TT, target) - 1;
+    const float shy = (float)h / (float)target, swx = (float)w / (float)target;
+    const int ya = (int)fmaxf(shy * ((float)ty0 + 0.5f) - 0.5f, 0.f), xa = (int)fmaxf(swx * ((float)tx0 + 0.5f) - 0.5f, 0.f);
+    const int yb = min((int)fmaxf(shy * ((float)ty1 + 0.5f) - 0.5f, 0.f) + 1, h - 1);
+    const int xb = min((int)fmaxf(swx * ((float)tx1 + 0.5f) - 0.5f, 0.f) + 1, w - 1);
+    const int nr = yb - ya + 1, nc = xb - xa + 1;               // <= rmax by construction (host)
+    const float* m = maps + (int64_t)n * h * w;
+    for (int i = tid; i < (nr + 2 * pad) * (nc + 2 * pad); i += blockDim.x) {
+        const int ly = i / (nc + 2 * pad), lx = i - ly * (nc + 2 * pad);
+        int yy = ya - pad + ly, xx = xa - pad + lx;
+        yy = yy < 0 ? -yy : (yy >= h ? 2 * h - 2 - yy : yy);
+        xx = xx < 0 ? -xx : (xx >= w ? 2 * w - 2 - xx : xx);
+        src[ly * sw + lx] = m[yy * w + xx];
+    }
+    if (tid == 0) {
+        float sigma = 0.15f * (float)ks + 0.35f;
+        float half = (float)(ks - 1) * 0.5f, sum = 0.f;
+        for (int i = 0; i < ks; ++i) {
+            float x = -half + (float)i;
+            float v = expf(-0.5f * (x / sigma) * (x / sigma));
+            k1[i] = v;
+            sum += v;
+        }
+        for (int i = 0; i < ks; ++i) k1[i] /= sum;
+    }
+    __syncthreads();
+    for (int i = tid; i < nr * nc; i += blockDim.x) {
+        const int ly = i / nc, lx = i - ly * nc;
+        float acc = 0.f;
+        for (int dy = 0; dy < ks; ++dy)
+            for (int dx = 0; dx < ks; ++dx) acc += src[(ly + dy) * sw + lx + dx] * (k1[dy] * k1[dx]);
+        blr[ly * rmax + lx] = fmaxf(acc, 0.f);
+    }
+    __syncthreads();
+    float* o = out + (int64_t)n * target * target;
+    const int th = ty1 - ty0 + 1, tw = tx1 - tx0 + 1;
+    for (int i = tid; i < th * tw; i += blockDim.x) {
+        const int y = ty0 + i / tw, x = tx0 + i % tw;
+        float sy = fmaxf(shy * ((float)y + 0.5f) - 0.5f, 0.f);
+        float sx = fmaxf(swx * ((float)x + 0.5f) - 0.5f, 0.f);
+        int y0 = (int)sy, x0 = (int)sx;
+        int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+        float ly = sy - (float)y0, lx = sx - (float)x0;
+        float hy = 1.f - ly, hx = 1.f - lx;
+        y0 -= ya; y1 -= ya; x0 -= xa; x1 -= xa;
+        o[(int64_t)y * target + x] = hy * (hx * blr[y0 * rmax + x0] + lx * blr[y0 * rmax + x1]) +
+                                     ly * (hx * blr[y1 * rmax + x0] + lx * blr[y1 * rmax + x1]);
+    }
+}
+
 }  // namespace
 
 static int repack(const float* src, float* dst, int O, int I, int KH, int KW, int to_ohwi, void* stream) {
@@ -263,8 +327,21 @@ extern "C" int ssad_blur_relu_bilinear(const float* maps, float* out, int n, int
     SSAD_CHECK_ARG(maps && out && n > 0 && h > 0 && w > 0 && target > 0, "bad argument");
     SSAD_CHECK_ARG(ksize >= 1 && (ksize & 1) && ksize / 2 < h && ksize / 2 < w, "kernel must be odd and reflect-pad must fit");
     size_t lds = (size_t)(2 * h * w + ksize) * sizeof(float);
-    SSAD_CHECK_ARG(lds <= 64 * 1024, "map too large for the single-workgroup kernel");
-    hipLaunchKernelGGL(blur_relu_bilinear_kernel, dim3(n), dim3(256), lds, (hipStream_t)stream, maps, out, h, w, ksize, target);
+    if (lds <= 48 * 1024) {
+        hipLaunchKernelGGL(blur_relu_bilinear_kernel, dim3(n), dim3(256), lds, (hipStream_t)stream, maps, out, h, w, ksize, target);
+        SSAD_CHECK_LAUNCH();
+        return 0;
+    }
+    // larger maps: one workgroup per 64 x 64 tile of the output
+    const int tiles = (target + BLUR_TT - 1) / BLUR_TT;
+    const int span = BLUR_TT < target ? BLUR_TT : target;
+    const int rmax_y = (int)((double)h / target * span) + 3, rmax_x = (int)((double)w / target * span) + 3;
+    const int rmax = rmax_y > rmax_x ? rmax_y : rmax_x;
+    const int sw = rmax + 2 * (ksize / 2);
+    lds = (size_t)(sw * sw + rmax * rmax + ksize) * sizeof(float);
+    SSAD_CHECK_ARG(lds <= 64 * 1024, "down-sampling ratio too large for the tiled kernel");
+    hipLaunchKernelGGL(blur_relu_bilinear_tiled_kernel, dim3(tiles * tiles, n), dim3(256), lds, (hipStream_t)stream, maps, out, h, w,
+                       ksize, target, tiles, rmax);
     SSAD_CHECK_LAUNCH();
     return 0;
 }

@@ -250,6 +250,20 @@ def test_scoring_pass_just_under_2_31_elements(dev, seeded_sd):
     assert torch.equal(o[77 * 841:78 * 841], rb)
 
 
+def test_upsample_tiled_equals_single_workgroup(dev):
+    """Maps too large for one workgroup's LDS take the tiled blur + bilinear kernel: bit-identical to the single-workgroup kernel
+    where both apply (forced here through the oracle), and equal to the oracle on a 128 x 128 -> 512 x 512 map and a ragged one."""
+    from self_supervised import ops
+    from oracle import scoring as osc
+    g = torch.Generator().manual_seed(8)
+    for n, h, w, target in ((2, 128, 128, 512), (1, 90, 90, 200), (3, 80, 80, 160)):
+        maps = torch.rand(n, 1, h, w, generator=g) - 0.3
+        got = ops.blur_relu_bilinear(maps.to(dev), 7, target).cpu()
+        want = osc.upsample(maps, target)
+        assert tuple(got.shape) == (n, 1, target, target)
+        assert (got - want).abs().max().item() < 2e-6, (h, w, target, (got - want).abs().max().item())
+
+
 def test_knn_golden(dev, golden):
     from self_supervised.models import AnomalyDetector
     from oracle import weights as ow
