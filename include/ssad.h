@@ -344,6 +344,10 @@ int ssad_aug_params_size(void);
 int ssad_cutpaste_augment(const uint8_t* imgs, const uint8_t* cuts, const ssad_aug_params* params, uint8_t* work,
                           float* gray_mean, float* out, int B, int H, int W, int h, int w, const float* mean3_host,
                           const float* std3_host, void* stream);
+/* AnomalyDetector.predict (models.py:363-370) in one kernel: out[n] = mean of the k (1..3) smallest clip(1 - cos(x_n, bank_r), 0, 2)
+ * over the R rows of an L2-normalised bank; the N x R similarity matrix is never written.  Bit-identical to
+ * ssad_l2_normalize_rows -> ssad_conv_igemm_fwd (1x1) -> ssad_cosine_knn_mean.  D % 32 == 0. */
+int ssad_cosine_knn_fused(const float* x, const float* bank_normalized, float* out, int64_t N, int D, int R, int k, void* stream);
 /* HOST function (no GPU work): per-channel integer sums of the window [top, top + h) x [left, left + w) of the NEAREST affine
  * transform of an H x W x 3 uint8 image (fix: the six 16.16 coefficients of ssad_aug_params.aff_fix; NULL: the image itself),
  * zero outside the image.  The sampler's colour-similarity test (datasets.py:300-312) needs this mean between two random

@@ -35,6 +35,7 @@ SIGNATURES = {
     "ssad_gap_fwd": [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
     "ssad_l2_normalize_rows": [_c_fp, _c_fp, _c_l, _c_i, _c_fp],
     "ssad_cosine_knn_mean": [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp],
+    "ssad_cosine_knn_fused": [_c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_fp],
     "ssad_blur_relu_bilinear": [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
     "ssad_flip_transpose_weight": [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp],
     "ssad_flip_transpose_batch": [_c_fp, _c_fp, ctypes.POINTER(ctypes.c_int64), _c_i, _c_fp],

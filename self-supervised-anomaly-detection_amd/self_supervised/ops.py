@@ -309,6 +309,16 @@ def cosine_knn_mean(sim, k=3):
     return out
 
 
+def cosine_knn_fused(x, bank_n, k=3):
+    """x [N][D] (not normalised), bank_n [R][D] L2-normalised -> [N] mean of the k smallest cosine distances, one kernel."""
+    n, d = x.shape
+    r = bank_n.shape[0]
+    out = _new((n,), x)
+    _run("knn_fused", 2.0 * n * d * r, 4.0 * (x.numel() + bank_n.numel() + n),
+         lambda: _hip.lib().ssad_cosine_knn_fused(_hip.ptr(x), _hip.ptr(bank_n), _hip.ptr(out), n, d, r, k, _hip.stream()))
+    return out
+
+
 def blur_relu_bilinear(maps, ksize=7, target=256):
     n, c, h, w = maps.shape
     out = _new((n, c, target, target), maps)

@@ -94,12 +94,7 @@ class FeatureDistanceScorer:
         out = None
         for f, bank in zip(feats, self.banks):
             n, h, w, c = f.shape
-            rows = f.reshape(n * h * w, c)
-            score = torch.empty(rows.shape[0], device=f.device, dtype=torch.float32)
-            step = 1 << 18
-            for i in range(0, rows.shape[0], step):
-                qn = ops.l2_normalize_rows(rows[i:i + step])
-                score[i:i + step] = ops.cosine_knn_mean(ops.linear_fwd(qn, bank), self.k)
+            score = ops.cosine_knn_fused(f.reshape(n * h * w, c), bank, self.k)
             up = ops.blur_relu_bilinear(score.view(n, 1, h, w), 7, size)
             out = up if out is None else out.add_(up)
         return out.div_(float(len(feats)))

@@ -264,6 +264,24 @@ def test_upsample_tiled_equals_single_workgroup(dev):
         assert (got - want).abs().max().item() < 2e-6, (h, w, target, (got - want).abs().max().item())
 
 
+@pytest.mark.parametrize("case", [(1000, 512, 588, 3), (129, 256, 70, 3), (128, 64, 128, 2), (5, 1024, 3, 1), (70000, 512, 300, 3)])
+def test_knn_fused_equals_the_three_kernel_chain(dev, case):
+    """csrc/knn.hip (normalise + similarity GEMM + k smallest in one kernel) == l2norm_rows -> igemm -> knn_mean bit for bit, on
+    ragged row / column tiles, and within 1e-6 of the numpy statement of sklearn's brute-force cosine k-NN."""
+    from self_supervised import ops
+    from oracle import scoring as osc
+    n, d, r, k = case
+    g = torch.Generator().manual_seed(sum(case))
+    x, bank = torch.randn(n, d, generator=g) * 3, torch.randn(r, d, generator=g)
+    bn = ops.l2_normalize_rows(bank.to(dev))
+    chain = ops.cosine_knn_mean(ops.linear_fwd(ops.l2_normalize_rows(x.to(dev)), bn), k)
+    fused = ops.cosine_knn_fused(x.to(dev), bn, k)
+    assert torch.equal(fused, chain)
+    if n <= 2000:
+        want, _, _ = osc.cosine_knn_mean(bank.numpy(), x.numpy(), k)
+        assert np.abs(fused.cpu().numpy() - want).max() < 1e-6
+
+
 def test_knn_golden(dev, golden):
     from self_supervised.models import AnomalyDetector
     from oracle import weights as ow
