@@ -112,6 +112,58 @@ def test_category_sweep(tmp_path):
     assert os.path.exists(out + "bottle/best_model.ckpt") and os.path.exists(out + "carpet/best_model.ckpt")
 
 
+def test_inference_maps_match_the_oracle_end_to_end(tmp_path, seeded_sd):
+    """tools.inference (checkpoint -> MVTec test images -> 841 patches each -> embeddings -> bank from the first training image,
+    70 / 30 split from the global numpy RNG -> cosine 3-NN maps) against the same pipeline run with the CPU oracle on the same
+    files, checkpoint and numpy seed: maps within 1e-4 (fp32), same bank split, same threshold."""
+    from self_supervised import tools, datasets
+    from oracle.peranet import OraclePeraNet
+    from oracle import scoring as osc
+    datasets._DataModule.num_workers = 0
+    import shutil
+    root = make_tree(str(tmp_path / "data"), categories=("bottle",), n_train=3, n_test_good=1, n_test_bad=1, size=96)
+    # tools.inference takes the first batch of a SHUFFLED loader as the normality set (tools.py:379-381): make every training
+    # image the same file so that the choice does not matter
+    for k in (1, 2):
+        shutil.copy(root + "bottle/train/good/000.png", root + f"bottle/train/good/{k:03d}.png")
+    ck = str(tmp_path / "seeded.ckpt")
+    torch.save({"state_dict": seeded_sd, "hyper_parameters": {}, "memory_bank": torch.tensor([])}, ck)
+    np.random.seed(3)
+    res = tools.inference(ck, root + "bottle/", "bottle", mvtec_inference=True, patch_localization=True)
+    assert tuple(res.anomaly_maps.shape) == (2, 1, 29, 29)
+    ref = OraclePeraNet(); ref.load_state_dict(seeded_sd); ref.eval(); ref.patch_level = True
+    dm = datasets.MVTecDatamodule(root + "bottle/", batch_size=1)
+    dm.setup()
+    with torch.no_grad():
+        test_emb = torch.cat([ref(x)["latent_space"] for x, _, _ in dm.predict_dataloader()])
+        normality = ref(next(iter(dm.train_dataloader()))[0])["latent_space"]
+    np.random.seed(3)
+    det = osc.OracleAnomalyDetector(patch_level=True, batch=2, num_patches=841)
+    det.fit(normality.numpy())
+    want = det.predict(test_emb.numpy())
+    assert (res.embedding_vectors - test_emb).abs().max().item() < 1e-4 * max(1.0, test_emb.abs().max().item())
+    assert (res.anomaly_maps - want).abs().max().item() < 1e-4
+
+
+def test_category_sweep_all_fifteen(tmp_path):
+    """BASELINE configs[4]'s shape of work on one GPU: tools.sweep over all fifteen MVTec-AD category names (objects with a fixed
+    mask, non-fixed objects with per-image object masks, textures cutting defects from other images, the SLIC pre-segmented
+    cable, capsule / screw with their fixed pre-crops) at 256 x 256 patch level, one short training each."""
+    from self_supervised import tools, datasets, constants
+    datasets._DataModule.num_workers = 0
+    cats = list(constants.TEXTURES()) + [o for o in constants.OBJECTS() if o not in constants.TEXTURES()]   # 'tile' is in both lists
+    assert len(cats) == 15
+    root = make_tree(str(tmp_path / "data"), categories=tuple(cats), n_train=4, n_test_good=1, n_test_bad=1, size=96)
+    out = str(tmp_path / "out") + "/"
+    np.random.seed(0)
+    df = tools.sweep(root, out, cats, imsize=(256, 256), batch_size=8, seed=0, projection_training_params=(1, 0.03),
+                     fine_tune_params=(1, 0.005), trainer_kwargs={"limit_train_batches": 1, "limit_val_batches": 1},
+                     tables_output=out + "tables/")
+    assert list(df.index) == cats + ["average"] and {"auroc", "aupro", "iou"} <= set(df.columns)
+    assert np.isfinite(df.values).all() and ((df["auroc"] >= 0) & (df["auroc"] <= 1)).all()
+    assert all(os.path.exists(out + c + "/best_model.ckpt") for c in cats)
+
+
 def test_gpu_auroc_matches_sklearn(golden):
     from sklearn.metrics import roc_auc_score
     from self_supervised import metrics as m
