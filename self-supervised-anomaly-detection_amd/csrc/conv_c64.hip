@@ -24,6 +24,10 @@
 #ifndef C64_ABL
 #define C64_ABL 0
 #endif
+// 1 = tiles inside the image store their accumulators directly (no LDS transpose); 0 = always the LDS epilogue
+#ifndef C64_DIRECT_EPI
+#define C64_DIRECT_EPI 1
+#endif
 
 #if C64_ABL & 16
 __device__ unsigned long long* g_c64_trace;      // [workgroups][8]: phase time stamps (tools/micro/c64_ablate.hip)
@@ -212,8 +216,70 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
         if (sum == 123.456f) p.out[0] = sum;
         return;
     }
-    float* Ct = halo;                               // [128 pixels][LDP]
     double s0[2] = {0.0, 0.0}, s1[2] = {0.0, 0.0};
+    // ---- direct epilogue (tiles that lie wholly inside the image): accumulator registers straight to HBM.  Register e of lane
+    // (r, h) is pixel m = (e & 3) + 8 (e >> 2) + 4 h of the wave's two tile rows, channel j * 32 + r: one wave store writes 2 pixels
+    // x 128 contiguous bytes.  No LDS transpose and no barrier -- the instructions outside the tap loop are what the co-resident
+    // workgroup's matrix stream cannot hide (profiles/r03_igemm_phases.md).  Training instantiation only: 5.37 -> 5.17 ms per step
+    // over its 8 launches; the inference form (16 x 16 maps of 15 979+ patches per launch) lost 2 % with 4-byte stores and keeps
+    // the LDS epilogue's 16-byte ones. ----
+    if (C64_DIRECT_EPI && !EVAL && y0 + TH <= p.H && x0 + TW <= p.W) {
+        const int64_t ops_ = EVAL ? p.out_ps : (int64_t)C, rps_ = EVAL ? p.res_ps : (int64_t)C;
+        const int64_t obase = (EVAL ? (int64_t)n * p.out_ss : (int64_t)n * p.H * p.W * C) + ((int64_t)(y0 + 2 * wave) * p.W + x0 + 4 * h) * ops_ + r;
+        const int64_t rbase = (EVAL ? (int64_t)n * p.res_ss : (int64_t)n * p.H * p.W * C) + ((int64_t)(y0 + 2 * wave) * p.W + x0 + 4 * h) * rps_ + r;
+        float scl[2] = {1.f, 1.f}, sft[2] = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (EVAL && p.scale) scl[j] = p.scale[j * 32 + r];
+            if (EVAL && p.shift) sft[j] = p.shift[j * 32 + r];
+        }
+        float rs[16][2];
+        if (p.residual) {                           // every residual load in flight before the first use
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int pm = (e & 3) + 8 * (e >> 2);                                  // pixel of the lane half h = 0
+                const int64_t po = (int64_t)(pm >> 4) * p.W + (pm & 15);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) rs[e][j] = p.residual[rbase + po * rps_ + j * 32];
+            }
+            if (!EVAL && p.res_mask) {
+                unsigned mk[16][2];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int pm = (e & 3) + 8 * (e >> 2);
+                    const int64_t po = (int64_t)(pm >> 4) * p.W + (pm & 15);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) mk[e][j] = p.res_mask[(rbase + po * rps_ + j * 32) >> 2];
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) rs[e][j] = (mk[e][j] >> (r & 3)) & 1u ? rs[e][j] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) rs[e][0] = rs[e][1] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int pm = (e & 3) + 8 * (e >> 2);
+            const int64_t po = (int64_t)(pm >> 4) * p.W + (pm & 15);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float a = acc[j][e];
+                if (!EVAL && p.stats) { s0[j] += (double)a; s1[j] += (double)a * (double)a; }
+                float v;
+                if (EVAL) {                          // the expression of the LDS epilogue / conv_igemm
+                    const float x = a * scl[j] + sft[j] + rs[e][j];
+                    v = p.relu ? fmaxf(x, 0.f) : x;
+                } else {
+                    v = a + rs[e][j];
+                }
+                p.out[obase + po * ops_ + j * 32] = v;
+            }
+        }
+    } else {
+    float* Ct = halo;                               // [128 pixels][LDP]
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int m = (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -265,6 +331,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
             }
             if (o[q] >= 0) *(f32x4*)(p.out + o[q]) = v;
         }
+    }
     }
     C64_STAMP(3);
     if (!EVAL && p.stats) {
