@@ -295,6 +295,21 @@ void conv_igemm_f32_kernel(ConvParams p) {
         }
     };
     auto load_piece = [&](int q, int set = 0) {         // one 16-byte piece: q < AR activation rows, then the BR weight rows
+#if IGEMM_ABL & 64      // timing experiment only (results are garbage): global -> LDS directly, no VGPR staging, no ds_write
+        {
+            const float* src;
+            if (q < AR) {
+                const bool ok = (a_mask[q] >> ld_ptap) & 1u;
+                src = ok ? a_ptr[q] + ld_koff : zero;
+            } else {
+                src = b_ptr[q - AR] ? b_ptr[q - AR] + ld_woff : zero;
+            }
+            float* dst = lds + 2 * STAGE + ((tid >> 6) * (AR + BR) + q) * 256;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            return;
+        }
+#endif
         if (q < AR) {
             const bool ok = (a_mask[q] >> ld_ptap) & 1u;
             const float* src = a_ptr[q] + ld_koff;
@@ -416,9 +431,14 @@ void conv_igemm_f32_kernel(ConvParams p) {
     auto kstep = [&](int ks, auto set_c) {
         constexpr int SET = decltype(set_c)::value;                              // register set the loads of this K-step fill
         constexpr int NCH = BK / 8, NPIECE = AR + BR, NM = 4 * TM * TN;          // chunks, pieces, MFMAs per chunk
-        constexpr int EVERY = NM / NPIECE > 0 ? NM / NPIECE : 1;
-        constexpr int SCH = PIPE2 ? (NCH > 1 ? 1 : 0) : NCH - 1;                 // chunk that carries the LDS stores
-        constexpr int SSET = PIPE2 ? SET ^ 1 : 0;                                // ... of this register set
+        constexpr int TOT = NCH * NM;                                            // MFMAs per K-step
+        // one piece per MFMA pair (a 16-byte-per-lane global load costs the matrix stream ~90 cycles, an MFMA is 64): the loads
+        // follow MFMAs 1, 3, 5, ... of the K-step, the stores of the other register set start at the next chunk boundary
+        constexpr int GAP = TOT >= 4 * NPIECE ? 2 : 1;
+        constexpr int S0 = PIPE2 ? (((GAP * NPIECE + NM - 1) / NM) * NM + GAP * NPIECE <= TOT ? ((GAP * NPIECE + NM - 1) / NM) * NM
+                                                                                             : TOT - GAP * NPIECE)
+                                 : TOT - GAP * NPIECE;                           // one register set: stores as late as possible
+        constexpr int SSET = PIPE2 ? SET ^ 1 : 0;                                // register set that is stored
         const float* cur = lds + (ks & 1) * STAGE;
         const float* As = cur + (wm * 32 * TM + r) * LDK + h * 4;
         const float* Bs = cur + BM * LDK + (wn * 32 * TN + r) * LDK + h * 4;
@@ -445,7 +465,7 @@ void conv_igemm_f32_kernel(ConvParams p) {
                 for (int j = 0; j < TN; ++j) b[nx][j] = b[cu][j];
             }
             __builtin_amdgcn_sched_barrier(0);
-            int q = 0, m = 0, q2 = 0;
+            int m = 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -453,21 +473,19 @@ void conv_igemm_f32_kernel(ConvParams p) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
                         acc[i][j] = mfma32(a[cu][i][e], b[cu][j][e], acc[i][j]);
+                        const int mi = kk * NM + m;                              // index of this MFMA inside the K-step
                         ++m;
-                        if (m % EVERY == (EVERY > 1 ? 1 : 0)) {
-                            if (kk == 0 && q < NPIECE && !(IGEMM_ABL & 4)) {
-                                __builtin_amdgcn_sched_barrier(0);
-                                load_piece(q, PIPE2 ? SET : 0);
-                                ++q;
-                                __builtin_amdgcn_sched_barrier(0);
-                            }
-                            if (kk == SCH && q2 < NPIECE && !(IGEMM_ABL & 8)) {
-                                __builtin_amdgcn_sched_barrier(0);
-                                if (q2 < AR) *(f32x4*)(nAs + (sr + RPP * q2) * LDK + sc * 4) = ra2[SSET][q2];
-                                else *(f32x4*)(nBs + (sr + RPP * (q2 - AR)) * LDK + sc * 4) = rb2[SSET][q2 - AR];
-                                ++q2;
-                                __builtin_amdgcn_sched_barrier(0);
-                            }
+                        if (mi % GAP == GAP - 1 && mi / GAP < NPIECE && !(IGEMM_ABL & 4)) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            load_piece(mi / GAP, PIPE2 ? SET : 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        if (mi >= S0 && (mi - S0) % GAP == GAP - 1 && (mi - S0) / GAP < NPIECE && !(IGEMM_ABL & 8)) {
+                            const int q2 = (mi - S0) / GAP;
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (q2 < AR) *(f32x4*)(nAs + (sr + RPP * q2) * LDK + sc * 4) = ra2[SSET][q2];
+                            else *(f32x4*)(nBs + (sr + RPP * (q2 - AR)) * LDK + sc * 4) = rb2[SSET][q2 - AR];
+                            __builtin_amdgcn_sched_barrier(0);
                         }
                     }
             __builtin_amdgcn_sched_barrier(0);
@@ -850,7 +868,7 @@ int launch(const ConvParams& p, hipStream_t st) {
     constexpr int stage_bytes = (DB ? 2 : 1) * (BM + BN) *
                                 (BF == 6 ? (3 * BK + 8) * 2 : (BF == 3 ? (2 * BK + 8) * 2 : (BF ? (BK + 8) * 2 : (BK + 4) * 4)));
     constexpr int epi_bytes = (BM / TM) * (BN + 4) * 4;
-    constexpr int lds_min = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
+    constexpr int lds_min = (stage_bytes > epi_bytes ? stage_bytes : epi_bytes) + ((IGEMM_ABL & 64) ? 40 * 1024 : 0);
     // SSAD_CONV_LDS_PAD_<BN>: extra LDS bytes per workgroup = fewer resident workgroups (launch-quantisation experiments)
     static const int lds_pad = getenv(BN == 64 ? "SSAD_CONV_LDS_PAD_64" : "SSAD_CONV_LDS_PAD_128")
                                    ? atoi(getenv(BN == 64 ? "SSAD_CONV_LDS_PAD_64" : "SSAD_CONV_LDS_PAD_128")) : 0;

@@ -324,7 +324,11 @@ __device__ __forceinline__ f32x4 pool_grad(const uint8_t* __restrict__ idx, cons
 
 // APPLY == 0: per-block partial sums  s0 = sum g, s1 = sum g * xhat  (double, [gridDim.x][2][C])
 // APPLY == 1: dz = gamma * invstd * (g - dbeta / R - xhat * dgamma / R)
-// (two rows per iteration were tried: no faster -- the gathers, not their latency, set the pace)
+// A thread works on a 2 x 2 block of pixels: the four pooled cells (2 x 2) that can have their argmax inside the block are read
+// ONCE (index word + gradient quad each) and dealt to the four pixels by slot, instead of four cell look-ups per pixel -- the
+// look-ups, not the streaming of z, set the pace of the one-pixel form (1.19 ms per step at 3.2 TB/s -> see DESIGN.md).
+// Block (a, b) = pixels (2a .. 2a+1, 2b .. 2b+1); cell (oy, ox) covers pixels 2oy-1 .. 2oy+1, so the block's pixels are covered by
+// cells oy in {a, a+1}, ox in {b, b+1} only; slot of pixel (y, x) in cell (oy, ox) = (y - 2oy + 1) * 3 + (x - 2ox + 1).
 template <int APPLY>
 __global__ __launch_bounds__(256) void pool_bn_bwd_kernel(const uint8_t* __restrict__ idx, const float* __restrict__ dpool,
                                                           const float* __restrict__ z, const float* __restrict__ mean,
@@ -342,30 +346,65 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_kernel(const uint8_t* __restr
     if (APPLY) { db = ((const f32x4*)dbeta)[c4]; dg = ((const f32x4*)dgamma)[c4]; }
     const float invR = 1.f / (float)R;
     double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    // "rows" here are 2 x 2 pixel blocks: Hb x Wb per image (H, W even or odd: the last block row / column may be half empty)
+    const int Hb = (H + 1) / 2, Wb = (W + 1) / 2;
+    const int64_t NB = (R / ((int64_t)H * W)) * Hb * Wb;
     const int64_t rb = (int64_t)blockIdx.x * rows_per_block;
-    const int64_t re = rb + rows_per_block < R ? rb + rows_per_block : R;
-    for (int64_t row = rb + ty; row < re; row += RL) {
-        const int x = (int)(row % W);
-        const int64_t t = row / W;
-        const int y = (int)(t % H);
-        const int64_t n = t / H;
-        f32x4 g = pool_grad(idx, dpool, n, y, x, c4, C4, Ho, Wo);
-        const f32x4 zz = ((const f32x4*)z)[row * C4 + c4];
-        f32x4 xh;
+    const int64_t re = rb + rows_per_block < NB ? rb + rows_per_block : NB;
+    for (int64_t blk = rb + ty; blk < re; blk += RL) {
+        const int b = (int)(blk % Wb);
+        const int64_t t = blk / Wb;
+        const int a = (int)(t % Hb);
+        const int64_t n = t / Hb;
+        // the four candidate cells
+        uint32_t pk[2][2];
+        f32x4 gq[2][2];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            xh[k] = (zz[k] - mu[k]) * is[k];
-            g[k] = (zz[k] - mu[k]) * is[k] * ga[k] + be[k] > 0.f ? g[k] : 0.f;      // the forward's expression
-        }
-        if (APPLY) {
-            f32x4 o;
+        for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = ga[k] * is[k] * (g[k] - db[k] * invR - xh[k] * dg[k] * invR);
-            ((f32x4*)dz)[row * C4 + c4] = o;
-        } else {
+            for (int dx = 0; dx < 2; ++dx) {
+                const int oy = a + dy, ox = b + dx;
+                const bool ok = oy < Ho && ox < Wo;
+                const int64_t o = ((n * Ho + (ok ? oy : 0)) * Wo + (ok ? ox : 0)) * C4 + c4;
+                pk[dy][dx] = ok ? ((const uint32_t*)idx)[o] : 0xffffffffu;        // slot 255 never matches
+                gq[dy][dx] = ((const f32x4*)dpool)[o];
+            }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { s0[k] += (double)g[k]; s1[k] += (double)g[k] * (double)xh[k]; }
-        }
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+                const int y = 2 * a + py, x = 2 * b + px;
+                if (y >= H || x >= W) continue;
+                f32x4 g = {0.f, 0.f, 0.f, 0.f};
+                // same cell order as the one-pixel form (oy ascending, then ox): cells oy in {y/2, (y+1)/2}, ox likewise
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        const int oy = a + dy, ox = b + dx;
+                        if (dy > py || dx > px) continue;       // pixel (py, px) of the block lies in cells a .. a + py, b .. b + px
+                        const uint32_t slot = (uint32_t)((y - (2 * oy - 1)) * 3 + (x - (2 * ox - 1)));
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) g[k] += ((pk[dy][dx] >> (8 * k)) & 0xffu) == slot ? gq[dy][dx][k] : 0.f;
+                    }
+                const int64_t row = (n * H + y) * W + x;
+                const f32x4 zz = ((const f32x4*)z)[row * C4 + c4];
+                f32x4 xh;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    xh[k] = (zz[k] - mu[k]) * is[k];
+                    g[k] = (zz[k] - mu[k]) * is[k] * ga[k] + be[k] > 0.f ? g[k] : 0.f;      // the forward's expression
+                }
+                if (APPLY) {
+                    f32x4 o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = ga[k] * is[k] * (g[k] - db[k] * invR - xh[k] * dg[k] * invR);
+                    ((f32x4*)dz)[row * C4 + c4] = o;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { s0[k] += (double)g[k]; s1[k] += (double)g[k] * (double)xh[k]; }
+                }
+            }
     }
     if (APPLY) return;
 #pragma unroll
@@ -730,9 +769,10 @@ extern "C" int ssad_pool_bn_relu_bwd(const uint8_t* idx, const float* dpool, con
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const int64_t R = N * H * W;
     const int RL = 256 / (C / 4);
-    int64_t nblk = cdiv64(R, (int64_t)RL * 32);
+    const int64_t NB = N * ((H + 1) / 2) * ((W + 1) / 2);          // 2 x 2 pixel blocks: the unit a thread works on
+    int64_t nblk = cdiv64(R, (int64_t)RL * 32);                      // = the rows ssad_colreduce_workspace(R, C) provides
     if (nblk > 2048) nblk = 2048;
-    const int64_t rows_per_block = cdiv64(R, nblk);
+    const int64_t rows_per_block = cdiv64(NB, nblk);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(pool_bn_bwd_kernel<0>, dim3((unsigned)nblk), dim3(256), 0, st, idx, dpool, z, mean, invstd, gamma, beta,
                        (const float*)nullptr, (const float*)nullptr, (float*)nullptr, workspace, R, H, W, C, Ho, Wo, rows_per_block);
