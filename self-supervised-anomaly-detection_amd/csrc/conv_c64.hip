@@ -6,8 +6,8 @@
 // issues 5 global loads + 5 LDS stores (Cout = 64 tile), and the wave's in-order stream cannot hide them: 85-100 TFLOP/s
 // on this shape against 125-132 on the wide layers.  Here a workgroup owns an 8 x 16 patch of output pixels of ONE image
 // and all 64 output channels:
-//   * the 10 x 18 x 64 input halo is loaded ONCE into LDS (48 960 B in 68-float rows, + the 17 408 B weight slice of a tap =
-//     66 368 B per workgroup; two workgroups per CU = 130 KB, which only gfx950's 160 KB of LDS per CU holds; zero padding
+//   * the 10 x 18 x 64 input halo is loaded ONCE into LDS (51 200 B: 68-float pixels, 1 280-float rows, + the 17 408 B weight slice
+//     of a tap = 68 608 B per workgroup; two workgroups per CU = 134 KB, which only gfx950's 160 KB of LDS per CU holds; zero padding
 //     written as zeros, so there are no tap masks), optionally through a per-channel affine + ReLU (the train-mode BatchNorm + ReLU of the producing layer:
 //     the normalised activation never makes a round trip through HBM) and optionally emitted for the weight-gradient
 //     kernel that needs it later;
@@ -42,7 +42,11 @@ constexpr int TH = 8, TW = 16;              // output pixels per workgroup
 constexpr int HH = TH + 2, HW = TW + 2;     // halo
 constexpr int C = 64;                       // channels in and out
 constexpr int LDP = C + 4;                  // LDS row pitch in floats (272 B: conflict-free ds_read_b128 over rows)
-constexpr int HALO_F = HH * HW * LDP;       // floats
+// halo row pitch: HW pixels + 56 floats of padding, so that the pitch is a multiple of 64 dwords (18 * 68 + 56 = 1280): the two tile
+// rows a wave reads in one ds_read_b128 (lanes 0-15 / 16-31) then fall on the same bank pattern shifted by whole pixels and the
+// 16-lane groups of the instruction stay conflict-free (round 2: pitch 1224 = 8 mod 64, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.19)
+constexpr int ROWP = HW * LDP + 56;
+constexpr int HALO_F = HH * ROWP;           // floats
 constexpr int WT_F = C * LDP;               // one tap's [co][ci] slice
 constexpr int LDS_BYTES = (HALO_F + WT_F) * 4;
 
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
 #pragma unroll
     for (int q = 0; q < NPASS; ++q) {
         const int hp = q * 16 + p0;
-        if (hp < HH * HW) *(f32x4*)(halo + hp * LDP + c4 * 4) = hv[q];
+        if (hp < HH * HW) *(f32x4*)(halo + (hp / HW) * ROWP + (hp % HW) * LDP + c4 * 4) = hv[q];
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) *(f32x4*)(Bs + ((tid >> 4) + 16 * i) * LDP + c4 * 4) = wv[i];
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-    const float* Ab = halo + ((2 * wave + (r >> 4)) * HW + (r & 15)) * LDP + h * 4;      // tap (0,0) of this lane's pixel
+    const float* Ab = halo + (2 * wave + (r >> 4)) * ROWP + (r & 15) * LDP + h * 4;      // tap (0,0) of this lane's pixel
     const float* Bb = Bs + r * LDP + h * 4;
 
 #pragma unroll
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) wv[i] = *(const f32x4*)(wrow + (int64_t)i * 16 * 9 * C + (t + 1) * C);
         }
-        const float* At = Ab + (ky * HW + kx) * LDP;
+        const float* At = Ab + ky * ROWP + kx * LDP;
         f32x4 a[2], b[2][2];
         a[0] = *(const f32x4*)(At);
         b[0][0] = *(const f32x4*)(Bb);
