@@ -725,8 +725,8 @@ void conv_igemm_f32_kernel(ConvParams p) {
                 }
             }
             __syncthreads();
-            if (tid < 2 * BN) {
-                const int which = tid / BN, cc = tid % BN;
+            for (int u = tid; u < 2 * BN; u += NT) {            // 2 BN sums, NT threads (BN = 256: two per thread)
+                const int which = u / BN, cc = u % BN;
                 double t = 0.0;
 #pragma unroll
                 for (int q = 0; q < WM; ++q) t += S[(q * 2 + which) * BN + cc];
@@ -823,8 +823,8 @@ void conv_igemm_f32_kernel(ConvParams p) {
         S[(ssl * 2 + 0) * BN + scol] = st0;
         S[(ssl * 2 + 1) * BN + scol] = st1;
         __syncthreads();
-        if (tid < 2 * BN) {
-            const int which = tid / BN, cc = tid % BN;
+        for (int u = tid; u < 2 * BN; u += NT) {
+            const int which = u / BN, cc = u % BN;
             double t = 0.0;
 #pragma unroll
             for (int q = 0; q < SL; ++q) t += S[(q * 2 + which) * BN + cc];
@@ -943,6 +943,15 @@ int dispatch(const ConvParams& p, hipStream_t st) {
     static const int big = getenv("SSAD_CONV128_VARIANT") ? atoi(getenv("SSAD_CONV128_VARIANT")) : 0;
     if (big == 1) return launch<256, 128, 2, 2, 32, TS, POS>(p, st);
     if (big == 2) return launch<256, 128, 4, 2, 32, TS, POS>(p, st);      // one workgroup per CU, four waves of 128 x 64
+    // 128 x 256 tile (four waves of 64 x 128, one workgroup per CU) where Cout is a multiple of 256 and the launch still fills the
+    // chip: 12 staged pieces per 128 MFMAs instead of 16 -- the per-piece cost is what a K-step loses (profiles/r03_igemm_phases.md).
+    // Measured (same run): layer3 / layer4 training convs 0.635 -> 0.612 / 0.606 -> 0.586 ms, position-major scoring convs
+    // 1.649 -> 1.605 / 1.056 -> 1.017 ms; batch-32 grids (64-128 workgroups) would lose 3-5x, hence the floor.
+    static const int wide_min = getenv("SSAD_CONV_WIDE_GRID") ? atoi(getenv("SSAD_CONV_WIDE_GRID")) : 256;
+    if (big != 5 && p.Cout % 256 == 0 && wide_min > 0) {
+        const int64_t rows = POS ? cdiv64(p.N, 128) * p.Ho * p.Wo : cdiv64(p.M, 128);
+        if (rows * (p.Cout / 256) >= wide_min) return launch<128, 256, 2, 4, 32, TS, POS>(p, st);
+    }
     // small problems (batch 32-96 on the 8x8 / 16x16 maps of layer3 / layer4): 128x128 tiles leave CUs idle -- fewer than
     // ~1.5 workgroups per CU -- so the 128x64 tile doubles the grid (measured at batch 96 / 32: see DESIGN.md)
     static const int small_min = getenv("SSAD_CONV_SMALL_GRID") ? atoi(getenv("SSAD_CONV_SMALL_GRID")) : 500;
