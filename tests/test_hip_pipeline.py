@@ -182,6 +182,16 @@ def test_gpu_auroc_matches_sklearn(golden):
         assert abs(m.auroc_gpu(y.to(dev), s.to(dev)) - want) < 1e-10, (n, levels)
     fpr, tpr, _ = m.compute_roc(y, s)
     assert abs(m.compute_auc(fpr, tpr) - want) < 1e-12
+    # the hand-written radix sort on negative scores, signed zeros (equal as floats, different bit patterns) and a size that is
+    # not a multiple of the 4 096-key tile
+    n = 3 * 4096 + 1234
+    y = torch.rand(n, generator=gen) > 0.7
+    s = (torch.randn(n, generator=gen) * 2).round() / 2
+    s[::5] = 0.0
+    s[1::5] = -0.0
+    s = s - 0.8 * y
+    want = roc_auc_score(y.numpy(), s.numpy())
+    assert abs(m.auroc_gpu(y.to(dev), s.to(dev)) - want) < 1e-10
 
 
 def test_training_with_gpu_resident_pipeline(tmp_path):
