@@ -198,15 +198,15 @@ class PeraNet(_Base):
             self._plan = engine.EvalPlan(self)
         return self._plan
 
-    def _samples_per_pass(self, b, p, hv, wv, pd):
+    def _samples_per_pass(self, b, p, hv, wv, pd, device=None):
         """Images per trunk pass: the configured cap, fewer than 2^31 elements in the largest activation (the stem map: 1/4 of the
         network input's pixels x 64 channels per sample; the 32 x 32 patch path fuses stem + pool: 1/16), and what the free HBM
         holds (free = the driver's free bytes + what torch's allocator has cached but not handed out)."""
         shrink = 4 if pd == 32 else 2
         act = max(1, (hv // shrink) * (wv // shrink) * 64)                       # floats of the largest activation per sample
         cap = min(self.max_samples_per_pass, self.max_elements_per_tensor // act)
-        free, _ = torch.cuda.mem_get_info()
-        free += torch.cuda.memory_reserved() - torch.cuda.memory_allocated()
+        free, _ = torch.cuda.mem_get_info(device)
+        free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
         live = 4 if pd == 32 else 3                                              # tensors of that size alive at once (+ 25 % for the deeper stages)
         cap = min(cap, int(self.hbm_fraction_per_pass * free / (act * 4 * live * 1.25)))
         per_pass = max(1, cap // p)
@@ -227,7 +227,7 @@ class PeraNet(_Base):
         plan = self._eval_plan()
         dim_in = self.concatenator[0].in_features
         pooled = torch.empty((b * p, dim_in), device=x.device, dtype=torch.float32)
-        per_pass = self._samples_per_pass(b, p, hv, wv, pd)
+        per_pass = self._samples_per_pass(b, p, hv, wv, pd, x.device)
         i0 = 0
         while i0 < b:
             i1 = min(b, i0 + per_pass)
