@@ -457,6 +457,49 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
     }
 }
 
+// The same sums, four consecutive outputs per thread (16-byte loads) and four splits in flight: identical order of additions per
+// output (lane g adds splits g, g + 8, ... in order, then the eight lane sums in order), so the result is bit-identical to the
+// one-float form; needs Kreal % 4 == 0 and Kpad % 4 == 0.
+__global__ void wgrad_reduce4_kernel(const float* __restrict__ slab, float* __restrict__ out, int splits, int Cout, int Kpad,
+                                     int KH, int KW, int Cin, int to_oihw, int accumulate) {
+    __shared__ f32x4 part[8][33];
+    const int lx = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int64_t idx = ((int64_t)blockIdx.x * 32 + lx) * 4;
+    const int Kreal = KH * KW * Cin;
+    const bool ok = idx < (int64_t)Cout * Kreal;
+    const int co = ok ? (int)(idx / Kreal) : 0, k = ok ? (int)(idx - (int64_t)co * Kreal) : 0;
+    const int64_t stride = (int64_t)Cout * Kpad;
+    const float* s = slab + (int64_t)co * Kpad + k;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+        int i = g;
+        for (; i + 24 < splits; i += 32) {
+            const f32x4 a = *(const f32x4*)(s + (int64_t)i * stride), b = *(const f32x4*)(s + (int64_t)(i + 8) * stride);
+            const f32x4 c = *(const f32x4*)(s + (int64_t)(i + 16) * stride), d = *(const f32x4*)(s + (int64_t)(i + 24) * stride);
+            v += a; v += b; v += c; v += d;
+        }
+        for (; i < splits; i += 8) v += *(const f32x4*)(s + (int64_t)i * stride);
+    }
+    part[g][lx] = v;
+    __syncthreads();
+    if (g == 0 && ok) {
+        f32x4 t = part[0][lx];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) t += part[q][lx];
+        if (to_oihw) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kk = k + j, tap = kk / Cin, ci = kk - tap * Cin;
+                const int64_t o = ((int64_t)co * Cin + ci) * (KH * KW) + tap;
+                out[o] = accumulate ? out[o] + t[j] : t[j];
+            }
+        } else {
+            f32x4* o = (f32x4*)(out + idx);
+            *o = accumulate ? *o + t : t;
+        }
+    }
+}
+
 }  // namespace
 
 // Number of pixel splits for a problem (the caller sizes the slab with it).  Workgroups are dealt round-robin to the 8
@@ -602,8 +645,12 @@ extern "C" int ssad_wgrad_reduce(const float* slab, float* dw, int splits, int C
     SSAD_CHECK_ARG(slab && dw && splits >= 1 && Cout > 0 && KH > 0 && KW > 0 && Cin > 0, "bad argument");
     SSAD_CHECK_ARG(Kpad >= KH * KW * Cin, "slab rows shorter than the filter");
     const int64_t total = (int64_t)Cout * KH * KW * Cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(total, 32)), dim3(256), 0, (hipStream_t)stream, slab, dw,
-                       splits, Cout, Kpad, KH, KW, Cin, to_oihw, accumulate);
+    if ((KH * KW * Cin) % 4 == 0 && Kpad % 4 == 0 && ((uintptr_t)slab & 15) == 0 && ((uintptr_t)dw & 15) == 0)
+        hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)cdiv64(total, 128)), dim3(256), 0, (hipStream_t)stream, slab, dw,
+                           splits, Cout, Kpad, KH, KW, Cin, to_oihw, accumulate);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(total, 32)), dim3(256), 0, (hipStream_t)stream, slab, dw,
+                           splits, Cout, Kpad, KH, KW, Cin, to_oihw, accumulate);
     SSAD_CHECK_LAUNCH();
     return 0;
 }
