@@ -349,7 +349,7 @@ class _Affine:
             if self.c64_ok() and dz.dim() == 4:
                 dx = ops.conv3x3_c64(dzz, self.eng.flipped(self.lin, wt), residual=dx_residual, res_mask=dx_res_mask)
             else:
-                wf = self.eng.flipped(self.lin, wt) if (self.is_conv and wt is w) else ops.flip_transpose_weight(wt)
+                wf = self.eng.flipped(self.lin, wt) if wt is w else ops.flip_transpose_weight(wt)
                 dx = ops.conv_dgrad(dzz, wf, self.x_shape, self.stride, self.pad, dx_residual, bf, res_mask=dx_res_mask)
         self.x = self.z = self.y = self.mask = None
         return dx, dres
@@ -446,14 +446,13 @@ class TrainEngine:
         if not self._flip_view:                      # build the table once: every conv of the residual blocks, arena offsets
             import ctypes
             a, desc, off = self.arena, [], 0
-            for d in self.blocks:
-                for k in ("c1", "c2", "ds"):
-                    if d[k] is not None:
-                        p = d[k].lin.weight
-                        o, c, kh, kw = p.shape
-                        desc += [a.offset[id(p)][0], off, o, c, kh, kw]
-                        self._flip_view[id(p)] = (off, (c, kh, kw, o))
-                        off += p.numel()
+            layers = [d[k] for d in self.blocks for k in ("c1", "c2", "ds") if d[k] is not None] + list(self.head)
+            for layer in layers:                 # every block conv and (round 3) the head's linear layers, as 1 x 1 filters
+                p = layer.lin.weight
+                o, c, kh, kw = p.shape if p.dim() == 4 else (p.shape[0], p.shape[1], 1, 1)
+                desc += [a.offset[id(p)][0], off, o, c, kh, kw]
+                self._flip_view[id(p)] = (off, (c, kh, kw, o))
+                off += p.numel()
             self._flip_buf = torch.empty(off, device=a.p.device, dtype=torch.float32)
             self._flip_desc = (ctypes.c_int64 * len(desc))(*desc)
             self._flip_n = len(desc) // 6
