@@ -69,6 +69,41 @@ def case_step(res):
     res["finite"] = bool(torch.isfinite(dp.eng.arena.p).all().item())
 
 
+def case_rccl1(res):
+    """The transport the gloo cases cannot reach: a ONE-rank RCCL communicator on the box's card, with the step told it
+    has two replicas (world_size=2), so every bucket goes through ProcessGroupNCCL's stream / event hand-over between the
+    hipGraph segments.  A one-rank sum is the identity, so the weights must equal an eager single-rank run whose SGD
+    kernel applies the same 1/2 factor -- bit for bit, eager and replayed."""
+    from oracle import weights as ow
+    from self_supervised import training
+    from self_supervised.models import PeraNet
+    dev = torch.device("cuda", 0)
+    sd = ow.seeded_state_dict(3)
+    x = ow.synthetic_images(4, 64, seed=71).to(dev)
+    y = ow.synthetic_labels(4, seed=81).to(dev)
+    m = PeraNet(); m.load_state_dict(sd); m.to(dev).train(); m.unfreeze()
+    dp = training.DataParallelStep(m, lr=0.03, world_size=2)
+    m1 = PeraNet(); m1.load_state_dict(sd); m1.to(dev).train(); m1.unfreeze()
+    s1 = training.DataParallelStep(m1, lr=0.03, world_size=1, graph=False)
+    s1.opt.grad_scale = 0.5
+    losses = []
+    for i in range(5):                                   # step 1 eager, step 2 captures, 3-5 replay
+        a = dp.step(x, y); b = s1.step(x, y)
+        losses.append((float(a[0]), float(b[0])))
+        if i == 0:
+            res["buckets"] = len(dp.bucketer.launched)
+            res["eager_max_abs"] = (dp.eng.arena.p - s1.eng.arena.p).abs().max().item()
+    torch.cuda.synchronize()
+    plan = next(iter(dp._plans.values())) if dp._plans else None
+    res["graph_segments"] = sum(1 for o in plan["ops"] if o[0] == "graph") if plan else 0
+    res["graph_allreduces"] = sum(1 for o in plan["ops"] if o[0] == "allreduce") if plan else 0
+    res["replay_max_abs"] = (dp.eng.arena.p - s1.eng.arena.p).abs().max().item()
+    res["momentum_max_abs"] = (dp.eng.arena.m - s1.eng.arena.m).abs().max().item()
+    res["losses_equal"] = all(a == b for a, b in losses)
+    res["finite"] = bool(torch.isfinite(dp.eng.arena.p).all().item())
+    res["backend"] = dist.get_backend()
+
+
 def case_fit(res, tmp):
     """tools.training on two ranks: identical parameters on both ranks at the end, one loadable checkpoint."""
     from fake_mvtec import make_tree
@@ -105,10 +140,15 @@ def main():
     case, tmp = sys.argv[1], sys.argv[2]
     os.environ.setdefault("SSAD_ALLOW_RANDOM_BACKBONE", "1")
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo")
+    if case == "rccl1":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo")
     res = {}
     if case == "step":
         case_step(res)
+    elif case == "rccl1":
+        case_rccl1(res)
     else:
         case_fit(res, tmp)
     if dist.get_rank() == 0:

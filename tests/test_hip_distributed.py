@@ -42,3 +42,13 @@ def test_two_rank_tools_training(tmp_path):
     r = _run("fit", tmp_path)
     assert r["fit_params_equal"] and r["fit_bank_equal"], r
     assert r["ckpt_exists"] and r["ckpt_loads"] and r["hist_ok"], r
+
+
+def test_graph_segments_with_rccl_allreduces_one_rank(tmp_path):
+    """hipGraph segments interleaved with real RCCL all-reduces (a one-rank communicator: the gloo cases above cover two
+    ranks but not ProcessGroupNCCL's streams and events)."""
+    r = _run("rccl1", tmp_path, nproc=1)
+    assert r["backend"] == "nccl", r
+    assert r["buckets"] >= 2 and r["graph_segments"] >= 3 and r["graph_allreduces"] == r["buckets"], r
+    assert r["eager_max_abs"] == 0.0 and r["replay_max_abs"] == 0.0 and r["momentum_max_abs"] == 0.0, r
+    assert r["losses_equal"] and r["finite"], r

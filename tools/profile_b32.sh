@@ -1,0 +1,3 @@
+# batch-32 training step: kernel-trace statistics (the launch-bound case of VERDICT r2 item 1)
+R=$PWD; OUT=$R/gpurun_out; cd /tmp; export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_b32 -o s -- python3 $R/bench.py --batch 32 --scaling weak --phase train --no-cpu-baseline --no-e2e --no-partition-extra --steps 30 --warmup 5 > $OUT/r03_batch32_bench_line_under_rocprof.json 2>/tmp/p_b32.err && cp $(find /tmp/p_b32 -name "*kernel_stats.csv" | head -1) $OUT/r03_batch32_kernel_stats.csv
