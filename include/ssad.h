@@ -143,6 +143,13 @@ int ssad_conv_igemm_fwd_x6(const float* in, const float* w_ohwi, float* out, con
                            int stride, int pad, int hwnc, void* stream);
 int ssad_conv_igemm_dgrad_x6(const float* dy, const float* w_flipT, float* dx, const float* residual, int64_t N, int Hy,
                              int Wy, int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride, int pad, void* stream);
+/* Linear layers over a training batch's few rows (the projection head and classifier, models.py:65-99, :247-252): 1 x 1 layers on
+ * 1 x 1 maps with N <= ssad_linear_small_max_rows() rows are served by a dedicated kernel (contraction dealt over the waves of a
+ * 32 x 32 output tile) inside ssad_conv_igemm_fwd / _fwd_stats / _dgrad -- those then accept any Cin (Cout for dgrad) % 4 == 0 --
+ * and their weight gradient by ssad_linear_wgrad_small: dw[Cout][Cin] (+)= dy[M][Cout]^T x[M][Cin], one launch, no slab.
+ * SSAD_LINEAR_SMALL=0 in the environment switches the range off (max_rows 0). */
+int ssad_linear_small_max_rows(void);
+int ssad_linear_wgrad_small(const float* dy, const float* x, float* dw, int64_t M, int Cin, int Cout, int accumulate, void* stream);
 /* Replaces autograd's conv2d/linear weight-gradient.  Two launches: partial tiles per pixel split into
  * slab[splits][Cout][KH*KW*Cin], then a fixed-order sum written as OIHW (to_oihw=1, checkpoint layout) or OHWI. */
 int ssad_wgrad_splits(int64_t M, int Cin, int Cout, int KH, int KW);

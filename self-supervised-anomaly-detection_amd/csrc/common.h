@@ -46,6 +46,12 @@ void ssad_set_error(const char* fmt, ...);
 int ssad_bn_finalize_partials(const double* partial, int nblk, int64_t R, int C, float eps, float momentum, float* mean,
                               float* invstd, float* running_mean, float* running_var, void* stream);
 
+// linear_small.hip: linear layers over few rows (training batches of the projection head); conv_igemm.hip's entry points route
+// 1 x 1 layers on 1 x 1 maps there when ssad_linear_small_ok says so
+bool ssad_linear_small_ok(const void* a, const void* b, int64_t M, int K);
+int ssad_linear_small_launch(const float* a, const float* b, float* y, const float* scale, const float* shift,
+                             const float* residual, int relu, int M, int K, int N, double* stats, int* stat_rows, void* stream);
+
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // v_mfma_f32_32x32x2_f32: lane l feeds A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];

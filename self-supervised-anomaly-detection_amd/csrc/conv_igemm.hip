@@ -971,6 +971,9 @@ int conv_fwd_impl(const float* in, const float* w_ohwi, float* out, const float*
                   int pad, int hwnc, void* stream, int bf16 = 0, double* stats = nullptr, int* stat_rows = nullptr) {
     SSAD_CHECK_ARG(in && w_ohwi && out, "null pointer");
     SSAD_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "empty shape");
+    if (!bf16 && !hwnc && KH == 1 && KW == 1 && H == 1 && W == 1 && stride == 1 && pad == 0 &&
+        ssad_linear_small_ok(in, w_ohwi, N, Cin))          // a linear layer over a training batch's few rows
+        return ssad_linear_small_launch(in, w_ohwi, out, scale, shift, residual, relu, (int)N, Cin, Cout, stats, stat_rows, stream);
     SSAD_CHECK_ARG(Cin % KALIGN == 0, "Cin must be a multiple of 32");
     SSAD_CHECK_ARG(KH > 0 && KW > 0 && stride > 0 && pad >= 0 && KH * KW <= 32, "bad filter geometry (<= 32 taps)");
     ConvParams p;
@@ -1052,7 +1055,7 @@ extern "C" int ssad_conv_igemm_fwd(const float* in, const float* w_ohwi, float* 
 // double-precision column sums of its tile in `workspace` (ssad_conv_stats_workspace doubles) and the finalize kernel of
 // ssad_bn_stats turns them into mean / invstd / running statistics.  Saves the separate read of z.
 extern "C" int64_t ssad_conv_stats_workspace(int64_t N, int Ho, int Wo, int Cout) {
-    return cdiv64(N * Ho * Wo, 64) * 2 * Cout;           // 64 = the smallest row tile any instantiation uses
+    return cdiv64(N * Ho * Wo, 32) * 2 * Cout;           // 32 = the smallest row tile any kernel uses (linear_small.hip)
 }
 
 extern "C" int ssad_conv_igemm_fwd_stats(const float* in, const float* w_ohwi, float* out, int64_t N, int H, int W, int Cin,
@@ -1087,6 +1090,9 @@ static int dgrad_impl(const float* dy, const float* w_flipT, float* dx, const fl
                                      int pad, void* stream, int bf16, const uint8_t* res_mask = nullptr) {
     SSAD_CHECK_ARG(dy && w_flipT && dx, "null pointer");
     SSAD_CHECK_ARG(N > 0 && Hy > 0 && Wy > 0 && Hx > 0 && Wx > 0 && Cin > 0 && Cout > 0, "empty shape");
+    if (!bf16 && !res_mask && KH == 1 && KW == 1 && Hy == 1 && Wy == 1 && Hx == 1 && Wx == 1 && stride == 1 && pad == 0 &&
+        ssad_linear_small_ok(dy, w_flipT, N, Cout))        // dx[M][Cin] = dy[M][Cout] . w_flipT[Cin][Cout]^T
+        return ssad_linear_small_launch(dy, w_flipT, dx, nullptr, nullptr, residual, 0, (int)N, Cout, Cin, nullptr, nullptr, stream);
     SSAD_CHECK_ARG(Cout % KALIGN == 0, "Cout (the contraction) must be a multiple of 32");
     SSAD_CHECK_ARG(KH > 0 && KW > 0 && pad >= 0 && pad < KH && pad < KW, "bad filter geometry");
     SSAD_CHECK_ARG(stride == 1 || stride == 2, "stride 1 or 2");

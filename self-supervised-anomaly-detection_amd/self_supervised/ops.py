@@ -381,6 +381,12 @@ def conv_wgrad(dy, x, dw_out, kh, kw, stride, pad, kreal=None, to_oihw=False, ac
     lib = _hip.lib()
     if bf16 == 6 and not force_x6:
         bf16 = False            # (see below)
+    if (not bf16 and kreal is None and kh == 1 and kw == 1 and h == 1 and w == 1 and m <= lib.ssad_linear_small_max_rows()):
+        # linear layer over a training batch's rows: one launch straight into the gradient (OIHW == OHWI for 1 x 1)
+        _run("wgrad_f32", 2.0 * m * cout * cin, 4.0 * (dy.numel() + x.numel() + cout * cin),
+             lambda: lib.ssad_linear_wgrad_small(_hip.ptr(dy), _hip.ptr(x), _hip.ptr(dw_out), m, cin, cout, int(accumulate),
+                                                 _hip.stream()))
+        return dw_out
     if (not bf16 and kreal is None and x.shape[:3] == dy.shape[:3] and os.environ.get("SSAD_WGRAD_HALO", "1") != "0"
             and lib.ssad_wgrad3x3_halo_ok(cin, cout, kh, kw, stride, pad)):
         # 3x3 / stride 1 / pad 1 on the exact fp32 path: halo-tile kernel (one workgroup = a 64 x 64 block, all nine taps)

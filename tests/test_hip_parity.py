@@ -264,10 +264,12 @@ def test_upsample_tiled_equals_single_workgroup(dev):
         assert (got - want).abs().max().item() < 2e-6, (h, w, target, (got - want).abs().max().item())
 
 
-@pytest.mark.parametrize("case", [(1000, 512, 588, 3), (129, 256, 70, 3), (128, 64, 128, 2), (5, 1024, 3, 1), (70000, 512, 300, 3)])
+@pytest.mark.parametrize("case", [(1000, 512, 588, 3), (641, 256, 70, 3), (640, 64, 128, 2), (517, 1024, 3, 1), (70000, 512, 300, 3),
+                                  (129, 256, 70, 3), (128, 64, 128, 2), (5, 1024, 3, 1)])
 def test_knn_fused_equals_the_three_kernel_chain(dev, case):
     """csrc/knn.hip (normalise + similarity GEMM + k smallest in one kernel) == l2norm_rows -> igemm -> knn_mean bit for bit, on
-    ragged row / column tiles, and within 1e-6 of the numpy statement of sklearn's brute-force cosine k-NN."""
+    ragged row / column tiles, and within 1e-6 of the numpy statement of sklearn's brute-force cosine k-NN.  (Up to 512 query rows
+    the chain's similarity product runs on csrc/linear_small.hip, whose contraction order differs: 1e-6 there.)"""
     from self_supervised import ops
     from oracle import scoring as osc
     n, d, r, k = case
@@ -276,7 +278,10 @@ def test_knn_fused_equals_the_three_kernel_chain(dev, case):
     bn = ops.l2_normalize_rows(bank.to(dev))
     chain = ops.cosine_knn_mean(ops.linear_fwd(ops.l2_normalize_rows(x.to(dev)), bn), k)
     fused = ops.cosine_knn_fused(x.to(dev), bn, k)
-    assert torch.equal(fused, chain)
+    if n > 512:
+        assert torch.equal(fused, chain)
+    else:
+        assert (fused - chain).abs().max().item() < 1e-6
     if n <= 2000:
         want, _, _ = osc.cosine_knn_mean(bank.numpy(), x.numpy(), k)
         assert np.abs(fused.cpu().numpy() - want).max() < 1e-6

@@ -54,6 +54,51 @@ def test_wgrad_dgrad_kernels(dev):
         assert torch.equal(dw2.view(cout, cin, k, k), dw.view(cout, k, k, cin).permute(0, 3, 1, 2))
 
 
+@pytest.mark.parametrize("m", [1, 5, 32, 33, 256, 512])
+def test_linear_small_kernels(dev, m):
+    """Linear layers over a training batch's rows (csrc/linear_small.hip): forward with the fused epilogue, forward + train-mode
+    BatchNorm1d statistics, input gradient (any contraction that is a multiple of 4: the 4-class classifier) and weight gradient,
+    against float64 torch; ragged row and column tiles; the same layer one row above the range (implicit-GEMM kernel) agrees."""
+    from self_supervised import _hip, ops
+    assert _hip.lib().ssad_linear_small_max_rows() == 512
+    for (k, n) in [(512, 512), (896, 512), (512, 4), (512, 70), (36, 44)]:
+        g = torch.Generator().manual_seed(m * 131 + k + n)
+        x = torch.randn(m, k, generator=g, dtype=torch.float64)
+        wt = torch.randn(n, k, generator=g, dtype=torch.float64) / k ** 0.5
+        sc, sh = torch.rand(n, generator=g, dtype=torch.float64) + 0.5, torch.randn(n, generator=g, dtype=torch.float64)
+        r = torch.randn(m, n, generator=g, dtype=torch.float64)
+        z = x @ wt.T
+        xd, wd = x.float().view(m, 1, 1, k).to(dev), wt.float().view(n, 1, 1, k).to(dev)
+        got = ops.conv_fwd(xd, wd, sc.float().to(dev), sh.float().to(dev), r.float().view(m, 1, 1, n).to(dev), True, 1, 0)
+        assert rel_err(got.view(m, n), (z * sc + sh + r).relu()) < 2e-6
+        got = ops.conv_fwd(xd, wd, None, sh.float().to(dev), None, False, 1, 0)          # bias only (the classifier)
+        assert rel_err(got.view(m, n), z + sh) < 2e-6
+        if n % 4 == 0 and m > 1:
+            rm, rv = torch.zeros(n, device=dev), torch.ones(n, device=dev)
+            zz, mean, invstd = ops.conv_fwd_stats(xd, wd, 1e-5, 0.1, rm, rv, 1, 0)
+            zf = zz.view(m, n).double().cpu()
+            assert rel_err(zz.view(m, n), z) < 2e-6
+            assert rel_err(mean, zf.mean(0)) < 1e-6 and rel_err(invstd, (zf.var(0, unbiased=False) + 1e-5).rsqrt()) < 1e-5
+            assert rel_err(rm, 0.1 * zf.mean(0)) < 1e-6 and rel_err(rv, 0.9 + 0.1 * zf.var(0, unbiased=True)) < 1e-5
+        # input gradient: dx[m][k] = dz[m][n] . w[n][k]; the contraction is n (4, 44, 70 are not multiples of 32)
+        dz = torch.randn(m, n, generator=g, dtype=torch.float64)
+        if n % 4 == 0:
+            wf = ops.flip_transpose_weight(wd)
+            dx = ops.conv_dgrad(dz.float().view(m, 1, 1, n).to(dev), wf, (m, 1, 1, k), 1, 0, residual=xd)
+            assert rel_err(dx.view(m, k), dz @ wt + x) < 2e-6
+        dw = torch.full((n * k,), 0.5, device=dev)
+        ops.conv_wgrad(dz.float().view(m, 1, 1, n).to(dev), xd, dw, 1, 1, 1, 0, accumulate=True)
+        assert rel_err(dw.view(n, k), dz.T @ x + 0.5) < 2e-6
+        ops.conv_wgrad(dz.float().view(m, 1, 1, n).to(dev), xd, dw, 1, 1, 1, 0)
+        assert rel_err(dw.view(n, k), dz.T @ x) < 2e-6
+    if m == 512:        # one row more: the implicit-GEMM kernel takes over; both are fp32 contractions of the same numbers
+        g = torch.Generator().manual_seed(5)
+        x, wt = torch.randn(513, 512, generator=g), torch.randn(512, 512, generator=g) / 512 ** 0.5
+        big = ops.conv_fwd(x.view(513, 1, 1, 512).to(dev), wt.view(512, 1, 1, 512).to(dev), None, None, None, False, 1, 0)
+        small = ops.conv_fwd(x[:512].view(512, 1, 1, 512).to(dev), wt.view(512, 1, 1, 512).to(dev), None, None, None, False, 1, 0)
+        assert rel_err(small.view(512, 512), big.view(513, 512)[:512]) < 2e-6
+
+
 def test_bn_pool_kernels(dev):
     from self_supervised import ops
     g = torch.Generator().manual_seed(1)

@@ -41,9 +41,11 @@ def test_x3_kernels_against_fp64(case):
 
 
 @pytest.mark.parametrize("case", [(3, 9, 9, 64, 64, 3, 1, 1), (2, 9, 9, 64, 128, 3, 2, 1), (5, 4, 4, 256, 512, 3, 1, 1),
-                                  (300, 1, 1, 896, 512, 1, 1, 0), (130, 2, 2, 512, 512, 3, 1, 1)])
+                                  (600, 1, 1, 896, 512, 1, 1, 0), (130, 2, 2, 512, 512, 3, 1, 1)])
 def test_x6_kernels_are_fp32_faithful(case):
-    """Three-way split, six products: as close to fp64 as the exact fp32 MFMA kernel (which sits at ~1e-6)."""
+    """Three-way split, six products: as close to fp64 as the exact fp32 MFMA kernel (which sits at ~1e-6).  (The linear case has
+    600 rows so that both sides are the implicit-GEMM kernel: up to 512 rows exact fp32 runs on csrc/linear_small.hip, whose
+    four-way split of the contraction rounds less.)"""
     from self_supervised import ops
     n, h, w, cin, cout, k, s, p = case
     g = torch.Generator().manual_seed(n * 13 + k)

@@ -1,0 +1,24 @@
+# per-dispatch kernel trace of the batch-32 training step (last replayed step -> gpurun_out/r03_b32_trace_last_step.csv)
+R=$PWD; OUT=$R/gpurun_out; cd /tmp; export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/t_b32 -o s -- python3 $R/bench.py --batch 32 --scaling weak --phase train --no-cpu-baseline --no-e2e --no-partition-extra --steps 6 --warmup 3 > $OUT/r03_b32_trace_line.json 2>/tmp/t_b32.err && python3 - <<'PY'
+import csv, glob, os
+f = glob.glob('/tmp/t_b32/**/*kernel_trace.csv', recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+# a step starts at each stem_conv7x7 launch
+idx = [i for i, r in enumerate(rows) if 'stem_conv7x7' in r['Kernel_Name']]
+spans = [(int(rows[idx[k+1]]['Start_Timestamp']) - int(rows[idx[k]]['Start_Timestamp']), k) for k in range(len(idx) - 1)]
+print('step spans (us):', [round(a / 1e3) for a, _ in spans])
+k = min(spans)[1]            # a replayed step (eager steps are the long ones)
+lo, hi = idx[k], idx[k + 1]
+out = os.environ.get('GRAFT_REPO_ROOT', '/root/repo') + '/gpurun_out/r03_b32_trace_last_step.csv'
+with open(out, 'w') as o:
+    o.write('kernel,grid,wg,start_us,dur_us,gap_before_us\n')
+    t0 = int(rows[lo]['Start_Timestamp']); prev_end = t0
+    for r in rows[lo:hi]:
+        s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+        name = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '')
+        name = name.split('(')[0][:70]
+        o.write(f"{name},{r['Grid_Size_X']}x{r['Grid_Size_Y']}x{r['Grid_Size_Z']},{r['Workgroup_Size_X']},{(s-t0)/1e3:.1f},{(e-s)/1e3:.1f},{(s-prev_end)/1e3:.1f}\n")
+        prev_end = e
+PY
