@@ -250,7 +250,7 @@ class GpuCutPaste:
         """Device half: every per-pixel operation of the batch (csrc/augment.hip) from the records."""
         b, (h, w) = len(idx), hw
         _, H, W, _ = self.images.shape
-        params = torch.from_numpy(recs.view(np.uint8).reshape(b, -1)).to(self.device)
+        params = torch.from_numpy(np.array(recs.view(np.uint8).reshape(b, -1))).to(self.device)   # records from a worker are read-only
         batch = self.images[torch.from_numpy(idx).to(self.device)].contiguous()
         work = torch.empty((b, h, w, 3), dtype=torch.uint8, device=self.device)
         gmean = torch.empty(b, dtype=torch.float32, device=self.device)
