@@ -196,10 +196,13 @@ int ssad_conv3x3_c64_eval(const float* in, const float* w_ohwi, float* out, cons
 /* Weight gradient of the 3x3 / stride 1 / pad 1 convolutions (Cin, Cout multiples of 64) as a halo-tile kernel: a workgroup
  * owns a 64 x 64 (co, ci) block for all nine taps and walks over pixel tiles (csrc/wgrad_halo.hip).  Same contract as
  * ssad_conv_wgrad: slab[splits][Cout][9 * Cin] with splits = ssad_wgrad3x3_halo_splits(...), then ssad_wgrad_reduce. */
-int ssad_wgrad3x3_halo_ok(int Cin, int Cout, int KH, int KW, int stride, int pad);
-int ssad_wgrad3x3_halo_splits(int64_t N, int H, int W, int Cin, int Cout);
+int ssad_wgrad3x3_halo_ok(int Cin, int Cout, int KH, int KW, int stride, int pad);   /* 0 no, 1 stride-1 form, 2 stride-2 form */
+int ssad_wgrad3x3_halo_splits(int64_t N, int H, int W, int Cin, int Cout);            /* H, W: size of dz (the conv's OUTPUT) */
 int ssad_conv_wgrad3x3_halo(const float* dz, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin, int Cout,
                             void* stream);
+/* 3x3 / stride 2 / pad 1 (the first convolution of layer2-4): dz [N][Ho][Wo][Cout], x [N][H][W][Cin], Ho = (H - 1) / 2 + 1. */
+int ssad_conv_wgrad3x3s2_halo(const float* dz, const float* x, float* slab, int splits, int64_t N, int Ho, int Wo, int H, int W,
+                              int Cin, int Cout, void* stream);
 /* fp16-operand forms: the reference trains under fp16 autocast (pl.Trainer(precision=16), src/self_supervised/tools.py:263,
  * :296), i.e. its Conv2d / Linear products take fp16 operands and accumulate in fp32.  Same contract as the _bf16 forms
  * with v_mfma_f32_32x32x16_f16 (11-bit significands); the slab of ssad_conv_wgrad_f16 is sized by ssad_wgrad_splits_bf16. */

@@ -31,16 +31,20 @@ namespace {
 
 struct WgHaloParams {
     const float* dz;     // [N][H][W][Cout]
-    const float* x;      // [N][H][W][Cin]
+    const float* x;      // [N][Hx][Wx][Cin]   (Hx, Wx) = (H, W) for stride 1, the stride-2 conv's input size otherwise
     float* slab;         // [splits][Cout][9 * Cin]
-    int N, H, W, Cin, Cout;
+    int N, H, W, Cin, Cout, Hx, Wx;
     int tiles_y, tiles_x, ci_tiles, npairs, splits;
     int64_t ntiles, chunk;
 };
 
-template <int TH, int TW>
-__global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(WgHaloParams p) {
-    constexpr int P = TH * TW, HWp = TW + 2, NH = (TH + 2) * HWp;
+// S = 2 (round 3): the three stride-2 3x3 convolutions.  The tile is still 64 OUTPUT pixels; its X halo is the (2 TH + 1) x
+// (2 TW + 1) input window those pixels touch (297 / 289 positions instead of 108 / 100: 92 KB of LDS, one workgroup per CU),
+// and pixel (py, px)'s tap (ky, kx) sits at halo position (2 py + ky, 2 px + kx).  X is read ~1.2x and dZ once, where the
+// split-over-pixels kernel read them once per tap.
+template <int TH, int TW, int S = 1>
+__global__ __launch_bounds__(256, (S == 1 || TH * TW <= 32) ? 2 : 1) void wgrad3x3_halo_kernel(WgHaloParams p) {
+    constexpr int P = TH * TW, HWp = S * (TW - 1) + 3, NH = (S * (TH - 1) + 3) * HWp;
     constexpr int NDZ = P / 16;                 // 16-byte pieces of the dZ tile per thread
     constexpr int NX = (NH + 15) / 16;          // ... of the X halo
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(WgHaloParams p) {
         y0n = ty * TH;
         x0n = tx * TW;
         dzn = p.dz + (int64_t)n * p.H * p.W * p.Cout + co0;
-        xn = p.x + (int64_t)n * p.H * p.W * p.Cin + ci0;
+        xn = p.x + (int64_t)n * p.Hx * p.Wx * p.Cin + ci0;
     };
     auto load_piece = [&](int g) {              // g is a compile-time constant wherever this is called
         if (g < NDZ) {
@@ -91,10 +95,10 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(WgHaloParams p) {
             const int q = g - NDZ;
             const int hp = q * 16 + p0;
             const int hy = hp / HWp, hx = hp - hy * HWp;
-            const int y = y0n - 1 + hy, x = x0n - 1 + hx;
+            const int y = S * y0n - 1 + hy, x = S * x0n - 1 + hx;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (hp < NH && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
-                v = *(const f32x4*)(xn + (unsigned)((y * p.W + x) * p.Cin + c4 * 4));
+            if (hp < NH && (unsigned)y < (unsigned)p.Hx && (unsigned)x < (unsigned)p.Wx)
+                v = *(const f32x4*)(xn + (unsigned)((y * p.Wx + x) * p.Cin + c4 * 4));
             xv[q] = v;
         }
     };
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(WgHaloParams p) {
 
         // lane (r, h): k slot h = pixel (py, 2 pp + h); A = dZ[pixel][co0 + 32 cb + r], B_tap = X[pixel + tap][ci0 + 32 ib + r]
         const float* ap = dzt + h * 64 + cb * 32 + r;
-        const float* bp = halo + h * 64 + ib * 32 + r;
+        const float* bp = halo + h * S * 64 + ib * 32 + r;
         // fragments of group g + 1 are requested before the MFMAs of group g (LDS latency in the shadow as well)
         constexpr int NG = TH * (TW / 2);
         float a[2], b[2][9];
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(WgHaloParams p) {
             const int py = g / (TW / 2), pp = g % (TW / 2);
             a[slot] = ap[(py * TW + 2 * pp) * 64];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) b[slot][t] = bp[((py + t / 3) * HWp + 2 * pp + t % 3) * 64];
+            for (int t = 0; t < 9; ++t) b[slot][t] = bp[((S * py + t / 3) * HWp + S * 2 * pp + t % 3) * 64];
         };
         read_group(0, 0);
 #pragma unroll
@@ -142,6 +146,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(WgHaloParams p) {
 #pragma unroll
             for (int t = 0; t < 9; ++t) acc[t] = mfma32(a[g & 1], b[g & 1][t], acc[t]);
             if (!(WGH_ABL & 1)) load_piece(g);       // one piece of the next tile in this group's shadow
+            static_assert(NDZ + NX <= NG, "more staged pieces than MFMA groups to hide them in");
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -179,7 +184,9 @@ static int halo_splits(int64_t ntiles, int npairs) {
 
 // 1 when ssad_conv_wgrad3x3_halo handles the layer.
 extern "C" int ssad_wgrad3x3_halo_ok(int Cin, int Cout, int KH, int KW, int stride, int pad) {
-    return KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin % 64 == 0 && Cout % 64 == 0;
+    static const int s2 = getenv("SSAD_WGRAD_HALO_S2") ? atoi(getenv("SSAD_WGRAD_HALO_S2")) : 1;
+    if (!(KH == 3 && KW == 3 && pad == 1 && Cin % 64 == 0 && Cout % 64 == 0)) return 0;
+    return stride == 1 ? 1 : (stride == 2 && s2) ? 2 : 0;
 }
 
 extern "C" int ssad_wgrad3x3_halo_splits(int64_t N, int H, int W, int Cin, int Cout) {
@@ -188,30 +195,61 @@ extern "C" int ssad_wgrad3x3_halo_splits(int64_t N, int H, int W, int Cin, int C
     return halo_splits(ntiles, (Cin / 64) * (Cout / 64));
 }
 
-// dz NHWC [N][H][W][Cout], x NHWC [N][H][W][Cin] (3x3, stride 1, pad 1) -> slab[splits][Cout][9 * Cin] with splits =
-// ssad_wgrad3x3_halo_splits(...); follow with ssad_wgrad_reduce(slab, dw, splits, Cout, 9 * Cin, 3, 3, Cin, ...).
-extern "C" int ssad_conv_wgrad3x3_halo(const float* dz, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin,
-                                       int Cout, void* stream) {
+static int halo_launch(const float* dz, const float* x, float* slab, int splits, int64_t N, int H, int W, int Hx, int Wx, int Cin,
+                       int Cout, int S, void* stream) {
     SSAD_CHECK_ARG(dz && x && slab && N > 0 && H > 0 && W > 0, "bad argument");
     SSAD_CHECK_ARG(Cin % 64 == 0 && Cout % 64 == 0, "channel counts must be multiples of 64");
-    const int TW = W > 8 ? 16 : 8, TH = W > 8 ? 4 : 8;     // 64-pixel tiles: 144 accumulator + 44 staging registers fit
+    SSAD_CHECK_ARG(N * (int64_t)Hx * Wx * Cin < (int64_t)1 << 32 && N * (int64_t)H * W * Cout < (int64_t)1 << 32,
+                   "per-image offsets are 32-bit");
+    static const int s2_tile = getenv("SSAD_WGRAD_HALO_S2_TILE") ? atoi(getenv("SSAD_WGRAD_HALO_S2_TILE")) : 32;
+    const bool half = S == 2 && s2_tile == 32;             // stride 2: 4 x 8 output pixels, so that two workgroups fit a CU
+    const int TW = half ? 8 : W > 8 ? 16 : 8, TH = half ? 4 : W > 8 ? 4 : 8;     // 64-pixel tiles: 144 accumulator + 44 staging registers fit
     WgHaloParams p;
-    p.dz = dz; p.x = x; p.slab = slab; p.N = (int)N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    p.dz = dz; p.x = x; p.slab = slab; p.N = (int)N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.Hx = Hx; p.Wx = Wx;
     p.tiles_y = (H + TH - 1) / TH; p.tiles_x = (W + TW - 1) / TW;
     p.ci_tiles = Cin / 64; p.npairs = (Cin / 64) * (Cout / 64);
     p.ntiles = N * p.tiles_y * p.tiles_x;
-    SSAD_CHECK_ARG(splits >= 1 && splits == halo_splits(p.ntiles, p.npairs), "splits must come from ssad_wgrad3x3_halo_splits");
+    SSAD_CHECK_ARG(splits >= 1 && splits == halo_splits(N * ((H + (W > 8 ? 4 : 8) - 1) / (W > 8 ? 4 : 8)) * ((W + (W > 8 ? 16 : 8) - 1) / (W > 8 ? 16 : 8)), p.npairs),
+                   "splits must come from ssad_wgrad3x3_halo_splits");
     p.splits = splits;
     p.chunk = (p.ntiles + splits - 1) / splits;
     const unsigned grid = (unsigned)(p.npairs * splits);
     hipStream_t st = (hipStream_t)stream;
-    if (TW == 16) {
+    if (S == 1 && TW == 16) {
         constexpr int bytes = (4 * 16 + 6 * 18) * 64 * 4;
         hipLaunchKernelGGL((wgrad3x3_halo_kernel<4, 16>), dim3(grid), dim3(256), bytes, st, p);
-    } else {
+    } else if (S == 1) {
         constexpr int bytes = (8 * 8 + 10 * 10) * 64 * 4;
         hipLaunchKernelGGL((wgrad3x3_halo_kernel<8, 8>), dim3(grid), dim3(256), bytes, st, p);
+    } else if (half) {
+        constexpr int bytes = (4 * 8 + 9 * 17) * 64 * 4;
+        hipLaunchKernelGGL((wgrad3x3_halo_kernel<4, 8, 2>), dim3(grid), dim3(256), bytes, st, p);
+    } else if (TW == 16) {
+        constexpr int bytes = (4 * 16 + 9 * 33) * 64 * 4;
+        static bool set = false;
+        if (!set) { SSAD_SET_DYN_LDS((wgrad3x3_halo_kernel<4, 16, 2>), bytes); set = true; }
+        hipLaunchKernelGGL((wgrad3x3_halo_kernel<4, 16, 2>), dim3(grid), dim3(256), bytes, st, p);
+    } else {
+        constexpr int bytes = (8 * 8 + 17 * 17) * 64 * 4;
+        static bool set = false;
+        if (!set) { SSAD_SET_DYN_LDS((wgrad3x3_halo_kernel<8, 8, 2>), bytes); set = true; }
+        hipLaunchKernelGGL((wgrad3x3_halo_kernel<8, 8, 2>), dim3(grid), dim3(256), bytes, st, p);
     }
     SSAD_CHECK_LAUNCH();
     return 0;
+}
+
+// dz NHWC [N][H][W][Cout], x NHWC [N][H][W][Cin] (3x3, stride 1, pad 1) -> slab[splits][Cout][9 * Cin] with splits =
+// ssad_wgrad3x3_halo_splits(...); follow with ssad_wgrad_reduce(slab, dw, splits, Cout, 9 * Cin, 3, 3, Cin, ...).
+extern "C" int ssad_conv_wgrad3x3_halo(const float* dz, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin,
+                                       int Cout, void* stream) {
+    return halo_launch(dz, x, slab, splits, N, H, W, H, W, Cin, Cout, 1, stream);
+}
+
+// The stride-2 form (ssad_wgrad3x3_halo_ok() == 2): dz NHWC [N][Ho][Wo][Cout] with Ho = (H - 1) / 2 + 1, x NHWC [N][H][W][Cin];
+// splits = ssad_wgrad3x3_halo_splits(N, Ho, Wo, Cin, Cout).
+extern "C" int ssad_conv_wgrad3x3s2_halo(const float* dz, const float* x, float* slab, int splits, int64_t N, int Ho, int Wo, int H,
+                                         int W, int Cin, int Cout, void* stream) {
+    SSAD_CHECK_ARG(Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1, "dz / x sizes disagree for stride 2, pad 1");
+    return halo_launch(dz, x, slab, splits, N, Ho, Wo, H, W, Cin, Cout, 2, stream);
 }

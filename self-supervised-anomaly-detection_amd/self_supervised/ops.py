@@ -387,14 +387,21 @@ def conv_wgrad(dy, x, dw_out, kh, kw, stride, pad, kreal=None, to_oihw=False, ac
              lambda: lib.ssad_linear_wgrad_small(_hip.ptr(dy), _hip.ptr(x), _hip.ptr(dw_out), m, cin, cout, int(accumulate),
                                                  _hip.stream()))
         return dw_out
-    if (not bf16 and kreal is None and x.shape[:3] == dy.shape[:3] and os.environ.get("SSAD_WGRAD_HALO", "1") != "0"
-            and lib.ssad_wgrad3x3_halo_ok(cin, cout, kh, kw, stride, pad)):
-        # 3x3 / stride 1 / pad 1 on the exact fp32 path: halo-tile kernel (one workgroup = a 64 x 64 block, all nine taps)
-        splits = lib.ssad_wgrad3x3_halo_splits(n, h, w, cin, cout)
+    halo = (lib.ssad_wgrad3x3_halo_ok(cin, cout, kh, kw, stride, pad)
+            if not bf16 and kreal is None and os.environ.get("SSAD_WGRAD_HALO", "1") != "0" else 0)
+    if halo:
+        # 3x3 / pad 1 on the exact fp32 path: halo-tile kernel (one workgroup = a 64 x 64 block, all nine taps); stride 1 or 2
+        ho, wo = dy.shape[1], dy.shape[2]
+        assert (ho, wo) == ((h - 1) // stride + 1, (w - 1) // stride + 1)
+        splits = lib.ssad_wgrad3x3_halo_splits(n, ho, wo, cin, cout)
         slab = _new((splits, cout, 9 * cin), dy)
-        _run("wgrad_f32", 2.0 * m * cout * 9 * cin, 4.0 * (dy.numel() + x.numel() + slab.numel()),
-             lambda: lib.ssad_conv_wgrad3x3_halo(_hip.ptr(dy), _hip.ptr(x), _hip.ptr(slab), splits, n, h, w, cin, cout,
-                                                 _hip.stream()))
+        if halo == 1:
+            fn = lambda: lib.ssad_conv_wgrad3x3_halo(_hip.ptr(dy), _hip.ptr(x), _hip.ptr(slab), splits, n, h, w, cin, cout,
+                                                     _hip.stream())
+        else:
+            fn = lambda: lib.ssad_conv_wgrad3x3s2_halo(_hip.ptr(dy), _hip.ptr(x), _hip.ptr(slab), splits, n, ho, wo, h, w, cin,
+                                                       cout, _hip.stream())
+        _run("wgrad_f32", 2.0 * m * cout * 9 * cin, 4.0 * (dy.numel() + x.numel() + slab.numel()), fn)
         _run("wgrad_reduce", 0.0, 4.0 * slab.numel(),
              lambda: lib.ssad_wgrad_reduce(_hip.ptr(slab), _hip.ptr(dw_out), splits, cout, 9 * cin, 3, 3, cin, int(to_oihw),
                                            int(accumulate), _hip.stream()))

@@ -855,32 +855,37 @@ def test_conv3x3_c64_eval_form(dev, monkeypatch):
 
 
 def test_wgrad3x3_halo_kernel(dev, monkeypatch):
-    """Halo-tile weight gradient (3x3 / stride 1 / pad 1, channels multiples of 64) against autograd and against the
+    """Halo-tile weight gradient (3x3 / stride 1 or 2 / pad 1, channels multiples of 64) against autograd and against the
     split-over-pixels kernel it replaces: ragged tiles, maps narrower than a tile, several (co, ci) blocks, many splits."""
-    from self_supervised import ops
-    for (n, h, w, cin, cout) in [(3, 8, 8, 64, 64), (2, 12, 20, 64, 128), (5, 2, 2, 128, 256), (4, 16, 16, 128, 64),
-                                 (70, 9, 17, 64, 64), (16, 64, 64, 64, 64)]:
+    from self_supervised import _hip, ops
+    assert _hip.lib().ssad_wgrad3x3_halo_ok(64, 128, 3, 3, 2, 1) == 2 and _hip.lib().ssad_wgrad3x3_halo_ok(64, 128, 3, 3, 1, 1) == 1
+    # the last five: stride 2 (round 3) -- even and odd input sizes (the last output row / column then has no kx = 2 tap inside),
+    # maps narrower than a tile, both tile shapes (output wider than 8 or not)
+    for (n, h, w, cin, cout, s) in [(3, 8, 8, 64, 64, 1), (2, 12, 20, 64, 128, 1), (5, 2, 2, 128, 256, 1), (4, 16, 16, 128, 64, 1),
+                                    (70, 9, 17, 64, 64, 1), (16, 64, 64, 64, 64, 1),
+                                    (3, 16, 16, 64, 128, 2), (2, 9, 21, 64, 64, 2), (5, 4, 4, 128, 256, 2), (4, 64, 64, 64, 128, 2),
+                                    (33, 7, 40, 64, 64, 2)]:
         g = torch.Generator().manual_seed(n * 31 + h)
         x = torch.randn(n, cin, h, w, generator=g)
         wt = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).requires_grad_()
-        y = F.conv2d(x, wt, None, 1, 1)
+        y = F.conv2d(x, wt, None, s, 1)
         dy = torch.randn(y.shape, generator=g)
         y.backward(dy)
         nh = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().to(dev)
         dw = torch.empty(cout * 9 * cin, device=dev)
         monkeypatch.setenv("SSAD_WGRAD_HALO", "1")
-        ops.conv_wgrad(nh(dy), nh(x), dw, 3, 3, 1, 1)
-        assert rel_err(dw.view(cout, 3, 3, cin).permute(0, 3, 1, 2), wt.grad) < 2e-5, (n, h, w, cin, cout)
+        ops.conv_wgrad(nh(dy), nh(x), dw, 3, 3, s, 1)
+        assert rel_err(dw.view(cout, 3, 3, cin).permute(0, 3, 1, 2), wt.grad) < 2e-5, (n, h, w, cin, cout, s)
         dw2 = torch.empty_like(dw)
-        ops.conv_wgrad(nh(dy), nh(x), dw2, 3, 3, 1, 1)
+        ops.conv_wgrad(nh(dy), nh(x), dw2, 3, 3, s, 1)
         assert torch.equal(dw, dw2)                                   # deterministic
         monkeypatch.setenv("SSAD_WGRAD_HALO", "0")
         dw3 = torch.empty_like(dw)
-        ops.conv_wgrad(nh(dy), nh(x), dw3, 3, 3, 1, 1)
+        ops.conv_wgrad(nh(dy), nh(x), dw3, 3, 3, s, 1)
         assert rel_err(dw, dw3) < 2e-5
         dwo = torch.zeros(cout * 9 * cin, device=dev)
         monkeypatch.setenv("SSAD_WGRAD_HALO", "1")
-        ops.conv_wgrad(nh(dy), nh(x), dwo, 3, 3, 1, 1, to_oihw=True)
+        ops.conv_wgrad(nh(dy), nh(x), dwo, 3, 3, s, 1, to_oihw=True)
         assert torch.equal(dwo.view(cout, cin, 3, 3), dw.view(cout, 3, 3, cin).permute(0, 3, 1, 2))
 
 
