@@ -3,11 +3,11 @@
 //
 // Why a kernel of its own (round 3, profiles/r03_b32_trace.md): with M = 32 .. 256 rows the implicit-GEMM tiles leave a grid of
 // 8 - 16 workgroups that walk K = 512 .. 896 serially -- 22 us per 512 x 512 layer, 46 us for the 512 -> 4 classifier, 0.5 ms of a
-// 6 ms batch-32 step for 0.06 % of its FLOPs.  Here the output is cut into 32 x 32 tiles, one 256-thread workgroup each, and the
-// CONTRACTION is dealt over the four waves (8-float chunks, wave w takes chunks w, w+4, ...): every lane streams 16-byte pieces
-// of its own A row and B row straight into v_mfma_f32_32x32x2_f32 operands (no LDS staging: lane half h supplies
+// 6 ms batch-32 step for 0.06 % of its FLOPs.  Here the output is cut into 32 x 32 tiles, one workgroup each, and the CONTRACTION
+// is dealt over the workgroup's waves (eight for forward / dgrad: 8-float chunks, wave w takes chunks w, w+8, ...; four for
+// wgrad): every lane streams 16-byte pieces of its own A row and B row straight into v_mfma_f32_32x32x2_f32 operands (no LDS staging: lane half h supplies
 // k = 8c + 4h + e for the e-th MFMA of chunk c, the same permutation on both operands), eight chunks of loads in flight, and
-// the four partial tiles are added in wave order through LDS (a fixed order: the result does not depend on scheduling).
+// the partial tiles are added in wave order through LDS (a fixed order: the result does not depend on scheduling).
 //
 //   y[M][N] = a[M][K] . b[N][K]^T   (* scale[n] + shift[n]) (+ residual) (relu)        forward / input gradient
 //   dw[O][K] (+)= dz[M][O]^T . x[M][K]                                                   weight gradient
@@ -38,9 +38,11 @@ __device__ __forceinline__ void spill_tile(float* red, const f32x16& acc, int la
     for (int v = 0; v < 16; ++v) red[((v & 3) + 8 * (v >> 2) + 4 * h) * RP + j] = acc[v];
 }
 
-__global__ __launch_bounds__(256) void small_gemm_kernel(SmallGemm p) {
-    __shared__ float red[4][32 * RP];
-    __shared__ float cs[2][8][32];
+constexpr int GW = 8;         // waves of a forward / input-gradient workgroup: K = 512 is one batch of eight chunks per wave
+
+__global__ __launch_bounds__(64 * GW) void small_gemm_kernel(SmallGemm p) {
+    __shared__ float red[GW][32 * RP];
+    __shared__ float cs[2][2 * GW][32];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
@@ -53,11 +55,11 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(SmallGemm p) {
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[v] = 0.f;
     constexpr int U = 8;
-    for (int c = w; c < nchunk; c += 4 * U) {
+    for (int c = w; c < nchunk; c += GW * U) {
         f32x4 av[U], bv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int cc = c + 4 * u;
+            const int cc = c + GW * u;
             const bool ok = cc < nchunk && cc * 8 + 4 * h < p.K;       // K % 4 == 0: a 16-byte piece is inside or outside
             av[u] = ok && aok ? *(const f32x4*)(ap + (size_t)cc * 8) : zero;
             bv[u] = ok && bok ? *(const f32x4*)(bp + (size_t)cc * 8) : zero;
@@ -69,16 +71,18 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(SmallGemm p) {
     }
     spill_tile(red[w], acc, lane);
     __syncthreads();
-    // thread (j, ig): column j, rows ig, ig + 8, ig + 16, ig + 24
+    // thread (j, ig): column j, rows ig and ig + 16; the eight partial tiles are added in wave order
     const int j = tid & 31, ig = tid >> 5;
     const int n = n0 + j;
     const float sc = (p.scale && n < p.N) ? p.scale[n] : 1.f;
     const float sh = (p.shift && n < p.N) ? p.shift[n] : 0.f;
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int i = ig + 8 * q, m = m0 + i;
-        float v = ((red[0][i * RP + j] + red[1][i * RP + j]) + red[2][i * RP + j]) + red[3][i * RP + j];
+    for (int q = 0; q < 32 / (2 * GW); ++q) {
+        const int i = ig + 2 * GW * q, m = m0 + i;
+        float v = red[0][i * RP + j];
+#pragma unroll
+        for (int ww = 1; ww < GW; ++ww) v += red[ww][i * RP + j];
         if (m < p.M && n < p.N) {
             s0 += v;
             s1 += v * v;
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(SmallGemm p) {
             const int which = tid >> 5;
             float t = 0.f;
 #pragma unroll
-            for (int g = 0; g < 8; ++g) t += cs[which][g][j];
+            for (int g = 0; g < 2 * GW; ++g) t += cs[which][g][j];
             if (n < p.N) p.stats[((size_t)blockIdx.y * 2 + which) * p.N + n] = (double)t;
         }
     }
@@ -161,7 +165,7 @@ int ssad_linear_small_launch(const float* a, const float* b, float* y, const flo
                              const float* residual, int relu, int M, int K, int N, double* stats, int* stat_rows, void* stream) {
     SmallGemm p{a, b, y, scale, shift, residual, stats, M, K, N, relu};
     dim3 grid((N + 31) / 32, (M + 31) / 32);
-    hipLaunchKernelGGL(small_gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(small_gemm_kernel, grid, dim3(64 * GW), 0, (hipStream_t)stream, p);
     if (stat_rows) *stat_rows = (int)grid.y;
     SSAD_CHECK_LAUNCH();
     return 0;
