@@ -199,8 +199,8 @@ static int halo_launch(const float* dz, const float* x, float* slab, int splits,
                        int Cout, int S, void* stream) {
     SSAD_CHECK_ARG(dz && x && slab && N > 0 && H > 0 && W > 0, "bad argument");
     SSAD_CHECK_ARG(Cin % 64 == 0 && Cout % 64 == 0, "channel counts must be multiples of 64");
-    SSAD_CHECK_ARG(N * (int64_t)Hx * Wx * Cin < (int64_t)1 << 32 && N * (int64_t)H * W * Cout < (int64_t)1 << 32,
-                   "per-image offsets are 32-bit");
+    SSAD_CHECK_ARG((int64_t)Hx * Wx * Cin < (int64_t)1 << 32 && (int64_t)H * W * Cout < (int64_t)1 << 32 &&
+                   N * (int64_t)((H + 3) / 4) * ((W + 7) / 8) < (int64_t)1 << 31, "offsets inside an image are 32-bit, tile numbers int");
     static const int s2_tile = getenv("SSAD_WGRAD_HALO_S2_TILE") ? atoi(getenv("SSAD_WGRAD_HALO_S2_TILE")) : 32;
     const bool half = S == 2 && s2_tile == 32;             // stride 2: 4 x 8 output pixels, so that two workgroups fit a CU
     const int TW = half ? 8 : W > 8 ? 16 : 8, TH = half ? 4 : W > 8 ? 4 : 8;     // 64-pixel tiles: 144 accumulator + 44 staging registers fit
