@@ -143,6 +143,15 @@ int ssad_conv_igemm_fwd_x6(const float* in, const float* w_ohwi, float* out, con
                            int stride, int pad, int hwnc, void* stream);
 int ssad_conv_igemm_dgrad_x6(const float* dy, const float* w_flipT, float* dx, const float* residual, int64_t N, int Hy,
                              int Wy, int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride, int pad, void* stream);
+/* BatchNorm over a few hundred rows (the BatchNorm1d layers of the projection head on a training batch, models.py:65-95) in one
+ * launch each way: statistics + running-statistics update + apply (+ ReLU) forward; the two column sums, their use and optionally
+ * the bias gradient of the Linear in front (dbias = column sums of dz) backward.  zmask_beta != NULL: the layer's ReLU mask is
+ * recomputed from z (no residual in between).  ssad_bn_small_ok(R, C): R <= 512 rows, C a multiple of 32. */
+int ssad_bn_small_ok(int64_t R, int C);
+int ssad_bn_small_fwd(const float* z, const float* gamma, const float* beta, float* y, float* mean, float* invstd,
+                      float* running_mean, float* running_var, int64_t R, int C, float eps, float momentum, int relu, void* stream);
+int ssad_bn_small_bwd(const float* dy, const float* z, const float* mean, const float* invstd, const float* gamma,
+                      const float* zmask_beta, float* dbeta, float* dgamma, float* dbias, float* dz, int64_t R, int C, void* stream);
 /* Linear layers over a training batch's few rows (the projection head and classifier, models.py:65-99, :247-252): 1 x 1 layers on
  * 1 x 1 maps with N <= ssad_linear_small_max_rows() rows are served by a dedicated kernel (contraction dealt over the waves of a
  * 32 x 32 output tile) inside ssad_conv_igemm_fwd / _fwd_stats / _dgrad -- those then accept any Cin (Cout for dgrad) % 4 == 0 --

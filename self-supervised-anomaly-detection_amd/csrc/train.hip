@@ -8,6 +8,7 @@
 // Per-channel sums accumulate in fp64 and are combined in a fixed order (two-stage, no atomics), so batch
 // statistics and BN gradients are deterministic and free of E[x^2]-E[x]^2 cancellation.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -756,6 +757,140 @@ extern "C" int ssad_bn_apply_bwd_zmask(const float* dy, const float* z, const fl
                                        int64_t R, int C, void* stream) {
     SSAD_CHECK_ARG(z && beta, "mask-from-z needs z and beta");
     return bn_apply_bwd_impl(dy, nullptr, z, mean, invstd, gamma, dbeta, dgamma, dz, nullptr, R, C, 0, stream, beta);
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm over a few hundred rows -- the BatchNorm1d layers of the projection head on a training batch
+// (src/self_supervised/models.py:65-95) -- statistics, finalisation and apply in ONE launch each way (round 3: at batch 32 the
+// three launches of the general path cost 15 us per layer for 64 KB of data, profiles/r03_b32_trace.md).  A workgroup owns 32
+// channels for ALL rows: thread (j, ig) = channel j of the group, rows ig, ig + 8, ...; column sums in double per thread, the
+// eight row groups added in order through LDS (deterministic); the rows are then read again (R x 128 bytes per workgroup: cache
+// hits) for the apply.  Formulas are those of bn_stats_finalize_kernel / bn_apply_fwd_kernel / col_reduce_kernel<1> /
+// bn_apply_bwd_kernel.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ void small_col_totals(double (*sh)[8][32], int nsum, const double* part, int ig, int j, double* tot) {
+    for (int k = 0; k < nsum; ++k) sh[k][ig][j] = part[k];
+    __syncthreads();
+    for (int k = 0; k < nsum; ++k) {
+        double t = 0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += sh[k][g][j];
+        tot[k] = t;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restrict__ z, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ invstd,
+                                                            float* __restrict__ running_mean, float* __restrict__ running_var, int R,
+                                                            int C, float eps, float momentum, int relu) {
+    __shared__ double sh[2][8][32];
+    const int j = threadIdx.x & 31, ig = threadIdx.x >> 5, c = blockIdx.x * 32 + j;
+    double part[2] = {0, 0}, tot[2];
+    for (int r = ig; r < R; r += 8) {
+        const double v = (double)z[(size_t)r * C + c];
+        part[0] += v;
+        part[1] += v * v;
+    }
+    small_col_totals(sh, 2, part, ig, j, tot);
+    const double m = tot[0] / (double)R;
+    double var = tot[1] / (double)R - m * m;
+    if (var < 0) var = 0;
+    const float mu = (float)m, is = (float)(1.0 / sqrt(var + (double)eps));
+    if (ig == 0) {
+        mean[c] = mu;
+        invstd[c] = is;
+        if (running_mean) {
+            const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
+            running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+        }
+    }
+    const float g = gamma[c], b = beta[c];
+    for (int r = ig; r < R; r += 8) {
+        float v = (z[(size_t)r * C + c] - mu) * is * g + b;
+        if (relu) v = fmaxf(v, 0.f);
+        y[(size_t)r * C + c] = v;
+    }
+}
+
+// g = dy (under the ReLU mask recomputed from z when zmask_beta is given); dbeta = sum g, dgamma = sum g xhat,
+// dz = gamma invstd (g - dbeta / R - xhat dgamma / R); optionally dbias = sum dz (the Linear bias in front of the BatchNorm).
+__global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ zmask_beta,
+                                                            float* __restrict__ dbeta, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbias, float* __restrict__ dz, int R, int C) {
+    __shared__ double sh[2][8][32];
+    const int j = threadIdx.x & 31, ig = threadIdx.x >> 5, c = blockIdx.x * 32 + j;
+    const float mu = mean[c], is = invstd[c], ga = gamma[c];
+    const float zb = zmask_beta ? zmask_beta[c] : 0.f;
+    double part[2] = {0, 0}, tot[2];
+    for (int r = ig; r < R; r += 8) {
+        const float zz = z[(size_t)r * C + c];
+        float g = dy[(size_t)r * C + c];
+        if (zmask_beta) g = (zz - mu) * is * ga + zb > 0.f ? g : 0.f;
+        part[0] += (double)g;
+        part[1] += (double)g * (double)((zz - mu) * is);
+    }
+    small_col_totals(sh, 2, part, ig, j, tot);
+    const float db = (float)tot[0], dg = (float)tot[1];
+    if (ig == 0) {
+        if (dbeta) dbeta[c] = db;
+        if (dgamma) dgamma[c] = dg;
+    }
+    const float invR = 1.f / (float)R;
+    double sdz[1] = {0};
+    for (int r = ig; r < R; r += 8) {
+        const float zz = z[(size_t)r * C + c];
+        float g = dy[(size_t)r * C + c];
+        if (zmask_beta) g = (zz - mu) * is * ga + zb > 0.f ? g : 0.f;
+        const float xh = (zz - mu) * is;
+        const float o = ga * is * (g - db * invR - xh * dg * invR);
+        dz[(size_t)r * C + c] = o;
+        sdz[0] += (double)o;
+    }
+    if (dbias) {
+        double t[1];
+        small_col_totals(sh, 1, sdz, ig, j, t);
+        if (ig == 0) dbias[c] = (float)t[0];
+    }
+}
+
+int bn_small_rows() {
+    static const int v = getenv("SSAD_BN_SMALL") ? atoi(getenv("SSAD_BN_SMALL")) : 512;
+    return v;
+}
+
+}  // namespace
+
+// 1 when the one-launch BatchNorm kernels take R rows x C channels (SSAD_BN_SMALL=0 switches them off).
+extern "C" int ssad_bn_small_ok(int64_t R, int C) { return R > 0 && R <= bn_small_rows() && C > 0 && C % 32 == 0; }
+
+extern "C" int ssad_bn_small_fwd(const float* z, const float* gamma, const float* beta, float* y, float* mean, float* invstd,
+                                 float* running_mean, float* running_var, int64_t R, int C, float eps, float momentum, int relu,
+                                 void* stream) {
+    SSAD_CHECK_ARG(z && gamma && beta && y && mean && invstd, "null pointer");
+    SSAD_CHECK_ARG(ssad_bn_small_ok(R, C), "outside the small-batch range (ssad_bn_small_ok)");
+    SSAD_CHECK_ARG(!running_mean == !running_var, "running_mean and running_var come together");
+    hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(C / 32), dim3(256), 0, (hipStream_t)stream, z, gamma, beta, y, mean, invstd,
+                       running_mean, running_var, (int)R, C, eps, momentum, relu);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ssad_bn_small_bwd(const float* dy, const float* z, const float* mean, const float* invstd, const float* gamma,
+                                 const float* zmask_beta, float* dbeta, float* dgamma, float* dbias, float* dz, int64_t R, int C,
+                                 void* stream) {
+    SSAD_CHECK_ARG(dy && z && mean && invstd && gamma && dz, "null pointer");
+    SSAD_CHECK_ARG(ssad_bn_small_ok(R, C), "outside the small-batch range (ssad_bn_small_ok)");
+    hipLaunchKernelGGL(bn_small_bwd_kernel, dim3(C / 32), dim3(256), 0, (hipStream_t)stream, dy, z, mean, invstd, gamma, zmask_beta,
+                       dbeta, dgamma, dbias, dz, (int)R, C);
+    SSAD_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int ssad_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int64_t N, int H, int W, int C, void* stream) {

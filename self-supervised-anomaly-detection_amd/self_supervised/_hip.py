@@ -41,6 +41,9 @@ SIGNATURES = {
     "ssad_flip_transpose_batch": [_c_fp, _c_fp, ctypes.POINTER(ctypes.c_int64), _c_i, _c_fp],
     "ssad_conv_igemm_dgrad": [_c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
                               _c_fp],
+    "ssad_bn_small_ok": [_c_l, _c_i],
+    "ssad_bn_small_fwd": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_f, _c_f, _c_i, _c_fp],
+    "ssad_bn_small_bwd": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_fp],
     "ssad_linear_small_max_rows": [],
     "ssad_linear_wgrad_small": [_c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_fp],
     "ssad_wgrad_splits": [_c_l, _c_i, _c_i, _c_i, _c_i],

@@ -468,6 +468,34 @@ def bn_stats(z, c, eps, momentum, running_mean, running_var):
     return mean, invstd
 
 
+def bn_small_ok(rows, c):
+    return bool(_hip.lib().ssad_bn_small_ok(rows, c))
+
+
+def bn_small_fwd(z, gamma, beta, eps, momentum, running_mean, running_var, relu):
+    """Train-mode BatchNorm over a few hundred rows in one launch (statistics, running statistics, apply).  -> (y, mean, invstd)"""
+    c = z.shape[-1]
+    r = z.numel() // c
+    y, mean, invstd = torch.empty_like(z), _new((c,), z), _new((c,), z)
+    _run("bn_small_fwd", 0.0, 4.0 * 3 * z.numel(),
+         lambda: _hip.lib().ssad_bn_small_fwd(_hip.ptr(z), _hip.ptr(gamma), _hip.ptr(beta), _hip.ptr(y), _hip.ptr(mean),
+                                              _hip.ptr(invstd), _hip.ptr(running_mean, True), _hip.ptr(running_var, True), r, c,
+                                              eps, momentum, int(relu), _hip.stream()))
+    return y, mean, invstd
+
+
+def bn_small_bwd(dy, z, mean, invstd, gamma, zmask_beta, dbeta, dgamma, dbias=None):
+    """Its backward in one launch: dbeta, dgamma (and dbias = column sums of dz) written, dz returned."""
+    c = z.shape[-1]
+    r = z.numel() // c
+    dz = torch.empty_like(dy)
+    _run("bn_small_bwd", 0.0, 4.0 * 5 * z.numel(),
+         lambda: _hip.lib().ssad_bn_small_bwd(_hip.ptr(dy), _hip.ptr(z), _hip.ptr(mean), _hip.ptr(invstd), _hip.ptr(gamma),
+                                              _hip.ptr(zmask_beta, True), _hip.ptr(dbeta, True), _hip.ptr(dgamma, True),
+                                              _hip.ptr(dbias, True), _hip.ptr(dz), r, c, _hip.stream()))
+    return dz
+
+
 def bn_apply_fwd(z, mean, invstd, gamma, beta, residual, relu):
     c = mean.numel()
     y = torch.empty_like(z)

@@ -254,6 +254,15 @@ class _Affine:
         c = bn.num_features
         if bn.training:
             mom = 0.1 if bn.momentum is None else bn.momentum
+            if not self.is_conv and residual is None and ops.bn_small_ok(x.numel() // x.shape[-1], c):
+                # BatchNorm1d over a training batch's rows: Linear, then statistics + running statistics + apply in one launch
+                z = ops.conv_fwd(x, w, None, a.w(bias) if bias is not None else None, None, False, self.stride, self.pad, bf)
+                y, self.mean, self.invstd = ops.bn_small_fwd(z, a.w(bn.weight), a.w(bn.bias), bn.eps, mom, bn.running_mean,
+                                                             bn.running_var, self.relu)
+                with torch.no_grad():
+                    self.eng.count_batch(bn)
+                self.z, self.y = z, (y if self.relu else None)
+                return y
             if bias is None and c % 4 == 0:
                 # batch statistics taken in the conv epilogue (no second pass over z)
                 z, self.mean, self.invstd = ops.conv_fwd_stats(x, w, bn.eps, mom, bn.running_mean, bn.running_var,
@@ -298,7 +307,17 @@ class _Affine:
             train_stats = self.z is not None
             pg = self.eng.param_grads
             wg, bg = bn.weight.requires_grad and pg, bn.bias.requires_grad and pg
-            if train_stats and (dy_mask is not None or (mask is not None and want_dres)):
+            small_bias = None
+            if (train_stats and not self.is_conv and dy_mask is None and mask is None and not want_dres and not self.res_used
+                    and ops.bn_small_ok(dy.numel() // c, c)):
+                # the one-launch form of the two branches below that a BatchNorm1d of the head can take (ReLU without residual:
+                # mask from z; or no ReLU), with the bias gradient of the Linear in front (column sums of dz) in the same launch
+                dbeta = a.grad(bn.bias) if bg else None
+                dgamma = a.grad(bn.weight) if wg else None
+                small_bias = a.grad(bias) if (bias is not None and bias.requires_grad and pg) else None
+                dz = ops.bn_small_bwd(dy, self.z, self.mean, self.invstd, a.w(bn.weight), a.w(bn.bias) if self.relu else None,
+                                      dbeta, dgamma, small_bias)
+            elif train_stats and (dy_mask is not None or (mask is not None and want_dres)):
                 # residual block without re-reading activations: g = dy * mask inside the two BatchNorm passes
                 dbeta = a.grad(bn.bias) if bg else torch.empty(c, device=dy.device)
                 dgamma = a.grad(bn.weight) if wg else torch.empty(c, device=dy.device)
@@ -324,7 +343,7 @@ class _Affine:
                 dz, dres = ops.bn_apply_bwd(dy, self.y, self.z, self.mean, self.invstd, a.w(bn.weight), None, None,
                                             want_dres, eval_mode=True)
         cout = dz.shape[-1]
-        if bias is not None and bias.requires_grad and self.eng.param_grads:
+        if bias is not None and bias.requires_grad and self.eng.param_grads and not (bn is not None and small_bias is not None):
             ops.bn_bwd_reduce(dz, None, None, None, None, a.grad(bias), None, cout)
         bf = self.eng.bf16
         if self.lin.weight.requires_grad and self.eng.param_grads:

@@ -99,6 +99,42 @@ def test_linear_small_kernels(dev, m):
         assert rel_err(small.view(512, 512), big.view(513, 512)[:512]) < 2e-6
 
 
+@pytest.mark.parametrize("rows", [8, 32, 45, 256, 512])
+def test_bn_small_kernels(dev, rows):
+    """One-launch BatchNorm over a training batch's rows (csrc/train.hip, bn_small_*): forward (statistics, running statistics,
+    apply, ReLU) and backward (dbeta, dgamma, dz, bias gradient of the Linear in front) against float64 autograd, and against
+    the three-launch path they replace."""
+    from self_supervised import ops
+    assert ops.bn_small_ok(rows, 512) and not ops.bn_small_ok(513, 512) and not ops.bn_small_ok(rows, 48)
+    for c, relu in [(512, True), (512, False), (64, True)]:
+        g = torch.Generator().manual_seed(rows + c + relu)
+        z = (torch.randn(rows, c, generator=g, dtype=torch.float64) * 1.7 + 0.3).requires_grad_()
+        bn = torch.nn.BatchNorm1d(c).double()
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(c, generator=g, dtype=torch.float64) + 0.5)
+            bn.bias.copy_(torch.randn(c, generator=g, dtype=torch.float64) * 0.3)
+        y = bn(z)
+        y = y.relu() if relu else y
+        dy = torch.randn(rows, c, generator=g, dtype=torch.float64)
+        y.backward(dy)
+        f = lambda t: t.detach().float().to(dev)
+        rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+        yy, mean, invstd = ops.bn_small_fwd(f(z), f(bn.weight), f(bn.bias), bn.eps, 0.1, rm, rv, relu)
+        assert rel_err(yy, y) < 1e-5 and rel_err(rm, bn.running_mean) < 1e-6 and rel_err(rv, bn.running_var) < 1e-6     # mean kept in float32: two close rows cancel
+        db, dg, dbias = torch.empty(c, device=dev), torch.empty(c, device=dev), torch.empty(c, device=dev)
+        dz = ops.bn_small_bwd(f(dy), f(z), mean, invstd, f(bn.weight), f(bn.bias) if relu else None, db, dg, dbias)
+        tol = 2e-6 if rows >= 32 else 2e-5        # few rows: xhat carries the rounding of the float32 mean and invstd
+        assert rel_err(db, bn.bias.grad) < tol and rel_err(dg, bn.weight.grad) < tol
+        assert rel_err(dz, z.grad, floor=1e-3) < 5 * tol
+        assert dbias.abs().max().item() < 1e-4 * max(1.0, dz.abs().max().item()) * rows    # analytically zero: sum of dz over the batch
+        assert rel_err(dbias, dz.double().sum(0), floor=1e-3) < 1e-3
+        # the general path: col_reduce + finalize + apply
+        m2, i2 = ops.bn_stats(f(z), c, bn.eps, 0.1, None, None)
+        assert rel_err(mean, m2) < 1e-6 and rel_err(invstd, i2) < 1e-5
+        y2 = ops.bn_apply_fwd(f(z), m2, i2, f(bn.weight), f(bn.bias), None, relu)
+        assert rel_err(yy, y2) < 1e-5
+
+
 def test_bn_pool_kernels(dev):
     from self_supervised import ops
     g = torch.Generator().manual_seed(1)
