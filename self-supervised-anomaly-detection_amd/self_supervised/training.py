@@ -468,8 +468,8 @@ class TrainEngine:
         if not self._flip_view:                      # build the table once: every conv of the residual blocks, arena offsets
             import ctypes
             a, desc, off = self.arena, [], 0
-            layers = [d[k] for d in self.blocks for k in ("c1", "c2", "ds") if d[k] is not None] + list(self.head)
-            for layer in layers:                 # every block conv and (round 3) the head's linear layers, as 1 x 1 filters
+            layers = [d[k] for d in self.blocks for k in ("c1", "c2", "ds") if d[k] is not None] + list(self.head) + [self.cls]
+            for layer in layers:                 # every block conv and (round 3) the head's and classifier's linear layers, as 1 x 1 filters
                 p = layer.lin.weight
                 o, c, kh, kw = p.shape if p.dim() == 4 else (p.shape[0], p.shape[1], 1, 1)
                 desc += [a.offset[id(p)][0], off, o, c, kh, kw]
