@@ -138,17 +138,21 @@ __global__ __launch_bounds__(256, 2) void stem_conv7x7_kernel(StemParams p) {
             if (oy >= p.Ho) continue;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
+                // statistics: the 16 values of this lane's channel in float, then one double add per tile row (the conv epilogues of
+                // conv_igemm.hip sum 128 rows in float the same way); 64 double-precision FMAs per tile row cost the wave ~10 % of it
+                float fs = 0.f, fq = 0.f;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     int ox = tx0 + (e & 3) + 8 * (e >> 2) + 4 * h;
                     if (ox < p.Wo) {
-                        if (p.stats) { const double a = (double)acc[i][j][e]; st0[j] += a; st1[j] += a * a; }
+                        if (p.stats) { fs += acc[i][j][e]; fq += acc[i][j][e] * acc[i][j][e]; }
                         float v = acc[i][j][e] * sc[j] + sh[j];
                         if (p.relu) v = fmaxf(v, 0.f);
                         const int64_t pix = p.hwnc ? ((int64_t)oy * p.Wo + ox) * p.Nsamp + n : (n * p.Ho + oy) * p.Wo + ox;
                         p.out[pix * 64 + j * 32 + r] = v;
                     }
                 }
+                if (p.stats) { st0[j] += (double)fs; st1[j] += (double)fq; }
             }
         }
     }
