@@ -197,13 +197,14 @@ def end_to_end(args):
     (which records the hipGraph)."""
     import contextlib
     import tempfile
+    import torch
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from fake_mvtec import make_tree
     from self_supervised import tools
     res = {"workload": "tools.training(gpu_pipeline=True), bottle-shaped synthetic category, 256x256 image level, batch 96, "
                        "1 + 5 epochs of ~10 steps; median fine-tune epoch after the first"}
     with tempfile.TemporaryDirectory() as tmp:
-        root = make_tree(os.path.join(tmp, "data"), categories=("bottle",), n_train=40, n_test_good=2, n_test_bad=2, size=256)
+        root = make_tree(os.path.join(tmp, "data"), categories=("bottle",), n_train=40, n_test_good=48, n_test_bad=48, size=256)
         for prec in (32, 16):
             with contextlib.redirect_stdout(sys.stderr):
                 hist = tools.training(root + "bottle/", os.path.join(tmp, f"out{prec}") + "/", "bottle", imsize=(args.size, args.size),
@@ -215,6 +216,21 @@ def end_to_end(args):
                 "epochs": [[n, round(t, 4)] for n, t in hist["throughput"]["fine_tune"]],
                 "projection_stage_images_per_sec": round(sum(n for n, _ in hist["throughput"]["projection_train"]) /
                                                          sum(t for _, t in hist["throughput"]["projection_train"]), 1)}
+        # tools.inference as the reference runs it (tools.py:310-390): PNG files -> predict loop at batch size 1, 841 patches per
+        # image -> bank from the first training image -> k-NN maps -> blur + bilinear.  One image per launch leaves the GPU mostly
+        # idle; the figure is there so that the host-side share of an MVTec evaluation is on record beside the kernel-only rate.
+        with contextlib.redirect_stdout(sys.stderr):
+            ck = os.path.join(tmp, "out32") + "/best_model.ckpt"
+            tools.inference(ck, root + "bottle/", "bottle", mvtec_inference=True, patch_localization=True)      # warm-up (plans, lazy init)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = tools.inference(ck, root + "bottle/", "bottle", mvtec_inference=True, patch_localization=True)
+            up = tools.upsample(r.anomaly_maps, args.size)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        res["inference"] = {"workload": "tools.inference(patch_localization=True) + tools.upsample on 96 test PNGs of 256x256 (+ the 40 training images the reference also predicts to pick its bank image), batch size 1 "
+                                        "as in the reference; includes checkpoint load, PNG decode and the bank image",
+                            "end_to_end_maps_per_sec": round(up.shape[0] / dt, 1), "images": int(up.shape[0]), "seconds": round(dt, 3)}
     return res
 
 

@@ -70,13 +70,31 @@ class MVTecDataset(Dataset):
         return len(self.images_filenames)
 
 
+def _worker_context():
+    """How DataLoader workers are started.  fork()ing a process that has initialised the GPU is what the reference's
+    DataLoader(num_workers=8) does on Linux, and on this ROCm stack every such fork leaves the parent's GPU queues stalling for
+    ~0.1 s at a time afterwards (copy-on-write faults on pages the driver has registered; `tools.inference` measured 10-13 s per
+    call and growing with 2 workers against 1.6 s with none, round 3).  Once the GPU is up, workers therefore come from a fork
+    SERVER (a clean helper process started once, torch preloaded); SSAD_LOADER_CONTEXT=fork|forkserver|spawn overrides."""
+    import multiprocessing as mp
+    name = os.environ.get("SSAD_LOADER_CONTEXT")
+    if not name:
+        name = "forkserver" if torch.cuda.is_initialized() else "fork"
+    if name == "forkserver":
+        try:
+            mp.set_forkserver_preload(["torch", "numpy", "PIL.Image", "self_supervised.datasets"])
+        except Exception:
+            pass
+    return mp.get_context(name)
+
+
 class _DataModule:
     num_workers = 8
 
     def _loader(self, ds, shuffle, drop_last=False):
         nw = min(self.num_workers, os.cpu_count() or 1)
         return DataLoader(ds, batch_size=self.batch_size, shuffle=shuffle, drop_last=drop_last, num_workers=nw,
-                          persistent_workers=False)
+                          persistent_workers=False, multiprocessing_context=_worker_context() if nw else None)
 
     def prepare_data(self) -> None:
         pass

@@ -55,6 +55,9 @@ class ModelCheckpoint(Callback):
 
 
 def _to_device(batch, dev):
+    """Host batch -> device.  (Round 3: staging through pinned buffers was tried against the stalls described at
+    datasets._worker_context -- it did not remove them, the fork server does -- and writing 786 KB into pinned memory took 1.6 ms
+    against 0.1 ms for the pageable copy, so the copy stays direct.)"""
     return tuple(b.to(dev, non_blocking=True) if torch.is_tensor(b) else b for b in batch)
 
 

@@ -72,6 +72,25 @@ def test_datasets_on_synthetic_tree(tmp_path):
     assert tuple(xb.shape) == (2, 3, 96, 96)
 
 
+def test_loader_workers_from_a_fork_server(tmp_path, monkeypatch):
+    """datasets._worker_context: plain fork while no GPU is initialised (the reference's DataLoader default), a fork server once it is
+    (or on request) -- the datasets pickle, the workers deliver the same batches as the in-process loader."""
+    from self_supervised import datasets as ds
+    monkeypatch.delenv("SSAD_LOADER_CONTEXT", raising=False)
+    assert ds._worker_context().get_start_method() == ("forkserver" if torch.cuda.is_initialized() else "fork")
+    monkeypatch.setenv("SSAD_LOADER_CONTEXT", "forkserver")
+    assert ds._worker_context().get_start_method() == "forkserver"
+    root = make_tree(str(tmp_path / "data"))
+    monkeypatch.setattr(ds._DataModule, "num_workers", 2)
+    mv = ds.MVTecDatamodule(root + "bottle/", imsize=(96, 96), batch_size=1)
+    mv.setup("predict")
+    got = [b for b in mv.predict_dataloader()]
+    assert len(got) == 6
+    monkeypatch.setattr(ds._DataModule, "num_workers", 0)
+    want = [b for b in mv.predict_dataloader()]
+    assert all(torch.equal(u, v) for a, b in zip(got, want) for u, v in zip(a, b))
+
+
 def test_metrics(golden):
     from self_supervised import metrics as m
     g = golden("auroc")
