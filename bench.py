@@ -216,9 +216,10 @@ def end_to_end(args):
                 "epochs": [[n, round(t, 4)] for n, t in hist["throughput"]["fine_tune"]],
                 "projection_stage_images_per_sec": round(sum(n for n, _ in hist["throughput"]["projection_train"]) /
                                                          sum(t for _, t in hist["throughput"]["projection_train"]), 1)}
-        # tools.inference as the reference runs it (tools.py:310-390): PNG files -> predict loop at batch size 1, 841 patches per
-        # image -> bank from the first training image -> k-NN maps -> blur + bilinear.  One image per launch leaves the GPU mostly
-        # idle; the figure is there so that the host-side share of an MVTec evaluation is on record beside the kernel-only rate.
+        # tools.inference as the reference runs it (tools.py:310-390): PNG files -> DataLoader(batch_size=1, 8 workers) -> predict
+        # (16 images per launch here) -> bank from the first training image -> k-NN maps -> blur + bilinear.  Worker start-up,
+        # checkpoint load and PNG decode are most of it; the figure is there so that the host-side share of an MVTec evaluation is
+        # on record beside the kernel-only rate.
         with contextlib.redirect_stdout(sys.stderr):
             ck = os.path.join(tmp, "out32") + "/best_model.ckpt"
             tools.inference(ck, root + "bottle/", "bottle", mvtec_inference=True, patch_localization=True)      # warm-up (plans, lazy init)
@@ -228,7 +229,7 @@ def end_to_end(args):
             up = tools.upsample(r.anomaly_maps, args.size)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-        res["inference"] = {"workload": "tools.inference(patch_localization=True) + tools.upsample on 96 test PNGs of 256x256 (+ the 40 training images the reference also predicts to pick its bank image), batch size 1 "
+        res["inference"] = {"workload": "tools.inference(patch_localization=True) + tools.upsample on 96 test PNGs of 256x256 (+ the one training image that becomes the bank), batch size 1 "
                                         "as in the reference; includes checkpoint load, PNG decode and the bank image",
                             "end_to_end_maps_per_sec": round(up.shape[0] / dt, 1), "images": int(up.shape[0]), "seconds": round(dt, 3)}
     return res

@@ -182,7 +182,12 @@ def inference(model_input_dir: str, dataset_dir: str, subject: str, mvtec_infere
         else:
             normality_datamodule = PretextTaskDatamodule(subject=subject, root_dir=dataset_dir, batch_size=1)
         normality_datamodule.setup()
-        output_normality = tester.predict(model, dataloaders=normality_datamodule.train_dataloader())[0]
+        # the reference predicts the WHOLE training loader and keeps element [0] (tools.py:379-381); the first batch of a loader
+        # does not depend on how far the loader is consumed afterwards (the shuffle permutation and the one draw for the workers'
+        # base seed happen when iteration starts), so only that batch is predicted: same image, same RNG state, 1 / 209 of the work
+        # (MVTec loader only: its __getitem__ draws no random numbers, so this also holds with in-process loading)
+        output_normality = tester.predict(model, dataloaders=normality_datamodule.train_dataloader(),
+                                          max_batches=1 if mvtec_inference else None)[0]
         output_normality.to_cpu()
         normality = output_normality.embedding_vectors
     output.to_cpu()

@@ -149,7 +149,7 @@ class Trainer:
                 s.step()
         model.eval()
 
-    def predict(self, model, datamodule=None, dataloaders=None, shard=False):
+    def predict(self, model, datamodule=None, dataloaders=None, shard=False, max_batches=None):
         """shard=True (multi-GPU scoring, SURVEY s.8e): this rank scores batches rank, rank + world, ... only -- images
         are independent, no data-path collective -- and returns its own list; `gather_in_order` rebuilds the full one."""
         self.model = model
@@ -189,6 +189,8 @@ class Trainer:
 
         with torch.no_grad():
             for i, batch in enumerate(dataloaders):
+                if max_batches is not None and i >= max_batches:
+                    break               # the caller only uses the first batches (tools.inference's normality image)
                 if shard and i % self.world != self.global_rank:
                     continue
                 batch = _to_device(batch, self.device)
