@@ -142,8 +142,10 @@ def test_x3_training_step_matches_autograd(seeded_sd):
     assert step.eng.bf16 == 3
     logits, emb = step.eng.forward(x.to(dev))
     # train-mode BatchNorm over a batch of 8 amplifies any rounding difference ~50x (the exact-fp32 step sits at 6e-5
-    # here); the split products carry ~3x the fp32 rounding error, hence 5e-4 -- the eval-mode vectors above hold 1e-4
-    assert rel(logits, out_ref["classifier"]) < 5e-4 and rel(emb, out_ref["latent_space"]) < 5e-4
+    # here); the split products carry ~3x the fp32 rounding error, hence 5e-4 on the logits -- the eval-mode vectors above hold
+    # 1e-4.  The embedding (five BatchNorm1d over 8 rows behind each other) measures 5.1e-4 since round 3's one-launch
+    # BatchNorm1d (statistics summed in double from z instead of float partial sums: closer to fp64, a different rounding)
+    assert rel(logits, out_ref["classifier"]) < 5e-4 and rel(emb, out_ref["latent_space"]) < 7.5e-4
     dlogits = torch.empty_like(logits)
     la = ops.softmax_ce(logits, y.to(dev), dlogits, 1.0 / 8)
     np.testing.assert_allclose(la[0].item(), loss_ref.item(), rtol=1e-4)
