@@ -181,6 +181,8 @@ def inference(model_input_dir: str, dataset_dir: str, subject: str, mvtec_infere
             normality_datamodule = MVTecDatamodule(dataset_dir, batch_size=1)
         else:
             normality_datamodule = PretextTaskDatamodule(subject=subject, root_dir=dataset_dir, batch_size=1)
+        if mvtec_inference:
+            normality_datamodule.num_workers = 0      # one deterministic image is read: not worth eight worker processes
         normality_datamodule.setup()
         # the reference predicts the WHOLE training loader and keeps element [0] (tools.py:379-381); the first batch of a loader
         # does not depend on how far the loader is consumed afterwards (the shuffle permutation and the one draw for the workers'

@@ -173,7 +173,9 @@ class Trainer:
             else:
                 sizes = [b[0].shape[0] for _, b in pend]
                 merged = tuple(torch.cat([b[k] for _, b in pend]) for k in range(len(pend[0][1])))
-                per_image = model.predict_step(merged, pend[0][0]).split(sum(sizes))
+                whole = model.predict_step(merged, pend[0][0])
+                whole.to_cpu()          # nine device-to-host copies per group instead of nine per image; the split is host work
+                per_image = whole.split(sum(sizes))
                 o = 0
                 for n in sizes:
                     c = type(per_image[0])()

@@ -18,7 +18,7 @@ from self_supervised import tools
 
 def main():
     with tempfile.TemporaryDirectory() as tmp:
-        root = make_tree(os.path.join(tmp, "data"), categories=("bottle",), n_train=40, n_test_good=12, n_test_bad=12, size=256)
+        root = make_tree(os.path.join(tmp, "data"), categories=("bottle",), n_train=40, n_test_good=48, n_test_bad=48, size=256)
         out = os.path.join(tmp, "out") + "/"
         tools.training(root + "bottle/", out, "bottle", imsize=(256, 256), batch_size=32, seed=0, projection_training_params=(1, 0.03),
                        fine_tune_params=(1, 0.005), trainer_kwargs={"limit_train_batches": 2, "limit_val_batches": 1}, gpu_pipeline=True)
