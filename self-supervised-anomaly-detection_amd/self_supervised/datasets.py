@@ -75,7 +75,8 @@ def _worker_context():
     DataLoader(num_workers=8) does on Linux, and on this ROCm stack every such fork leaves the parent's GPU queues stalling for
     ~0.1 s at a time afterwards (copy-on-write faults on pages the driver has registered; `tools.inference` measured 10-13 s per
     call and growing with 2 workers against 1.6 s with none, round 3).  Once the GPU is up, workers therefore come from a fork
-    SERVER (a clean helper process started once, torch preloaded); SSAD_LOADER_CONTEXT=fork|forkserver|spawn overrides."""
+    SERVER (a clean helper process started once, torch preloaded); SSAD_LOADER_CONTEXT=fork|forkserver|spawn overrides.
+    (_Loader below keeps unguarded driver scripts working with such workers.)"""
     import multiprocessing as mp
     name = os.environ.get("SSAD_LOADER_CONTEXT")
     if not name:
@@ -88,13 +89,36 @@ def _worker_context():
     return mp.get_context(name)
 
 
+class _Loader(DataLoader):
+    """DataLoader whose fork-server / spawn workers do not re-import the caller's ``__main__``: the reference's driver scripts
+    (src/test_training.py, ...) call ``training(...)`` at module level without an ``if __name__ == "__main__"`` guard, which is
+    fine under fork() and would re-run the whole script inside every worker otherwise.  The datasets and transforms the workers
+    unpickle live in this package, so ``__main__`` is not needed there; it is hidden only while the workers are started."""
+
+    def __iter__(self):
+        ctx = self.multiprocessing_context
+        if not self.num_workers or ctx is None or ctx.get_start_method() == "fork":
+            return super().__iter__()
+        import sys
+        main = sys.modules.get("__main__")
+        saved = {k: main.__dict__[k] for k in ("__spec__", "__file__") if main is not None and k in main.__dict__}
+        try:
+            if main is not None:
+                main.__dict__["__spec__"] = None
+                main.__dict__.pop("__file__", None)
+            return super().__iter__()
+        finally:
+            if main is not None:
+                main.__dict__.update(saved)
+
+
 class _DataModule:
     num_workers = 8
 
     def _loader(self, ds, shuffle, drop_last=False):
         nw = min(self.num_workers, os.cpu_count() or 1)
-        return DataLoader(ds, batch_size=self.batch_size, shuffle=shuffle, drop_last=drop_last, num_workers=nw,
-                          persistent_workers=False, multiprocessing_context=_worker_context() if nw else None)
+        return _Loader(ds, batch_size=self.batch_size, shuffle=shuffle, drop_last=drop_last, num_workers=nw,
+                       persistent_workers=False, multiprocessing_context=_worker_context() if nw else None)
 
     def prepare_data(self) -> None:
         pass

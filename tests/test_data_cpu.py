@@ -91,6 +91,29 @@ def test_loader_workers_from_a_fork_server(tmp_path, monkeypatch):
     assert all(torch.equal(u, v) for a, b in zip(got, want) for u, v in zip(a, b))
 
 
+def test_unguarded_driver_script_with_fork_server_workers(tmp_path):
+    """The reference's drivers call training(...) at module level (src/test_training.py has no __main__ guard).  With fork-server
+    workers such a script must still run ONCE: the loader hides __main__ from the worker bootstrap."""
+    import subprocess
+    import sys
+    root = make_tree(str(tmp_path / "data"))
+    script = tmp_path / "driver.py"
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "self-supervised-anomaly-detection_amd")
+    script.write_text(
+        "import sys\n"
+        f"sys.path.insert(0, {pkg!r})\n"
+        "from self_supervised import datasets as ds\n"
+        "print('DRIVER BODY RUNS', flush=True)\n"
+        "ds._DataModule.num_workers = 2\n"
+        f"mv = ds.MVTecDatamodule({root + 'bottle/'!r}, imsize=(96, 96), batch_size=1)\n"
+        "mv.setup('predict')\n"
+        "print('BATCHES', sum(1 for _ in mv.predict_dataloader()), flush=True)\n")
+    env = dict(os.environ, SSAD_LOADER_CONTEXT="forkserver")
+    p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:]
+    assert p.stdout.count("DRIVER BODY RUNS") == 1 and "BATCHES 6" in p.stdout, p.stdout[-2000:]
+
+
 def test_metrics(golden):
     from self_supervised import metrics as m
     g = golden("auroc")
