@@ -56,6 +56,7 @@ def parse_args():
                          "maps at 512x512 batch 64 on one GPU (throughput only: the reference has no such model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end tools.training measurement (N = 1 only)")
+    ap.add_argument("--no-wrn50", action="store_true", help="skip the BASELINE configs[3] (WideResNet-50 512x512 bs64) member of the N = 1 line")
     ap.add_argument("--no-partition-extra", action="store_true", help="skip the strong-partition / batch-32 extra line")
     ap.add_argument("--no-faithful", action="store_true", help="skip the bf16x6 (fp32-faithful split products) side measurement")
     ap.add_argument("--no-graph", action="store_true", help="launch the training step eagerly instead of replaying hipGraphs")
@@ -236,15 +237,18 @@ def end_to_end(args):
     return res
 
 
-def bench_wrn50(args):
+def measure_wrn50(args, steps=None, warmup=None):
     """BASELINE configs[3]: 64 synthetic 512 x 512 images -> WideResNet-50-2 layer1-3 features -> per-scale cosine 3-NN maps against
-    588-row banks -> blur + bilinear 512 x 512, mean over the scales.  One GPU; throughput only (no reference counterpart)."""
+    588-row banks -> blur + bilinear 512 x 512, mean over the scales.  One GPU; throughput only (no reference counterpart).
+    Returns the bench object (a full line under --config wrn50, the "wrn50" member of the default line otherwise)."""
     import torch
     from self_supervised import ops
     from self_supervised.wrn50 import FeatureDistanceScorer, WideResNet50Features
     from oracle import wrn50 as ow
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     dev = torch.device("cuda", 0)
     size, batch = 512, 64
     ref = ow.seeded_trunk(0)
@@ -258,37 +262,42 @@ def bench_wrn50(args):
     def step():
         with torch.no_grad():
             return scorer(m(x), size)
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(max(warmup, 1)):
         step()
     torch.cuda.synchronize()
     ops.PROFILE = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof = ops.drain_profile()
     ops.PROFILE = None
     out = {"metric": "anomaly-maps/sec, WideResNet-50-2 layer1-3 feature-distance maps 512x512 bs64", "unit": "anomaly-maps/sec",
-           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "n_gpus": 1, "steps": steps, "warmup": warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": "WideResNet-50 multi-scale (layer1-3) feature-distance maps, 512x512 bs64, 1 GPU (BASELINE configs[3]; "
                                   "no reference counterpart: the reference hard-wires resnet18, models.py:58-62)",
+                      "definition": "torchvision wide_resnet50_2 (Bottleneck v1.5, width 128) up to layer3, eval-mode BatchNorm, random-init "
+                                    "weights; per scale the reference's scorer (cosine 3-NN mean against a 588-row bank, models.py:345-370) on "
+                                    "every pixel, then relu(gaussian_blur k=7) + bilinear to 512 (tools.py:394-399); mean over the three scales "
+                                    "(self_supervised/wrn50.py, oracle/wrn50.py)",
                       "images_per_gpu": batch, "bank_rows": 588, "scales": [[128, 256], [64, 512], [32, 1024]]},
-           "value": round(batch * args.steps / dt, 2), "ms_per_step": round(1e3 * dt / args.steps, 3)}
+           "value": round(batch * steps / dt, 2), "ms_per_step": round(1e3 * dt / steps, 3)}
     recs = [r for r in prof if r["kernel"].startswith("conv_igemm")]
     t = sum(r["ms"] for r in recs) * 1e-3
     fl = sum(r["flops"] for r in recs)
     allk = sum(r["ms"] for r in prof) * 1e-3
     out["roofline"] = {"bound": "mfma", "achieved": round(fl / t / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                       "frac": round(fl / t / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "kernel": "conv_igemm_f32_kernel (NHWC)",
+                       "frac": round(fl / t / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                       "kernel": "conv_igemm_f32_kernel (NHWC instantiations: every FLOP counted is issued, no tap skipping)",
                        "launches": len(recs), "avg_launch_ms": round(1e3 * t / len(recs), 4),
                        "alg_gflop_per_launch": round(fl / len(recs) / 1e9, 3), "share_of_gpu_time": round(t / allk, 4),
-                       "gflop_per_image": round(sum(r["flops"] for r in prof) / args.steps / batch / 1e9, 2)}
+                       "gflop_per_image": round(sum(r["flops"] for r in prof) / steps / batch / 1e9, 2)}
     by = {}
     for r in prof:
         e = by.setdefault(r["kernel"], [0.0, 0, 0.0]); e[0] += r["ms"]; e[1] += 1; e[2] += r["flops"]
-    out["kernel_ms"] = {k: [round(v[0] / args.steps, 3), v[1] // args.steps, round(v[2] / max(v[0], 1e-9) / 1e9, 1)] for k, v in sorted(by.items())}
+    out["kernel_ms"] = {k: [round(v[0] / steps, 3), v[1] // steps, round(v[2] / max(v[0], 1e-9) / 1e9, 1)] for k, v in sorted(by.items())}
     if not args.no_cpu_baseline:
         cores = host_cores()
         torch.set_num_threads(cores)
@@ -297,11 +306,17 @@ def bench_wrn50(args):
         def once():
             with torch.no_grad():
                 ow.distance_maps(ref(xc), banks, size)
-        tt, w, k = _timed_median(once, 30.0)
+        tt, w, k = _timed_median(once, 15.0, max_iters=3)
         out["cpu_baseline"] = {"value": round(1.0 / tt, 3), "unit": "anomaly-maps/sec", "cores": cores, "kind": "port",
                                "sample": f"oracle/wrn50.py on torch-CPU fp32: 1 image 512x512 (trunk + three k-NN maps + blur / bilinear), "
                                          f"{w} warm-up(s), median of {k}"}
-    print(json.dumps(out))
+    del m, scorer, x
+    torch.cuda.empty_cache()
+    return out
+
+
+def bench_wrn50(args):
+    print(json.dumps(measure_wrn50(args)))
 
 
 def main():
@@ -446,6 +461,16 @@ def main():
         res["score_s"] = timed(lambda: score_batch(model, det, x, args.size), args.steps, 0)
         prof["score"] = ops.drain_profile()
         ops.PROFILE = None
+        if world == 1 and per_rank > 32 and not args.no_partition_extra:
+            # scoring side of the 8-GPU strong partition: 32 images = 26 912 patches per rank
+            def score32():
+                xs = x[:32].contiguous()
+                d32 = AnomalyDetector(patch_level=True, batch=32, num_patches=841)
+                d32.fit_bank(bank)
+                n = max(args.steps, 5)
+                dt = timed(lambda: score_batch(model, d32, xs, args.size), n, 1)
+                return {"anomaly_maps_per_sec": round(32 * n / dt, 2), "score_ms_per_step": round(1e3 * dt / n, 3), "steps": n}
+            res["score32"] = optional("batch-32 scoring", score32)
         if "bf16x6" in extras:                 # how far the bf16x6 maps are from the exact-fp32 ones on this very batch
             def map_diff():
                 ref = score_batch(model, det, x[:32].contiguous(), args.size)
@@ -496,6 +521,10 @@ def main():
         tot_s += res["train_s"]
     if "partition" in res:
         out["batch32" if world == 1 else ("weak" if strong_headline else "strong")] = res["partition"]
+    if res.get("score32"):
+        b32 = out.setdefault("batch32", {"images_per_gpu": 32, "global_batch": 32})
+        b32["anomaly_maps_per_sec"] = res["score32"]["anomaly_maps_per_sec"]
+        b32["score_ms_per_step"] = res["score32"]["score_ms_per_step"]
     if faithful and ("train_extra_bf16x6" in res or "score_extra_bf16x6" in res):
         f = {"arithmetic": "every fp32 product as the six largest partial products of three bf16 parts per operand "
                            "(v_mfma_f32_32x32x16_bf16), fp32 accumulate; weight gradients and everything outside the matrix cores exact fp32; "
@@ -522,47 +551,63 @@ def main():
             out["metric"] = "anomaly-maps/sec, ResNet-18 256x256 bs256 (scoring phase only)"
     out["ms_per_step"] = round(1e3 * tot_s / args.steps, 3)
 
-    # roofline of the dominant kernel, live HIP events on the launch stream.  Scoring: the position-major instantiation of the
-    # implicit-GEMM conv (conv_igemm_f32_kernel<128,128,2,2,32,1,POS=true>, 30 launches per 128-image pass: layers 2-4);
-    # training-only runs: the NHWC instantiations of the same kernel (forward + input-gradient convs, linear layers).
-    phase = "score" if "score" in prof else "train"
-    tag = "conv_igemm_pos_f32" if phase == "score" else "conv_igemm_f32"
-    recs = [r for r in prof.get(phase, []) if r["kernel"] == tag] or \
-           [r for r in prof.get(phase, []) if r["kernel"].startswith("conv_igemm")]
-    if recs:
+    # roofline of the dominant kernel of each phase, live HIP events on the launch stream.  Scoring: the position-major
+    # instantiations of the implicit-GEMM conv (layers 2-4, 30 launches per pass); training: its NHWC instantiations (forward +
+    # input-gradient convs of layers 2-4, linear layers).  The top-level "roofline" is the scoring one when scoring ran.
+    def latest_traffic(samples):
+        """HBM-side bytes per launch of the position-major kernel need rocprofv3 PMC passes, which cannot run inside this
+        process: the newest committed, counter-corrected pass of this command line with the same launch geometry."""
+        import glob
+        for tj in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+            tjd = json.load(open(tj))
+            if tjd.get("patches_per_launch") == samples:
+                return {"file": "profiles/" + os.path.basename(tj), "traffic_MB_per_launch": tjd["traffic_MB_per_launch"],
+                        "ratio_to_algorithmic": tjd.get("ratio_to_algorithmic"), "counters": tjd.get("correction")}
+        return None
+
+    def roofline_of(phase, tag):
+        recs = [r for r in prof.get(phase, []) if r["kernel"] == tag]
+        if not recs:
+            return None
         t = sum(r["ms"] for r in recs) * 1e-3
         fl = sum(r["flops"] for r in recs)
         xfl = sum(r["exec_flops"] for r in recs)
         allk = sum(r["ms"] for r in prof[phase]) * 1e-3
-        ach = fl / t / 1e12
-        kname = "conv_igemm_f32_kernel<128,128,2,2,32,1,POS=true>" if tag == "conv_igemm_pos_f32" else "conv_igemm_f32_kernel"
+        tiles = {}
+        for r in recs:
+            e = tiles.setdefault(r.get("tile") or "<small-batch linear / other>", [0, 0.0, 0.0]); e[0] += 1; e[1] += r["ms"]; e[2] += r["exec_flops"]
+        inst = {k: {"launches": v[0], "ms": round(v[1], 3), "TFLOPs": round(v[2] / max(v[1], 1e-9) / 1e9, 1)}
+                for k, v in sorted(tiles.items(), key=lambda kv: -kv[1][1])}
         # `frac` prices the MFMA FLOPs the kernel really ISSUES against the dense fp32-MFMA peak: position-major convs skip the
         # filter taps that fall into the zero padding (exact: only x * 0 products are dropped), so the algorithmic count of
         # SURVEY s.8d (2 M K Cout per conv) over the kernel's time can exceed the peak; that figure is kept as alg_frac.
-        # `traffic` (HBM-side bytes per launch) needs rocprofv3 PMC passes, which cannot run inside this process: null here;
-        # the committed passes of this command line are named in traffic_profile.
-        tprof = None
-        tj = os.path.join(ROOT, "profiles", "r03_traffic.json")
-        if phase == "score" and os.path.exists(tj):
-            tjd = json.load(open(tj))
-            if tjd.get("patches_per_launch") == getattr(model, "last_pass_samples", None):      # same launch geometry only
-                tprof = {"file": "profiles/r03_traffic.json", "traffic_MB_per_launch": tjd["traffic_MB_per_launch"],
-                         "ratio_to_algorithmic": tjd.get("ratio_to_algorithmic")}
-        out["roofline"] = {"bound": "mfma", "achieved": round(xfl / t / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(xfl / t / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                           "alg_achieved": round(ach, 2), "alg_frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                           "skipped_tap_share": round(1.0 - xfl / fl, 4),
-                           "traffic": None, "traffic_profile": tprof,
-                           "kernel": kname, "phase": phase, "launches": len(recs),
-                           "avg_launch_ms": round(1e3 * t / len(recs), 4),
-                           "alg_gflop_per_launch": round(fl / len(recs) / 1e9, 3),
-                           "exec_gflop_per_launch": round(xfl / len(recs) / 1e9, 3),
-                           "alg_MB_per_launch": round(sum(r["bytes"] for r in recs) / len(recs) / 1e6, 1),
-                           "alg_GBps": round(sum(r["bytes"] for r in recs) / t / 1e9, 1),
-                           "share_of_gpu_time": round(t / allk, 4),
-                           "note": "achieved / frac = MFMA FLOPs issued per second of kernel time (HIP events on the launch stream) "
+        tprof = latest_traffic(getattr(model, "last_pass_samples", None)) if phase == "score" else None
+        rf = {"bound": "mfma", "achieved": round(xfl / t / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+              "frac": round(xfl / t / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+              "alg_achieved": round(fl / t / 1e12, 2), "alg_frac": round(fl / t / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+              "skipped_tap_share": round(1.0 - xfl / fl, 4),
+              "traffic": round(tprof["traffic_MB_per_launch"] * 1e6) if tprof else None,
+              "traffic_unit": "fabric-side bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, rocprofv3 PMC passes of this command; "
+                              "Infinity-Cache hits included)" if tprof else None,
+              "traffic_profile": tprof,
+              "kernel": "conv_igemm_f32_kernel" + " + ".join(f"{k} x {v['launches']}" for k, v in inst.items()),
+              "instantiations": inst, "phase": phase, "launches": len(recs),
+              "avg_launch_ms": round(1e3 * t / len(recs), 4),
+              "alg_gflop_per_launch": round(fl / len(recs) / 1e9, 3),
+              "exec_gflop_per_launch": round(xfl / len(recs) / 1e9, 3),
+              "alg_MB_per_launch": round(sum(r["bytes"] for r in recs) / len(recs) / 1e6, 1),
+              "alg_GBps": round(sum(r["bytes"] for r in recs) / t / 1e9, 1),
+              "share_of_gpu_time": round(t / allk, 4)}
+        return rf
+    rf_score, rf_train = roofline_of("score", "conv_igemm_pos_f32"), roofline_of("train", "conv_igemm_f32")
+    if rf_score or rf_train:
+        out["roofline"] = dict(rf_score or rf_train)
+        out["roofline"]["note"] = ("achieved / frac = MFMA FLOPs issued per second of kernel time (HIP events on the launch stream) "
                                    "over the dense fp32-MFMA peak; alg_* count SURVEY 8d's 2 M K Cout, which includes the taps in "
-                                   "the zero padding that the position-major kernel skips (skipped_tap_share)."}
+                                   "the zero padding that the position-major kernel skips (skipped_tap_share).")
+        if rf_score and rf_train:
+            out["roofline_train"] = rf_train
+    if prof:
         # HBM-bound kernels: algorithmic bytes (each operand read once, each result written once) over their event time
         hbm = {}
         for ph in prof:
@@ -585,6 +630,14 @@ def main():
             out["end_to_end"] = r
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args)
+    if world == 1 and not args.no_wrn50 and args.phase == "both":
+        model = det = trainer = None
+        torch.cuda.empty_cache()
+        w50 = optional("wrn50", lambda: measure_wrn50(args, steps=max(min(args.steps, 10), 3), warmup=2))
+        if w50:
+            for k in ("n_gpus", "higher_is_better", "scaling", "vs_baseline", "data"):
+                w50.pop(k, None)
+            out["wrn50"] = w50
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -90,6 +90,11 @@ int ssad_conv_igemm_fwd_hwnc(const float* in, const float* w_ohwi, float* out, c
                              const float* residual, int relu, int64_t N, int H, int W, int Cin, int Cout, int KH, int KW,
                              int stride, int pad, void* stream);
 
+/* Which exact-fp32 instantiation ssad_conv_igemm_fwd (hwnc = 0) / ssad_conv_igemm_fwd_hwnc (hwnc = 1) gives a problem:
+ * BM * 100000 + BN * 100 + BK of the workgroup tile, negated when its rows are position-major.  Measurement aid only
+ * (bench.py names the instantiations its roofline figure sums over); no reference counterpart. */
+int ssad_conv_igemm_tile(int64_t N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int hwnc);
+
 /* Replaces F.adaptive_avg_pool2d(., (1,1)) + flatten + torch.cat (models.py:227-245):
  * out[n*out_stride + out_offset + c] = mean over HW of in[n][hw][c]. */
 int ssad_gap_fwd(const float* in, float* out, int64_t N, int HW, int C, int out_stride, int out_offset, int hwnc,
@@ -123,7 +128,7 @@ int ssad_auroc(const float* scores, const uint8_t* labels, int64_t n, void* work
 /* Replaces autograd's conv2d/linear input-gradient (loss.backward() inside pl.Trainer.fit, tools.py:270,:303).
  * w_flipT = ssad_flip_transpose_weight(w_ohwi).  dx = dgrad(dy) (+ residual).  Cout % 32 == 0. */
 int ssad_flip_transpose_weight(const float* w_ohwi, float* out, int O, int I, int KH, int KW, void* stream);
-/* ... for up to 32 filters of one arena in one launch: desc[k] = {src offset, dst offset, O, I, KH, KW} (host memory). */
+/* ... for n filters of one arena, one launch per 32 of them: desc[k] = {src offset, dst offset, O, I, KH, KW} (host memory). */
 int ssad_flip_transpose_batch(const float* src, float* dst, const int64_t* desc, int n, void* stream);
 int ssad_conv_igemm_dgrad(const float* dy, const float* w_flipT, float* dx, const float* residual, int64_t N, int Hy, int Wy,
                           int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride, int pad, void* stream);

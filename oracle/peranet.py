@@ -25,7 +25,7 @@ def _mlp(dim=512, n_hidden=3):
 class OraclePeraNet(nn.Module):
     """state_dict keys identical to the reference's PeraNet (153 entries, SURVEY s.5)."""
 
-    def __init__(self, layer_outputs=("layer2", "layer3"), num_classes=4):
+    def __init__(self, layer_outputs=("layer2", "layer3"), num_classes=4, latent_space_layers=5):
         super().__init__()
         self.feature_extractor = ResNet18()
         self.feature_extractor.fc = nn.Identity()          # models.py:60-61
@@ -33,7 +33,8 @@ class OraclePeraNet(nn.Module):
         dim = 512 + (64 if "layer1" in layer_outputs else 0) \
             + (128 if "layer2" in layer_outputs else 0) + (256 if "layer3" in layer_outputs else 0)
         self.concatenator = nn.Sequential(nn.Linear(dim, 512, bias=False), nn.BatchNorm1d(512))  # :91-95
-        self.latent_space = _mlp()
+        # models.py:138-141 hands latent_space_layers - 1 to the builder of :65-88: that many entries, all but the last hidden
+        self.latent_space = _mlp(n_hidden=max(latent_space_layers - 1, 1) - 1)
         self.classifier = nn.Linear(512, num_classes)       # :98-99
         self.patch_level = False
         self.batch = None

@@ -12,7 +12,7 @@ IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 
 
-def seeded_state_dict(seed=0, layer_outputs=("layer2", "layer3")):
+def seeded_state_dict(seed=0, layer_outputs=("layer2", "layer3"), latent_space_layers=5):
     """Reference-named state_dict (feature_extractor.*, concatenator.*, latent_space.*, classifier.*).
 
     Convs: kaiming-normal fan_out/relu (the torchvision ResNet init, keeps the signal alive through
@@ -23,7 +23,7 @@ def seeded_state_dict(seed=0, layer_outputs=("layer2", "layer3")):
     g = torch.Generator().manual_seed(seed)
     with torch.random.fork_rng():
         torch.manual_seed(seed)
-        m = OraclePeraNet(layer_outputs=layer_outputs)
+        m = OraclePeraNet(layer_outputs=layer_outputs, latent_space_layers=latent_space_layers)
     with torch.no_grad():
         for mod in m.modules():
             if isinstance(mod, nn.Conv2d):

@@ -945,17 +945,17 @@ int dispatch_x3(const ConvParams& p, hipStream_t st) {
     return launch<128, 128, 2, 2, 32, TS, POS, true, 3>(p, st);
 }
 
-template <int TS, bool POS>
-int dispatch(const ConvParams& p, hipStream_t st) {
+// Tile of the exact-fp32 instantiation a problem is given (also reported by ssad_conv_igemm_tile: bench.py names the
+// instantiations its roofline sums over)
+enum IgemmTile { T_256x64_K16 = 0, T_256x64_SB, T_128x64, T_256x128, T_256x128_W4, T_128x256, T_64x64, T_128x128 };
+
+template <bool POS>
+IgemmTile pick_tile(const ConvParams& p) {
     static const int variant = getenv("SSAD_CONV64_VARIANT") ? atoi(getenv("SSAD_CONV64_VARIANT")) : 1;
-    if (p.Cout <= 64) {
-        if (variant == 2) return launch<256, 64, 2, 2, 32, TS, POS, false>(p, st);
-        if (variant == 1) return launch<256, 64, 2, 2, 16, TS, POS>(p, st);
-        return launch<128, 64, 1, 2, 32, TS, POS>(p, st);
-    }
+    if (p.Cout <= 64) return variant == 2 ? T_256x64_SB : variant == 1 ? T_256x64_K16 : T_128x64;
     static const int big = getenv("SSAD_CONV128_VARIANT") ? atoi(getenv("SSAD_CONV128_VARIANT")) : 0;
-    if (big == 1) return launch<256, 128, 2, 2, 32, TS, POS>(p, st);
-    if (big == 2) return launch<256, 128, 4, 2, 32, TS, POS>(p, st);      // one workgroup per CU, four waves of 128 x 64
+    if (big == 1) return T_256x128;
+    if (big == 2) return T_256x128_W4;                                    // one workgroup per CU, four waves of 128 x 64
     // 128 x 256 tile (four waves of 64 x 128, one workgroup per CU) where Cout is a multiple of 256 and the launch still fills the
     // chip: 12 staged pieces per 128 MFMAs instead of 16 -- the per-piece cost is what a K-step loses (profiles/r03_igemm_phases.md).
     // Measured (same run): layer3 / layer4 training convs 0.635 -> 0.612 / 0.606 -> 0.586 ms, position-major scoring convs
@@ -963,7 +963,7 @@ int dispatch(const ConvParams& p, hipStream_t st) {
     static const int wide_min = getenv("SSAD_CONV_WIDE_GRID") ? atoi(getenv("SSAD_CONV_WIDE_GRID")) : 256;
     if (big != 5 && p.Cout % 256 == 0 && wide_min > 0) {
         const int64_t rows = POS ? cdiv64(p.N, 128) * p.Ho * p.Wo : cdiv64(p.M, 128);
-        if (rows * (p.Cout / 256) >= wide_min) return launch<128, 256, 2, 4, 32, TS, POS>(p, st);
+        if (rows * (p.Cout / 256) >= wide_min) return T_128x256;
     }
     // small problems (batch 32-96 on the 8x8 / 16x16 maps of layer3 / layer4): 128x128 tiles leave CUs idle -- fewer than
     // ~1.5 workgroups per CU -- so the 128x64 tile doubles the grid (measured at batch 96 / 32: see DESIGN.md)
@@ -973,10 +973,24 @@ int dispatch(const ConvParams& p, hipStream_t st) {
     static const int tiny_min = getenv("SSAD_CONV_TINY_GRID") ? atoi(getenv("SSAD_CONV_TINY_GRID")) : 200;
     if (!POS) {
         const int64_t g128 = cdiv64(p.M, 128) * ((p.Cout + 127) / 128);
-        if (cdiv64(p.M, 128) * ((p.Cout + 63) / 64) < tiny_min && p.M > 128) return launch<64, 64, 1, 1, 32, TS, POS>(p, st);
-        if (g128 < small_min) return launch<128, 64, 1, 2, 32, TS, POS>(p, st);
+        if (cdiv64(p.M, 128) * ((p.Cout + 63) / 64) < tiny_min && p.M > 128) return T_64x64;
+        if (g128 < small_min) return T_128x64;
     }
-    return launch<128, 128, 2, 2, 32, TS, POS>(p, st);
+    return T_128x128;
+}
+
+template <int TS, bool POS>
+int dispatch(const ConvParams& p, hipStream_t st) {
+    switch (pick_tile<POS>(p)) {
+        case T_256x64_SB: return launch<256, 64, 2, 2, 32, TS, POS, false>(p, st);
+        case T_256x64_K16: return launch<256, 64, 2, 2, 16, TS, POS>(p, st);
+        case T_128x64: return launch<128, 64, 1, 2, 32, TS, POS>(p, st);
+        case T_256x128: return launch<256, 128, 2, 2, 32, TS, POS>(p, st);
+        case T_256x128_W4: return launch<256, 128, 4, 2, 32, TS, POS>(p, st);
+        case T_128x256: return launch<128, 256, 2, 4, 32, TS, POS>(p, st);
+        case T_64x64: return launch<64, 64, 1, 1, 32, TS, POS>(p, st);
+        default: return launch<128, 128, 2, 2, 32, TS, POS>(p, st);
+    }
 }
 
 int conv_fwd_impl(const float* in, const float* w_ohwi, float* out, const float* scale, const float* shift,
@@ -1093,6 +1107,22 @@ extern "C" int ssad_conv_igemm_fwd_hwnc(const float* in, const float* w_ohwi, fl
                                         const float* shift, const float* residual, int relu, int64_t N, int H, int W,
                                         int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream) {
     return conv_fwd_impl(in, w_ohwi, out, scale, shift, residual, relu, N, H, W, Cin, Cout, KH, KW, stride, pad, 1, stream);
+}
+
+// Which instantiation ssad_conv_igemm_fwd (hwnc = 0) / ssad_conv_igemm_fwd_hwnc (hwnc = 1) runs a problem on, as
+// BM * 100000 + BN * 100 + BK, negative when the rows are position-major (POS): what bench.py's roofline object names.
+extern "C" int ssad_conv_igemm_tile(int64_t N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int hwnc) {
+    ConvParams p;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
+    p.Ho = (H + 2 * pad - KH) / stride + 1;
+    p.Wo = (W + 2 * pad - KW) / stride + 1;
+    p.M = N * p.Ho * p.Wo;
+    const bool posmajor = hwnc || (pad > 0 && N >= 128 && p.Ho * p.Wo <= 4);
+    static const int dims[8][3] = {{256, 64, 16}, {256, 64, 32}, {128, 64, 32}, {256, 128, 32}, {256, 128, 32}, {128, 256, 32},
+                                   {64, 64, 32}, {128, 128, 32}};
+    const int t = posmajor ? (int)pick_tile<true>(p) : (int)pick_tile<false>(p);
+    const int code = dims[t][0] * 100000 + dims[t][1] * 100 + dims[t][2];
+    return posmajor ? -code : code;
 }
 
 // dgrad: dx[n][iy][ix][ci] = sum_{ky,kx,co} dy[n][(iy+pad-ky)/s][(ix+pad-kx)/s][co] * w[co][ky][kx][ci] (+ residual).

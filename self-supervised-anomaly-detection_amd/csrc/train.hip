@@ -1055,22 +1055,26 @@ extern "C" int ssad_bn_apply_bwd_mask(const float* dy, const uint8_t* mask4, con
 }
 
 
-// ssad_flip_transpose_weight for n <= 32 filters at once: desc[k] = {src offset, dst offset, O, I, KH, KW} (floats, host
-// memory), sources inside `src`, results inside `dst`.
+// ssad_flip_transpose_weight for n filters at once: desc[k] = {src offset, dst offset, O, I, KH, KW} (floats, host
+// memory), sources inside `src`, results inside `dst`.  One launch per 32 filters (the kernel's table travels as a launch
+// argument): PeraNet() with its default head is one launch, a deeper latent_space_layers two or more.
 extern "C" int ssad_flip_transpose_batch(const float* src, float* dst, const int64_t* desc, int n, void* stream) {
-    SSAD_CHECK_ARG(src && dst && desc && n > 0 && n <= 32, "bad argument");
-    FlipTable t;
-    t.n = n;
-    int64_t acc = 0;
-    for (int k = 0; k < n; ++k) {
-        for (int j = 0; j < 6; ++j) t.e[k][j] = desc[6 * k + j];
-        SSAD_CHECK_ARG(t.e[k][2] > 0 && t.e[k][3] > 0 && t.e[k][4] > 0 && t.e[k][5] > 0, "bad filter shape");
-        t.e[k][6] = acc;
-        acc += t.e[k][4] * t.e[k][5] * ((t.e[k][2] + 31) / 32) * ((t.e[k][3] + 31) / 32);     // taps x (o, i) tiles
+    SSAD_CHECK_ARG(src && dst && desc && n > 0, "bad argument");
+    for (int k = 0; k < n; ++k)
+        SSAD_CHECK_ARG(desc[6 * k + 2] > 0 && desc[6 * k + 3] > 0 && desc[6 * k + 4] > 0 && desc[6 * k + 5] > 0, "bad filter shape");
+    for (int base = 0; base < n; base += 32) {
+        FlipTable t;
+        t.n = n - base < 32 ? n - base : 32;
+        int64_t acc = 0;
+        for (int k = 0; k < t.n; ++k) {
+            for (int j = 0; j < 6; ++j) t.e[k][j] = desc[6 * (base + k) + j];
+            t.e[k][6] = acc;
+            acc += t.e[k][4] * t.e[k][5] * ((t.e[k][2] + 31) / 32) * ((t.e[k][3] + 31) / 32);     // taps x (o, i) tiles
+        }
+        t.total = acc;
+        SSAD_CHECK_ARG(acc < (int64_t)2147483647, "too many tiles");
+        hipLaunchKernelGGL(flip_transpose_batch_kernel, dim3((unsigned)acc), dim3(256), 0, (hipStream_t)stream, src, dst, t);
+        SSAD_CHECK_LAUNCH();
     }
-    t.total = acc;
-    SSAD_CHECK_ARG(acc < (int64_t)2147483647, "too many tiles");
-    hipLaunchKernelGGL(flip_transpose_batch_kernel, dim3((unsigned)acc), dim3(256), 0, (hipStream_t)stream, src, dst, t);
-    SSAD_CHECK_LAUNCH();
     return 0;
 }

@@ -7,6 +7,7 @@ helpers (dataset_generator) and the same distributions.  It only produces number
 one record per sample to csrc/augment.hip, which does every per-pixel operation for the whole batch.
 """
 import ctypes
+import os
 import random
 
 import numpy as np
@@ -202,44 +203,111 @@ def sample_defect(subject, img_u8, seg_mask, cuts_u8=None, patch_localization=Fa
     return rec, (h, w)
 
 
+class DefectSampler:
+    """Host half of the pipeline: one ssad_aug_params record per sample from the category's uint8 images and object masks.
+    Holds numpy arrays only (no device, no torch state), so a sampler worker rebuilds it from arrays mapped out of shared memory."""
+
+    def __init__(self, subject, images_u8, seg_masks, cuts_u8=None, patch_localization=False, patch_size=64, mask_index=None):
+        self.subject, self.patch_localization, self.patch_size = subject, patch_localization, patch_size
+        self.images_cpu = images_u8 if isinstance(images_u8, np.memmap) else np.ascontiguousarray(images_u8, dtype=np.uint8)
+        self.cuts_cpu = None if cuts_u8 is None else (cuts_u8 if isinstance(cuts_u8, np.memmap) else
+                                                        np.ascontiguousarray(cuts_u8, dtype=np.uint8))
+        masks = np.asarray(seg_masks, dtype=bool)
+        if masks.ndim == 2:
+            masks = masks[None]
+        n = self.images_cpu.shape[0]
+        if mask_index is None:
+            # one mask for the whole category (fixed objects, textures) or one per image (screw, ...): identical masks are kept once
+            if masks.shape[0] == 1 or (masks.strides[0] == 0):
+                masks, mask_index = np.ascontiguousarray(masks[:1]), np.zeros(n, np.int64)
+            else:
+                assert masks.shape[0] == n
+                uniq, mask_index, seen = [], np.zeros(n, np.int64), {}
+                for i in range(n):
+                    k = masks[i].tobytes()
+                    if k not in seen:
+                        seen[k] = len(uniq)
+                        uniq.append(masks[i])
+                    mask_index[i] = seen[k]
+                masks = np.stack(uniq)
+        self.masks_unique, self.mask_index = masks, np.asarray(mask_index, dtype=np.int64)
+        self._coords = {}
+
+    def mask_of(self, i):
+        return self.masks_unique[self.mask_index[i]]
+
+    @property
+    def masks(self):
+        return self.masks_unique[self.mask_index]
+
+    def sample(self, indices):
+        """One record per index, drawn from the process-global python / numpy / torch RNG streams in the order
+        PretextTaskDataset.__getitem__ draws.  -> (records [B] of AUG_DTYPE, (h, w) of the synthesised images)."""
+        recs, hw = [], None
+        for i in np.asarray(indices, dtype=np.int64):
+            r, hw = sample_defect(self.subject, self.images_cpu[i], self.mask_of(i), self.cuts_cpu, self.patch_localization,
+                                  self.patch_size, coords=self._coords_of(i))
+            recs.append(r)
+        return np.stack(recs), hw
+
+    def _coords_of(self, i):
+        """mask_coordinates of image i's object mask, computed once per distinct mask (fixed-object categories share one; for
+        per-image masks the cache keeps the most recent 64)."""
+        if self.patch_localization:
+            return None                      # the mask is cropped per sample there
+        key = int(self.mask_index[i])
+        c = self._coords.get(key)
+        if c is None:
+            if len(self._coords) >= 64:
+                self._coords.pop(next(iter(self._coords)))
+            c = self._coords[key] = mask_coordinates(self.masks_unique[key])
+        return c
+
+    # ---- publication to sampler workers: arrays as .npy files in shared memory, mapped read-only by the workers ----
+    def publish(self):
+        """-> (descriptor, paths): a small picklable description a worker rebuilds this sampler from."""
+        import tempfile
+        base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+        d = tempfile.mkdtemp(prefix="ssad_sampler_", dir=base)
+        files = {}
+        for name, arr in (("images", self.images_cpu), ("masks", self.masks_unique), ("mask_index", self.mask_index),
+                          ("cuts", self.cuts_cpu)):
+            if arr is not None:
+                files[name] = os.path.join(d, name + ".npy")
+                np.save(files[name], np.ascontiguousarray(arr))
+        desc = {"key": d, "subject": self.subject, "patch_localization": self.patch_localization, "patch_size": self.patch_size,
+                "files": files}
+        return desc, d
+
+    @staticmethod
+    def attach(desc):
+        f = desc["files"]
+        ld = lambda k: np.load(f[k], mmap_mode="r") if k in f else None
+        return DefectSampler(desc["subject"], ld("images"), np.asarray(ld("masks")), ld("cuts"), desc["patch_localization"],
+                             desc["patch_size"], mask_index=np.asarray(ld("mask_index")))
+
+
 class GpuCutPaste:
     """Batch augmenter: images stay on the GPU as uint8 HWC; returns (x fp32 NCHW normalised, y int64, original fp32)."""
 
     def __init__(self, subject, images_u8, seg_masks, cuts_u8=None, patch_localization=False, patch_size=64, device="cuda"):
         assert _hip.lib().ssad_aug_params_size() == AUG_DTYPE.itemsize, "ssad_aug_params layout drifted from augment.py"
         self.subject, self.patch_localization, self.patch_size = subject, patch_localization, patch_size
-        self.images_cpu = np.ascontiguousarray(images_u8, dtype=np.uint8)
-        self.cuts_cpu = None if cuts_u8 is None else np.ascontiguousarray(cuts_u8, dtype=np.uint8)
-        self.masks = np.asarray(seg_masks, dtype=bool)
-        if self.masks.ndim == 2:
-            self.masks = np.broadcast_to(self.masks, self.images_cpu.shape[:3])
+        self.host = DefectSampler(subject, images_u8, seg_masks, cuts_u8, patch_localization, patch_size)
+        self.images_cpu, self.cuts_cpu = self.host.images_cpu, self.host.cuts_cpu
         self.device = torch.device(device)
         self.images = torch.from_numpy(self.images_cpu).to(self.device)
         self.cuts = None if self.cuts_cpu is None else torch.from_numpy(self.cuts_cpu).to(self.device)
         self._mean = (ctypes.c_float * 3)(*IMAGENET_MEAN)
         self._std = (ctypes.c_float * 3)(*IMAGENET_STD)
-        self._coords = {}
+
+    @property
+    def masks(self):
+        return self.host.masks
 
     def sample(self, indices):
-        """Host half: one record per index, drawn from the process-global python / numpy / torch RNG streams in the order
-        PretextTaskDataset.__getitem__ draws.  -> (records [B] of AUG_DTYPE, (h, w) of the synthesised images)."""
-        recs, hw = [], None
-        for i in np.asarray(indices, dtype=np.int64):
-            r, hw = sample_defect(self.subject, self.images_cpu[i], self.masks[i], self.cuts_cpu, self.patch_localization,
-                                  self.patch_size, coords=self._coords_of(i))
-            recs.append(r)
-        return np.stack(recs), hw
-
-    def _coords_of(self, i):
-        """mask_coordinates of image i's object mask, computed once per distinct mask (fixed-object categories share one)."""
-        if self.patch_localization:
-            return None                      # the mask is cropped per sample there
-        m = self.masks[i]
-        key = m.__array_interface__["data"][0]
-        c = self._coords.get(key)
-        if c is None:
-            c = self._coords[key] = mask_coordinates(m)
-        return c
+        """Host half (DefectSampler.sample) in this process."""
+        return self.host.sample(indices)
 
     def __call__(self, indices):
         idx = np.asarray(indices, dtype=np.int64)
@@ -265,21 +333,74 @@ class GpuCutPaste:
         return out, y, orig
 
 
-_POOL_STATE = {}      # key -> GpuCutPaste of the forking parent; read by the sampler workers (fork: no pickling of the images)
+# ---------------------------------------------------------------------------------------------
+# sampler workers
+# ---------------------------------------------------------------------------------------------
+_POOL_STATE = {}      # key -> sampler (DefectSampler / GpuCutPaste) of THIS process: in-process lookups and, in a worker, the
+                      # samplers it has attached so far
+_POOL = {"exe": None, "size": 0, "ctx": None}
 
 
-def _batch_seed(base, epoch, batch_no, rank):
-    return (((int(base) * 1000003 + int(epoch)) * 1000003 + int(batch_no)) * 1000003 + int(rank)) % (2 ** 63)
+def _batch_seed(base, epoch, batch_no, rank, stage=0):
+    """Seed of one batch: a function of (loader base seed, stage, epoch, batch number, rank) only.  `stage` counts how often the
+    loader's epoch counter has restarted (tools.training fits twice -- projection head, then fine tuning -- and each fit numbers its
+    epochs from 0): without it the second fit would replay the first one's synthetic batches."""
+    s = (int(base) * 1000003 + int(stage)) if stage else int(base)
+    return (((s * 1000003 + int(epoch)) * 1000003 + int(batch_no)) * 1000003 + int(rank)) % (2 ** 63)
 
 
-def _pool_sample(key, seed, idx):
-    """Runs in a sampler worker: the records of one batch under that batch's own seed."""
-    aug = _POOL_STATE[key]
+def _sampler_for(desc):
+    if not isinstance(desc, dict):
+        return _POOL_STATE[desc]
+    smp = _POOL_STATE.get(desc["key"])
+    if smp is None:
+        if len(_POOL_STATE) >= 8:            # a worker outlives the loaders it served: drop the oldest mappings
+            _POOL_STATE.pop(next(iter(_POOL_STATE)))
+        smp = _POOL_STATE[desc["key"]] = DefectSampler.attach(desc)
+    return smp
+
+
+def _pool_sample(desc, seed, idx):
+    """Runs in a sampler worker: the records of one batch under that batch's own seed.  desc: a key of _POOL_STATE or the
+    descriptor DefectSampler.publish returned."""
+    smp = _sampler_for(desc)
     random.seed(seed)
     np.random.seed(seed % (2 ** 32))
     torch.manual_seed(seed)
-    recs, hw = aug.sample(idx)
+    recs, hw = smp.sample(idx)
     return recs.tobytes(), hw
+
+
+def _pool_warm(_):
+    return os.getpid()
+
+
+def sampler_pool(num_workers):
+    """The process-wide pool of sampler workers (created on first use, grown when a loader asks for more workers, shut down at
+    exit).  Workers hold no GPU state: they are started through datasets._worker_context() -- plain fork while this process has not
+    touched the GPU, a fork SERVER afterwards (fork()ing a process with live HIP queues stalls them: datasets._worker_context) --
+    and receive a loader's arrays through shared-memory files, not through the fork."""
+    from concurrent.futures import ProcessPoolExecutor
+    from .datasets import _hidden_main, _worker_context
+    if _POOL["exe"] is not None and _POOL["size"] >= num_workers:
+        return _POOL["exe"]
+    if _POOL["exe"] is not None:
+        _POOL["exe"].shutdown(wait=False, cancel_futures=True)
+    ctx = _worker_context(preload=("self_supervised.augment",))
+    exe = ProcessPoolExecutor(num_workers, mp_context=ctx)
+    with _hidden_main(ctx):
+        list(exe.map(_pool_warm, range(4 * num_workers)))       # start the workers now (imports done before the first epoch)
+    if _POOL["exe"] is None:
+        import atexit
+        atexit.register(_shutdown_pool)
+    _POOL.update(exe=exe, size=num_workers, ctx=ctx)
+    return exe
+
+
+def _shutdown_pool():
+    if _POOL["exe"] is not None:
+        _POOL["exe"].shutdown(wait=False, cancel_futures=True)
+        _POOL.update(exe=None, size=0)
 
 
 class GpuPretextLoader:
@@ -290,10 +411,14 @@ class GpuPretextLoader:
     Host side of a batch = drawing one parameter record per sample (0.4 ms each: label, boxes, polygon, scar, poly-line, jitter
     -- numbers only).  ``num_workers = 0``: drawn in this process from the global RNG streams, sample after sample in the
     order the reference's ``__getitem__`` draws (what the parity tests pin).  ``num_workers > 0`` (the counterpart of the
-    reference's ``DataLoader(num_workers=8)``, src/self_supervised/datasets.py:501-533): forked sampler processes draw whole
-    batches ahead of the training loop, batch b of epoch e under its own seed (base_seed, e, b, rank), so the stream does not
+    reference's ``DataLoader(num_workers=8)``, src/self_supervised/datasets.py:501-533): sampler processes draw whole
+    batches ahead of the training loop, batch b of epoch e under its own seed (base_seed, stage, e, b, rank), so the stream does not
     depend on the number of workers or on their timing; the device work of a batch is unchanged.  Measured: 2.4 k samples/s per
-    worker at 256 x 256 image level; 8 workers keep up with the 7.4 k img/s of the training step."""
+    worker at 256 x 256 image level; 8 workers keep up with the 7.4 k img/s of the training step.
+
+    Epochs: ``shard(world, rank, epoch)`` / ``set_epoch(epoch)`` name the epoch about to be iterated; when the counter does not
+    advance (a second ``fit`` numbering its epochs from 0 again) the loader's ``stage`` moves on, so no two passes over the loader
+    ever share a shuffle or a batch seed -- the reference draws fresh augmentations continuously."""
 
     def __init__(self, dataset, batch_size, shuffle=True, drop_last=True, device="cuda", rank=0, world=1, num_workers=0,
                  base_seed=0, prefetch_batches=None):
@@ -301,24 +426,31 @@ class GpuPretextLoader:
         from .dataset_generator import obj_mask
         self.dataset, self.batch_size, self.shuffle, self.drop_last = dataset, batch_size, shuffle, drop_last
         self.rank, self.world, self.epoch = rank, world, 0
+        self.stage, self._last_epoch = 0, None
         names = list(dict.fromkeys(dataset.images_filenames))            # duplicated file lists decode once
         self.slot = {n: i for i, n in enumerate(names)}
         imgs = [np.asarray(Image.open(n).resize(dataset.imsize).convert('RGB')) for n in names]
         if dataset.subject in constants.NON_FIXED_OBJECTS():
-            masks = [np.asarray(obj_mask(Image.fromarray(im)).convert('1')) for im in imgs]
+            masks = np.stack([np.asarray(obj_mask(Image.fromarray(im)).convert('1')) for im in imgs])
         else:
-            masks = [np.asarray(dataset.fixed_segmentation.convert('1'))] * len(imgs)
+            masks = np.asarray(dataset.fixed_segmentation.convert('1'))
         cuts = np.stack([np.asarray(c) for c in dataset.images_for_cut]) if dataset.subject in constants.TEXTURES() else None
-        self.aug = GpuCutPaste(dataset.subject, np.stack(imgs), np.stack(masks), cuts, dataset.patch_localization,
+        self.aug = GpuCutPaste(dataset.subject, np.stack(imgs), masks, cuts, dataset.patch_localization,
                                dataset.patch_size, device)
         self.index = np.array([self.slot[n] for n in dataset.images_filenames])
         self.num_workers = int(num_workers)
         self.base_seed = int(base_seed)
         self.prefetch_batches = prefetch_batches if prefetch_batches is not None else 2 * max(self.num_workers, 1)
-        self._pool, self._key = None, None
+        self._desc, self._dir = None, None
+
+    def set_epoch(self, epoch):
+        if self._last_epoch is not None and epoch <= self._last_epoch:
+            self.stage += 1
+        self.epoch = self._last_epoch = int(epoch)
 
     def shard(self, world, rank, epoch):
-        self.world, self.rank, self.epoch = world, rank, epoch
+        self.world, self.rank = world, rank
+        self.set_epoch(epoch)
         return self
 
     def __len__(self):
@@ -328,26 +460,21 @@ class GpuPretextLoader:
     def _batches(self):
         order = np.arange(len(self.index))
         if self.shuffle:
-            order = np.random.RandomState(1234 + self.epoch).permutation(len(order))
+            order = np.random.RandomState((1234 + self.epoch + 7919 * self.stage) % (2 ** 32)).permutation(len(order))
         order = order[self.rank::self.world]
         return [self.index[order[i * self.batch_size:(i + 1) * self.batch_size]] for i in range(len(self))]
 
-    def _ensure_pool(self):
-        if self._pool is None:
-            import multiprocessing
-            from concurrent.futures import ProcessPoolExecutor
-            self._key = id(self)
-            _POOL_STATE[self._key] = self.aug            # visible to the children through fork
-            for i in range(len(self.aug.images_cpu)):    # fill the coordinate cache before forking: children inherit it
-                self.aug._coords_of(i)
-            self._pool = ProcessPoolExecutor(self.num_workers, mp_context=multiprocessing.get_context("fork"))
-        return self._pool
+    def _published(self):
+        if self._desc is None:
+            self._desc, self._dir = self.aug.host.publish()
+        return self._desc
 
     def close(self):
-        if self._pool is not None:
-            self._pool.shutdown(wait=False, cancel_futures=True)
-            _POOL_STATE.pop(self._key, None)
-            self._pool = None
+        """Removes the shared-memory copy of the category (workers that still map it keep their mapping until they drop it)."""
+        if self._dir is not None:
+            import shutil
+            shutil.rmtree(self._dir, ignore_errors=True)
+            self._desc = self._dir = None
 
     def __del__(self):
         try:
@@ -361,14 +488,17 @@ class GpuPretextLoader:
             for idx in batches:
                 yield self.aug(idx)
             return
-        pool = self._ensure_pool()
+        from .datasets import _hidden_main
+        pool, desc = sampler_pool(self.num_workers), self._published()
         pending, nxt = [], 0
 
         def submit():
             nonlocal nxt
             if nxt < len(batches):
-                pending.append((batches[nxt], pool.submit(_pool_sample, self._key,
-                                                          _batch_seed(self.base_seed, self.epoch, nxt, self.rank), batches[nxt])))
+                with _hidden_main(_POOL["ctx"]):
+                    fut = pool.submit(_pool_sample, desc, _batch_seed(self.base_seed, self.epoch, nxt, self.rank, self.stage),
+                                      batches[nxt])
+                pending.append((batches[nxt], fut))
                 nxt += 1
         for _ in range(self.prefetch_batches):
             submit()

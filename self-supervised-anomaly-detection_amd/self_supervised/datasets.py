@@ -70,8 +70,8 @@ class MVTecDataset(Dataset):
         return len(self.images_filenames)
 
 
-def _worker_context():
-    """How DataLoader workers are started.  fork()ing a process that has initialised the GPU is what the reference's
+def _worker_context(preload=()):
+    """How DataLoader workers (and the sampler workers of augment.GpuPretextLoader) are started.  fork()ing a process that has initialised the GPU is what the reference's
     DataLoader(num_workers=8) does on Linux, and on this ROCm stack every such fork leaves the parent's GPU queues stalling for
     ~0.1 s at a time afterwards (copy-on-write faults on pages the driver has registered; `tools.inference` measured 10-13 s per
     call and growing with 2 workers against 1.6 s with none, round 3).  Once the GPU is up, workers therefore come from a fork
@@ -83,33 +83,45 @@ def _worker_context():
         name = "forkserver" if torch.cuda.is_initialized() else "fork"
     if name == "forkserver":
         try:
-            mp.set_forkserver_preload(["torch", "numpy", "PIL.Image", "self_supervised.datasets"])
+            mp.set_forkserver_preload(["torch", "numpy", "PIL.Image", "self_supervised.datasets", *preload])
         except Exception:
             pass
     return mp.get_context(name)
 
 
+class _hidden_main:
+    """While fork-server / spawn workers are being started, hide the caller's ``__main__`` from their bootstrap: the reference's
+    driver scripts (src/test_training.py, ...) call ``training(...)`` at module level without an ``if __name__ == "__main__"``
+    guard, which is fine under fork() and would re-run the whole script inside every worker otherwise.  What the workers unpickle
+    lives in this package, so ``__main__`` is not needed there."""
+
+    def __init__(self, ctx):
+        self.active = ctx is not None and ctx.get_start_method() != "fork"
+
+    def __enter__(self):
+        import sys
+        self.main = sys.modules.get("__main__") if self.active else None
+        self.saved = {}
+        if self.main is not None:
+            self.saved = {k: self.main.__dict__[k] for k in ("__spec__", "__file__") if k in self.main.__dict__}
+            self.main.__dict__["__spec__"] = None
+            self.main.__dict__.pop("__file__", None)
+        return self
+
+    def __exit__(self, *exc):
+        if self.main is not None:
+            self.main.__dict__.update(self.saved)
+        return False
+
+
 class _Loader(DataLoader):
-    """DataLoader whose fork-server / spawn workers do not re-import the caller's ``__main__``: the reference's driver scripts
-    (src/test_training.py, ...) call ``training(...)`` at module level without an ``if __name__ == "__main__"`` guard, which is
-    fine under fork() and would re-run the whole script inside every worker otherwise.  The datasets and transforms the workers
-    unpickle live in this package, so ``__main__`` is not needed there; it is hidden only while the workers are started."""
+    """DataLoader whose fork-server / spawn workers do not re-import the caller's ``__main__`` (see _hidden_main)."""
 
     def __iter__(self):
-        ctx = self.multiprocessing_context
-        if not self.num_workers or ctx is None or ctx.get_start_method() == "fork":
+        if not self.num_workers:
             return super().__iter__()
-        import sys
-        main = sys.modules.get("__main__")
-        saved = {k: main.__dict__[k] for k in ("__spec__", "__file__") if main is not None and k in main.__dict__}
-        try:
-            if main is not None:
-                main.__dict__["__spec__"] = None
-                main.__dict__.pop("__file__", None)
+        with _hidden_main(self.multiprocessing_context):
             return super().__iter__()
-        finally:
-            if main is not None:
-                main.__dict__.update(saved)
 
 
 class _DataModule:
@@ -259,6 +271,7 @@ class PretextTaskDatamodule(_DataModule):
                  train_val_split: float = 0.2, seed: int = 0, min_dataset_length: int = 1000, duplication: bool = True,
                  patch_localization: bool = False, patch_size: tuple = 64, dataset_root: str = None,
                  swap_train_val: bool = True, gpu_pipeline: bool = False):
+        self._gpu_loaders = {}
         self.root_dir_train, self.root_dir_test = root_dir + '/train/good/', root_dir + '/test/good/'
         self.subject, self.imsize, self.batch_size, self.train_val_split = subject, imsize, batch_size, train_val_split
         self.seed, self.min_dataset_length, self.duplication = seed, min_dataset_length, duplication
@@ -294,18 +307,25 @@ class PretextTaskDatamodule(_DataModule):
         if stage in ('test', 'predict') or stage is None:
             self.test_dataset = self._ds(self.test_images_filenames)
 
+    def _gpu_loader(self, which, dataset, shuffle, seed):
+        """One GPU-resident loader per split for the life of the datamodule: the category is decoded / uploaded once, and a second
+        ``fit`` on the same datamodule (tools.training: projection head, then fine tuning) continues the loader's random stream
+        instead of replaying it (GpuPretextLoader.stage)."""
+        ld = self._gpu_loaders.get(which)
+        if ld is None or ld.dataset is not dataset:
+            from .augment import GpuPretextLoader
+            ld = self._gpu_loaders[which] = GpuPretextLoader(dataset, self.batch_size, shuffle=shuffle, drop_last=True,
+                                                             num_workers=min(self.num_workers, os.cpu_count() or 1), base_seed=seed)
+        return ld
+
     def train_dataloader(self):
         if self.gpu_pipeline:
-            from .augment import GpuPretextLoader
-            return GpuPretextLoader(self.train_dataset, self.batch_size, shuffle=True, drop_last=True,
-                                    num_workers=min(self.num_workers, os.cpu_count() or 1), base_seed=self.seed)
+            return self._gpu_loader("train", self.train_dataset, True, self.seed)
         return self._loader(self.train_dataset, True, drop_last=True)
 
     def val_dataloader(self):
         if self.gpu_pipeline:
-            from .augment import GpuPretextLoader
-            return GpuPretextLoader(self.val_dataset, self.batch_size, shuffle=False, drop_last=True,
-                                    num_workers=min(self.num_workers, os.cpu_count() or 1), base_seed=self.seed + 1)
+            return self._gpu_loader("val", self.val_dataset, False, self.seed + 1)
         return self._loader(self.val_dataset, False, drop_last=True)
 
     def test_dataloader(self):

@@ -13,10 +13,11 @@ def _new(shape, like):
     return torch.empty(shape, device=like.device, dtype=torch.float32)
 
 
-def _run(kernel, flops, nbytes, rc_fn, exec_flops=None):
+def _run(kernel, flops, nbytes, rc_fn, exec_flops=None, tile=None):
     """Launch through the C ABI; when PROFILE is on, bracket the launch with events on the launch stream.
     flops = ALGORITHMIC FLOPs of the op; exec_flops = the FLOPs the kernel really issues to the matrix cores when that
-    is fewer (position-major convs skip the taps that fall into the zero padding)."""
+    is fewer (position-major convs skip the taps that fall into the zero padding); tile = a callable returning the
+    instantiation's tile code (ssad_conv_igemm_tile), evaluated only while profiling."""
     if PROFILE is None:
         _hip.check(rc_fn())
         return
@@ -24,7 +25,7 @@ def _run(kernel, flops, nbytes, rc_fn, exec_flops=None):
     e0.record()
     _hip.check(rc_fn())
     e1.record()
-    PROFILE.append((kernel, flops, nbytes, e0, e1, flops if exec_flops is None else exec_flops))
+    PROFILE.append((kernel, flops, nbytes, e0, e1, flops if exec_flops is None else exec_flops, tile() if tile else None))
 
 
 def drain_profile():
@@ -32,7 +33,8 @@ def drain_profile():
     global PROFILE
     recs = PROFILE or []
     torch.cuda.synchronize()
-    out = [{"kernel": k, "flops": f, "bytes": b, "ms": e0.elapsed_time(e1), "exec_flops": x} for k, f, b, e0, e1, x in recs]
+    out = [{"kernel": k, "flops": f, "bytes": b, "ms": e0.elapsed_time(e1), "exec_flops": x, "tile": t}
+           for k, f, b, e0, e1, x, t in recs]
     PROFILE = [] if PROFILE is not None else None
     return out
 
@@ -43,6 +45,17 @@ def _inbounds_taps(h, w, kh, kw, stride, pad):
     ny = sum(sum(1 for ky in range(kh) if 0 <= oy * stride - pad + ky < h) for oy in range(ho))
     nx = sum(sum(1 for kx in range(kw) if 0 <= ox * stride - pad + kx < w) for ox in range(wo))
     return ny * nx
+
+
+def igemm_tile_name(n, h, w, cin, cout, kh, kw, stride, pad, hwnc):
+    """Template arguments of the exact-fp32 implicit-GEMM instantiation a problem runs on (csrc/conv_igemm.hip: BM, BN, TM, TN, BK)."""
+    if not hwnc and kh == kw == h == w == 1 and n <= _hip.lib().ssad_linear_small_max_rows():
+        return "<linear_small: 32 x 32 tiles, csrc/linear_small.hip>"
+    code = _hip.lib().ssad_conv_igemm_tile(n, h, w, cin, cout, kh, kw, stride, pad, int(hwnc))
+    pos, code = code < 0, abs(code)
+    bm, bn, bk = code // 100000, code // 100 % 1000, code % 100
+    tm, tn = {(256, 64): (2, 2), (128, 64): (1, 2), (256, 128): (2, 2), (128, 256): (2, 4), (64, 64): (1, 1)}.get((bm, bn), (2, 2))
+    return f"<{bm},{bn},{tm},{tn},{bk},1,{'true' if pos else 'false'}>"
 
 
 def _kname(base, mode):
@@ -165,7 +178,8 @@ def conv_fwd_hwnc(x, w_ohwi, scale=None, shift=None, residual=None, relu=False, 
          lambda: _hip.lib().ssad_conv_igemm_fwd_hwnc(_hip.ptr(x), _hip.ptr(w_ohwi), _hip.ptr(out), _hip.ptr(scale, True),
                                                      _hip.ptr(shift, True), _hip.ptr(residual, True), int(relu), n, h, w,
                                                      cin, cout, kh, kw, stride, pad, _hip.stream()),
-         exec_flops=2.0 * n * cout * cin * _inbounds_taps(h, w, kh, kw, stride, pad) if PROFILE is not None else None)
+         exec_flops=2.0 * n * cout * cin * _inbounds_taps(h, w, kh, kw, stride, pad) if PROFILE is not None else None,
+         tile=lambda: igemm_tile_name(n, h, w, cin, cout, kh, kw, stride, pad, 1))
     return out
 
 
@@ -189,7 +203,8 @@ def conv_fwd(x, w_ohwi, scale=None, shift=None, residual=None, relu=False, strid
           _hip.lib().ssad_conv_igemm_fwd)
     _run(_kname("conv_igemm", bf16), 2.0 * out.numel() * kh * kw * cin, nb,
          lambda: fn(_hip.ptr(x), _hip.ptr(w_ohwi), _hip.ptr(out), _hip.ptr(scale, True), _hip.ptr(shift, True),
-                    _hip.ptr(residual, True), int(relu), n, h, w, cin, cout, kh, kw, stride, pad, _hip.stream()))
+                    _hip.ptr(residual, True), int(relu), n, h, w, cin, cout, kh, kw, stride, pad, _hip.stream()),
+         tile=None if bf16 else (lambda: igemm_tile_name(n, h, w, cin, cout, kh, kw, stride, pad, 0)))
     return out
 
 
@@ -208,7 +223,8 @@ def conv_fwd_stats(x, w_ohwi, eps, momentum, running_mean, running_var, stride=1
          lambda: lib.ssad_conv_igemm_fwd_stats(_hip.ptr(x), _hip.ptr(w_ohwi), _hip.ptr(out), n, h, w, cin, cout, kh, kw,
                                                stride, pad, int(bf16), eps, momentum, _hip.ptr(mean), _hip.ptr(invstd),
                                                _hip.ptr(running_mean, True), _hip.ptr(running_var, True), ws.data_ptr(),
-                                               _hip.stream()))
+                                               _hip.stream()),
+         tile=None if bf16 else (lambda: igemm_tile_name(n, h, w, cin, cout, kh, kw, stride, pad, 0)))
     return out, mean, invstd
 
 
@@ -280,7 +296,8 @@ def linear_fwd(x, w, scale=None, shift=None, relu=False, x3=False):
     _run("conv_igemm_f32", 2.0 * n * cin * cout, 4.0 * (x.numel() + out.numel() + w.numel()),
          lambda: _hip.lib().ssad_conv_igemm_fwd(_hip.ptr(x), _hip.ptr(w), _hip.ptr(out), _hip.ptr(scale, True),
                                                 _hip.ptr(shift, True), None, int(relu), n, 1, 1, cin, cout, 1, 1, 1, 0,
-                                                _hip.stream()))
+                                                _hip.stream()),
+         tile=lambda: igemm_tile_name(n, 1, 1, cin, cout, 1, 1, 1, 0, 0))
     return out
 
 
@@ -359,7 +376,9 @@ def conv_dgrad(dy, w_flipT, x_shape, stride, pad, residual=None, bf16=False, res
              4.0 * (dy.numel() + dx.numel() * 2 + w_flipT.numel()),
              lambda: _hip.lib().ssad_conv_igemm_dgrad_masked(_hip.ptr(dy), _hip.ptr(w_flipT), _hip.ptr(dx), _hip.ptr(residual),
                                                              res_mask.data_ptr(), n, hy, wy, cout, x_shape[1], x_shape[2], cin, kh,
-                                                             kw, stride, pad, _hip.stream()))
+                                                             kw, stride, pad, _hip.stream()),
+             tile=lambda: igemm_tile_name(n, x_shape[1], x_shape[2], cout, cin, kh, kw, 1, kh - 1 - pad, 0).replace(
+                 ",1,false>", f",{stride},false>"))
         return dx
     fn = (_hip.lib().ssad_conv_igemm_dgrad_x6 if bf16 == 6 else _hip.lib().ssad_conv_igemm_dgrad_x3 if bf16 == 3 else
           _hip.lib().ssad_conv_igemm_dgrad_f16 if bf16 == 2 else
@@ -368,7 +387,9 @@ def conv_dgrad(dy, w_flipT, x_shape, stride, pad, residual=None, bf16=False, res
          2.0 * dx.numel() * kh * kw * cout / (stride * stride),
          4.0 * (dy.numel() + dx.numel() * (2 if residual is not None else 1) + w_flipT.numel()),
          lambda: fn(_hip.ptr(dy), _hip.ptr(w_flipT), _hip.ptr(dx), _hip.ptr(residual, True), n, hy, wy, cout, x_shape[1],
-                    x_shape[2], cin, kh, kw, stride, pad, _hip.stream()))
+                    x_shape[2], cin, kh, kw, stride, pad, _hip.stream()),
+         tile=None if bf16 else (lambda: igemm_tile_name(n, x_shape[1], x_shape[2], cout, cin, kh, kw, 1, kh - 1 - pad, 0).replace(
+             ",1,false>", f",{stride},false>")))
     return dx
 
 

@@ -85,11 +85,14 @@ def training(dataset_dir: str, outputs_dir: str, subject: str, imsize: tuple = (
              patchsize: int = 32, seed: int = 0, batch_size: int = 96, projection_training_params: tuple = (10, 0.03),
              fine_tune_params: tuple = (30, 0.005), trainer_kwargs: dict = None, gpu_pipeline: bool = None) -> dict:
     """tools.py:204-306.  Returns the two metric histories (the reference plots them).
-    gpu_pipeline: False = the reference's input path (PretextTaskDataset.__getitem__ in 8 DataLoader workers, its exact random
-    stream; ~300 img/s at 256 x 256), True = batches synthesised on the GPU from host-drawn parameter records (same sampler code,
-    per-batch seeds; 5.7 k img/s fp32 / 8.1 k precision 16 at batch 96); None = SSAD_GPU_PIPELINE from the environment (default 0)."""
+    gpu_pipeline: True = batches synthesised on the GPU from host-drawn parameter records (the sampler restates __getitem__'s draws,
+    the kernels are byte-identical to the PIL path per record; batches are seeded one by one; 5.7 k img/s fp32 / 8.1 k precision 16
+    at batch 96); False = the reference's input path (PretextTaskDataset.__getitem__ in 8 DataLoader workers, ~300 img/s at
+    256 x 256); None (default) = SSAD_GPU_PIPELINE from the environment when set, else True: the training loop needs the GPU anyway,
+    the two paths draw from the same distributions, and neither reproduces the reference's stream sample for sample (its workers
+    are seeded from torch's base seed per epoch)."""
     if gpu_pipeline is None:
-        gpu_pipeline = os.environ.get("SSAD_GPU_PIPELINE", "0") == "1"
+        gpu_pipeline = os.environ.get("SSAD_GPU_PIPELINE", "1") != "0"
     print('>>> initializing training')
     checkpoint_name = 'best_model.ckpt'
     proj_epochs, proj_lr = projection_training_params

@@ -85,8 +85,12 @@ class Trainer:
             return loader
         sampler = DistributedSampler(loader.dataset, num_replicas=self.world, rank=self.global_rank, shuffle=True)
         sampler.set_epoch(epoch)
-        return DataLoader(loader.dataset, batch_size=loader.batch_size, sampler=sampler, drop_last=True,
-                          num_workers=loader.num_workers)
+        # the same worker start-up rule as the single-rank loaders (datasets._worker_context: a fork server once the GPU is up,
+        # `__main__` hidden from the workers' bootstrap)
+        from .datasets import _Loader, _worker_context
+        return _Loader(loader.dataset, batch_size=loader.batch_size, sampler=sampler, drop_last=True,
+                       num_workers=loader.num_workers,
+                       multiprocessing_context=_worker_context() if loader.num_workers else None)
 
     def fit(self, model, datamodule=None, train_dataloaders=None, val_dataloaders=None):
         self.model = model
@@ -136,6 +140,8 @@ class Trainer:
             self.logged_metrics['train_loss'], self.logged_metrics['train_accuracy'] = sums[0] / n, sums[1] / n
             if val_dataloaders is not None and (epoch + 1) % self.check_val_every_n_epoch == 0:
                 vs = torch.zeros(3, device=self.device)
+                if hasattr(val_dataloaders, "set_epoch"):      # GPU-resident loader: fresh synthetic samples every validation pass
+                    val_dataloaders.set_epoch(epoch)
                 for i, batch in enumerate(val_dataloaders):
                     if self.limit_val_batches is not None and i >= self.limit_val_batches:
                         break
@@ -275,12 +281,27 @@ def gather_bank_rows(embeddings, mask):
 
 
 def gather_bank_steps(steps):
-    """steps: [(embeddings [B][D], mask [B])] of this rank's training steps (equal B: the loaders drop the last batch).  Returns
-    the selected rows of every rank in the order per-step gathering gives -- step 0 of rank 0, step 0 of rank 1, ..., step 1 of
-    rank 0, ... -- with ONE exchange per epoch instead of one per step."""
+    """steps: [(embeddings [B][D], mask [B])] of this rank's training steps.  Returns the selected rows of every rank in the order
+    per-step gathering gives -- step 0 of rank 0, step 0 of rank 1, ..., step 1 of rank 0, ... -- with ONE exchange per epoch
+    instead of one per step.  Batches may differ in size (a user's loader without drop_last, ranks with different last batches):
+    every step is padded to the largest batch of any rank with rows whose mask is off; the mask travels as uint8."""
     rank, world = world_info()
-    emb = torch.stack([e for e, _ in steps])                     # [S][B][D]
-    msk = torch.stack([m for _, m in steps])                     # [S][B]
+    dev, d = steps[0][0].device, steps[0][0].shape[-1]
+    sizes = [int(e.shape[0]) for e, _ in steps]
+    bmax = max(sizes)
+    if world > 1:
+        t = torch.tensor([bmax], device=dev, dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        bmax = int(t.item())
+    if all(b == bmax for b in sizes):
+        emb = torch.stack([e for e, _ in steps])                     # [S][B][D]
+        msk = torch.stack([m for _, m in steps]).to(torch.uint8)     # [S][B]
+    else:
+        emb = torch.zeros((len(steps), bmax, d), device=dev, dtype=steps[0][0].dtype)
+        msk = torch.zeros((len(steps), bmax), device=dev, dtype=torch.uint8)
+        for i, (e, m) in enumerate(steps):
+            emb[i, :e.shape[0]] = e
+            msk[i, :e.shape[0]] = m.to(torch.uint8)
     if world > 1:
         es = [torch.empty_like(emb) for _ in range(world)]
         ms = [torch.empty_like(msk) for _ in range(world)]
@@ -288,7 +309,7 @@ def gather_bank_steps(steps):
         dist.all_gather(ms, msk)
         emb = torch.stack(es, dim=1)                             # [S][W][B][D]
         msk = torch.stack(ms, dim=1)
-    return emb.reshape(-1, emb.shape[-1])[msk.reshape(-1)]
+    return emb.reshape(-1, emb.shape[-1])[msk.reshape(-1).bool()]
 
 
 def gather_in_order(local_items, total):

@@ -72,14 +72,16 @@ def test_window_sum_helper_matches_the_numpy_warp():
                     assert np.array_equal(got, want), (size, left, top, w, h, f is None)
 
 
-def test_sampler_pool_is_deterministic_per_batch():
-    """Forked sampler workers: the records of batch b depend on (base seed, epoch, b, rank) only -- not on how many workers draw
-    them or in which order they finish -- and equal what the same seed gives in-process."""
+def test_sampler_pool_is_deterministic_per_batch(monkeypatch):
+    """Sampler workers: the records of batch b depend on (base seed, stage, epoch, b, rank) only -- not on how many workers draw
+    them, in which order they finish or how they were started (forked with the sampler in memory / started from a fork server and
+    handed the category through shared-memory files) -- and equal what the same seed gives in-process."""
     import multiprocessing
     from concurrent.futures import ProcessPoolExecutor
     from self_supervised import augment
     imgs = np.stack([_image(s, 64) for s in range(6)])
     aug = augment.GpuCutPaste("bottle", imgs, np.broadcast_to(_mask(64), (6, 64, 64)), device="cpu")
+    assert aug.host.masks_unique.shape[0] == 1                      # one mask for the category, kept once
     key = "test-pool"
     augment._POOL_STATE[key] = aug
     batches = [np.array([0, 1, 2, 3]), np.array([4, 5, 0, 1]), np.array([2, 2, 3, 5])]
@@ -90,14 +92,55 @@ def test_sampler_pool_is_deterministic_per_batch():
             with ProcessPoolExecutor(nw, mp_context=multiprocessing.get_context("fork")) as pool:
                 futs = [pool.submit(augment._pool_sample, key, s, b) for s, b in zip(seeds, batches)]
                 results.append([f.result() for f in reversed(futs)][::-1])
-        assert results[0] == results[1]
+        # the product's pool: fork-server workers that map the published arrays
+        monkeypatch.setenv("SSAD_LOADER_CONTEXT", "forkserver")
+        desc, d = aug.host.publish()
+        try:
+            pool = augment.sampler_pool(2)
+            assert augment._POOL["ctx"].get_start_method() == "forkserver"
+            futs = [pool.submit(augment._pool_sample, desc, s, b) for s, b in zip(seeds, batches)]
+            results.append([f.result() for f in futs])
+        finally:
+            import shutil
+            shutil.rmtree(d, ignore_errors=True)
+            augment._shutdown_pool()
+        assert results[0] == results[1] == results[2]
         for (raw, hw), s, b in zip(results[0], seeds, batches):
             random.seed(s); np.random.seed(s % 2 ** 32); torch.manual_seed(s)
             recs, hw2 = aug.sample(b)
             assert recs.tobytes() == raw and tuple(hw) == tuple(hw2)
         assert len({r[0] for r in results[0]}) == 3 and augment._batch_seed(3, 1, 0, 0) != augment._batch_seed(3, 1, 0, 1)
+        # a second stage (another fit numbering its epochs from 0) has its own seeds; stage 0 keeps the round-3 values
+        assert augment._batch_seed(3, 1, 0, 0, stage=1) != augment._batch_seed(3, 1, 0, 0)
+        assert augment._batch_seed(3, 1, 0, 0, stage=0) == augment._batch_seed(3, 1, 0, 0)
     finally:
         augment._POOL_STATE.pop(key, None)
+
+
+def test_loader_stage_counter(tmp_path):
+    """tools.training fits twice on one datamodule and each fit numbers its epochs from 0: the loader notices the counter going
+    back and moves to the next stage, so neither the shuffle nor a batch seed of the first fit comes back; per-image masks
+    (screw-like categories) are deduplicated by content."""
+    import os
+    from fake_mvtec import make_tree
+    from self_supervised import augment, datasets
+    root = make_tree(str(tmp_path / "dataset"), categories=("bottle",), n_train=10, n_test_good=1, n_test_bad=1, size=96)
+    names = np.array(sorted(os.path.join(root, "bottle", "train/good", f) for f in os.listdir(os.path.join(root, "bottle", "train/good"))))
+    ds = datasets.PretextTaskDataset("bottle", np.tile(names, 4), imsize=(64, 64), transform=datasets._default_transform(),
+                                     dataset_root=root)
+    ld = augment.GpuPretextLoader(ds, 8, shuffle=True, drop_last=True, num_workers=0, base_seed=11, device="cpu")
+    seen = []
+    for fit in range(2):
+        for epoch in range(2):
+            ld.shard(1, 0, epoch)
+            seen.append((np.concatenate(ld._batches()).tobytes(), augment._batch_seed(ld.base_seed, ld.epoch, 0, ld.rank, ld.stage)))
+    assert ld.stage == 1
+    assert len({a for a, _ in seen}) == 4 and len({b for _, b in seen}) == 4
+    ld.set_epoch(1); ld.set_epoch(1)                    # a validation loader asked for the same epoch again (another fit)
+    assert ld.stage == 3
+    masks = np.stack([_mask(64), _mask(64), ~_mask(64)])
+    smp = augment.DefectSampler("screw", np.stack([_image(s, 64) for s in range(3)]), masks)
+    assert smp.masks_unique.shape[0] == 2 and list(smp.mask_index) == [0, 0, 1] and np.array_equal(smp.masks, masks)
 
 
 def _pil_reference(subject, names, size, patch, ps, root):
@@ -278,6 +321,14 @@ def test_loader_with_sampler_workers(tmp_path):
         ld = augment.GpuPretextLoader(ds, 8, shuffle=True, drop_last=True, num_workers=nw, base_seed=11)
         assert len(ld) == 5
         out[nw] = [[tuple(t.cpu() for t in b) for b in ld.shard(1, 0, e)] for e in (0, 1)]
+        if nw == 1:
+            # a second fit on the same loader numbers its epochs from 0 again: new stage, new synthetic batches; and a
+            # validation loader that is asked for the same epoch twice (two fits) does not repeat itself either
+            again = [tuple(t.cpu() for t in b) for b in ld.shard(1, 0, 0)]
+            assert ld.stage == 1 and not torch.equal(again[0][0], out[1][0][0][0])
+            ld.set_epoch(0)
+            third = [tuple(t.cpu() for t in b) for b in ld]
+            assert ld.stage == 2 and not torch.equal(third[0][0], again[0][0])
         ld.close()
     for e in (0, 1):
         assert len(out[1][e]) == 5

@@ -151,6 +151,11 @@ def _replica_worker(rank, world, port, q):
     steps = [(emb + 1000 * s, torch.roll(mask, s)) for s in range(3)]
     per_step = torch.cat([gather_bank_rows(e, m) for e, m in steps])
     ok = ok and torch.equal(gather_bank_steps(steps), per_step) and per_step.shape[0] > 0
+    # a ragged last batch (a user's loader without drop_last), and ranks whose last batches differ in size
+    last = 3 if rank == 0 else 2
+    steps.append((emb[:last] + 5000, torch.ones(last, dtype=torch.bool)))
+    per_step = torch.cat([gather_bank_rows(e, m) for e, m in steps])
+    ok = ok and torch.equal(gather_bank_steps(steps), per_step) and per_step.shape[0] > 5
     barrier()
     q.put((rank, ok))
     dist.destroy_process_group()

@@ -485,6 +485,33 @@ def test_layer1_in_layer_outputs(dev):
         assert rel_err(p.grad, ref_params[name].grad, floor) < 1e-3, name
 
 
+def test_deep_projection_head(dev):
+    """PeraNet(latent_space_layers=16), a public constructor argument (models.py:26, :65-88): 15 linear layers in the latent MLP,
+    so the step's batched weight flip holds 36 filters -- more than one launch of ssad_flip_transpose_batch takes."""
+    from self_supervised.models import PeraNet
+    from self_supervised import training
+    from oracle import weights as ow
+    from oracle.peranet import OraclePeraNet, train_step
+    sd = ow.seeded_state_dict(5, latent_space_layers=16)
+    ref = OraclePeraNet(latent_space_layers=16); ref.load_state_dict(sd)
+    m = PeraNet(latent_space_layers=16); m.load_state_dict(sd); m.to(dev)
+    assert len(m.latent_space) == 16 and len(list(ref.latent_space)) == 16
+    x, y = ow.synthetic_images(16, 64, seed=23), ow.synthetic_labels(16, seed=24)
+    ref.train(); m.train(); m.unfreeze()
+    loss_ref, _, _ = train_step(ref, x, y)
+    loss_ref.backward()
+    step = training.DataParallelStep(m, lr=0.01, world_size=1)
+    la = step.step(x.to(dev), y.to(dev))
+    assert step.eng._flip_n > 32
+    np.testing.assert_allclose(la[0].item(), loss_ref.item(), rtol=1e-5)
+    ref_params, floor = dict(ref.named_parameters()), grad_floor(ref)
+    for name, p in m.named_parameters():
+        assert rel_err(p.grad, ref_params[name].grad, floor) < 2e-3, name
+    for _ in range(3):                       # graph capture + replay with the two-launch flip
+        la = step.step(x.to(dev), y.to(dev))
+    assert np.isfinite(la[0].item())
+
+
 def test_rccl_bucketed_allreduce_single_rank(dev, seeded_sd):
     """The N > 1 code path on real RCCL: a one-rank "nccl" group, world_size forced to 2 so that the bucket hooks are
     live -- async all-reduces of arena prefixes interleaved with the backward kernels on the compute stream, waits,
