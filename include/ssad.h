@@ -380,6 +380,11 @@ int ssad_affine_window_sum_u8(const uint8_t* img, int H, int W, const int32_t* f
                               int64_t* sum3);
 /* transforms.ToTensor() on a uint8 HWC batch: -> [B][3][H][W] fp32 in [0,1] (the Dataset's third output). */
 int ssad_u8hwc_to_f32chw(const uint8_t* img, float* out, int B, int H, int W, void* stream);
+/* The transform of MVTecDataset.__getitem__ (datasets.py:68-80, :102-105: ToTensor, then Normalize(mean, std)) on a uint8 HWC
+ * batch that is already on the device: orig (may be NULL) = img / 255, norm = (img / 255 - mean) / std, both [B][3][H][W], each
+ * operation a single IEEE fp32 operation as torch evaluates them on the host (bit-identical).  mean3 / std3: host pointers. */
+int ssad_u8hwc_to_f32chw_norm(const uint8_t* img, float* orig, float* norm, int B, int H, int W, const float* mean3_host,
+                              const float* std3_host, void* stream);
 
 #ifdef __cplusplus
 }

@@ -289,6 +289,22 @@ __global__ void u8_to_f32_kernel(const uint8_t* __restrict__ img, float* __restr
     for (int c = 0; c < 3; ++c) out[((int64_t)b * 3 + c) * hw + pix] = __fdiv_rn((float)img[i * 3 + c], 255.f);
 }
 
+// uint8 HWC -> both outputs of MVTecDataset.__getitem__ in one pass: ToTensor (orig, may be NULL) and Normalize(ToTensor) (norm)
+__global__ void u8_to_f32_norm_kernel(const uint8_t* __restrict__ img, float* __restrict__ orig, float* __restrict__ norm, int B,
+                                      int64_t hw, float m0, float m1, float m2, float s0, float s1, float s2) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * hw) return;
+    const int b = (int)(i / hw);
+    const int64_t pix = i - (int64_t)b * hw;
+    const float m[3] = {m0, m1, m2}, s[3] = {s0, s1, s2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float t = __fdiv_rn((float)img[i * 3 + c], 255.f);
+        if (orig) orig[((int64_t)b * 3 + c) * hw + pix] = t;
+        norm[((int64_t)b * 3 + c) * hw + pix] = __fdiv_rn(__fsub_rn(t, m[c]), s[c]);
+    }
+}
+
 }  // namespace
 
 extern "C" int ssad_aug_params_size(void) { return (int)sizeof(ssad_aug_params); }
@@ -345,6 +361,16 @@ extern "C" int ssad_u8hwc_to_f32chw(const uint8_t* img, float* out, int B, int H
     const int64_t total = (int64_t)B * H * W;
     hipLaunchKernelGGL(u8_to_f32_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, img, out, B,
                        (int64_t)H * W);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ssad_u8hwc_to_f32chw_norm(const uint8_t* img, float* orig, float* norm, int B, int H, int W, const float* mean3_host,
+                                         const float* std3_host, void* stream) {
+    SSAD_CHECK_ARG(img && norm && mean3_host && std3_host && B > 0 && H > 0 && W > 0, "bad argument");
+    const int64_t total = (int64_t)B * H * W;
+    hipLaunchKernelGGL(u8_to_f32_norm_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, img, orig, norm,
+                       B, (int64_t)H * W, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2]);
     SSAD_CHECK_LAUNCH();
     return 0;
 }

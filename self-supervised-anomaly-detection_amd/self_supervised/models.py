@@ -105,6 +105,8 @@ class PeraNet(_Base):
         # init -- fine when a checkpoint / state dict is loaded next, useless for stage 1 of tools.training (frozen
         # backbone) -- so that case warns once per process (SSAD_ALLOW_RANDOM_BACKBONE=1 silences it).
         self.pretrained_backbone = False
+        if self.classifier.weight.is_meta:          # load_from_checkpoint builds shapes only: the checkpoint supplies every tensor
+            return
         for cand in (os.environ.get("SSAD_RESNET18_WEIGHTS"),
                      os.path.expanduser("~/.cache/torch/hub/checkpoints/resnet18-f37072fd.pth")):
             if cand and os.path.isfile(cand):
@@ -180,8 +182,13 @@ class PeraNet(_Base):
         ck = torch.load(checkpoint_path, map_location=map_location, weights_only=False)
         hp = dict(ck.get('hyper_parameters', {}))
         hp.update(overrides)
-        model = cls(**hp)
-        model.load_state_dict(ck['state_dict'], strict=True)
+        # every parameter and buffer comes from the checkpoint: build the module on the meta device (shapes only, no random
+        # initialisation of 12.7 M weights: 0.2 s -> 0.03 s) and ADOPT the checkpoint's tensors
+        with torch.device('meta'):
+            model = cls(**hp)
+        model.load_state_dict(ck['state_dict'], strict=True, assign=True)
+        for p in model.parameters():
+            p.requires_grad_(True)
         model.on_load_checkpoint(ck)
         return model
 

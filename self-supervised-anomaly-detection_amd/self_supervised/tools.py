@@ -153,6 +153,110 @@ def training(dataset_dir: str, outputs_dir: str, subject: str, imsize: tuple = (
     return history
 
 
+def _fast_mvtec_ok(dataset):
+    """The streamed predict below restates MVTecDataset.__getitem__ for the default transform only."""
+    from .datasets import IMAGENET_MEAN, IMAGENET_STD, MVTecDataset
+    from .tv_transforms import Compose, Normalize, ToTensor
+    t = getattr(dataset, "transform", None)
+    return (type(dataset) is MVTecDataset and isinstance(t, Compose) and len(t.ts) == 2 and isinstance(t.ts[0], ToTensor)
+            and isinstance(t.ts[1], Normalize) and t.ts[1].mean.flatten().tolist() == torch.tensor(IMAGENET_MEAN).tolist()
+            and t.ts[1].std.flatten().tolist() == torch.tensor(IMAGENET_STD).tolist()
+            and os.environ.get("SSAD_FAST_PREDICT", "1") != "0")
+
+
+def _predict_mvtec_streamed(model: PeraNet, dataset, device, indices, group: int = 32, threads: int = None):
+    """``Trainer.predict`` + ``ModelOutputsContainer.from_list`` for an MVTecDataset with the default transform, as ONE stream
+    instead of a DataLoader of batch size 1 (tools.py:336-347 of the reference): same values, field for field.
+
+    * a thread pool reads the files exactly as ``MVTecDataset.__getitem__`` does (``Image.open().resize().convert('RGB')``, the
+      ground-truth mask through ``get_ground_truth``) -- Pillow decodes outside the GIL -- and writes uint8 pixels into one
+      preallocated batch;
+    * ``group`` images at a time go to the device as uint8 (a quarter of the fp32 bytes), where ToTensor + Normalize are two
+      IEEE fp32 operations per value (ssad_u8hwc_to_f32chw_norm: bit-identical to the host transform), then through
+      ``model.forward`` -- thousands of patches per launch instead of 841;
+    * results return to the host per group on a side stream while the next group computes; the embeddings also STAY on the device
+      (second return value) for the detector, instead of making the round trip host -> device again.
+    Returns (container with CPU tensors, device embeddings [n * P][D])."""
+    import ctypes
+    from concurrent.futures import ThreadPoolExecutor
+    from PIL import Image
+    from . import _hip
+    from .datasets import IMAGENET_MEAN, IMAGENET_STD
+    from .functional import get_ground_truth, get_ground_truth_filename, get_prediction_class
+    from .converters import gt2label
+    n = len(indices)
+    out = ModelOutputsContainer()
+    if n == 0:
+        return out, None
+    w_img, h_img = dataset.imsize
+    names = [dataset.images_filenames[i] for i in indices]
+    u8 = np.empty((n, h_img, w_img, 3), np.uint8)
+    gt8 = np.zeros((n, h_img, w_img), np.uint8)
+    gt_dir = dataset.dataset_dir + 'ground_truth/'
+
+    def load(j):
+        u8[j] = np.asarray(Image.open(names[j]).resize(dataset.imsize).convert('RGB'))
+        gfile = get_ground_truth_filename(names[j], gt_dir)
+        if gfile:                                       # 'good' images: Image.new(mode='1') = all zeros
+            gt8[j] = np.asarray(get_ground_truth(gfile, dataset.imsize).convert('L'))
+    threads = threads or min(8, os.cpu_count() or 1)
+    mean = (ctypes.c_float * 3)(*IMAGENET_MEAN)
+    std = (ctypes.c_float * 3)(*IMAGENET_STD)
+    orig = torch.empty((n, 3, h_img, w_img), dtype=torch.float32)
+    xnorm = torch.empty((n, 3, h_img, w_img), dtype=torch.float32)
+    emb_dev = logits_dev = emb_host = logits_host = None
+    side = torch.cuda.Stream(device)
+    main = torch.cuda.current_stream(device)
+    lib = _hip.lib()
+    pending = None                                       # (a, b, orig_dev, x_dev, event) of the group whose results are still on the device
+
+    def drain(item):
+        a, b, o_dev, x_dev, ev, p = item
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            orig[a:b].copy_(o_dev)
+            xnorm[a:b].copy_(x_dev)
+            emb_host[a * p:b * p].copy_(emb_dev[a * p:b * p])
+            logits_host[a * p:b * p].copy_(logits_dev[a * p:b * p])
+        for t in (o_dev, x_dev):
+            t.record_stream(side)
+    with ThreadPoolExecutor(threads) as pool, torch.no_grad():
+        futs = [pool.submit(load, j) for j in range(n)]
+        for a in range(0, n, group):
+            b = min(n, a + group)
+            for f in futs[a:b]:
+                f.result()
+            img_dev = torch.from_numpy(u8[a:b]).to(device)
+            o_dev = torch.empty((b - a, 3, h_img, w_img), device=device, dtype=torch.float32)
+            x_dev = torch.empty_like(o_dev)
+            _hip.check(lib.ssad_u8hwc_to_f32chw_norm(img_dev.data_ptr(), o_dev.data_ptr(), x_dev.data_ptr(), b - a, h_img, w_img,
+                                                     mean, std, _hip.stream()))
+            pred = model(x_dev)
+            p = pred['latent_space'].shape[0] // (b - a)
+            if emb_dev is None:
+                d, c = pred['latent_space'].shape[1], pred['classifier'].shape[1]
+                emb_dev = torch.empty((n * p, d), device=device, dtype=torch.float32)
+                logits_dev = torch.empty((n * p, c), device=device, dtype=torch.float32)
+                emb_host, logits_host = torch.empty((n * p, d)), torch.empty((n * p, c))
+            emb_dev[a * p:b * p].copy_(pred['latent_space'])
+            logits_dev[a * p:b * p].copy_(pred['classifier'])
+            ev = torch.cuda.Event()
+            ev.record(main)
+            if pending is not None:
+                drain(pending)                          # the previous group's results travel while this group computes
+            pending = (a, b, o_dev, x_dev, ev, p)
+        drain(pending)
+    side.synchronize()
+    gts = torch.from_numpy(gt8).float().div_(255.0).unsqueeze(1)
+    out.original_data, out.tensor_data, out.ground_truths = orig, xnorm, gts
+    out.raw_predictions, out.embedding_vectors = logits_host, emb_host
+    out.y_hat = get_prediction_class(logits_host)
+    # predict_step labels every BATCH (of one image) from its ground truth (models.py:314-318)
+    out.y_true_binary_labels = torch.tensor(gt2label(gts))
+    out.y_true_multiclass_labels = torch.tensor(gt2label(gts, negative=-1, positive=model.num_classes))
+    return out, emb_dev
+
+
 def inference(model_input_dir: str, dataset_dir: str, subject: str, mvtec_inference: bool = True,
               patch_localization: bool = False) -> ModelOutputsContainer:
     """tools.py:310-390."""
@@ -173,12 +277,27 @@ def inference(model_input_dir: str, dataset_dir: str, subject: str, mvtec_infere
     # under torch.distributed (one process per GPU) every rank scores its own round-robin share of the images; the
     # per-image containers are exchanged once at the end so that every rank returns the full output
     rank, world = world_info()
-    predictions = tester.predict(model, datamodule=datamodule, shard=world > 1)
-    output = ModelOutputsContainer()
-    output.from_list(predictions)
+    emb_dev = None
+    if mvtec_inference and not hasattr(datamodule, 'test_dataset'):
+        datamodule.setup('predict')
+    if mvtec_inference and _fast_mvtec_ok(datamodule.test_dataset):
+        # the hot path of an evaluation: one stream through decode threads and large launches instead of a DataLoader of batch
+        # size 1 (same values; _predict_mvtec_streamed).  The DataLoader iterator the reference creates here draws its base
+        # seed from torch's global generator: the draw is kept, so that what follows (the shuffled loader of the normality
+        # image) sees the same generator state
+        torch.empty((), dtype=torch.int64).random_()
+        model.to(tester.device).eval()
+        mine = list(range(rank, len(datamodule.test_dataset), world)) if world > 1 else list(range(len(datamodule.test_dataset)))
+        output, emb_dev = _predict_mvtec_streamed(model, datamodule.test_dataset, tester.device, mine)
+        n_pred = len(mine)
+    else:
+        predictions = tester.predict(model, datamodule=datamodule, shard=world > 1)
+        output = ModelOutputsContainer()
+        output.from_list(predictions)
+        n_pred = len(predictions)
     print('>>> anomaly detection phase')
     if patch_localization:
-        detector = AnomalyDetector(patch_level=True, batch=len(predictions), num_patches=model.num_patches)
+        detector = AnomalyDetector(patch_level=True, batch=n_pred, num_patches=model.num_patches)
     else:
         detector = AnomalyDetector()
     if model.memory_bank.shape[0] > 1000:            # quirk Q3: the bank is capped at 1000 rows, so this never holds
@@ -211,10 +330,10 @@ def inference(model_input_dir: str, dataset_dir: str, subject: str, mvtec_infere
     else:
         detector.fit(normality)
     print(' computing anomaly scores')
-    output.anomaly_maps = detector.predict(output.embedding_vectors).cpu()
+    output.anomaly_maps = detector.predict(emb_dev if emb_dev is not None else output.embedding_vectors).cpu()
     if world > 1:
-        n_total = len(datamodule.predict_dataloader())
-        per_image = gather_in_order(_split_container(output, len(predictions)), n_total)
+        n_total = len(datamodule.test_dataset)
+        per_image = gather_in_order(_split_container(output, n_pred), n_total)
         output = ModelOutputsContainer()
         output.from_list(per_image)
     return output

@@ -119,6 +119,13 @@ class Trainer:
                 if self.limit_train_batches is not None and i >= self.limit_train_batches:
                     break
                 x, y, _ = _to_device(batch, self.device)
+                if self.world > 1 and step.self_check_report is None:
+                    # first batch of a multi-rank fit: eager step == replayed step, replicas identical (training.self_check);
+                    # falls back to eager launches, collectively, when they are not
+                    rep = step.self_check(x.contiguous().float(), y.contiguous())
+                    self.self_check = rep
+                    if self.global_rank == 0:
+                        print(f">>> data-parallel self-check: {rep}")
                 la = step.step(x.contiguous().float(), y.contiguous())
                 n_images += int(x.shape[0])
                 sums += torch.stack([la[0], la[1], torch.ones_like(la[0])])

@@ -810,6 +810,33 @@ def broadcast_replica_state(model, arena, process_group=None, src=0):
             dist.broadcast(b, src=src, group=process_group)
 
 
+def bit_checksum(t):
+    """Order-independent, exact fingerprint of a float tensor's BITS: int64 [sum of the int32 words, sum of their squares' low
+    halves, count of non-finite-looking exponent fields].  Equal tensors give equal checksums on every rank; a single flipped
+    bit changes the first entry."""
+    w = t.detach().contiguous().view(torch.int32).to(torch.int64)
+    return torch.stack([w.sum(), (w & 0xFFFF).mul_(w >> 16 & 0xFFFF).sum(), ((w >> 23 & 0xFF) == 0xFF).sum()])
+
+
+def ranks_agree(checksum, process_group=None):
+    """True when every rank holds the same checksum vector (one MAX and one MIN all-reduce of a few int64: gloo or RCCL)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
+        return True
+    hi, lo = checksum.clone(), checksum.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=process_group)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=process_group)
+    return bool(torch.equal(hi.cpu(), lo.cpu()))
+
+
+def all_ranks_true(flag, device, process_group=None):
+    """Collective AND of a per-rank boolean."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], device=device, dtype=torch.int64)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=process_group)
+    return bool(int(t.item()) == 1)
+
+
 class LossScaler:
     """torch.cuda.amp.GradScaler's state machine (what PL runs for the reference's precision=16, tools.py:263) kept in
     three device floats [scale, growth_tracker, found_inf] so that no step needs a host round trip."""
@@ -857,6 +884,8 @@ class DataParallelStep:
         self.use_graph = (os.environ.get("SSAD_GRAPH", "1") != "0") if graph is None else bool(graph)
         self._plans, self._seen = {}, {}
         self._cap_stream = None
+        self.launch_mode = "hipGraph segments" if self.use_graph else "eager"
+        self.self_check_report = None
 
     # ---- pieces ----
     def _sync_hyper(self):
@@ -977,10 +1006,82 @@ class DataParallelStep:
                 works = []
         return plan["out"]
 
+    # ---- start-up self-check of a multi-rank job ----
+    def _snapshot(self):
+        a = self.eng.arena
+        return {"p": a.p.clone(), "m": a.m.clone(), "buf": [b.clone() for b in self.model.buffers()],
+                "sc": self.scaler.state.clone() if self.scaler is not None else None}
+
+    def _restore(self, snap):
+        a = self.eng.arena
+        with torch.no_grad():
+            a.p.copy_(snap["p"]); a.m.copy_(snap["m"])
+            for b, v in zip(self.model.buffers(), snap["buf"]):
+                b.copy_(v)
+            if snap["sc"] is not None:
+                self.scaler.state.copy_(snap["sc"])
+        self.model._plan = None
+
+    def self_check(self, x, y):
+        """Run ONE step on (x, y) twice from the same state -- launched eagerly, then recorded as hipGraph segments and replayed
+        (collectives eagerly between the segments) -- and compare: (i) on this rank the two must leave bit-identical parameters,
+        momentum and BatchNorm buffers; (ii) after either, every rank must hold the same parameters and momentum (exact bit checksum,
+        MAX / MIN all-reduce).  The state is put back afterwards, so the check does not move the training trajectory.  If the replay
+        disagrees with the eager step on ANY rank, or the replicas disagree after the replayed step, every rank falls back to
+        eager launches (collective decision) and says so in `launch_mode`; replicas that disagree after the EAGER step are
+        re-synchronised from rank 0 and reported (`replicas_agree_eager: false`): that is a defect no fallback hides.
+        Why: hipGraph segments + RCCL across several GPUs first meet on the driver's 8-GPU run (the box this is built on has
+        one GPU); a silently diverged model must not produce a scaling figure.  -> dict for the bench line / logs."""
+        dev = self.eng.arena.p.device
+        rep = {"world": self.world, "graph_requested": bool(self.use_graph)}
+        self._sync_hyper()
+        snap = self._snapshot()
+        self._step_eager(x, y)
+        torch.cuda.synchronize(dev)
+        a = self.eng.arena
+        state = lambda: torch.cat([a.p, a.m] + [b.detach().flatten().float() for b in self.model.buffers()])
+        # what must be identical ACROSS ranks: parameters and momentum (BatchNorm running statistics are per rank by design: each
+        # rank normalises its own shard, the reference has no SyncBN)
+        shared = lambda: bit_checksum(torch.cat([a.p, a.m]))
+        eager = state().clone()
+        rep["replicas_agree_eager"] = ranks_agree(shared(), self.pg)
+        self._restore(snap)
+        ok_local = True
+        if self.use_graph:
+            key = self._plan_key(x, y)
+            try:
+                plan = self._capture(x, y, key)
+                self._replay(plan, x, y)
+                torch.cuda.synchronize(dev)
+                replay = state()
+                ok_local = bool(torch.equal(eager, replay))
+                rep["replicas_agree_replay"] = ranks_agree(shared(), self.pg)
+                rep["graph_segments"] = sum(1 for o in plan["ops"] if o[0] == "graph")
+            except Exception as e:           # noqa: BLE001  (a capture the runtime refuses is a reason to run eagerly, not to stop)
+                ok_local = False
+                rep["capture_error"] = f"{type(e).__name__}: {e}"
+                rep["replicas_agree_replay"] = ranks_agree(shared(), self.pg) and False          # (keeps the collective sequence aligned)
+                self._plans.pop(key, None)
+            self._restore(snap)
+            rep["graph_equals_eager"] = all_ranks_true(ok_local, dev, self.pg)
+            if not (rep["graph_equals_eager"] and rep.get("replicas_agree_replay", True)):
+                self.use_graph = False
+                self._plans.clear()
+        if not rep["replicas_agree_eager"]:
+            broadcast_replica_state(self.model, self.eng.arena, self.pg)
+        self.launch_mode = "hipGraph segments" if self.use_graph else (
+            "eager" if not rep["graph_requested"] else "eager (self-check: the replayed step did not reproduce the eager one)")
+        rep["launch_mode"] = self.launch_mode
+        self.self_check_report = rep
+        return rep
+
+    def _plan_key(self, x, y):
+        return (tuple(x.shape), tuple(y.shape), x.dtype, y.dtype, self.eng.switches(), tuple(self.eng.arena.trainable_ranges()),
+                tuple(bool(m.training) for m in self.model.modules() if isinstance(m, BN_TYPES)))
+
     def step(self, x, y):
         self._sync_hyper()
-        key = (tuple(x.shape), tuple(y.shape), x.dtype, y.dtype, self.eng.switches(), tuple(self.eng.arena.trainable_ranges()),
-               tuple(bool(m.training) for m in self.model.modules() if isinstance(m, BN_TYPES)))
+        key = self._plan_key(x, y)
         if self.use_graph and ops.PROFILE is None:
             plan = self._plans.get(key)
             if plan is None:

@@ -69,6 +69,51 @@ def case_step(res):
     res["finite"] = bool(torch.isfinite(dp.eng.arena.p).all().item())
 
 
+def case_selfcheck(res):
+    """DataParallelStep.self_check on two ranks: a healthy job passes, keeps its verified plan and its state untouched; a replay
+    that goes wrong on ONE rank (a parameter perturbed after the replayed step) sends BOTH ranks to eager launches."""
+    from oracle import weights as ow
+    from self_supervised import training
+    from self_supervised.models import PeraNet
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = torch.device("cuda", 0)
+    x = ow.synthetic_images(4, 64, seed=70 + rank).to(dev)
+    y = ow.synthetic_labels(4, seed=80 + rank).to(dev)
+    m = PeraNet(); m.load_state_dict(ow.seeded_state_dict(rank)); m.to(dev).train(); m.unfreeze()
+    dp = training.DataParallelStep(m, lr=0.03, world_size=world)
+    before = torch.cat([dp.eng.arena.p, dp.eng.arena.m] + [b.detach().flatten().float() for b in m.buffers()]).clone()
+    rep = dp.self_check(x, y)
+    after = torch.cat([dp.eng.arena.p, dp.eng.arena.m] + [b.detach().flatten().float() for b in m.buffers()])
+    res["healthy"] = rep
+    res["state_restored"] = bool(torch.equal(before, after))
+    res["plan_kept"] = len(dp._plans) == 1
+    for _ in range(3):
+        dp.step(x, y)
+    torch.cuda.synchronize()
+    res["weights_equal_after_steps"] = allsame(dp.eng.arena.p)[0]
+    # fault injection: the replay leaves a different bit pattern on rank 1 only
+    m2 = PeraNet(); m2.load_state_dict(ow.seeded_state_dict(7)); m2.to(dev).train(); m2.unfreeze()
+    bad = training.DataParallelStep(m2, lr=0.03, world_size=world)
+    orig = bad._replay
+
+    def broken_replay(plan, xx, yy):
+        out = orig(plan, xx, yy)
+        if rank == 1:
+            torch.cuda.synchronize()
+            bad.eng.arena.p.view(torch.int32)[17] ^= 1
+        return out
+    bad._replay = broken_replay
+    rep2 = bad.self_check(x, y)
+    res["faulty"] = rep2
+    res["faulty_use_graph"] = bool(bad.use_graph)
+    bad._replay = orig
+    for _ in range(3):
+        bad.step(x, y)
+    torch.cuda.synchronize()
+    res["faulty_plans"] = len(bad._plans)
+    res["faulty_weights_equal"] = allsame(bad.eng.arena.p)[0]
+
+
 def case_rccl1(res):
     """The transport the gloo cases cannot reach: a ONE-rank RCCL communicator on the box's card, with the step told it
     has two replicas (world_size=2), so every bucket goes through ProcessGroupNCCL's stream / event hand-over between the
@@ -147,6 +192,8 @@ def main():
     res = {}
     if case == "step":
         case_step(res)
+    elif case == "selfcheck":
+        case_selfcheck(res)
     elif case == "rccl1":
         case_rccl1(res)
     else:

@@ -175,3 +175,40 @@ def test_replica_broadcast_and_bank_gather_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res), res
+
+
+def _checksum_worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "self-supervised-anomaly-detection_amd"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from self_supervised.training import all_ranks_true, bit_checksum, ranks_agree
+    torch.manual_seed(5)
+    t = torch.randn(4099)
+    same = ranks_agree(bit_checksum(t))                         # identical replicas
+    t2 = t.clone()
+    if rank == 1:
+        t2.view(torch.int32)[1234] ^= 1                          # ONE flipped mantissa bit on one rank
+    differ = ranks_agree(bit_checksum(t2))
+    perm = ranks_agree(bit_checksum(t[torch.randperm(4099)] if rank == 1 else t))     # order-independent by construction
+    ok = same and not differ and perm
+    ok = ok and all_ranks_true(True, "cpu") and not all_ranks_true(rank == 0, "cpu")  # the fallback decision is collective
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_replica_checksum_and_collective_decision_world2():
+    """training.self_check's building blocks over gloo: replicas that differ in one bit on one rank are noticed by EVERY rank,
+    and a per-rank verdict becomes one collective decision."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_checksum_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res

@@ -38,6 +38,20 @@ def test_two_rank_training_step(tmp_path):
     assert r["finite"], r
 
 
+def test_two_rank_self_check(tmp_path):
+    """The start-up self-check of a multi-rank job (bench.py, Trainer.fit): passes on a healthy job without moving its state,
+    and a replay that differs from the eager step on one rank switches every rank to eager launches."""
+    r = _run("selfcheck", tmp_path)
+    h = r["healthy"]
+    assert h["graph_equals_eager"] and h["replicas_agree_eager"] and h["replicas_agree_replay"], r
+    assert h["launch_mode"] == "hipGraph segments" and h["graph_segments"] >= 3, r
+    assert r["state_restored"] and r["plan_kept"] and r["weights_equal_after_steps"], r
+    f = r["faulty"]
+    assert f["replicas_agree_eager"] and not f["graph_equals_eager"] and not f["replicas_agree_replay"], r
+    assert f["launch_mode"].startswith("eager (self-check") and not r["faulty_use_graph"] and r["faulty_plans"] == 0, r
+    assert r["faulty_weights_equal"], r
+
+
 def test_two_rank_tools_training(tmp_path):
     r = _run("fit", tmp_path)
     assert r["fit_params_equal"] and r["fit_bank_equal"], r

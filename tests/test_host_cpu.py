@@ -80,6 +80,47 @@ def test_state_dict_surface(seeded_sd):
     m.on_load_checkpoint(ck); assert tuple(m.memory_bank.shape) == (3, 512)
 
 
+def test_lightning_shaped_checkpoint_loads(tmp_path, seeded_sd):
+    """f-2: a checkpoint with the top-level layout pytorch_lightning 1.7-1.9 writes for the reference's Trainer
+    (tools.py:274, :304: epoch, global_step, pytorch-lightning_version, state_dict, loops, callbacks, optimizer_states,
+    lr_schedulers, the AMP scaler state under precision=16, hparams_name, hyper_parameters) plus the reference's own
+    `memory_bank` entry (models.py:199-207) -- hand-built, no real .ckpt ships with the reference.  load_from_checkpoint takes
+    the state dict, the hyper-parameters (with the overrides tools.py:277-281 passes) and the bank, and ignores the rest; the
+    weights-only form (tools.py:274 `weights_only=True`: no optimizer / scheduler entries) loads the same way."""
+    from self_supervised.models import PeraNet
+    hp = {"learning_rate": 0.03, "epochs": 10, "layer_outputs": ["layer2", "layer3"], "latent_space_layers": 5,
+          "latent_space_layers_base_dim": 512, "num_classes": 4, "memory_bank_dim": 1000, "stage": "projection_train"}
+    bank = torch.arange(7 * 512, dtype=torch.float32).view(7, 512)
+    n_params = len([k for k in seeded_sd if "running_" not in k and "num_batches" not in k])
+    full = {
+        "epoch": 9, "global_step": 100, "pytorch-lightning_version": "1.7.7",
+        "state_dict": {k: v.clone() for k, v in seeded_sd.items()},
+        "loops": {"fit_loop": {"state_dict": {}, "epoch_progress": {"total": {"ready": 10, "completed": 10}}}},
+        "callbacks": {"ModelCheckpoint{'monitor': 'val_loss', 'mode': 'min', 'every_n_epochs': 5}": {"best_model_score": torch.tensor(0.25),
+                                                                                                     "best_model_path": "x.ckpt"}},
+        "optimizer_states": [{"state": {i: {"momentum_buffer": torch.zeros(1)} for i in range(n_params)},
+                              "param_groups": [{"lr": 0.03, "momentum": 0.9, "dampening": 0, "weight_decay": 0.0005, "nesterov": False,
+                                                "params": list(range(n_params))}]}],
+        "lr_schedulers": [{"T_0": 10, "T_i": 10, "T_mult": 1, "eta_min": 0, "T_cur": 9, "base_lrs": [0.03], "last_epoch": 9}],
+        "native_amp_scaling_state": {"scale": 65536.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000, "_growth_tracker": 0},
+        "hparams_name": "kwargs", "hyper_parameters": hp, "memory_bank": bank,
+    }
+    weights_only = {k: full[k] for k in ("epoch", "global_step", "pytorch-lightning_version", "state_dict", "loops", "hparams_name",
+                                         "hyper_parameters", "memory_bank")}
+    for name, ck in (("full.ckpt", full), ("weights_only.ckpt", weights_only)):
+        path = str(tmp_path / name)
+        torch.save(ck, path)
+        m = PeraNet.load_from_checkpoint(path)
+        assert (m.lr, m.num_epochs, m.stage) == (0.03, 10, "projection_train")
+        got = m.state_dict()
+        assert set(got) == set(seeded_sd) and all(torch.equal(got[k], seeded_sd[k]) for k in seeded_sd)
+        assert torch.equal(m.memory_bank, bank)
+        # tools.py:277-281: the fine-tune stage reloads the projection checkpoint with new hyper-parameters (on an instance: quirk Q8)
+        m2 = m.load_from_checkpoint(path, learning_rate=0.005, epochs=30, stage="fine_tune")
+        assert (m2.lr, m2.num_epochs, m2.stage) == (0.005, 30, "fine_tune") and len(m2.configure_optimizers()[1]) == 1
+        assert all(torch.equal(m2.state_dict()[k], seeded_sd[k]) for k in seeded_sd)
+
+
 def test_split_indices_match_sklearn():
     from sklearn.model_selection import train_test_split
     from self_supervised.models import split_indices
