@@ -386,6 +386,16 @@ int ssad_u8hwc_to_f32chw(const uint8_t* img, float* out, int B, int H, int W, vo
 int ssad_u8hwc_to_f32chw_norm(const uint8_t* img, float* orig, float* norm, int B, int H, int W, const float* mean3_host,
                               const float* std3_host, void* stream);
 
+/* Image.resize(size) of Pillow (default filter: BICUBIC) for 8-bit 'L' (C = 1) / 'RGB' (C = 3) batches already on the device:
+ * what the reference applies to every file it opens (datasets.py:68, :211-213, :189-200).  in [B][Hin][Win][C] -> out
+ * [B][Hout][Wout][C]; tmp [B][Hin][Wout][C] when both extents change (else may be NULL).  bounds_* int32 [out][2] = (first source
+ * index, taps) and coef_* int32 [out][ksize_*] (22-bit fixed point) are DEVICE arrays holding libImaging's precompute_coeffs +
+ * normalize_coeffs_8bpc tables (self_supervised/pil_exact.resample_coeffs); the axis whose extent does not change takes no table.
+ * Bit-exact integer arithmetic (Resample.c, ImagingResampleHorizontal_8bpc / Vertical_8bpc). */
+int ssad_resize_bicubic_u8(const uint8_t* in, uint8_t* tmp, uint8_t* out, int B, int Hin, int Win, int C, int Hout, int Wout,
+                           const int32_t* bounds_x, const int32_t* coef_x, int ksize_x, const int32_t* bounds_y,
+                           const int32_t* coef_y, int ksize_y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -142,7 +142,22 @@ void conv_igemm_f32_kernel(ConvParams p) {
         // pos = block % HoWo the heavy interior positions pin to the same engines and tap skipping buys nothing).
         // Positions differ in work (corner 4 taps .. interior 9), so every stream sweeps ALL positions of its own
         // sample groups (nb = 32*q + stream): equal work per engine, and a sample group's maps stay in one XCD's L2.
-        if (p.pos_lpt) {
+        if (p.pos_lpt == 2) {
+            // XCD-local sweep (round 4).  Workgroups are dealt round-robin to the 8 XCDs, so x = block % 8 names the XCD (which
+            // one is not fixed, only that blocks b and b + 8 share it) and j = block / 8 counts the workgroups of that XCD in
+            // dispatch order.  An XCD takes pos_chunk sample groups at a time through ALL positions, heaviest position first:
+            // the ~64 workgroups resident on its 32 CUs are then the positions of the same few sample groups, whose input maps
+            // (4 MB at 8 x 8 x 128 channels) fit the XCD's 4 MB L2 while all nine taps of every position read them -- instead
+            // of one fetch from the fabric per filter row (profiles/r03_traffic.json: 1.52 x the algorithmic bytes).
+            const unsigned x = blockIdx.x & 7, j = blockIdx.x >> 3;
+            const unsigned per_blk = (unsigned)p.pos_chunk * (unsigned)HoWo;
+            const unsigned blk = j / per_blk, r = j - blk * per_blk;
+            const unsigned pi = r / (unsigned)p.pos_chunk, g = r - pi * (unsigned)p.pos_chunk;
+            const unsigned sg = (blk * (unsigned)p.pos_chunk + g) * 8u + x;
+            if (sg >= (unsigned)p.pos_sg) return;
+            pos = p.pos_tab[pi];
+            m0 = (int64_t)sg * BM;
+        } else if (p.pos_lpt) {
             // Positions differ in work (corner 4 taps .. interior 9) and workgroups are handed out in order: all the
             // 9-tap positions first, the 4-tap corners last, every position over all sample groups (consecutive
             // workgroups -> all XCDs / engines see the same mix), so the launch ends on its shortest workgroups.
@@ -416,7 +431,9 @@ void conv_igemm_f32_kernel(ConvParams p) {
     // Loads and stores are unconditional: past the last K-step the loader has wrapped to the first tap (valid addresses or
     // the zero page) and the pieces land in the stage nobody reads any more.
     constexpr bool PIPE = IGEMM_VAR >= 3 && BF == 0 && DB && BK >= 16;
-    constexpr bool PIPE2 = PIPE && IGEMM_VAR >= 4;          // two register sets (IGEMM_VAR 3: one set, loads chunk 0, stores last chunk)
+    // two register sets (IGEMM_VAR 3: one set, loads chunk 0, stores last chunk); the 256 x 256 tile (16 accumulator tiles = 256
+    // registers per wave, in the AGPR half of the file) has no room for a second staging set
+    constexpr bool PIPE2 = PIPE && IGEMM_VAR >= 4 && TM * TN <= 8;
     if (nk > 0) {
         load_step();
         store_step(lds);
@@ -837,11 +854,14 @@ void conv_igemm_f32_kernel(ConvParams p) {
 
 // Position order for the position-major kernels: heaviest (most in-bounds taps) first, see the kernel.
 static void sort_positions(ConvParams& p, int sample_groups) {
+    // 0: engine-stream mapping (round 1); 1: heaviest position first over chunks of SSAD_POS_CHUNK sample groups (rounds 2-3);
+    // 2: the same order inside XCD-local blocks of a few sample groups (round 4)
     static const int mode = getenv("SSAD_POS_LPT") ? atoi(getenv("SSAD_POS_LPT")) : 1;
     const int HoWo = p.Ho * p.Wo;
     // chunk of sample groups swept position by position: 32 groups x 128 samples = 4096 maps, 134 MB of layer2 input -- inside the
     // 256 MB Infinity Cache.  Same speed as one chunk (654 maps/s either way), 0 = one chunk
     static const int chunk = getenv("SSAD_POS_CHUNK") ? atoi(getenv("SSAD_POS_CHUNK")) : 32;
+    static const int xcd_wgs = getenv("SSAD_POS_XCD_WGS") ? atoi(getenv("SSAD_POS_XCD_WGS")) : 64;
     p.pos_lpt = 0;
     p.pos_sg = sample_groups;
     p.pos_chunk = chunk > 0 && chunk < sample_groups ? chunk : sample_groups;
@@ -857,11 +877,15 @@ static void sort_positions(ConvParams& p, int sample_groups) {
         order[pos] = pos;
         uniform = uniform && taps[pos] == taps[0];
     }
-    if (uniform) return;                                 // nothing to balance: keep the engine-stream mapping
+    if (uniform && mode != 2) return;                    // nothing to balance: keep the engine-stream mapping
     for (int i = 1; i < HoWo; ++i)                       // stable insertion sort, heaviest first
         for (int j = i; j > 0 && taps[order[j]] > taps[order[j - 1]]; --j) { int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
     for (int i = 0; i < HoWo; ++i) p.pos_tab[i] = (unsigned char)order[i];
     p.pos_lpt = 1;
+    if (mode == 2 && sample_groups >= 64) {
+        p.pos_lpt = 2;
+        p.pos_chunk = xcd_wgs / HoWo > 0 ? xcd_wgs / HoWo : 1;      // sample groups per XCD-local block: ~one round of resident workgroups
+    }
 }
 
 template <int BM, int BN, int TM, int TN, int BK, int TS, bool POS, bool DB = true, int BF = 0>
@@ -883,7 +907,9 @@ int launch(const ConvParams& p, hipStream_t st) {
     ConvParams q = p;
     q.pos_lpt = 0;
     if (POS) sort_positions(q, (int)cdiv64(p.N, BM));
-    int64_t gx = POS ? (q.pos_lpt ? cdiv64(q.pos_sg, q.pos_chunk) * q.pos_chunk * p.Ho * p.Wo : cdiv64(cdiv64(p.N, BM), 32) * 32 * p.Ho * p.Wo)
+    int64_t gx = POS ? (q.pos_lpt == 2 ? cdiv64(cdiv64(q.pos_sg, 8), q.pos_chunk) * q.pos_chunk * p.Ho * p.Wo * 8
+                        : q.pos_lpt ? cdiv64(q.pos_sg, q.pos_chunk) * q.pos_chunk * p.Ho * p.Wo
+                                    : cdiv64(cdiv64(p.N, BM), 32) * 32 * p.Ho * p.Wo)
                      : cdiv64(p.M, BM);
     if (TS > 1) {
         // parity classes ordered by the taps they keep, most first: the launch then ends on its lightest workgroups (measured,
@@ -947,7 +973,7 @@ int dispatch_x3(const ConvParams& p, hipStream_t st) {
 
 // Tile of the exact-fp32 instantiation a problem is given (also reported by ssad_conv_igemm_tile: bench.py names the
 // instantiations its roofline sums over)
-enum IgemmTile { T_256x64_K16 = 0, T_256x64_SB, T_128x64, T_256x128, T_256x128_W4, T_128x256, T_64x64, T_128x128 };
+enum IgemmTile { T_256x64_K16 = 0, T_256x64_SB, T_128x64, T_256x128, T_256x128_W4, T_128x256, T_64x64, T_128x128, T_256x256 };
 
 template <bool POS>
 IgemmTile pick_tile(const ConvParams& p) {
@@ -956,6 +982,9 @@ IgemmTile pick_tile(const ConvParams& p) {
     static const int big = getenv("SSAD_CONV128_VARIANT") ? atoi(getenv("SSAD_CONV128_VARIANT")) : 0;
     if (big == 1) return T_256x128;
     if (big == 2) return T_256x128_W4;                                    // one workgroup per CU, four waves of 128 x 64
+    // 256 x 256 tile, four waves of 128 x 128 (16 accumulator tiles each): 16 staged pieces per 256 MFMAs (SSAD_CONV128_VARIANT=6,
+    // position-major launches with Cout % 256 == 0 only: round-4 experiment)
+    if (big == 6 && POS && p.Cout % 256 == 0 && cdiv64(p.N, 256) * p.Ho * p.Wo * (p.Cout / 256) >= 256) return T_256x256;
     // 128 x 256 tile (four waves of 64 x 128, one workgroup per CU) where Cout is a multiple of 256 and the launch still fills the
     // chip: 12 staged pieces per 128 MFMAs instead of 16 -- the per-piece cost is what a K-step loses (profiles/r03_igemm_phases.md).
     // Measured (same run): layer3 / layer4 training convs 0.635 -> 0.612 / 0.606 -> 0.586 ms, position-major scoring convs
@@ -989,6 +1018,9 @@ int dispatch(const ConvParams& p, hipStream_t st) {
         case T_256x128_W4: return launch<256, 128, 4, 2, 32, TS, POS>(p, st);
         case T_128x256: return launch<128, 256, 2, 4, 32, TS, POS>(p, st);
         case T_64x64: return launch<64, 64, 1, 1, 32, TS, POS>(p, st);
+        case T_256x256:
+            if constexpr (POS && TS == 1) return launch<256, 256, 4, 4, 32, TS, POS>(p, st);
+            else return launch<128, 128, 2, 2, 32, TS, POS>(p, st);
         default: return launch<128, 128, 2, 2, 32, TS, POS>(p, st);
     }
 }
@@ -1118,8 +1150,8 @@ extern "C" int ssad_conv_igemm_tile(int64_t N, int H, int W, int Cin, int Cout, 
     p.Wo = (W + 2 * pad - KW) / stride + 1;
     p.M = N * p.Ho * p.Wo;
     const bool posmajor = hwnc || (pad > 0 && N >= 128 && p.Ho * p.Wo <= 4);
-    static const int dims[8][3] = {{256, 64, 16}, {256, 64, 32}, {128, 64, 32}, {256, 128, 32}, {256, 128, 32}, {128, 256, 32},
-                                   {64, 64, 32}, {128, 128, 32}};
+    static const int dims[9][3] = {{256, 64, 16}, {256, 64, 32}, {128, 64, 32}, {256, 128, 32}, {256, 128, 32}, {128, 256, 32},
+                                   {64, 64, 32}, {128, 128, 32}, {256, 256, 32}};
     const int t = posmajor ? (int)pick_tile<true>(p) : (int)pick_tile<false>(p);
     const int code = dims[t][0] * 100000 + dims[t][1] * 100 + dims[t][2];
     return posmajor ? -code : code;

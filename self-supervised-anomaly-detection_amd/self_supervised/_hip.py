@@ -120,6 +120,7 @@ SIGNATURES = {
     "ssad_affine_window_sum_u8": [_c_fp, _c_i, _c_i, ctypes.POINTER(ctypes.c_int32), _c_i, _c_i, _c_i, _c_i,
                                   ctypes.POINTER(ctypes.c_int64)],
     "ssad_u8hwc_to_f32chw": [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_resize_bicubic_u8": [_c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_i, _c_fp, _c_fp, _c_i, _c_fp],
     "ssad_u8hwc_to_f32chw_norm": [_c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
                                   _c_fp],
 }

@@ -429,7 +429,13 @@ class GpuPretextLoader:
         self.stage, self._last_epoch = 0, None
         names = list(dict.fromkeys(dataset.images_filenames))            # duplicated file lists decode once
         self.slot = {n: i for i, n in enumerate(names)}
-        imgs = [np.asarray(Image.open(n).resize(dataset.imsize).convert('RGB')) for n in names]
+        # decode on the host (threads), Pillow's bicubic resize on the device (gpu_io / csrc/resize.hip: bit-exact), one copy back
+        # for the host-side sampler; a CPU `device` (tests of the host half) keeps Pillow's resize
+        if torch.device(device).type == "cuda":
+            from .gpu_io import load_rgb_batch
+            imgs = list(load_rgb_batch(names, dataset.imsize, device).cpu().numpy())
+        else:
+            imgs = [np.asarray(Image.open(n).resize(dataset.imsize).convert('RGB')) for n in names]
         if dataset.subject in constants.NON_FIXED_OBJECTS():
             masks = np.stack([np.asarray(obj_mask(Image.fromarray(im)).convert('1')) for im in imgs])
         else:

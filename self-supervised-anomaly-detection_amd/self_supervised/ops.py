@@ -344,6 +344,42 @@ def blur_relu_bilinear(maps, ksize=7, target=256):
     return out
 
 
+_RESAMPLE_TABLES = {}
+
+
+def _resample_tables(n_in, n_out, device):
+    """Device copies of Pillow's per-axis resampling tables, one pair per (input extent, output extent, device)."""
+    key = (n_in, n_out, str(device))
+    t = _RESAMPLE_TABLES.get(key)
+    if t is None:
+        from .pil_exact import resample_coeffs
+        ks, bounds, kk = resample_coeffs(n_in, n_out)
+        t = _RESAMPLE_TABLES[key] = (ks, torch.from_numpy(bounds).to(device), torch.from_numpy(kk).to(device))
+    return t
+
+
+def resize_bicubic_u8(img, size):
+    """Pillow's ``Image.resize(size)`` (BICUBIC) on a uint8 batch [B][Hin][Win][C] (C = 1: mode 'L', 3: 'RGB') that lives on the
+    device; size = (width, height) as PIL takes it.  Bit-exact (csrc/resize.hip); same size = the input itself, as PIL copies."""
+    b, hin, win, c = img.shape
+    wout, hout = int(size[0]), int(size[1])
+    if (hin, win) == (hout, wout):
+        return img
+    assert img.dtype == torch.uint8 and img.is_cuda and img.is_contiguous()
+    out = torch.empty((b, hout, wout, c), dtype=torch.uint8, device=img.device)
+    kx = ky = (0, None, None)
+    if win != wout:
+        kx = _resample_tables(win, wout, img.device)
+    if hin != hout:
+        ky = _resample_tables(hin, hout, img.device)
+    tmp = torch.empty((b, hin, wout, c), dtype=torch.uint8, device=img.device) if (win != wout and hin != hout) else None
+    p = lambda t: None if t is None else t.data_ptr()
+    _run("resize_bicubic", 0.0, float(img.numel() + out.numel() + (2 * tmp.numel() if tmp is not None else 0)),
+         lambda: _hip.lib().ssad_resize_bicubic_u8(img.data_ptr(), p(tmp), out.data_ptr(), b, hin, win, c, hout, wout,
+                                                   p(kx[1]), p(kx[2]), kx[0], p(ky[1]), p(ky[2]), ky[0], _hip.stream()))
+    return out
+
+
 def gradcam_map(act, alpha):
     """act NHWC [B][U][V][C], alpha [B][C] (may be a column slice of a wider matrix) -> [B][1][U][V] weighted sums."""
     b, u, v, c = act.shape

@@ -268,3 +268,81 @@ def enhance_color(img, f):
 
 
 ENHANCERS = (enhance_brightness, enhance_contrast, enhance_color)       # indexed like ColorJitter's ops
+
+
+# ---------------------------------------------------------------------------------------------
+# Image.resize(size) with Pillow's default filter for 'L' / 'RGB' images, BICUBIC (libImaging Resample.c, 8 bits per channel:
+# precompute_coeffs, normalize_coeffs_8bpc, ImagingResampleHorizontal_8bpc / Vertical_8bpc) -- what the reference applies to
+# every image it opens (src/self_supervised/datasets.py:68, :211-213, functional.py:20-25).  csrc/resize.hip runs the two integer
+# passes on the device from the tables computed here.
+# ---------------------------------------------------------------------------------------------
+RESAMPLE_PRECISION_BITS = 32 - 8 - 2
+
+
+def _bicubic_filter(x):
+    a = -0.5
+    if x < 0.0:
+        x = -x
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+def resample_coeffs(in_size, out_size):
+    """One axis of Image.resize (box = the whole image): -> (ksize, bounds int32 [out][2] = (first input index, taps), coefficients
+    int32 [out][ksize] in 22-bit fixed point), exactly as precompute_coeffs + normalize_coeffs_8bpc compute them (C doubles)."""
+    scale = filterscale = float(in_size) / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    kk = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = 0.0 + (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        w = [_bicubic_filter((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = 0.0
+        for v in w:
+            ww += v
+        for x in range(xmax):
+            v = w[x] / ww if ww != 0.0 else w[x]
+            kk[xx, x] = int(-0.5 + v * (1 << RESAMPLE_PRECISION_BITS)) if v < 0 else int(0.5 + v * (1 << RESAMPLE_PRECISION_BITS))
+        bounds[xx] = (xmin, xmax)
+    return ksize, bounds, kk
+
+
+def _resample_axis(img, bounds, kk, axis):
+    """One pass over an H x W x C uint8 array (numpy statement of the kernel: int32 sums, rounding constant, arithmetic shift, clip)."""
+    src = np.moveaxis(img, axis, 0).astype(np.int64)
+    out = np.empty((bounds.shape[0],) + src.shape[1:], np.int64)
+    for xx in range(bounds.shape[0]):
+        x0, n = int(bounds[xx, 0]), int(bounds[xx, 1])
+        acc = np.full(src.shape[1:], 1 << (RESAMPLE_PRECISION_BITS - 1), np.int64)
+        for t in range(n):
+            acc += src[x0 + t] * int(kk[xx, t])
+        out[xx] = np.clip(acc >> RESAMPLE_PRECISION_BITS, 0, 255)
+    return np.moveaxis(out, 0, axis).astype(np.uint8)
+
+
+def resize_bicubic(img, size):
+    """Image.fromarray(img).resize(size) for an H x W (mode 'L') or H x W x 3 (mode 'RGB') uint8 array; size = (width, height).
+    Horizontal pass first, then vertical, each skipped when that extent does not change (ImagingResample)."""
+    a = img if img.ndim == 3 else img[:, :, None]
+    w_out, h_out = size
+    if a.shape[1] != w_out:
+        _, b, k = resample_coeffs(a.shape[1], w_out)
+        a = _resample_axis(a, b, k, 1)
+    if a.shape[0] != h_out:
+        _, b, k = resample_coeffs(a.shape[0], h_out)
+        a = _resample_axis(a, b, k, 0)
+    return a if img.ndim == 3 else a[:, :, 0]

@@ -168,19 +168,19 @@ def _predict_mvtec_streamed(model: PeraNet, dataset, device, indices, group: int
     """``Trainer.predict`` + ``ModelOutputsContainer.from_list`` for an MVTecDataset with the default transform, as ONE stream
     instead of a DataLoader of batch size 1 (tools.py:336-347 of the reference): same values, field for field.
 
-    * a thread pool reads the files exactly as ``MVTecDataset.__getitem__`` does (``Image.open().resize().convert('RGB')``, the
-      ground-truth mask through ``get_ground_truth``) -- Pillow decodes outside the GIL -- and writes uint8 pixels into one
-      preallocated batch;
-    * ``group`` images at a time go to the device as uint8 (a quarter of the fp32 bytes), where ToTensor + Normalize are two
-      IEEE fp32 operations per value (ssad_u8hwc_to_f32chw_norm: bit-identical to the host transform), then through
-      ``model.forward`` -- thousands of patches per launch instead of 841;
+    * a thread pool decodes the files (Pillow decodes outside the GIL) and reads the ground-truth masks exactly as
+      ``MVTecDataset.__getitem__`` does (``get_ground_truth``: resize + dither to mode '1' stay Pillow's);
+    * ``group`` images at a time go to the device as uint8 at their NATIVE size, where Pillow's bicubic ``resize(imsize)`` (csrc/resize.hip,
+      bit-exact), the 'L' -> 'RGB' replication and ToTensor + Normalize (two IEEE fp32 operations per value,
+      ssad_u8hwc_to_f32chw_norm: bit-identical to the host transform) run, then ``model.forward`` -- thousands of patches per launch
+      instead of 841;
     * results return to the host per group on a side stream while the next group computes; the embeddings also STAY on the device
       (second return value) for the detector, instead of making the round trip host -> device again.
     Returns (container with CPU tensors, device embeddings [n * P][D])."""
     import ctypes
     from concurrent.futures import ThreadPoolExecutor
     from PIL import Image
-    from . import _hip
+    from . import _hip, gpu_io
     from .datasets import IMAGENET_MEAN, IMAGENET_STD
     from .functional import get_ground_truth, get_ground_truth_filename, get_prediction_class
     from .converters import gt2label
@@ -190,12 +190,13 @@ def _predict_mvtec_streamed(model: PeraNet, dataset, device, indices, group: int
         return out, None
     w_img, h_img = dataset.imsize
     names = [dataset.images_filenames[i] for i in indices]
-    u8 = np.empty((n, h_img, w_img, 3), np.uint8)
     gt8 = np.zeros((n, h_img, w_img), np.uint8)
     gt_dir = dataset.dataset_dir + 'ground_truth/'
 
+    native = [None] * n
+
     def load(j):
-        u8[j] = np.asarray(Image.open(names[j]).resize(dataset.imsize).convert('RGB'))
+        native[j] = gpu_io.read_native(names[j])        # decoded at its native size; the resize runs on the device (gpu_io)
         gfile = get_ground_truth_filename(names[j], gt_dir)
         if gfile:                                       # 'good' images: Image.new(mode='1') = all zeros
             gt8[j] = np.asarray(get_ground_truth(gfile, dataset.imsize).convert('L'))
@@ -226,7 +227,8 @@ def _predict_mvtec_streamed(model: PeraNet, dataset, device, indices, group: int
             b = min(n, a + group)
             for f in futs[a:b]:
                 f.result()
-            img_dev = torch.from_numpy(u8[a:b]).to(device)
+            img_dev = gpu_io.to_rgb_batch(native[a:b], dataset.imsize, device)
+            native[a:b] = [None] * (b - a)
             o_dev = torch.empty((b - a, 3, h_img, w_img), device=device, dtype=torch.float32)
             x_dev = torch.empty_like(o_dev)
             _hip.check(lib.ssad_u8hwc_to_f32chw_norm(img_dev.data_ptr(), o_dev.data_ptr(), x_dev.data_ptr(), b - a, h_img, w_img,

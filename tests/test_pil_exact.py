@@ -71,3 +71,26 @@ def test_enhance_matches_pillow():
         for op in range(3):
             f = rng.uniform(0.75, 1.15) if it % 5 == 0 else float(np.float32(rng.uniform(0.7, 1.2)))
             assert np.array_equal(px.ENHANCERS[op](arr, f), np.array(enh[op](im).enhance(f))), (op, f)
+
+
+def test_bicubic_resize_tables_match_pillow():
+    """pil_exact.resample_coeffs / resize_bicubic (the tables csrc/resize.hip consumes and the numpy statement of its two integer
+    passes) against Image.resize of the installed Pillow: 'L' and 'RGB', down- and up-scaling, integer and fractional ratios,
+    one extent unchanged."""
+    from PIL import Image
+    from self_supervised import pil_exact as px
+    rng = np.random.RandomState(0)
+    cases = [((700, 700), (256, 256)), ((1024, 1024), (256, 256)), ((900, 900), (256, 256)), ((256, 256), (64, 64)),
+             ((100, 130), (256, 256)), ((257, 255), (256, 256)), ((840, 1000), (320, 200)), ((256, 300), (256, 256)),
+             ((300, 256), (256, 256)), ((33, 47), (64, 64)), ((96, 96), (256, 256))]
+    for (h, w), (oh, ow) in cases:
+        for c in (1, 3):
+            noise = rng.randint(0, 256, (h, w, c) if c == 3 else (h, w)).astype(np.uint8)
+            yy, xx = np.mgrid[0:h, 0:w]
+            smooth = (127 + 120 * np.sin(xx / 9.0) * np.cos(yy / 13.0)).astype(np.uint8)
+            smooth = smooth if c == 1 else np.stack([smooth, 255 - smooth, smooth // 2], -1)
+            for img in (noise, smooth):
+                want = np.asarray(Image.fromarray(img).resize((ow, oh)))
+                assert np.array_equal(px.resize_bicubic(img, (ow, oh)), want), ((h, w), (oh, ow), c)
+    ks, bounds, kk = px.resample_coeffs(1024, 256)
+    assert ks == 17 and bounds.shape == (256, 2) and kk.shape == (256, 17) and int(kk.sum(1).min()) > (1 << 22) - 16
