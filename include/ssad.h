@@ -90,25 +90,6 @@ int ssad_conv_igemm_fwd_hwnc(const float* in, const float* w_ohwi, float* out, c
                              const float* residual, int relu, int64_t N, int H, int W, int Cin, int Cout, int KH, int KW,
                              int stride, int pad, void* stream);
 
-/* Train-mode BatchNorm with one launch less per layer where the tensors are small (the batch-32 step of the 8-GPU partition):
- * the convolution leaves its partial sums un-finalized (ssad_conv_igemm_fwd_stats_deferred: *rows_out rows of [2][Cout] doubles in
- * `workspace`, ssad_conv_stats_workspace doubles) and the BatchNorm apply adds them up itself when there are at most 256 rows
- * (ssad_bn_apply_fwd_partials: statistics, running statistics, affine (+ residual) (+ ReLU) (+ nibble mask); otherwise it runs the
- * finalize kernel first).  Together they replace nn.Conv2d + nn.BatchNorm2d(train) (+ add) (+ ReLU) of a torchvision BasicBlock
- * under trainer.fit (models.py:224, tools.py:270), like ssad_conv_igemm_fwd_stats + ssad_bn_apply_fwd(_mask).
- * ssad_bn_bwd_fused is the backward of that BatchNorm in one call: g = dy under `mask4` (ssad_bn_apply_fwd_mask's nibble mask), or
- * under the ReLU mask recomputed from z when `zmask_beta` (= beta) is given, or dy; dbeta = sum g, dgamma = sum g * xhat (both
- * written; pass scratch for frozen parameters), dz = gamma * invstd * (g - dbeta / R - xhat * dgamma / R).
- * workspace: ssad_colreduce_workspace(R, C) doubles.  Replaces autograd's native_batch_norm_backward (+ threshold_backward). */
-int ssad_conv_igemm_fwd_stats_deferred(const float* in, const float* w_ohwi, float* out, int64_t N, int H, int W, int Cin, int Cout,
-                                       int KH, int KW, int stride, int pad, int bf16, double* workspace, int* rows_out, void* stream);
-int ssad_bn_apply_fwd_partials(const float* z, const double* partial, int rows, int64_t R, int C, float eps, float momentum,
-                               const float* gamma, const float* beta, const float* residual, float* y, uint8_t* mask4, float* mean,
-                               float* invstd, float* running_mean, float* running_var, int relu, void* stream);
-int ssad_bn_bwd_fused(const float* dy, const uint8_t* mask4, const float* z, const float* mean, const float* invstd,
-                      const float* gamma, const float* zmask_beta, float* dbeta, float* dgamma, float* dz, int64_t R, int C,
-                      double* workspace, void* stream);
-
 /* Which exact-fp32 instantiation ssad_conv_igemm_fwd (hwnc = 0) / ssad_conv_igemm_fwd_hwnc (hwnc = 1) gives a problem:
  * BM * 100000 + BN * 100 + BK of the workgroup tile, negated when its rows are position-major.  Measurement aid only
  * (bench.py names the instantiations its roofline figure sums over); no reference counterpart. */

@@ -1131,16 +1131,6 @@ extern "C" int ssad_conv_igemm_fwd_stats(const float* in, const float* w_ohwi, f
                                      running_var, stream);
 }
 
-// The same convolution leaving the partial sums un-finalized: *rows_out rows of [2][Cout] doubles in `workspace`, for
-// ssad_bn_apply_fwd_partials (which finalizes inside the BatchNorm apply when the rows are few: one launch less per layer).
-extern "C" int ssad_conv_igemm_fwd_stats_deferred(const float* in, const float* w_ohwi, float* out, int64_t N, int H, int W, int Cin,
-                                                  int Cout, int KH, int KW, int stride, int pad, int bf16, double* workspace,
-                                                  int* rows_out, void* stream) {
-    SSAD_CHECK_ARG(workspace && rows_out, "null pointer");
-    return conv_fwd_impl(in, w_ohwi, out, nullptr, nullptr, nullptr, 0, N, H, W, Cin, Cout, KH, KW, stride, pad, 0, stream, bf16,
-                         workspace, rows_out);
-}
-
 // Same contraction with every activation tensor (in, out, residual) stored position-major, [H][W][N][C].
 // This is the layout of the patch-scoring trunk: N = thousands of 64x64 patches whose maps are 16x16 .. 2x2,
 // so a workgroup's 128 rows (128 patches at one output position) are contiguous in HBM for every tap and taps

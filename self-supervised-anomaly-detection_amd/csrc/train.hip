@@ -227,146 +227,6 @@ __global__ void bn_apply_bwd_kernel(const float* __restrict__ dy, const float* _
 }
 
 // ---------------------------------------------------------------------------------------------
-// BatchNorm apply kernels that FINALIZE their own statistics (round 4).  On small tensors -- the batch-32 step of the 8-GPU
-// partition, layer4 at batch 256 -- a step is bound by its number of launches (~4.5 us each when replayed from a graph): a
-// BatchNorm was conv(+ partial sums) -> finalize -> apply and reduce -> finalize -> apply.  Here a workgroup owns 32 channels
-// and a chunk of rows, adds the (<= 256) partial rows of its channels itself -- every workgroup the same fixed order: eight row
-// lanes ascending, then lane sums 0..7 -- and goes straight on to the element-wise pass; the workgroups of row chunk 0 also write
-// mean / invstd / running statistics (forward) or dbeta / dgamma (backward) for whoever needs them later.
-// ---------------------------------------------------------------------------------------------
-constexpr int FOLD_MAX_ROWS = 256;       // partial rows a workgroup is asked to add itself (512 B each for its 32 channels)
-
-// -> sh[0][c], sh[1][c] = totals of channels c0 .. c0 + 31 (valid after the trailing barrier)
-__device__ __forceinline__ void fold_totals(const double* __restrict__ partial, int nblk, int C, int c0, double (*sh)[32]) {
-    __shared__ double lane[2][8][32];
-    const int c = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    double a = 0, b = 0;
-    for (int k = rl; k < nblk; k += 8) {
-        a += partial[(int64_t)k * 2 * C + c0 + c];
-        b += partial[(int64_t)k * 2 * C + C + c0 + c];
-    }
-    lane[0][rl][c] = a;
-    lane[1][rl][c] = b;
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const int w = threadIdx.x >> 5;
-        double t = lane[w][0][c];
-#pragma unroll
-        for (int l = 1; l < 8; ++l) t += lane[w][l][c];
-        sh[w][c] = t;
-    }
-    __syncthreads();
-}
-
-__global__ __launch_bounds__(256) void bn_apply_fwd_fold_kernel(const float* __restrict__ z, const double* __restrict__ partial, int nblk,
-                                                                int64_t R, int C, float eps, float momentum,
-                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                const float* __restrict__ res, float* __restrict__ y,
-                                                                uint8_t* __restrict__ mask4, float* __restrict__ mean,
-                                                                float* __restrict__ invstd, float* __restrict__ running_mean,
-                                                                float* __restrict__ running_var, int relu, int rows_per_block) {
-    __shared__ double tot[2][32];
-    __shared__ float st[2][32];
-    const int c0 = blockIdx.y * 32;
-    fold_totals(partial, nblk, C, c0, tot);
-    if (threadIdx.x < 32) {                               // bn_stats_finalize_kernel's arithmetic
-        const int c = c0 + threadIdx.x;
-        const double m = tot[0][threadIdx.x] / (double)R;
-        double var = tot[1][threadIdx.x] / (double)R - m * m;
-        if (var < 0) var = 0;
-        const float mf = (float)m, isf = (float)(1.0 / sqrt(var + (double)eps));
-        st[0][threadIdx.x] = mf;
-        st[1][threadIdx.x] = isf;
-        if (blockIdx.x == 0) {
-            mean[c] = mf;
-            invstd[c] = isf;
-            if (running_mean) {
-                const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
-                running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
-                running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
-            }
-        }
-    }
-    __syncthreads();
-    const int q = threadIdx.x & 7, r0 = threadIdx.x >> 3, C4 = C / 4, cq = c0 / 4 + q;
-    f32x4 mu, is;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { mu[k] = st[0][q * 4 + k]; is[k] = st[1][q * 4 + k]; }
-    const f32x4 g = ((const f32x4*)gamma)[cq], b = ((const f32x4*)beta)[cq];
-    const int64_t rb = (int64_t)blockIdx.x * rows_per_block;
-    const int64_t re = rb + rows_per_block < R ? rb + rows_per_block : R;
-    for (int64_t row = rb + r0; row < re; row += 32) {
-        const int64_t i = row * C4 + cq;
-        f32x4 v = ((const f32x4*)z)[i];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = (v[k] - mu[k]) * is[k] * g[k] + b[k];
-        if (res) {
-            const f32x4 rr = ((const f32x4*)res)[i];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] += rr[k];
-        }
-        if (mask4) mask4[i] = (uint8_t)((v[0] > 0.f) | ((v[1] > 0.f) << 1) | ((v[2] > 0.f) << 2) | ((v[3] > 0.f) << 3));
-        if (relu) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
-        }
-        ((f32x4*)y)[i] = v;
-    }
-}
-
-// train-mode backward apply (bn_apply_bwd_kernel's arithmetic) with dbeta / dgamma added up from the reduction's partial rows
-__global__ __launch_bounds__(256) void bn_apply_bwd_fold_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ mask4,
-                                                                const float* __restrict__ z, const float* __restrict__ mean,
-                                                                const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                                const float* __restrict__ zmask_beta,
-                                                                const double* __restrict__ partial, int nblk, float* __restrict__ dbeta,
-                                                                float* __restrict__ dgamma, float* __restrict__ dz, int64_t R, int C,
-                                                                float invR, int rows_per_block) {
-    __shared__ double tot[2][32];
-    __shared__ float st[2][32];
-    const int c0 = blockIdx.y * 32;
-    fold_totals(partial, nblk, C, c0, tot);
-    if (threadIdx.x < 32) {                               // bn_bwd_finalize_kernel: the sums rounded to float once
-        const float db = (float)tot[0][threadIdx.x], dg = (float)tot[1][threadIdx.x];
-        st[0][threadIdx.x] = db;
-        st[1][threadIdx.x] = dg;
-        if (blockIdx.x == 0) {
-            if (dbeta) dbeta[c0 + threadIdx.x] = db;
-            if (dgamma) dgamma[c0 + threadIdx.x] = dg;
-        }
-    }
-    __syncthreads();
-    const int q = threadIdx.x & 7, r0 = threadIdx.x >> 3, C4 = C / 4, cq = c0 / 4 + q;
-    f32x4 db, dg, zb = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { db[k] = st[0][q * 4 + k]; dg[k] = st[1][q * 4 + k]; }
-    const f32x4 mu = ((const f32x4*)mean)[cq], is = ((const f32x4*)invstd)[cq], ga = ((const f32x4*)gamma)[cq];
-    if (zmask_beta) zb = ((const f32x4*)zmask_beta)[cq];
-    const int64_t rb = (int64_t)blockIdx.x * rows_per_block;
-    const int64_t re = rb + rows_per_block < R ? rb + rows_per_block : R;
-    for (int64_t row = rb + r0; row < re; row += 32) {
-        const int64_t i = row * C4 + cq;
-        f32x4 g = ((const f32x4*)dy)[i];
-        const f32x4 zz = ((const f32x4*)z)[i];
-        if (mask4) {
-            const unsigned mk = mask4[i];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) g[k] = (mk >> k) & 1u ? g[k] : 0.f;
-        } else if (zmask_beta) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) g[k] = (zz[k] - mu[k]) * is[k] * ga[k] + zb[k] > 0.f ? g[k] : 0.f;
-        }
-        f32x4 o;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float xh = (zz[k] - mu[k]) * is[k];
-            o[k] = ga[k] * is[k] * (g[k] - db[k] * invR - xh * dg[k] * invR);
-        }
-        ((f32x4*)dz)[i] = o;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // pooling backward
 // ---------------------------------------------------------------------------------------------
 // dx[n][y][x][c] = sum over the (<= 4) 3x3/2 windows covering (y,x) whose FIRST maximum (row-major scan, as
@@ -775,31 +635,22 @@ static inline unsigned ew_grid(int64_t n) {
 }  // namespace
 
 // Number of doubles of workspace the column reductions need for R rows x C channels.
-// Row blocks of a column reduction over R rows: 32 row sweeps per workgroup on big tensors (<= 2048 blocks), but never fewer than
-// ~256 workgroups while a block still has one full sweep of 4 rows per row lane -- the tensors of a batch-32 step (2 048 .. 131 072
-// rows) used to get 32 .. 256 workgroups of eight dependent load rounds each: 11-15 us per reduction for 4-33 MB (round 4).
-static inline int64_t col_blocks(int64_t R, const ColReduce& g) {
-    int64_t nblk = cdiv64(R, (int64_t)g.RL * 32);
-    const int64_t fine = cdiv64(R, (int64_t)g.RL * 4);
-    const int64_t want = fine < FOLD_MAX_ROWS ? fine : FOLD_MAX_ROWS;      // (what a folding apply kernel adds up itself)
-    if (nblk < want) nblk = want;
-    if (nblk > 2048) nblk = 2048;
-    if (nblk < 1) nblk = 1;
-    return nblk;
-}
-
 extern "C" int64_t ssad_colreduce_workspace(int64_t R, int C) {
     ColReduce g = col_geom(C);
-    return col_blocks(R, g) * 2 * C;
+    int64_t nblk = cdiv64(R, (int64_t)g.RL * 32);
+    if (nblk > 2048) nblk = 2048;
+    if (nblk < 1) nblk = 1;
+    return nblk * 2 * C;
 }
 
 static int launch_col_reduce(int mode, const float* a, const float* yact, const float* z, const float* mean,
                              const float* invstd, double* ws, int64_t R, int C, int* nblk_out, hipStream_t st,
                              const float* zg = nullptr, const float* zb = nullptr, const uint8_t* mask4 = nullptr) {
     ColReduce g = col_geom(C);
-    int64_t nblk = col_blocks(R, g);
+    int64_t nblk = cdiv64(R, (int64_t)g.RL * 32);
+    if (nblk > 2048) nblk = 2048;
+    if (nblk < 1) nblk = 1;
     int rows_per_block = (int)cdiv64(R, nblk);
-    nblk = cdiv64(R, rows_per_block);                 // no empty trailing blocks (their partial rows would be read uninitialised)
     int gx = (C / 4 + g.TC - 1) / g.TC;
     dim3 grid(gx, (unsigned)nblk);
     if (mode == 0)
@@ -1203,71 +1054,6 @@ extern "C" int ssad_bn_apply_bwd_mask(const float* dy, const uint8_t* mask4, con
     return bn_apply_bwd_impl(dy, nullptr, z, mean, invstd, gamma, dbeta, dgamma, dz, nullptr, R, C, 0, stream, nullptr, mask4);
 }
 
-
-// How many rows of a folded element-wise pass one workgroup takes: enough workgroups (x C / 32 channel groups) to fill the chip,
-// at least one sweep of 32 rows each
-static inline int fold_rows_per_block(int64_t R, int C) {
-    const int64_t groups = C / 32;
-    int64_t chunks = cdiv64(1024, groups);
-    if (chunks > cdiv64(R, 32)) chunks = cdiv64(R, 32);
-    if (chunks < 1) chunks = 1;
-    return (int)cdiv64(R, chunks);
-}
-
-// BatchNorm(train) forward from the partial sums a convolution left (ssad_conv_igemm_fwd_stats_deferred): statistics, running
-// statistics and the apply (+ residual, ReLU, nibble mask) -- ONE launch when there are at most 256 partial rows and C % 32 == 0
-// (the workgroups add the partial rows themselves), else the finalize kernel followed by the element-wise kernel.  Same
-// results as ssad_conv_igemm_fwd_stats + ssad_bn_apply_fwd(_mask) up to the summation order of the partial rows.
-extern "C" int ssad_bn_apply_fwd_partials(const float* z, const double* partial, int rows, int64_t R, int C, float eps, float momentum,
-                                          const float* gamma, const float* beta, const float* residual, float* y, uint8_t* mask4,
-                                          float* mean, float* invstd, float* running_mean, float* running_var, int relu,
-                                          void* stream) {
-    SSAD_CHECK_ARG(z && partial && rows > 0 && gamma && beta && y && mean && invstd && R > 0 && C > 0 && C % 4 == 0, "bad argument");
-    hipStream_t st = (hipStream_t)stream;
-    static const int fold_on = getenv("SSAD_BN_FOLD") ? atoi(getenv("SSAD_BN_FOLD")) : 1;
-    if (fold_on && rows <= FOLD_MAX_ROWS && C % 32 == 0) {
-        const int rpb = fold_rows_per_block(R, C);
-        hipLaunchKernelGGL(bn_apply_fwd_fold_kernel, dim3((unsigned)cdiv64(R, rpb), (unsigned)(C / 32)), dim3(256), 0, st, z, partial,
-                           rows, R, C, eps, momentum, gamma, beta, residual, y, mask4, mean, invstd, running_mean, running_var, relu,
-                           rpb);
-        SSAD_CHECK_LAUNCH();
-        return 0;
-    }
-    int rc = ssad_bn_finalize_partials(partial, rows, R, C, eps, momentum, mean, invstd, running_mean, running_var, stream);
-    if (rc) return rc;
-    const int64_t total4 = R * (C / 4);
-    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, st, z, mean, invstd, gamma, beta, residual, y,
-                       total4, C / 4, relu, mask4);
-    SSAD_CHECK_LAUNCH();
-    return 0;
-}
-
-// BatchNorm(train) backward in one call: dbeta / dgamma (column sums of g and g * xhat, g = dy under the nibble mask `mask4`, or
-// under the ReLU mask recomputed from z when `zmask_beta` is given, or dy itself) and dz.  Two launches (reduction, folding
-// apply) where the reduction leaves at most 256 partial rows and C % 32 == 0, else reduction, finalize, apply.  dbeta / dgamma
-// must be writable (scratch when the parameter is frozen).  workspace: ssad_colreduce_workspace(R, C) doubles.
-extern "C" int ssad_bn_bwd_fused(const float* dy, const uint8_t* mask4, const float* z, const float* mean, const float* invstd,
-                                 const float* gamma, const float* zmask_beta, float* dbeta, float* dgamma, float* dz, int64_t R,
-                                 int C, double* workspace, void* stream) {
-    SSAD_CHECK_ARG(dy && z && mean && invstd && gamma && dbeta && dgamma && dz && workspace && R > 0 && C > 0 && C % 4 == 0,
-                   "bad argument");
-    SSAD_CHECK_ARG(!(mask4 && zmask_beta), "one mask source");
-    hipStream_t st = (hipStream_t)stream;
-    int nblk;
-    launch_col_reduce(1, dy, nullptr, z, mean, invstd, workspace, R, C, &nblk, st, zmask_beta ? gamma : nullptr, zmask_beta, mask4);
-    SSAD_CHECK_LAUNCH();
-    static const int fold_on = getenv("SSAD_BN_FOLD") ? atoi(getenv("SSAD_BN_FOLD")) : 1;
-    if (fold_on && nblk <= FOLD_MAX_ROWS && C % 32 == 0) {
-        const int rpb = fold_rows_per_block(R, C);
-        hipLaunchKernelGGL(bn_apply_bwd_fold_kernel, dim3((unsigned)cdiv64(R, rpb), (unsigned)(C / 32)), dim3(256), 0, st, dy, mask4, z,
-                           mean, invstd, gamma, zmask_beta, workspace, nblk, dbeta, dgamma, dz, R, C, 1.f / (float)R, rpb);
-        SSAD_CHECK_LAUNCH();
-        return 0;
-    }
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, workspace, nblk, C, dbeta, dgamma);
-    SSAD_CHECK_LAUNCH();
-    return bn_apply_bwd_impl(dy, nullptr, z, mean, invstd, gamma, dbeta, dgamma, dz, nullptr, R, C, 0, stream, zmask_beta, mask4);
-}
 
 // ssad_flip_transpose_weight for n filters at once: desc[k] = {src offset, dst offset, O, I, KH, KW} (floats, host
 // memory), sources inside `src`, results inside `dst`.  One launch per 32 filters (the kernel's table travels as a launch

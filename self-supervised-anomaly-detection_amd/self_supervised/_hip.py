@@ -32,11 +32,6 @@ SIGNATURES = {
                             _c_i, _c_i, _c_fp],
     "ssad_conv_igemm_fwd_hwnc": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
                                  _c_i, _c_i, _c_fp],
-    "ssad_conv_igemm_fwd_stats_deferred": [_c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp,
-                                           ctypes.POINTER(ctypes.c_int), _c_fp],
-    "ssad_bn_apply_fwd_partials": [_c_fp, _c_fp, _c_i, _c_l, _c_i, _c_f, _c_f, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp,
-                                   _c_fp, _c_i, _c_fp],
-    "ssad_bn_bwd_fused": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_fp, _c_fp],
     "ssad_conv_igemm_tile": [_c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i],
     "ssad_gap_fwd": [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
     "ssad_l2_normalize_rows": [_c_fp, _c_fp, _c_l, _c_i, _c_fp],

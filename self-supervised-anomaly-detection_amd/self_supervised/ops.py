@@ -228,56 +228,6 @@ def conv_fwd_stats(x, w_ohwi, eps, momentum, running_mean, running_var, stride=1
     return out, mean, invstd
 
 
-def conv_fwd_stats_deferred(x, w_ohwi, stride=1, pad=0, bf16=False):
-    """Bias-free conv whose train-mode BatchNorm statistics stay as partial sums: -> (z, workspace, rows) for
-    bn_apply_fwd_partials (one launch less per layer where the partial rows are few)."""
-    import ctypes
-    n, h, w, cin = x.shape
-    cout, kh, kw, cin2 = w_ohwi.shape
-    assert cin == cin2
-    ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
-    out = _new((n, ho, wo, cout), x)
-    lib = _hip.lib()
-    ws = torch.empty(lib.ssad_conv_stats_workspace(n, ho, wo, cout), device=x.device, dtype=torch.float64)
-    rows = ctypes.c_int(0)
-    nb = 4.0 * (x.numel() + out.numel() + w_ohwi.numel())
-    _run(_kname("conv_igemm", bf16), 2.0 * out.numel() * kh * kw * cin, nb,
-         lambda: lib.ssad_conv_igemm_fwd_stats_deferred(_hip.ptr(x), _hip.ptr(w_ohwi), _hip.ptr(out), n, h, w, cin, cout, kh, kw,
-                                                        stride, pad, int(bf16), ws.data_ptr(), ctypes.byref(rows), _hip.stream()),
-         tile=None if bf16 else (lambda: igemm_tile_name(n, h, w, cin, cout, kh, kw, stride, pad, 0)))
-    return out, ws, rows.value
-
-
-def bn_apply_fwd_partials(z, ws, rows, gamma, beta, residual, relu, eps, momentum, running_mean, running_var, want_mask=False):
-    """Train-mode BatchNorm from a conv's partial sums: statistics + running statistics + apply (+ residual, ReLU, nibble mask).
-    -> (y, mean, invstd, mask or None)"""
-    c = gamma.numel()
-    r = z.numel() // c
-    y, mean, invstd = torch.empty_like(z), _new((c,), z), _new((c,), z)
-    mask = torch.empty(z.numel() // 4, device=z.device, dtype=torch.uint8) if want_mask else None
-    _run("bn_apply_fwd", 0.0, 4.0 * z.numel() * (3 if residual is not None else 2) + (mask.numel() if want_mask else 0),
-         lambda: _hip.lib().ssad_bn_apply_fwd_partials(_hip.ptr(z), ws.data_ptr(), rows, r, c, eps, momentum, _hip.ptr(gamma),
-                                                       _hip.ptr(beta), _hip.ptr(residual, True), _hip.ptr(y),
-                                                       mask.data_ptr() if want_mask else None, _hip.ptr(mean), _hip.ptr(invstd),
-                                                       _hip.ptr(running_mean, True), _hip.ptr(running_var, True), int(relu),
-                                                       _hip.stream()))
-    return y, mean, invstd, mask
-
-
-def bn_bwd_fused(dy, mask, z, mean, invstd, gamma, zmask_beta, dbeta, dgamma):
-    """Train-mode BatchNorm backward in one call (reduction + an apply that finalizes dbeta / dgamma itself on small tensors):
-    g = dy under the nibble `mask`, or under the ReLU mask recomputed from z when `zmask_beta` is given, or dy.  Returns dz."""
-    c = mean.numel()
-    r = dy.numel() // c
-    ws = _colreduce_ws(r, c, dy)
-    dz = torch.empty_like(dy)
-    _run("bn_bwd", 0.0, 20.0 * dy.numel() + 2 * (mask.numel() if mask is not None else 0),
-         lambda: _hip.lib().ssad_bn_bwd_fused(_hip.ptr(dy), mask.data_ptr() if mask is not None else None, _hip.ptr(z), _hip.ptr(mean),
-                                              _hip.ptr(invstd), _hip.ptr(gamma), _hip.ptr(zmask_beta, True), _hip.ptr(dbeta),
-                                              _hip.ptr(dgamma), _hip.ptr(dz), r, c, ws.data_ptr(), _hip.stream()))
-    return dz
-
-
 def conv3x3_c64(x, w_ohwi, residual=None, transform=None, emit=False, stats=None, res_mask=None):
     """Halo-tile 3x3 / stride 1 / pad 1 convolution, 64 -> 64 channels (layer1 forward and input-gradient convs).
     x NHWC [N][H][W][64], w OHWI [64][3][3][64].  transform = (mean, invstd, gamma, beta): the input is taken through

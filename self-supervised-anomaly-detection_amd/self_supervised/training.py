@@ -264,21 +264,9 @@ class _Affine:
                 self.z, self.y = z, (y if self.relu else None)
                 return y
             if bias is None and c % 4 == 0:
-                # batch statistics taken in the conv epilogue (no second pass over z), left as per-workgroup partial sums that the
-                # BatchNorm apply adds up itself where they are few (one launch less per layer: the batch-32 step is launch bound)
-                z, ws, rows = ops.conv_fwd_stats_deferred(x, w, self.stride, self.pad, bf)
-                with torch.no_grad():
-                    self.eng.count_batch(bn)
-                self.z = z
-                want_mask = residual is not None and self.relu and self.eng.use_relu_mask()
-                y, self.mean, self.invstd, mk = ops.bn_apply_fwd_partials(z, ws, rows, a.w(bn.weight), a.w(bn.bias), residual,
-                                                                          self.relu, bn.eps, mom, bn.running_mean, bn.running_var,
-                                                                          want_mask)
-                if want_mask:
-                    self.mask, self.y = mk, None
-                else:
-                    self.y = y if self.relu else None
-                return y
+                # batch statistics taken in the conv epilogue (no second pass over z)
+                z, self.mean, self.invstd = ops.conv_fwd_stats(x, w, bn.eps, mom, bn.running_mean, bn.running_var,
+                                                               self.stride, self.pad, bf)
             else:
                 z = ops.conv_fwd(x, w, None, a.w(bias) if bias is not None else None, None, False, self.stride, self.pad, bf)
                 self.mean, self.invstd = ops.bn_stats(z, c, bn.eps, mom, bn.running_mean, bn.running_var)
@@ -334,14 +322,14 @@ class _Affine:
                 dbeta = a.grad(bn.bias) if bg else torch.empty(c, device=dy.device)
                 dgamma = a.grad(bn.weight) if wg else torch.empty(c, device=dy.device)
                 mk = dy_mask if dy_mask is not None else mask
-                dz = ops.bn_bwd_fused(dy, mk, self.z, self.mean, self.invstd, a.w(bn.weight), None, dbeta, dgamma)
+                dz = ops.bn_bwd_mask(dy, mk, self.z, self.mean, self.invstd, a.w(bn.weight), dbeta, dgamma)
                 if want_dres:
                     dres = (dy, mk)
             elif train_stats and self.relu and not self.res_used and not want_dres:
                 # y = relu(bn(z)) with nothing added in between: take the mask from z, skip re-reading y
                 dbeta = a.grad(bn.bias) if bg else torch.empty(c, device=dy.device)
                 dgamma = a.grad(bn.weight) if wg else torch.empty(c, device=dy.device)
-                dz = ops.bn_bwd_fused(dy, None, self.z, self.mean, self.invstd, a.w(bn.weight), a.w(bn.bias), dbeta, dgamma)
+                dz = ops.bn_bwd_zmask(dy, self.z, self.mean, self.invstd, a.w(bn.weight), a.w(bn.bias), dbeta, dgamma)
             elif train_stats or wg or bg:
                 dbeta = a.grad(bn.bias) if bg else torch.empty(c, device=dy.device)
                 dgamma = a.grad(bn.weight) if wg else torch.empty(c, device=dy.device)
