@@ -635,22 +635,32 @@ static inline unsigned ew_grid(int64_t n) {
 }  // namespace
 
 // Number of doubles of workspace the column reductions need for R rows x C channels.
-extern "C" int64_t ssad_colreduce_workspace(int64_t R, int C) {
-    ColReduce g = col_geom(C);
+// Row blocks of a column reduction over R rows: 32 row sweeps per workgroup on big tensors (<= 2048 blocks), but never fewer than
+// ~256 workgroups while a block still has one full sweep of 4 rows per row lane -- the tensors of a batch-32 step (2 048 .. 131 072
+// rows) used to get 32 .. 256 workgroups of eight dependent load rounds each: 11-15 us per reduction for 4-33 MB, now 5-8 (round 4:
+// batch-32 step 5.59 -> 5.51 ms).
+static inline int64_t col_blocks(int64_t R, const ColReduce& g) {
     int64_t nblk = cdiv64(R, (int64_t)g.RL * 32);
+    const int64_t fine = cdiv64(R, (int64_t)g.RL * 4);
+    const int64_t want = fine < 256 ? fine : 256;
+    if (nblk < want) nblk = want;
     if (nblk > 2048) nblk = 2048;
     if (nblk < 1) nblk = 1;
-    return nblk * 2 * C;
+    return nblk;
+}
+
+extern "C" int64_t ssad_colreduce_workspace(int64_t R, int C) {
+    ColReduce g = col_geom(C);
+    return col_blocks(R, g) * 2 * C;
 }
 
 static int launch_col_reduce(int mode, const float* a, const float* yact, const float* z, const float* mean,
                              const float* invstd, double* ws, int64_t R, int C, int* nblk_out, hipStream_t st,
                              const float* zg = nullptr, const float* zb = nullptr, const uint8_t* mask4 = nullptr) {
     ColReduce g = col_geom(C);
-    int64_t nblk = cdiv64(R, (int64_t)g.RL * 32);
-    if (nblk > 2048) nblk = 2048;
-    if (nblk < 1) nblk = 1;
+    int64_t nblk = col_blocks(R, g);
     int rows_per_block = (int)cdiv64(R, nblk);
+    nblk = cdiv64(R, rows_per_block);                 // no empty trailing blocks (their partial rows would be read uninitialised)
     int gx = (C / 4 + g.TC - 1) / g.TC;
     dim3 grid(gx, (unsigned)nblk);
     if (mode == 0)
@@ -704,6 +714,34 @@ extern "C" int ssad_bn_apply_fwd_mask(const float* z, const float* mean, const f
     return 0;
 }
 
+// Column sums of a tiny matrix (the bias gradient of the 512 -> 4 classifier over a training batch: 32 x 4 values) in ONE launch:
+// the general two-stage reduction gives such a matrix one workgroup whose thread 0 adds 256 LDS values one after the other, then
+// a finalize launch -- 13 + 4 us for 128 numbers.  Lane l of column c adds rows l, l + L, ...; eight lane groups are added in
+// order, then the eight group sums: a fixed order, in double.
+__global__ __launch_bounds__(256) void col_sum_tiny_kernel(const float* __restrict__ a, float* __restrict__ out, int R, int C) {
+    __shared__ double sh[256];
+    __shared__ double grp[8][32];
+    const int c = threadIdx.x % C, l = threadIdx.x / C, L = 256 / C;        // C in {4, 8, 16, 32}: L = 64 .. 8
+    double s = 0;
+    for (int r = l; r < R; r += L) s += (double)a[(int64_t)r * C + c];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    const int per = L / 8;                                                   // lanes per group
+    if (threadIdx.x < 8 * C) {
+        const int g = threadIdx.x / C, cc = threadIdx.x % C;
+        double t = 0;
+        for (int k = 0; k < per; ++k) t += sh[(g * per + k) * C + cc];
+        grp[g][cc] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < C) {
+        double t = grp[0][threadIdx.x];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) t += grp[g][threadIdx.x];
+        out[threadIdx.x] = (float)t;
+    }
+}
+
 // dbeta/dgamma over rows of g = dy*(yact>0); with z == NULL only dbeta (= column sums: Linear bias gradient).
 static int bn_bwd_reduce_impl(const float* dy, const float* yact, const float* z, const float* mean, const float* invstd,
                               float* dbeta, float* dgamma, int64_t R, int C, double* workspace, void* stream,
@@ -711,6 +749,11 @@ static int bn_bwd_reduce_impl(const float* dy, const float* yact, const float* z
     SSAD_CHECK_ARG(dy && workspace && R > 0 && C > 0 && C % 4 == 0, "bad argument");
     SSAD_CHECK_ARG(!z || (mean && invstd), "z needs mean/invstd");
     SSAD_CHECK_ARG(!zg || (z && zb && !yact), "mask-from-z needs z, gamma, beta and no yact");
+    if (!z && !yact && !mask4 && dbeta && R <= 4096 && (C == 4 || C == 8 || C == 16 || C == 32)) {     // plain column sums, tiny
+        hipLaunchKernelGGL(col_sum_tiny_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, dy, dbeta, (int)R, C);
+        SSAD_CHECK_LAUNCH();
+        return 0;
+    }
     int nblk;
     launch_col_reduce(1, dy, yact, z, mean, invstd, workspace, R, C, &nblk, (hipStream_t)stream, zg, zb, mask4);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, workspace, nblk, C, dbeta,

@@ -1,8 +1,8 @@
 # per-dispatch kernel trace of one replayed training step: bash tools/trace_step.sh [batch, default 32]
-# -> gpurun_out/r03_b<batch>_trace_step.csv
+# -> gpurun_out/<TAG, default r04>_b<batch>_trace_step.csv
 B=${1:-32}
 R=$PWD; OUT=$R/gpurun_out; cd /tmp; export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/t_b$B -o s -- python3 $R/bench.py --batch $B --scaling weak --phase train --no-cpu-baseline --no-e2e --no-partition-extra --steps 6 --warmup 3 > $OUT/r03_b${B}_trace_line.json 2>/tmp/t_b$B.err && B=$B python3 - <<'PY'
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/t_b$B -o s -- python3 $R/bench.py --batch $B --scaling weak --phase train --no-cpu-baseline --no-e2e --no-partition-extra --steps 6 --warmup 3 > $OUT/${TAG:-r04}_b${B}_trace_line.json 2>/tmp/t_b$B.err && B=$B python3 - <<'PY'
 import csv, glob, os
 f = glob.glob('/tmp/t_b%s/**/*kernel_trace.csv' % os.environ['B'], recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
@@ -13,7 +13,7 @@ spans = [(int(rows[idx[k+1]]['Start_Timestamp']) - int(rows[idx[k]]['Start_Times
 print('step spans (us):', [round(a / 1e3) for a, _ in spans])
 k = min(spans)[1]            # a replayed step (eager steps are the long ones)
 lo, hi = idx[k], idx[k + 1]
-out = os.environ.get('GRAFT_REPO_ROOT', '/root/repo') + '/gpurun_out/r03_b%s_trace_step.csv' % os.environ['B']
+out = os.environ.get('GRAFT_REPO_ROOT', '/root/repo') + '/gpurun_out/%s_b%s_trace_step.csv' % (os.environ.get('TAG', 'r04'), os.environ['B'])
 with open(out, 'w') as o:
     o.write('kernel,grid,wg,start_us,dur_us,gap_before_us\n')
     t0 = int(rows[lo]['Start_Timestamp']); prev_end = t0
