@@ -396,6 +396,16 @@ int ssad_resize_bicubic_u8(const uint8_t* in, uint8_t* tmp, uint8_t* out, int B,
                            const int32_t* bounds_x, const int32_t* coef_x, int ksize_x, const int32_t* bounds_y,
                            const int32_t* coef_y, int ksize_y, void* stream);
 
+/* dataset_generator.obj_mask (dataset_generator.py:27-39: skimage.feature.canny(sigma = 1.5, low 5, high 15) -> binary dilation 3 x 3
+ * -> closing 3 x 3 -> fill holes -> erosion 4 x 4 -> largest 8-connected component) for a uint8 RGB batch on the device:
+ * rgb [B][H][W][3] -> mask [B][H][W] (0 / 1) and edges [B][H][W] (the Canny edge map, 0 / 1).  gauss_w_host: the 2 * radius + 1
+ * normalised Gaussian weights as scipy.ndimage computes them (host memory); low / high: the thresholds on the [0, 1] scale.
+ * workspace: ssad_obj_mask_workspace(B, H, W) bytes of device memory.  Bit-exact against the host statement (fp64, scipy's
+ * operation order, glibc's hypot restated; fixed points for hysteresis / filling / labelling). */
+int64_t ssad_obj_mask_workspace(int B, int H, int W);
+int ssad_obj_mask(const uint8_t* rgb, uint8_t* mask, uint8_t* edges, int B, int H, int W, const double* gauss_w_host, int radius,
+                  double low, double high, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

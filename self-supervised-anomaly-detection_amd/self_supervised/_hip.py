@@ -120,11 +120,14 @@ SIGNATURES = {
     "ssad_affine_window_sum_u8": [_c_fp, _c_i, _c_i, ctypes.POINTER(ctypes.c_int32), _c_i, _c_i, _c_i, _c_i,
                                   ctypes.POINTER(ctypes.c_int64)],
     "ssad_u8hwc_to_f32chw": [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_obj_mask_workspace": [_c_i, _c_i, _c_i],
+    "ssad_obj_mask": [_c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, ctypes.POINTER(ctypes.c_double), _c_i, ctypes.c_double, ctypes.c_double,
+                      _c_fp, _c_fp],
     "ssad_resize_bicubic_u8": [_c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_i, _c_fp, _c_fp, _c_i, _c_fp],
     "ssad_u8hwc_to_f32chw_norm": [_c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
                                   _c_fp],
 }
-RESTYPES = {"ssad_conv3x3_c64_stats_rows": _c_l, "ssad_colreduce_workspace": _c_l, "ssad_conv_stats_workspace": _c_l, "ssad_stem_wgrad_workspace": _c_l, "ssad_auroc_workspace": _c_l}
+RESTYPES = {"ssad_conv3x3_c64_stats_rows": _c_l, "ssad_colreduce_workspace": _c_l, "ssad_conv_stats_workspace": _c_l, "ssad_stem_wgrad_workspace": _c_l, "ssad_auroc_workspace": _c_l, "ssad_obj_mask_workspace": _c_l}
 
 _lib = None
 

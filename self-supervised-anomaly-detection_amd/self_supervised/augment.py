@@ -437,7 +437,11 @@ class GpuPretextLoader:
         else:
             imgs = [np.asarray(Image.open(n).resize(dataset.imsize).convert('RGB')) for n in names]
         if dataset.subject in constants.NON_FIXED_OBJECTS():
-            masks = np.stack([np.asarray(obj_mask(Image.fromarray(im)).convert('1')) for im in imgs])
+            if torch.device(device).type == "cuda":          # Canny -> morphology -> largest component on the device (csrc/objmask.hip)
+                from . import ops
+                masks = ops.obj_mask_batch(torch.from_numpy(np.stack(imgs)).to(device)).cpu().numpy()
+            else:
+                masks = np.stack([np.asarray(obj_mask(Image.fromarray(im)).convert('1')) for im in imgs])
         else:
             masks = np.asarray(dataset.fixed_segmentation.convert('1'))
         cuts = np.stack([np.asarray(c) for c in dataset.images_for_cut]) if dataset.subject in constants.TEXTURES() else None

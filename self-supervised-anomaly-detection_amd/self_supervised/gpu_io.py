@@ -33,7 +33,7 @@ def to_rgb_batch(items, size, device, chunk=32):
     groups = {}
     for i, (mode, a) in enumerate(items):
         if mode is None:                                         # Pillow's own path (rare modes)
-            out[i] = torch.from_numpy(np.asarray(a.resize((w, h)).convert('RGB'))).to(device)
+            out[i] = torch.from_numpy(np.array(a.resize((w, h)).convert('RGB'))).to(device)
         else:
             groups.setdefault((mode, a.shape[0], a.shape[1]), []).append(i)
     for (mode, hin, win), idx in groups.items():

@@ -380,6 +380,31 @@ def resize_bicubic_u8(img, size):
     return out
 
 
+def obj_mask_batch(rgb, sigma=1.5, low=5, high=15, chunk=64, return_edges=False):
+    """dataset_generator.obj_mask for a uint8 RGB batch [B][H][W][3] on the device -> bool [B][H][W] (csrc/objmask.hip; bit-exact
+    against the host statement).  The Gaussian weights are scipy.ndimage's (numpy's exp on the host), everything per pixel runs on
+    the device.  return_edges: also the Canny edge maps."""
+    import ctypes
+    import numpy as np
+    assert rgb.dtype == torch.uint8 and rgb.is_cuda and rgb.is_contiguous() and rgb.shape[-1] == 3
+    b, h, w, _ = rgb.shape
+    radius = int(4.0 * float(sigma) + 0.5)                       # scipy.ndimage.gaussian_filter1d: truncate = 4
+    xs = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (sigma * sigma) * xs ** 2)
+    phi = (phi / phi.sum())[::-1].copy()
+    wts = (ctypes.c_double * len(phi))(*phi.tolist())
+    lib = _hip.lib()
+    mask = torch.empty((b, h, w), dtype=torch.uint8, device=rgb.device)
+    edges = torch.empty((b, h, w), dtype=torch.uint8, device=rgb.device)
+    for s in range(0, b, chunk):
+        e = min(b, s + chunk)
+        ws = torch.empty(lib.ssad_obj_mask_workspace(e - s, h, w), dtype=torch.uint8, device=rgb.device)
+        _hip.check(lib.ssad_obj_mask(rgb[s:e].data_ptr(), mask[s:e].data_ptr(), edges[s:e].data_ptr(), e - s, h, w, wts, radius,
+                                     low / 255.0, high / 255.0, ws.data_ptr(), _hip.stream()))
+        torch.cuda.current_stream().synchronize()               # the weights live in this frame: the upload must have happened
+    return (mask.bool(), edges.bool()) if return_edges else mask.bool()
+
+
 def gradcam_map(act, alpha):
     """act NHWC [B][U][V][C], alpha [B][C] (may be a column slice of a wider matrix) -> [B][1][U][V] weighted sums."""
     b, u, v, c = act.shape

@@ -337,3 +337,27 @@ def test_canny_restatement_properties():
     assert not dg._canny(faint, 1.5, 5, 15).any()
     faint[:, 32:] = (160 - 55 * np.arange(64) / 63).astype(np.uint8)[:, None]   # the same edge, fading from strong to faint
     assert dg._canny(faint, 1.5, 5, 15)[56:62, 30:35].any()
+
+
+def test_glibc_hypot_restatement_matches_numpy():
+    """csrc/objmask.hip restates np.hypot (= this image's libm: glibc 2.35, sqrt + one correction step, NOT correctly rounded in
+    ~0.2 % of inputs) operation by operation; the same statement in numpy must agree with np.hypot bit for bit, or the device-side
+    Canny cannot be expected to match the host one."""
+    def hyp(x, y):
+        x, y = np.abs(x), np.abs(y)
+        ax, ay = np.where(x < y, y, x), np.where(x < y, x, y)
+        h = np.sqrt(ax * ax + ay * ay)
+        d1, d2 = h - ay, h - ax
+        first = h <= 2.0 * ay
+        t1 = np.where(first, ax * (2.0 * d1 - ax), 2.0 * d2 * (ax - 2.0 * ay))
+        t2 = np.where(first, (d1 - 2.0 * (ax - ay)) * d1, (4.0 * d2 - ay) * ay + d2 * d2)
+        with np.errstate(all="ignore"):
+            r = h - (t1 + t2) / (2.0 * h)
+            return np.where(ax >= ay / 2.0 ** -54, ax + ay, r)
+    rng = np.random.RandomState(0)
+    for scale in (1.0, 1e-3, 10.0):
+        a = (rng.rand(400000) - 0.5) * 2 * scale * 10 ** rng.uniform(-5, 0, 400000)
+        b = (rng.rand(400000) - 0.5) * 2 * scale * 10 ** rng.uniform(-5, 0, 400000)
+        assert np.array_equal(np.hypot(a, b), hyp(a, b))
+    z = np.array([0.0, 0.0, 3.0, -0.0]); w = np.array([0.0, 2.0, 4.0, -0.0])
+    assert np.array_equal(np.hypot(z, w), hyp(z, w))

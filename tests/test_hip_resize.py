@@ -88,3 +88,61 @@ def test_loaders_on_native_size_files(tmp_path):
     with torch.no_grad():
         ref = model(out.tensor_data[1:2].cuda())
     assert torch.equal(ref["latent_space"].cpu(), out.embedding_vectors[model.num_patches:2 * model.num_patches])
+
+
+def _blob_image(rng, size, kind):
+    yy, xx = np.mgrid[0:size, 0:size]
+    bg = np.clip(40 + 8 * rng.randn(size, size, 3), 0, 255)
+    img = bg.copy()
+    if kind == "disc":
+        sel = (yy - size * 0.52) ** 2 + (xx - size * 0.47) ** 2 < (size * 0.31) ** 2
+        img[sel] = np.clip(170 + 25 * np.sin(xx / 5.0)[..., None] + 10 * rng.randn(size, size, 3), 0, 255)[sel]
+    elif kind == "two":
+        for cy, cx, r, v in ((0.3, 0.3, 0.16, 200), (0.68, 0.66, 0.2, 120)):
+            sel = (yy - size * cy) ** 2 + (xx - size * cx) ** 2 < (size * r) ** 2
+            img[sel] = np.clip(v + 12 * rng.randn(size, size, 3), 0, 255)[sel]
+    elif kind == "ring":
+        d = np.sqrt((yy - size / 2) ** 2 + (xx - size / 2) ** 2)
+        sel = (d < size * 0.4) & (d > size * 0.22)
+        img[sel] = np.clip(210 + 10 * rng.randn(size, size, 3), 0, 255)[sel]
+    elif kind == "flat":
+        img[:] = 77
+    elif kind == "noise":
+        img = rng.randint(0, 256, (size, size, 3)).astype(np.float64)
+    return img.astype(np.uint8)
+
+
+def test_obj_mask_kernels_match_the_host_statement(golden):
+    """ops.obj_mask_batch (csrc/objmask.hip) against dataset_generator.obj_mask / _canny -- the host statement that is pinned to
+    scikit-image 0.18.3 -- and against the scikit-image fixture itself: edge maps and object masks identical, bit for bit."""
+    from self_supervised import dataset_generator as dg, ops
+    dev = torch.device("cuda:0")
+    d = golden("skimage")
+    for k in range(int(d["n"])):
+        img = d[f"img{k}"]
+        mask, edges = ops.obj_mask_batch(torch.from_numpy(img[None]).to(dev), return_edges=True)
+        assert np.array_equal(edges[0].cpu().numpy(), d[f"canny{k}"]), k
+        assert np.array_equal(mask[0].cpu().numpy(), d[f"mask{k}"]), k
+    rng = np.random.RandomState(5)
+    for size in (64, 96, 256):
+        imgs = np.stack([_blob_image(rng, size, kind) for kind in ("disc", "two", "ring", "flat", "noise", "disc")])
+        mask, edges = ops.obj_mask_batch(torch.from_numpy(imgs).to(dev), return_edges=True, chunk=4)
+        for i, im in enumerate(imgs):
+            gray = np.array(Image.fromarray(im).convert("L"))
+            want_e = dg._canny(gray, sigma=1.5, low=5, high=15)
+            want_m = np.asarray(dg.obj_mask(Image.fromarray(im)).convert("1"))
+            assert np.array_equal(edges[i].cpu().numpy(), want_e), (size, i)
+            assert np.array_equal(mask[i].cpu().numpy(), want_m), (size, i)
+    assert bool(mask[3].all())                       # a flat image has no edges: the reference's all-white mask
+
+
+def test_screw_loader_builds_its_masks_on_the_device(tmp_path):
+    """A non-fixed-object category: the GPU-resident loader's per-image object masks (device kernels) equal obj_mask on the host."""
+    from fake_mvtec import make_tree
+    from self_supervised import augment, datasets, dataset_generator as dg
+    root = make_tree(str(tmp_path / "dataset"), categories=("screw",), n_train=6, n_test_good=1, n_test_bad=1, size=160)
+    tr = sorted(os.path.join(root, "screw", "train/good", f) for f in os.listdir(os.path.join(root, "screw", "train/good")))
+    ds = datasets.PretextTaskDataset("screw", np.array(tr), imsize=(128, 128), transform=datasets._default_transform(), dataset_root=root)
+    ld = augment.GpuPretextLoader(ds, 4, num_workers=0)
+    want = np.stack([np.asarray(dg.obj_mask(Image.open(n).resize((128, 128)).convert("RGB")).convert("1")) for n in tr])
+    assert np.array_equal(ld.aug.masks, want)
