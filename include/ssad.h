@@ -378,6 +378,25 @@ int ssad_cosine_knn_fused(const float* x, const float* bank_normalized, float* o
  * draws. */
 int ssad_affine_window_sum_u8(const uint8_t* img, int H, int W, const int32_t* fix, int left, int top, int w, int h,
                               int64_t* sum3);
+/* The other sort-bound metrics of an evaluation, for maps that are already on the device (same hand-written radix sort as
+ * ssad_auroc; no library sort).
+ * ssad_pro_curve: the MVTec per-region-overlap curve of metrics.compute_pro (src/self_supervised/metrics.py:58-190): scores fp32
+ *   [n]; fp_w uint8 [n] = 1 on defect-free pixels; pro_w fp64 [n] = 1 / (size of the pixel's ground-truth region), 0 elsewhere;
+ *   n_ok = number of defect-free pixels, n_regions = number of regions (each at least 1, numpy's max(., 1)).  Writes one curve
+ *   point per distinct score in descending order -- fprs fp32, pros fp64, both clipped at 1 -- and their number to count[0]
+ *   (device memory; the arrays need room for n entries).  The caller adds the end points (0, 0) and (1, 1).
+ * ssad_best_f1_threshold: the threshold maximising F1 over torchmetrics' precision-recall curve (tools.py:141-146), float32
+ *   arithmetic as there, the smallest threshold among equal F1.  targets: 1 = positive.  out[0] = threshold, out[1] = F1.
+ * ssad_confusion_counts: tp, fp, fn, tn of (scores >= threshold) against (targets != 0), added into out[0..3] (int64, zeroed by
+ *   the caller): what compute_f1 / compute_iou (tools.py:131-139) need. */
+int64_t ssad_pro_curve_workspace(int64_t n);
+int ssad_pro_curve(const float* scores, const uint8_t* fp_w, const double* pro_w, int64_t n, double n_ok, double n_regions,
+                   void* workspace, int64_t workspace_bytes, float* fprs, double* pros, int64_t* count, void* stream);
+int64_t ssad_best_f1_workspace(int64_t n);
+int ssad_best_f1_threshold(const float* scores, const uint8_t* targets, int64_t n, void* workspace, int64_t workspace_bytes, float* out,
+                           void* stream);
+int ssad_confusion_counts(const float* scores, const uint8_t* targets, int64_t n, float threshold, int64_t* out, void* stream);
+
 /* transforms.ToTensor() on a uint8 HWC batch: -> [B][3][H][W] fp32 in [0,1] (the Dataset's third output). */
 int ssad_u8hwc_to_f32chw(const uint8_t* img, float* out, int B, int H, int W, void* stream);
 /* The transform of MVTecDataset.__getitem__ (datasets.py:68-80, :102-105: ToTensor, then Normalize(mean, std)) on a uint8 HWC

@@ -114,6 +114,11 @@ SIGNATURES = {
     "ssad_sgd_step": [_c_fp, _c_fp, _c_fp, _c_l, _c_f, _c_f, _c_f, _c_f, _c_fp],
     "ssad_auroc_workspace": [_c_l],
     "ssad_auroc": [_c_fp, _c_fp, _c_l, _c_fp, _c_l, _c_fp, _c_fp],
+    "ssad_pro_curve_workspace": [_c_l],
+    "ssad_pro_curve": [_c_fp, _c_fp, _c_fp, _c_l, ctypes.c_double, ctypes.c_double, _c_fp, _c_l, _c_fp, _c_fp, _c_fp, _c_fp],
+    "ssad_best_f1_workspace": [_c_l],
+    "ssad_best_f1_threshold": [_c_fp, _c_fp, _c_l, _c_fp, _c_l, _c_fp, _c_fp],
+    "ssad_confusion_counts": [_c_fp, _c_fp, _c_l, _c_f, _c_fp, _c_fp],
     "ssad_aug_params_size": [],
     "ssad_cutpaste_augment": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i,
                               ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _c_fp],
@@ -127,7 +132,8 @@ SIGNATURES = {
     "ssad_u8hwc_to_f32chw_norm": [_c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
                                   _c_fp],
 }
-RESTYPES = {"ssad_conv3x3_c64_stats_rows": _c_l, "ssad_colreduce_workspace": _c_l, "ssad_conv_stats_workspace": _c_l, "ssad_stem_wgrad_workspace": _c_l, "ssad_auroc_workspace": _c_l, "ssad_obj_mask_workspace": _c_l}
+RESTYPES = {"ssad_conv3x3_c64_stats_rows": _c_l, "ssad_colreduce_workspace": _c_l, "ssad_conv_stats_workspace": _c_l, "ssad_stem_wgrad_workspace": _c_l, "ssad_auroc_workspace": _c_l, "ssad_obj_mask_workspace": _c_l, "ssad_pro_curve_workspace": _c_l,
+            "ssad_best_f1_workspace": _c_l}
 
 _lib = None
 

@@ -1,6 +1,8 @@
 """Evaluation metrics (mirrors src/self_supervised/metrics.py:49-228): ROC/AUC through scikit-learn as the
 reference does, F1 at a threshold, and the MVTec per-region-overlap (PRO) curve with its clipped trapezoid area.
-CPU side: these report parity (AUROC within 1e-4), they are not on the accelerated path (SURVEY s.8 f-1)."""
+The host functions are the parity statement (pinned to the reference's own metrics.py by tests/golden/metrics.npz); the `*_gpu`
+functions below compute the same quantities for device-resident maps with the hand-written radix sort of csrc/auroc.hip
+(three argsorts of 83 x 65 536 scores cost ~9 s per category on the host -- more than training that category on this card)."""
 from bisect import bisect
 
 import numpy as np
@@ -152,3 +154,87 @@ def auroc_gpu(labels, scores) -> float:
     out = torch.empty(2, dtype=torch.float64, device=s.device)
     _hip.check(_hip.lib().ssad_auroc(s.data_ptr(), l.data_ptr(), n, ws.data_ptr(), nbytes, out.data_ptr(), _hip.stream()))
     return float(out[0].item())
+
+
+
+def _dev_flat(scores, targets=None):
+    s = scores.detach().reshape(-1).float().contiguous()
+    if not s.is_cuda:
+        raise RuntimeError("the *_gpu metrics need GPU tensors; use the host functions of this module otherwise")
+    t = None if targets is None else (torch.as_tensor(targets).detach().reshape(-1).to(s.device) > 0).to(torch.uint8).contiguous()
+    return s, t
+
+
+def best_f1_threshold_gpu(scores, targets) -> float:
+    """best_f1_threshold for device-resident scores (csrc/auroc.hip: descending radix sort with the label as payload, running
+    count of positives, the curve in torchmetrics' float32 arithmetic, arg-max with its tie rule)."""
+    from . import _hip
+    s, _ = _dev_flat(scores)
+    t = (torch.as_tensor(targets).detach().reshape(-1).to(s.device) == 1).to(torch.uint8).contiguous()
+    n = s.numel()
+    nbytes = _hip.lib().ssad_best_f1_workspace(n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=s.device)
+    out = torch.empty(2, dtype=torch.float32, device=s.device)
+    _hip.check(_hip.lib().ssad_best_f1_threshold(s.data_ptr(), t.data_ptr(), n, ws.data_ptr(), nbytes, out.data_ptr(), _hip.stream()))
+    return float(out[0].item())
+
+
+def confusion_gpu(scores, targets, threshold):
+    """(tp, fp, fn, tn) of (scores >= threshold) against (targets > 0) for device-resident scores."""
+    from . import _hip
+    s, t = _dev_flat(scores, targets)
+    out = torch.zeros(4, dtype=torch.int64, device=s.device)
+    _hip.check(_hip.lib().ssad_confusion_counts(s.data_ptr(), t.data_ptr(), s.numel(), float(threshold), out.data_ptr(), _hip.stream()))
+    return tuple(int(v) for v in out.tolist())
+
+
+def compute_f1_gpu(targets, predictions, threshold) -> float:
+    tp, fp, fn, _ = confusion_gpu(predictions, targets, threshold)
+    denom = 2 * tp + fp + fn
+    return 2 * tp / denom if denom else 0.0
+
+
+def compute_iou_gpu(scores, targets, threshold) -> float:
+    tp, fp, fn, tn = confusion_gpu(scores, targets, threshold)
+    ious = []
+    for inter, union in ((tn, tn + fp + fn), (tp, tp + fp + fn)):          # class "normal", class "anomalous"
+        ious.append(inter / union if union else 0.0)
+    return float(np.mean(ious))
+
+
+def compute_pro_gpu(anomaly_maps, ground_truth_maps):
+    """compute_pro for device-resident maps [n][H][W]: the ground-truth regions are labelled on the host (a few dozen small masks),
+    the 6 M scores are sorted, weighted, accumulated and compacted on the device (ssad_pro_curve).  Returns (fprs, pros) as numpy
+    arrays from (0, 0) to (1, 1); equal to compute_pro up to the summation order of the fp64 running sum (~1e-13)."""
+    from . import _hip
+    maps = anomaly_maps.detach().float().contiguous()
+    if not maps.is_cuda:
+        raise RuntimeError("compute_pro_gpu needs GPU maps; use compute_pro on the host")
+    gts = _np(ground_truth_maps)
+    gts = gts.reshape((-1,) + gts.shape[-2:])
+    fp_w = np.zeros(gts.shape, dtype=np.uint8)
+    pro_w = np.zeros(gts.shape, dtype=np.float64)
+    n_regions = 0
+    eight = np.ones((3, 3), dtype=int)
+    for i, gt in enumerate(gts):
+        lab, k = ndimage.label(gt, eight)
+        n_regions += k
+        fp_w[i] = lab == 0
+        if k:
+            sizes = np.bincount(lab.ravel())[1:]
+            pro_w[i] = np.concatenate([[0.0], 1.0 / sizes])[lab]
+    n = maps.numel()
+    assert n == fp_w.size, "maps and ground truths differ in size"
+    n_ok = float(fp_w.sum())
+    dev = maps.device
+    fpd, prd = torch.from_numpy(fp_w.reshape(-1)).to(dev), torch.from_numpy(pro_w.reshape(-1)).to(dev)
+    nbytes = _hip.lib().ssad_pro_curve_workspace(n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    fprs = torch.empty(n, dtype=torch.float32, device=dev)
+    pros = torch.empty(n, dtype=torch.float64, device=dev)
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    _hip.check(_hip.lib().ssad_pro_curve(maps.data_ptr(), fpd.data_ptr(), prd.data_ptr(), n, max(n_ok, 1.0), float(max(n_regions, 1)),
+                                         ws.data_ptr(), nbytes, fprs.data_ptr(), pros.data_ptr(), count.data_ptr(), _hip.stream()))
+    k = int(count.item())
+    f, p = fprs[:k].cpu().numpy(), pros[:k].cpu().numpy()
+    return np.concatenate(([0.0], f, [1.0])), np.concatenate(([0.0], p, [1.0]))

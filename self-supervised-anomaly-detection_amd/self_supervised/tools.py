@@ -41,29 +41,42 @@ class Evaluator:
             targets = torch.flatten(output_container.ground_truths, 0, -1)
             scores = torch.flatten(scores, 0, -1)
         on_gpu = scores.is_cuda
-        targets_dev, scores_dev = targets, scores
-        targets, scores = targets.detach().cpu(), scores.detach().cpu()
         for m in self.evaluation_metrics:
             if m != 'auroc' and ((m == 'f1-score') == patch_level):
                 raise ValueError(f"'{m}' not a valid metric for '{'patch' if patch_level else 'image'}-level' mode")
-        threshold = self._get_threshold(scores, targets)
-        if 'auroc' in self.evaluation_metrics:
-            print(' pixel auroc' if patch_level else '>>> image auroc')
-            if on_gpu:       # maps still on the device (e.g. straight from tools.upsample): sort-based AUROC kernel
-                self.scores.auroc = mtr.auroc_gpu(targets_dev.to(scores_dev.device), scores_dev)
-            else:
+        if on_gpu:
+            # maps still on the device (straight from tools.upsample): every sort-bound metric runs there (csrc/auroc.hip) --
+            # on the host the three argsorts of a category's 6 M pixel scores take longer than training the category
+            targets_dev = targets.to(scores.device)
+            threshold = mtr.best_f1_threshold_gpu(scores, targets_dev)
+            if 'auroc' in self.evaluation_metrics:
+                print(' pixel auroc' if patch_level else '>>> image auroc')
+                self.scores.auroc = mtr.auroc_gpu(targets_dev, scores)
+            if 'f1-score' in self.evaluation_metrics:
+                self.scores.f1_score = mtr.compute_f1_gpu(targets_dev, scores, threshold)
+            if 'aupro' in self.evaluation_metrics:
+                fprs, pros = mtr.compute_pro_gpu(output_container.anomaly_maps.squeeze(1), output_container.ground_truths.squeeze(1))
+                self.scores.aupro = mtr.compute_aupro(fprs, pros, 0.3)
+                self.curves['pro'] = (fprs, pros)
+            if 'iou' in self.evaluation_metrics:
+                self.scores.iou = mtr.compute_iou_gpu(scores, targets_dev, threshold)
+        else:
+            targets, scores = targets.detach().cpu(), scores.detach().cpu()
+            threshold = self._get_threshold(scores, targets)
+            if 'auroc' in self.evaluation_metrics:
+                print(' pixel auroc' if patch_level else '>>> image auroc')
                 fpr, tpr, _ = mtr.compute_roc(targets, scores)
                 self.scores.auroc = mtr.compute_auc(fpr, tpr)
                 self.curves['roc'] = (fpr, tpr)
-        if 'f1-score' in self.evaluation_metrics:
-            self.scores.f1_score = mtr.compute_f1(targets, scores, threshold)
-        if 'aupro' in self.evaluation_metrics:
-            fprs, pros = mtr.compute_pro(output_container.anomaly_maps.detach().cpu().squeeze(1).numpy(),
-                                         output_container.ground_truths.detach().cpu().squeeze(1).numpy())
-            self.scores.aupro = mtr.compute_aupro(fprs, pros, 0.3)
-            self.curves['pro'] = (fprs, pros)
-        if 'iou' in self.evaluation_metrics:
-            self.scores.iou = mtr.compute_iou(scores, targets, threshold)
+            if 'f1-score' in self.evaluation_metrics:
+                self.scores.f1_score = mtr.compute_f1(targets, scores, threshold)
+            if 'aupro' in self.evaluation_metrics:
+                fprs, pros = mtr.compute_pro(output_container.anomaly_maps.detach().cpu().squeeze(1).numpy(),
+                                             output_container.ground_truths.detach().cpu().squeeze(1).numpy())
+                self.scores.aupro = mtr.compute_aupro(fprs, pros, 0.3)
+                self.curves['pro'] = (fprs, pros)
+            if 'iou' in self.evaluation_metrics:
+                self.scores.iou = mtr.compute_iou(scores, targets, threshold)
         if outputs_dir:
             os.makedirs(outputs_dir, exist_ok=True)
             with open(os.path.join(outputs_dir, subject + ('_pixel' if patch_level else '_image') + '_scores.json'), 'w') as f:
@@ -396,7 +409,7 @@ def sweep(dataset_dir: str, outputs_dir: str, categories: list, imsize: tuple = 
             out = inference(sub_out + 'best_model.ckpt', data, subject, mvtec_inference=True,
                             patch_localization=patch_localization)
         if patch_localization:
-            out.anomaly_maps = upsample(out.anomaly_maps, int(out.ground_truths.shape[-1]), verbose=False).cpu()
+            out.anomaly_maps = upsample(out.anomaly_maps, int(out.ground_truths.shape[-1]), verbose=False)      # stays on the device: the Evaluator's GPU metrics
         ev = Evaluator(evaluation_metrics=[m for m in metrics if (m != 'f1-score') == patch_localization or m == 'auroc'])
         ev.evaluate(out, subject, sub_out, patch_level=patch_localization)
         rows[subject] = {k: v for k, v in vars(ev.scores).items() if v is not None}

@@ -208,3 +208,55 @@ def test_training_with_gpu_resident_pipeline(tmp_path):
     assert len(hist["fine_tune"]["train"]["loss"]) == 2 and np.isfinite(hist["fine_tune"]["val"]["loss"]).all()
     m = PeraNet.load_from_checkpoint(out + "best_model.ckpt")
     assert m.stage == "fine_tune" and m.memory_bank.ndim in (1, 2)
+
+
+def test_gpu_evaluation_metrics_match_the_host_functions(golden):
+    """The PRO curve / AUPRO, the F1-optimal threshold, F1 and IoU of device-resident maps (csrc/auroc.hip: radix sort + scans)
+    against metrics.compute_pro / best_f1_threshold / compute_f1 / compute_iou -- the host functions that tests/golden/metrics.npz
+    pins to the reference's own metrics.py and Evaluator: thresholds EQUAL, curves point for point (fprs exact, pros to 1e-12: only
+    the association of the fp64 running sum differs), Evaluator.evaluate on device maps == on host maps."""
+    from self_supervised import metrics as m, tools
+    from self_supervised.constants import ModelOutputsContainer
+    dev = torch.device("cuda:0")
+    g = golden("metrics")
+    cases = [(torch.from_numpy(g[str(c) + "_maps"]), torch.from_numpy(g[str(c) + "_gts"]).float()) for c in g["cases"]]
+    gen = torch.Generator().manual_seed(7)
+    # a larger case: 24 maps of 128 x 128, heavy ties (scores on a grid of 97 levels), two defect-free images, touching regions
+    maps = (torch.rand(24, 1, 128, 128, generator=gen) * 96).round() / 96
+    gts = torch.zeros(24, 1, 128, 128)
+    for i in range(22):
+        y0, x0 = [int(v) for v in torch.randint(8, 90, (2,), generator=gen)]
+        gts[i, 0, y0:y0 + 20 + i, x0:x0 + 14] = 1
+        gts[i, 0, y0 + 21 + i:y0 + 30 + i, x0 + 14:x0 + 20] = 1          # touches the first block at a corner: one 8-connected region
+        maps[i] += 0.5 * gts[i]
+    cases.append((maps, gts))
+    cases.append((torch.rand(3, 1, 64, 64, generator=gen), torch.zeros(3, 1, 64, 64)))          # no defect at all
+    for maps, gts in cases:
+        md = maps.to(dev)
+        fprs, pros = m.compute_pro(maps.squeeze(1).numpy(), gts.squeeze(1).numpy())
+        gf, gp = m.compute_pro_gpu(md.squeeze(1), gts.squeeze(1))
+        assert gf.shape == fprs.shape and np.array_equal(gf, fprs) and np.abs(gp - pros).max() < 1e-12
+        flat_s, flat_t = maps.flatten(), gts.flatten()
+        thr = m.best_f1_threshold(flat_s, flat_t)
+        assert m.best_f1_threshold_gpu(md.flatten(), flat_t) == thr
+        assert abs(m.compute_f1_gpu(flat_t, md.flatten(), thr) - m.compute_f1(flat_t, flat_s, thr)) < 1e-15
+        assert abs(m.compute_iou_gpu(md.flatten(), flat_t, thr) - m.compute_iou(flat_s, flat_t, thr)) < 1e-15
+        host, devc = ModelOutputsContainer(), ModelOutputsContainer()
+        host.anomaly_maps, host.ground_truths = maps, gts
+        devc.anomaly_maps, devc.ground_truths = md, gts
+        host.y_true_binary_labels = devc.y_true_binary_labels = (gts.flatten(1).sum(1) > 0).long()
+        if gts.sum() > 0:
+            a, b = tools.Evaluator(['auroc', 'aupro', 'iou']), tools.Evaluator(['auroc', 'aupro', 'iou'])
+            a.evaluate(host, "x", None, patch_level=True)
+            b.evaluate(devc, "x", None, patch_level=True)
+            assert abs(a.scores.auroc - b.scores.auroc) < 1e-10 and abs(a.scores.aupro - b.scores.aupro) < 1e-10
+            assert abs(a.scores.iou - b.scores.iou) < 1e-15
+    # image level: a few hundred scores, the f1-score metric
+    s, l = torch.from_numpy(g["image_scores"]), torch.from_numpy(g["image_labels"])
+    host, devc = ModelOutputsContainer(), ModelOutputsContainer()
+    host.anomaly_maps, host.y_true_binary_labels = s, l
+    devc.anomaly_maps, devc.y_true_binary_labels = s.to(dev), l
+    a, b = tools.Evaluator(['auroc', 'f1-score']), tools.Evaluator(['auroc', 'f1-score'])
+    a.evaluate(host, "image", None)
+    b.evaluate(devc, "image", None)
+    assert abs(a.scores.auroc - b.scores.auroc) < 1e-12 and abs(a.scores.f1_score - b.scores.f1_score) < 1e-15
