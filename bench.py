@@ -231,6 +231,23 @@ def end_to_end(args):
             up = tools.upsample(r.anomaly_maps, args.size)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
+        # tools.Evaluator on the upsampled maps: device-resident maps take the hand-written sort / scan kernels (csrc/auroc.hip), host
+        # maps the reference's sklearn / numpy route -- both timed once, same scores
+        def evaluate(maps):
+            r.anomaly_maps = maps
+            ev = tools.Evaluator(evaluation_metrics=["auroc", "aupro", "iou"])
+            with contextlib.redirect_stdout(sys.stderr):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                ev.evaluate(r, "bottle", None, patch_level=True)
+                torch.cuda.synchronize()
+            return time.perf_counter() - t1, [ev.scores.auroc, ev.scores.aupro, ev.scores.iou]
+        evaluate(up)                                       # warm-up (lazy imports)
+        t_dev, sc_dev = evaluate(up)
+        t_host, sc_host = evaluate(up.cpu())
+        res["evaluation"] = {"workload": "tools.Evaluator(['auroc', 'aupro', 'iou']).evaluate on the 96 upsampled 256x256 maps (6.3 M pixel scores)",
+                             "seconds_device_maps": round(t_dev, 4), "seconds_host_maps": round(t_host, 3),
+                             "max_abs_score_difference": float(max(abs(a - b) for a, b in zip(sc_dev, sc_host)))}
         res["inference"] = {"workload": "tools.inference(patch_localization=True) + tools.upsample on 96 test PNGs of 256x256 (+ the one training image that becomes the bank), "
                                         "default arguments; includes checkpoint load, PNG decode, the bank image and the returned CPU container",
                             "end_to_end_maps_per_sec": round(up.shape[0] / dt, 1), "images": int(up.shape[0]), "seconds": round(dt, 3)}
