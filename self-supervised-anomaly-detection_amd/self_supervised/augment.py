@@ -277,6 +277,10 @@ class DefectSampler:
                 np.save(files[name], np.ascontiguousarray(arr))
         desc = {"key": d, "subject": self.subject, "patch_localization": self.patch_localization, "patch_size": self.patch_size,
                 "files": files}
+        if not _PUBLISHED:
+            import atexit
+            atexit.register(_remove_published)          # a loader that is never closed must not leave its arrays in /dev/shm
+        _PUBLISHED.add(d)
         return desc, d
 
     @staticmethod
@@ -285,6 +289,16 @@ class DefectSampler:
         ld = lambda k: np.load(f[k], mmap_mode="r") if k in f else None
         return DefectSampler(desc["subject"], ld("images"), np.asarray(ld("masks")), ld("cuts"), desc["patch_localization"],
                              desc["patch_size"], mask_index=np.asarray(ld("mask_index")))
+
+
+_PUBLISHED = set()      # shared-memory directories of this process's published samplers
+
+
+def _remove_published():
+    import shutil
+    for d in list(_PUBLISHED):
+        shutil.rmtree(d, ignore_errors=True)
+        _PUBLISHED.discard(d)
 
 
 class GpuCutPaste:
@@ -484,6 +498,7 @@ class GpuPretextLoader:
         if self._dir is not None:
             import shutil
             shutil.rmtree(self._dir, ignore_errors=True)
+            _PUBLISHED.discard(self._dir)
             self._desc = self._dir = None
 
     def __del__(self):
