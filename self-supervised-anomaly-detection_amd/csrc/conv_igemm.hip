@@ -755,6 +755,57 @@ void conv_igemm_f32_kernel(ConvParams p) {
         return;
     }
     }
+    // ---- direct epilogue of the transposed gather (TS == 2, round 4): the rows of a tile are the pixels of one parity class, so they
+    // are not equally spaced -- their output offsets go through a 1 KB table in LDS (one decode per row instead of one per element)
+    // and every accumulator register is stored straight from there, as above.  A stride-2 input-gradient tile is 4-32 K-steps
+    // between a prologue and an epilogue (one to four filter taps): the LDS-transpose epilogue (~10 k cycles alone, 33-40 k beside a
+    // streaming partner) was a tenth to a third of such a workgroup. ----
+    if constexpr (TS > 1) {
+        if (IGEMM_EPI && !p.stats && Mc - m0 >= BM && n0 + BN <= p.Cout && !p.scale && !p.shift && !p.relu) {
+            int64_t* rowoff = (int64_t*)lds;                    // the stages are dead: the K loop ended on a barrier
+            for (int lr = tid; lr < BM; lr += NT) {
+                int64_t n;
+                int oy, ox;
+                decode_row(m0 + lr, n, oy, ox);
+                rowoff[lr] = ((n * p.Ho + oy) * p.Wo + ox) * (int64_t)p.Cout;
+            }
+            __syncthreads();
+            const int colb = n0 + wn * 32 * TN + r;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                int64_t off[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) off[e] = rowoff[wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] + colb;
+                float res[16][TN];
+                if (p.residual) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) res[e][j] = p.residual[off[e] + 32 * j];
+                    if (p.res_mask) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) {
+                                const unsigned mk = p.res_mask[(off[e] + 32 * j) >> 2];
+                                res[e][j] = (mk >> (r & 3)) & 1u ? res[e][j] : 0.f;
+                            }
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) res[e][j] = 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) p.out[off[e] + 32 * j] = acc[i][j][e] * 1.f + 0.f + res[e][j];   // the LDS epilogue's expression (scale 1, shift 0)
+            }
+            IG_STAMP(3);
+            return;
+        }
+    }
     // ---- epilogue: accumulators -> LDS tile [BM/TM][BN+4] -> 16-byte pieces of contiguous output rows; one pass per
     // accumulator row-tile so the tile never needs more LDS than the K-loop stages ----
     float* C = lds;
