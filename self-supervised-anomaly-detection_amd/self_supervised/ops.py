@@ -365,6 +365,8 @@ def resize_bicubic_u8(img, size):
     wout, hout = int(size[0]), int(size[1])
     if (hin, win) == (hout, wout):
         return img
+    if b == 0:
+        return torch.empty((0, hout, wout, c), dtype=torch.uint8, device=img.device)
     assert img.dtype == torch.uint8 and img.is_cuda and img.is_contiguous()
     out = torch.empty((b, hout, wout, c), dtype=torch.uint8, device=img.device)
     kx = ky = (0, None, None)
