@@ -466,6 +466,7 @@ class GpuPretextLoader:
         self.base_seed = int(base_seed)
         self.prefetch_batches = prefetch_batches if prefetch_batches is not None else 2 * max(self.num_workers, 1)
         self._desc, self._dir = None, None
+        self._side = None
 
     def set_epoch(self, epoch):
         if self._last_epoch is not None and epoch <= self._last_epoch:
@@ -527,8 +528,29 @@ class GpuPretextLoader:
                 nxt += 1
         for _ in range(self.prefetch_batches):
             submit()
-        while pending:
+        # Device half one batch ahead, on a side stream: the uploads of a batch's records / indices / labels come from pageable host
+        # memory and synchronise the stream they are issued on -- on the training stream the host would wait for the step in flight
+        # before it could even begin to prepare the next batch (measured: 1.9 ms of a 16.6 ms step at batch 96).  On the side stream
+        # they wait for nothing, the synthesis kernels run beside the training step, and the consumer's stream is made to wait for
+        # the batch's event before it reads the tensors.
+        side = self._side if getattr(self, "_side", None) is not None else torch.cuda.Stream(self.aug.device)
+        self._side = side
+
+        def produce():
             idx, fut = pending.pop(0)
             raw, hw = fut.result()
             submit()
-            yield self.aug.synthesise(np.asarray(idx, dtype=np.int64), np.frombuffer(raw, dtype=AUG_DTYPE), hw)
+            with torch.cuda.stream(side):
+                out = self.aug.synthesise(np.asarray(idx, dtype=np.int64), np.frombuffer(raw, dtype=AUG_DTYPE), hw)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            return out, ev
+        ahead = produce() if pending else None
+        while ahead is not None:
+            out, ev = ahead
+            ahead = produce() if pending else None
+            cur = torch.cuda.current_stream(self.aug.device)
+            cur.wait_event(ev)
+            for t in out:
+                t.record_stream(cur)
+            yield out
