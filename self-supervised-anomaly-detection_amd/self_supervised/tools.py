@@ -177,12 +177,44 @@ def _fast_mvtec_ok(dataset):
             and os.environ.get("SSAD_FAST_PREDICT", "1") != "0")
 
 
-def _predict_mvtec_streamed(model: PeraNet, dataset, device, indices, group: int = 32, threads: int = None):
+class _MVTecPrefetch:
+    """The host half of the streamed predict, startable before the model exists: a thread pool decodes the test files (Pillow decodes
+    outside the GIL) at their native size and reads the ground-truth masks exactly as ``MVTecDataset.__getitem__`` does
+    (``get_ground_truth``: resize + dither to mode '1' stay Pillow's).  tools.inference starts it before it loads the checkpoint."""
+
+    def __init__(self, dataset, indices, threads: int = None):
+        from concurrent.futures import ThreadPoolExecutor
+        from . import gpu_io
+        from .functional import get_ground_truth, get_ground_truth_filename
+        self.dataset, self.indices = dataset, list(indices)
+        n = len(self.indices)
+        w_img, h_img = dataset.imsize
+        names = [dataset.images_filenames[i] for i in self.indices]
+        self.gt8 = np.zeros((n, h_img, w_img), np.uint8)
+        self.native = [None] * n
+        gt_dir = dataset.dataset_dir + 'ground_truth/'
+
+        def load(j):
+            self.native[j] = gpu_io.read_native(names[j])   # decoded at its native size; the resize runs on the device (gpu_io)
+            gfile = get_ground_truth_filename(names[j], gt_dir)
+            if gfile:                                        # 'good' images: Image.new(mode='1') = all zeros
+                self.gt8[j] = np.asarray(get_ground_truth(gfile, dataset.imsize).convert('L'))
+        self.pool = ThreadPoolExecutor(threads or min(8, os.cpu_count() or 1))
+        self.futs = [self.pool.submit(load, j) for j in range(n)]
+
+    def wait(self, a, b):
+        for f in self.futs[a:b]:
+            f.result()
+
+    def close(self):
+        self.pool.shutdown(wait=True)
+
+
+def _predict_mvtec_streamed(model: PeraNet, dataset, device, indices, group: int = 32, threads: int = None, prefetch=None):
     """``Trainer.predict`` + ``ModelOutputsContainer.from_list`` for an MVTecDataset with the default transform, as ONE stream
     instead of a DataLoader of batch size 1 (tools.py:336-347 of the reference): same values, field for field.
 
-    * a thread pool decodes the files (Pillow decodes outside the GIL) and reads the ground-truth masks exactly as
-      ``MVTecDataset.__getitem__`` does (``get_ground_truth``: resize + dither to mode '1' stay Pillow's);
+    * a thread pool (``_MVTecPrefetch``) decodes the files and reads the ground-truth masks;
     * ``group`` images at a time go to the device as uint8 at their NATIVE size, where Pillow's bicubic ``resize(imsize)`` (csrc/resize.hip,
       bit-exact), the 'L' -> 'RGB' replication and ToTensor + Normalize (two IEEE fp32 operations per value,
       ssad_u8hwc_to_f32chw_norm: bit-identical to the host transform) run, then ``model.forward`` -- thousands of patches per launch
@@ -191,29 +223,18 @@ def _predict_mvtec_streamed(model: PeraNet, dataset, device, indices, group: int
       (second return value) for the detector, instead of making the round trip host -> device again.
     Returns (container with CPU tensors, device embeddings [n * P][D])."""
     import ctypes
-    from concurrent.futures import ThreadPoolExecutor
-    from PIL import Image
     from . import _hip, gpu_io
     from .datasets import IMAGENET_MEAN, IMAGENET_STD
-    from .functional import get_ground_truth, get_ground_truth_filename, get_prediction_class
+    from .functional import get_prediction_class
     from .converters import gt2label
     n = len(indices)
     out = ModelOutputsContainer()
     if n == 0:
         return out, None
     w_img, h_img = dataset.imsize
-    names = [dataset.images_filenames[i] for i in indices]
-    gt8 = np.zeros((n, h_img, w_img), np.uint8)
-    gt_dir = dataset.dataset_dir + 'ground_truth/'
-
-    native = [None] * n
-
-    def load(j):
-        native[j] = gpu_io.read_native(names[j])        # decoded at its native size; the resize runs on the device (gpu_io)
-        gfile = get_ground_truth_filename(names[j], gt_dir)
-        if gfile:                                       # 'good' images: Image.new(mode='1') = all zeros
-            gt8[j] = np.asarray(get_ground_truth(gfile, dataset.imsize).convert('L'))
-    threads = threads or min(8, os.cpu_count() or 1)
+    pre = prefetch if prefetch is not None else _MVTecPrefetch(dataset, indices, threads)
+    assert pre.indices == list(indices)
+    native, gt8 = pre.native, pre.gt8
     mean = (ctypes.c_float * 3)(*IMAGENET_MEAN)
     std = (ctypes.c_float * 3)(*IMAGENET_STD)
     orig = torch.empty((n, 3, h_img, w_img), dtype=torch.float32)
@@ -234,12 +255,10 @@ def _predict_mvtec_streamed(model: PeraNet, dataset, device, indices, group: int
             logits_host[a * p:b * p].copy_(logits_dev[a * p:b * p])
         for t in (o_dev, x_dev):
             t.record_stream(side)
-    with ThreadPoolExecutor(threads) as pool, torch.no_grad():
-        futs = [pool.submit(load, j) for j in range(n)]
+    with torch.no_grad():
         for a in range(0, n, group):
             b = min(n, a + group)
-            for f in futs[a:b]:
-                f.result()
+            pre.wait(a, b)
             img_dev = gpu_io.to_rgb_batch(native[a:b], dataset.imsize, device)
             native[a:b] = [None] * (b - a)
             o_dev = torch.empty((b - a, 3, h_img, w_img), device=device, dtype=torch.float32)
@@ -261,6 +280,7 @@ def _predict_mvtec_streamed(model: PeraNet, dataset, device, indices, group: int
                 drain(pending)                          # the previous group's results travel while this group computes
             pending = (a, b, o_dev, x_dev, ev, p)
         drain(pending)
+    pre.close()
     side.synchronize()
     gts = torch.from_numpy(gt8).float().div_(255.0).unsqueeze(1)
     out.original_data, out.tensor_data, out.ground_truths = orig, xnorm, gts
@@ -276,6 +296,16 @@ def inference(model_input_dir: str, dataset_dir: str, subject: str, mvtec_infere
               patch_localization: bool = False) -> ModelOutputsContainer:
     """tools.py:310-390."""
     print('>>> initializing inference')
+    # MVTec test data: file lists and decode threads start BEFORE the checkpoint is read, so that the first group of images is
+    # decoded by the time the model is on the device (the datamodule draws nothing from the global generators)
+    rank, world = world_info()
+    datamodule = prefetch = mine = None
+    if mvtec_inference:
+        datamodule = MVTecDatamodule(dataset_dir, batch_size=1)
+        datamodule.setup('predict')
+        if _fast_mvtec_ok(datamodule.test_dataset):
+            mine = list(range(rank, len(datamodule.test_dataset), world)) if world > 1 else list(range(len(datamodule.test_dataset)))
+            prefetch = _MVTecPrefetch(datamodule.test_dataset, mine)
     print('>>> preparing model')
     model = PeraNet.load_from_checkpoint(model_input_dir)
     model.eval()
@@ -285,25 +315,20 @@ def inference(model_input_dir: str, dataset_dir: str, subject: str, mvtec_infere
     print('>>> preparing datamodule')
     if mvtec_inference:
         model.enable_mvtec_inference()
-        datamodule = MVTecDatamodule(dataset_dir, batch_size=1)
     else:
         datamodule = PretextTaskDatamodule(subject=subject, root_dir=dataset_dir, min_dataset_length=500, batch_size=1)
     print('>>> doing prediction')
     # under torch.distributed (one process per GPU) every rank scores its own round-robin share of the images; the
     # per-image containers are exchanged once at the end so that every rank returns the full output
-    rank, world = world_info()
     emb_dev = None
-    if mvtec_inference and not hasattr(datamodule, 'test_dataset'):
-        datamodule.setup('predict')
-    if mvtec_inference and _fast_mvtec_ok(datamodule.test_dataset):
+    if prefetch is not None:
         # the hot path of an evaluation: one stream through decode threads and large launches instead of a DataLoader of batch
         # size 1 (same values; _predict_mvtec_streamed).  The DataLoader iterator the reference creates here draws its base
         # seed from torch's global generator: the draw is kept, so that what follows (the shuffled loader of the normality
         # image) sees the same generator state
         torch.empty((), dtype=torch.int64).random_()
         model.to(tester.device).eval()
-        mine = list(range(rank, len(datamodule.test_dataset), world)) if world > 1 else list(range(len(datamodule.test_dataset)))
-        output, emb_dev = _predict_mvtec_streamed(model, datamodule.test_dataset, tester.device, mine)
+        output, emb_dev = _predict_mvtec_streamed(model, datamodule.test_dataset, tester.device, mine, prefetch=prefetch)
         n_pred = len(mine)
     else:
         predictions = tester.predict(model, datamodule=datamodule, shard=world > 1)
