@@ -467,6 +467,7 @@ class GpuPretextLoader:
         self.prefetch_batches = prefetch_batches if prefetch_batches is not None else 2 * max(self.num_workers, 1)
         self._desc, self._dir = None, None
         self._side = None
+        self._spec, self.speculate, self.spec_hits = None, os.environ.get("SSAD_LOADER_SPECULATE", "1") != "0", 0
 
     def set_epoch(self, epoch):
         if self._last_epoch is not None and epoch <= self._last_epoch:
@@ -482,10 +483,11 @@ class GpuPretextLoader:
         n = len(self.index) // self.world
         return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
 
-    def _batches(self):
+    def _batches(self, epoch=None):
+        epoch = self.epoch if epoch is None else epoch
         order = np.arange(len(self.index))
         if self.shuffle:
-            order = np.random.RandomState((1234 + self.epoch + 7919 * self.stage) % (2 ** 32)).permutation(len(order))
+            order = np.random.RandomState((1234 + epoch + 7919 * self.stage) % (2 ** 32)).permutation(len(order))
         order = order[self.rank::self.world]
         return [self.index[order[i * self.batch_size:(i + 1) * self.batch_size]] for i in range(len(self))]
 
@@ -496,6 +498,10 @@ class GpuPretextLoader:
 
     def close(self):
         """Removes the shared-memory copy of the category (workers that still map it keep their mapping until they drop it)."""
+        spec, self._spec = getattr(self, "_spec", None), None
+        if spec is not None:
+            for _, fut in spec["pending"]:
+                fut.cancel()
         if self._dir is not None:
             import shutil
             shutil.rmtree(self._dir, ignore_errors=True)
@@ -516,17 +522,45 @@ class GpuPretextLoader:
             return
         from .datasets import _hidden_main
         pool, desc = sampler_pool(self.num_workers), self._published()
-        pending, nxt = [], 0
+        key = (self.stage, self.epoch, self.rank, self.world)
+        # The sampling of a batch takes one worker ~45 ms (96 images): at the start of an epoch nothing is in flight and the training
+        # stream would sit idle for that long, every epoch.  So once every batch of THIS epoch has been handed to the pool, the
+        # hand-out goes on with the first batches of the NEXT epoch of the same stage (its order and seeds are functions of the epoch
+        # number); the next __iter__ takes them over when it is that epoch, and cancels them when it is not (a new fit, the end).
+        spec, self._spec = getattr(self, "_spec", None), None
+        if spec is not None and spec["key"] == key:
+            pending, nxt = spec["pending"], spec["nxt"]
+            self.spec_hits += 1
+        else:
+            if spec is not None:
+                for _, fut in spec["pending"]:
+                    fut.cancel()
+            pending, nxt = [], 0
+        nxt_batches = nxt_pending = None
+        nxt_n = 0
 
         def submit():
-            nonlocal nxt
+            nonlocal nxt, nxt_batches, nxt_pending, nxt_n
             if nxt < len(batches):
                 with _hidden_main(_POOL["ctx"]):
                     fut = pool.submit(_pool_sample, desc, _batch_seed(self.base_seed, self.epoch, nxt, self.rank, self.stage),
                                       batches[nxt])
                 pending.append((batches[nxt], fut))
                 nxt += 1
-        for _ in range(self.prefetch_batches):
+                return
+            if not self.speculate:
+                return
+            if nxt_batches is None:
+                nxt_batches, nxt_pending = self._batches(self.epoch + 1), []
+                self._spec = {"key": (self.stage, self.epoch + 1, self.rank, self.world), "pending": nxt_pending, "nxt": 0}
+            if nxt_n < len(nxt_batches) and nxt_n < max(1, self.num_workers):
+                with _hidden_main(_POOL["ctx"]):
+                    fut = pool.submit(_pool_sample, desc, _batch_seed(self.base_seed, self.epoch + 1, nxt_n, self.rank, self.stage),
+                                      nxt_batches[nxt_n])
+                nxt_pending.append((nxt_batches[nxt_n], fut))
+                nxt_n += 1
+                self._spec["nxt"] = nxt_n
+        for _ in range(self.prefetch_batches - len(pending)):
             submit()
         # Device half one batch ahead, on a side stream: the uploads of a batch's records / indices / labels come from pageable host
         # memory and synchronise the stream they are issued on -- on the training stream the host would wait for the step in flight
@@ -545,12 +579,16 @@ class GpuPretextLoader:
                 ev = torch.cuda.Event()
                 ev.record(side)
             return out, ev
-        ahead = produce() if pending else None
-        while ahead is not None:
-            out, ev = ahead
+        try:
             ahead = produce() if pending else None
-            cur = torch.cuda.current_stream(self.aug.device)
-            cur.wait_event(ev)
-            for t in out:
-                t.record_stream(cur)
-            yield out
+            while ahead is not None:
+                out, ev = ahead
+                ahead = produce() if pending else None
+                cur = torch.cuda.current_stream(self.aug.device)
+                cur.wait_event(ev)
+                for t in out:
+                    t.record_stream(cur)
+                yield out
+        finally:
+            for _, fut in pending:           # an epoch the consumer left early (limit_*_batches): what has not started is dropped
+                fut.cancel()

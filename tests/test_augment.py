@@ -319,8 +319,9 @@ def test_loader_with_sampler_workers(tmp_path):
     out = {}
     for nw in (1, 3):
         ld = augment.GpuPretextLoader(ds, 8, shuffle=True, drop_last=True, num_workers=nw, base_seed=11)
-        assert len(ld) == 5
+        assert len(ld) == 5 and ld.speculate
         out[nw] = [[tuple(t.cpu() for t in b) for b in ld.shard(1, 0, e)] for e in (0, 1)]
+        assert ld.spec_hits == 1                     # epoch 1 began with batches the pool had been handed during epoch 0
         if nw == 1:
             # a second fit on the same loader numbers its epochs from 0 again: new stage, new synthetic batches; and a
             # validation loader that is asked for the same epoch twice (two fits) does not repeat itself either
@@ -330,10 +331,16 @@ def test_loader_with_sampler_workers(tmp_path):
             third = [tuple(t.cpu() for t in b) for b in ld]
             assert ld.stage == 2 and not torch.equal(third[0][0], again[0][0])
         ld.close()
+    # the cross-epoch hand-out changes when a batch is sampled, never what it is
+    ld = augment.GpuPretextLoader(ds, 8, shuffle=True, drop_last=True, num_workers=2, base_seed=11)
+    ld.speculate = False
+    out[0] = [[tuple(t.cpu() for t in b) for b in ld.shard(1, 0, e)] for e in (0, 1)]
+    assert ld.spec_hits == 0 and ld._spec is None
+    ld.close()
     for e in (0, 1):
         assert len(out[1][e]) == 5
-        for a, b in zip(out[1][e], out[3][e]):
-            assert all(torch.equal(u, v) for u, v in zip(a, b))
+        for a, b, c in zip(out[1][e], out[3][e], out[0][e]):
+            assert all(torch.equal(u, v) and torch.equal(u, w) for u, v, w in zip(a, b, c))
     assert not torch.equal(out[1][0][0][0], out[1][1][0][0])
     x, y, orig = out[1][0][0]
     assert tuple(x.shape) == (8, 3, 64, 64) and y.dtype == torch.int64 and tuple(orig.shape) == (8, 3, 64, 64)
