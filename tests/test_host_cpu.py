@@ -232,3 +232,40 @@ def test_precision_modes():
     import pytest
     with pytest.raises(ValueError):
         precision_mode("fp8")
+
+
+def test_save_checkpoint_layout_and_background_writer(tmp_path, seeded_sd):
+    """Trainer.save_checkpoint (tools.py:274, :304 of the reference call Lightning's): Lightning's top-level keys, every tensor of
+    the state dict with a storage of its own (the state leaves the device as one flat copy per dtype and is cloned apart on the
+    host), the bank through on_save_checkpoint; wait=False hands the file to a writer thread that _join_save waits for -- and a
+    failed write surfaces there, on the training thread."""
+    import pytest
+    from self_supervised.models import PeraNet
+    from self_supervised.trainer import Trainer
+    m = PeraNet(); m.load_state_dict(seeded_sd)
+    m.memory_bank = torch.arange(5 * 512, dtype=torch.float32).view(5, 512)
+    tr = Trainer.__new__(Trainer)                      # the constructor insists on a GPU; saving needs none
+    tr.global_rank, tr.current_epoch, tr.global_step, tr.model = 0, 3, 40, m
+    for wait in (True, False):
+        path = str(tmp_path / f"w{int(wait)}" / "x.ckpt")
+        tr.save_checkpoint(path, wait=wait)
+        tr._join_save()
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        assert {"epoch", "global_step", "pytorch-lightning_version", "state_dict", "hyper_parameters", "memory_bank"} <= set(ck)
+        assert (ck["epoch"], ck["global_step"]) == (3, 40) and list(ck["state_dict"]) == list(seeded_sd)
+        for k, v in ck["state_dict"].items():
+            assert torch.equal(v, seeded_sd[k]) and v.dtype == seeded_sd[k].dtype
+        m2 = PeraNet.load_from_checkpoint(path)
+        assert all(torch.equal(m2.state_dict()[k], seeded_sd[k]) for k in seeded_sd) and torch.equal(m2.memory_bank, m.memory_bank)
+    blocker = tmp_path / "file"
+    blocker.write_text("x")
+    import os
+    real = os.makedirs
+    try:
+        os.makedirs = lambda *a, **k: None             # the directory "exists": the writer thread is the one that fails
+        tr.save_checkpoint(str(blocker / "sub" / "y.ckpt"), wait=False)
+    finally:
+        os.makedirs = real
+    with pytest.raises(Exception):
+        tr._join_save()
+    tr._join_save()                                    # nothing pending: a no-op
