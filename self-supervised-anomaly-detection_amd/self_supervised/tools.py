@@ -206,8 +206,8 @@ class _MVTecPrefetch:
         for f in self.futs[a:b]:
             f.result()
 
-    def close(self):
-        self.pool.shutdown(wait=True)
+    def close(self, cancel=False):
+        self.pool.shutdown(wait=True, cancel_futures=cancel)
 
 
 def _predict_mvtec_streamed(model: PeraNet, dataset, device, indices, group: int = 32, threads: int = None, prefetch=None):
@@ -307,11 +307,16 @@ def inference(model_input_dir: str, dataset_dir: str, subject: str, mvtec_infere
             mine = list(range(rank, len(datamodule.test_dataset), world)) if world > 1 else list(range(len(datamodule.test_dataset)))
             prefetch = _MVTecPrefetch(datamodule.test_dataset, mine)
     print('>>> preparing model')
-    model = PeraNet.load_from_checkpoint(model_input_dir)
-    model.eval()
-    if patch_localization:
-        model.enable_patch_level_mode()
-    tester = Trainer(accelerator='auto', devices=1)
+    try:
+        model = PeraNet.load_from_checkpoint(model_input_dir)
+        model.eval()
+        if patch_localization:
+            model.enable_patch_level_mode()
+        tester = Trainer(accelerator='auto', devices=1)
+    except BaseException:
+        if prefetch is not None:               # no model, no predict: the decode threads are not left behind
+            prefetch.close(cancel=True)
+        raise
     print('>>> preparing datamodule')
     if mvtec_inference:
         model.enable_mvtec_inference()
