@@ -217,6 +217,14 @@ int ssad_conv_wgrad3x3_halo(const float* dz, const float* x, float* slab, int sp
 /* 3x3 / stride 2 / pad 1 (the first convolution of layer2-4): dz [N][Ho][Wo][Cout], x [N][H][W][Cin], Ho = (H - 1) / 2 + 1. */
 int ssad_conv_wgrad3x3s2_halo(const float* dz, const float* x, float* slab, int splits, int64_t N, int Ho, int Wo, int H, int W,
                               int Cin, int Cout, void* stream);
+/* The same halo-tile weight gradient with 16-bit OPERANDS (fp32 tensors in memory, rounded to fp16 -- f16 != 0 -- or bf16 while
+ * staged, fp32 accumulation; csrc/wgrad_halo16.hip): the conv2d weight gradient of the reference's fp16-autocast training
+ * (pl.Trainer(precision=16), src/self_supervised/tools.py:263, :270, :303) for the 3 x 3 / stride 1 / pad 1 layers.  Same slab contract:
+ * splits = ssad_wgrad3x3_halo16_splits(...), then ssad_wgrad_reduce. */
+int ssad_wgrad3x3_halo16_ok(int Cin, int Cout, int KH, int KW, int stride, int pad);
+int ssad_wgrad3x3_halo16_splits(int64_t N, int H, int W, int Cin, int Cout);
+int ssad_conv_wgrad3x3_halo16(const float* dz, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin, int Cout,
+                              int f16, void* stream);
 /* fp16-operand forms: the reference trains under fp16 autocast (pl.Trainer(precision=16), src/self_supervised/tools.py:263,
  * :296), i.e. its Conv2d / Linear products take fp16 operands and accumulate in fp32.  Same contract as the _bf16 forms
  * with v_mfma_f32_32x32x16_f16 (11-bit significands); the slab of ssad_conv_wgrad_f16 is sized by ssad_wgrad_splits_bf16. */

@@ -75,6 +75,9 @@ SIGNATURES = {
     "ssad_wgrad3x3_halo_ok": [_c_i, _c_i, _c_i, _c_i, _c_i, _c_i],
     "ssad_wgrad3x3_halo_splits": [_c_l, _c_i, _c_i, _c_i, _c_i],
     "ssad_conv_wgrad3x3_halo": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_wgrad3x3_halo16_ok": [_c_i, _c_i, _c_i, _c_i, _c_i, _c_i],
+    "ssad_wgrad3x3_halo16_splits": [_c_l, _c_i, _c_i, _c_i, _c_i],
+    "ssad_conv_wgrad3x3_halo16": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
     "ssad_conv_wgrad3x3s2_halo": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
     "ssad_conv_igemm_fwd_f16": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
                                 _c_i, _c_i, _c_fp],

@@ -490,6 +490,18 @@ def conv_wgrad(dy, x, dw_out, kh, kw, stride, pad, kreal=None, to_oihw=False, ac
              lambda: lib.ssad_wgrad_reduce(_hip.ptr(slab), _hip.ptr(dw_out), splits, cout, 9 * cin, 3, 3, cin, int(to_oihw),
                                            int(accumulate), _hip.stream()))
         return dw_out
+    if bf16 in (1, 2, True) and kreal is None and lib.ssad_wgrad3x3_halo16_ok(cin, cout, kh, kw, stride, pad):
+        # 16-bit operands, 3x3 / stride 1 / pad 1: halo-tile kernel (dZ and X fetched, converted and transposed once per pixel tile
+        # instead of once per filter tap; csrc/wgrad_halo16.hip)
+        splits = lib.ssad_wgrad3x3_halo16_splits(n, h, w, cin, cout)
+        slab = _new((splits, cout, 9 * cin), dy)
+        _run(_kname("wgrad", bf16), 2.0 * m * cout * 9 * cin, 4.0 * (dy.numel() + x.numel() + slab.numel()),
+             lambda: lib.ssad_conv_wgrad3x3_halo16(_hip.ptr(dy), _hip.ptr(x), _hip.ptr(slab), splits, n, h, w, cin, cout,
+                                                   int(bf16 == 2), _hip.stream()))
+        _run("wgrad_reduce", 0.0, 4.0 * slab.numel(),
+             lambda: lib.ssad_wgrad_reduce(_hip.ptr(slab), _hip.ptr(dw_out), splits, cout, 9 * cin, 3, 3, cin, int(to_oihw),
+                                           int(accumulate), _hip.stream()))
+        return dw_out
     if bf16 == 6 and not force_x6:
         # bf16x6 training keeps weight gradients on the exact fp32 kernel: the wave-specialised fp32 wgrad (110 TFLOP/s) is
         # as fast as the six-product bf16 form (measured), and exact; ssad_conv_wgrad_x6 stays available (tests)

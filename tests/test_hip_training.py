@@ -772,6 +772,41 @@ def test_f16_operand_kernels(dev):
         assert rel_err(dw.view(cout, k, k, cin).permute(0, 3, 1, 2), gw) < 2e-5
 
 
+def test_halo_wgrad_with_16_bit_operands(dev):
+    """csrc/wgrad_halo16.hip (3x3 / stride 1 / pad 1 weight gradients of the precision-16 step): fp32 math on fp16- (bf16-) rounded
+    operands, on maps that are ragged against both tile shapes (4 x 16 for widths above 8, 8 x 8 below), one and several (co, ci)
+    blocks, one and many pixel tiles per workgroup; and the same numbers as the split-over-pixels kernel it replaces, to fp32
+    summation order."""
+    from self_supervised import _hip, ops
+    lib = _hip.lib()
+    for (n, h, w, cin, cout) in [(3, 8, 8, 64, 64), (2, 5, 7, 64, 128), (4, 6, 6, 128, 256), (2, 20, 20, 64, 64), (5, 16, 16, 128, 64),
+                                 (64, 32, 32, 128, 128), (3, 13, 33, 64, 64), (40, 64, 64, 64, 64)]:
+        assert lib.ssad_wgrad3x3_halo16_ok(cin, cout, 3, 3, 1, 1) == 1
+        g = torch.Generator().manual_seed(n * 1000 + h)
+        x = torch.randn(n, cin, h, w, generator=g)
+        wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+        dy = torch.randn(n, cout, h, w, generator=g)
+        nh = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().to(dev)
+        for mode, rnd in ((2, _h), (1, lambda t: t.to(torch.bfloat16).float())):
+            xr, wr = rnd(x).requires_grad_(), rnd(wt).requires_grad_()
+            gw, = torch.autograd.grad(F.conv2d(xr, wr, None, 1, 1), wr, rnd(dy))
+            dw = torch.empty(cout * 9 * cin, device=dev)
+            dyd, xd = nh(dy), nh(x)
+            ops.conv_wgrad(dyd, xd, dw, 3, 3, 1, 1, bf16=mode)
+            assert rel_err(dw.view(cout, 3, 3, cin).permute(0, 3, 1, 2), gw) < 2e-5, (n, h, w, cin, cout, mode)
+            # the kernel it replaces (one tap per workgroup), called through the C ABI directly
+            m = n * h * w
+            splits = lib.ssad_wgrad_splits_bf16(m, cin, cout, 3, 3)
+            slab = torch.empty((splits, cout, 9 * cin), device=dev)
+            fn = lib.ssad_conv_wgrad_f16 if mode == 2 else lib.ssad_conv_wgrad_bf16
+            _hip.check(fn(_hip.ptr(dyd), _hip.ptr(xd), _hip.ptr(slab), splits, n, h, w, cin, cout, 3, 3, 1, 1, _hip.stream()))
+            old = torch.empty_like(dw)
+            _hip.check(lib.ssad_wgrad_reduce(_hip.ptr(slab), _hip.ptr(old), splits, cout, 9 * cin, 3, 3, cin, 0, 0, _hip.stream()))
+            assert rel_err(dw, old) < 2e-6, (n, h, w, cin, cout, mode)
+    assert lib.ssad_wgrad3x3_halo16_ok(64, 128, 3, 3, 2, 1) == 0 and lib.ssad_wgrad3x3_halo16_ok(64, 64, 1, 1, 1, 0) == 0
+    assert lib.ssad_wgrad3x3_halo16_ok(96, 64, 3, 3, 1, 1) == 0
+
+
 def test_loss_scaler_state_machine(dev):
     """GradScaler semantics on the device: scale, inf detection, skipped update + backoff, growth after `interval` clean steps."""
     from self_supervised import ops
