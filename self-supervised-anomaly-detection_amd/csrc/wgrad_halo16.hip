@@ -11,13 +11,15 @@
 //
 // v_mfma_f32_32x32x16_f16 contracts over 16 PIXELS per instruction and wants, per lane, 8 consecutive pixels of one channel: the tiles
 // live TRANSPOSED in LDS, [channel][pixel] halves.  A filter tap shifts the pixels an X fragment starts at; the row part of the shift
-// (ky) is a multiple of the tile width and keeps 16-byte alignment, the column part (kx) does not -- so the halo is kept in THREE copies,
-// copy kx holding columns kx .. kx + TW - 1, and every fragment read is an aligned ds_read_b128 at an immediate offset:
-//   A (dZ^T): dzT[co][py * TW + px]                      72-half rows  (144 B: conflict-free b128 reads over 16 lanes)
-//   B (X^T) : xT[kx][ci][hy * TW + j] = X[y0 - 1 + hy][x0 - 1 + j + kx]     104 / 88-half rows (208 / 176 B: likewise)
-// 49 KB (43 KB) of LDS per workgroup, two workgroups per CU; nine 32 x 32 accumulators per wave (144 registers) across all tiles of
-// the workgroup; per-workgroup blocks go to slab[split] and ssad_wgrad_reduce sums the splits in a fixed order, exactly as for the
-// fp32 kernel.  Zero padding and ragged tiles are staged as zeros.
+// (ky) is a whole halo row and keeps 16-byte alignment, the column part (kx) does not -- so a lane reads, per (K-step, ky), the aligned
+// 16 bytes of columns 0-7 of its row piece plus the 4 bytes of columns 8-9, and forms the three kx fragments in registers: kx = 0 as
+// read, kx = 2 by renaming dwords, kx = 1 with four v_alignbit_b32 (the matrix waves have the issue slots to spare):
+//   A (dZ^T): dzT[co][py * TW + px]                                   72-half rows (144 B: conflict-free b128 reads over 16 lanes)
+//   B (X^T) : xT[ci][hy * RP + hx] = X[y0 - 1 + hy][x0 - 1 + hx]      rows of RP = 24 (TW = 16) or 16 (TW = 8) halves, 152 / 168 halves
+//             per channel (304 / 336 B: likewise conflict-free)
+// 29 KB (31 KB) of LDS per stage, two stages, one workgroup of eight waves per CU (four matrix waves, four staging waves); nine
+// 32 x 32 accumulators per matrix wave (144 registers) across all tiles of the workgroup; per-workgroup blocks go to slab[split] and
+// ssad_wgrad_reduce sums the splits in a fixed order, exactly as for the fp32 kernel.  Zero padding and ragged tiles are staged as zeros.
 //
 // Replaces the same autograd node as wgrad.hip's 16-bit kernels (conv2d weight gradient under loss.backward() with autocast,
 // tools.py:263, :270, :303); the stride-2 layers and the 1 x 1 layers stay on wgrad_bf16_kernel.
@@ -45,22 +47,28 @@ template <> struct Op16<true> {
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
 
+// 512 threads: waves 0-3 run the matrix instructions, waves 4-7 only stage (fetch -> convert -> transposed LDS stores), one tile
+// ahead in LDS (two stages) and one more in registers.  With MFMAs this short a tile is 0.5 us of matrix work against 2-4 us of
+// memory latency: a workgroup that does both in turn spends its life waiting (first version of this kernel: 8 us per tile).
 template <int TH, int TW, bool F16>
-__global__ __launch_bounds__(256, 2) void wgrad3x3_halo16_kernel(WgH16Params p) {
+__global__ __launch_bounds__(512, 1) void wgrad3x3_halo16_kernel(WgH16Params p) {
     using op_t = typename Op16<F16>::t;
     using op4 = typename Op16<F16>::v4;
     using op8 = typename Op16<F16>::v8;
     constexpr int P = TH * TW, HH = TH + 2;
     static_assert(P == 64 && TW % 8 == 0, "64-pixel tiles, rows of 8 or 16 pixels");
     constexpr int DP = P + 8;                   // halves per dzT row
-    constexpr int XP = HH * TW + 8;             // halves per xT row
-    constexpr int XG = HH * TW / 4;             // 4-pixel groups of one halo copy
-    constexpr int NXB = 3 * XG * 16;            // (copy, pixel group, channel quad) blocks of the halo
+    constexpr int RP = TW + 8;                  // halves per halo row: TW + 2 pixels, padded to a multiple of 8
+    constexpr int XP = HH * RP + 8;             // halves per channel of the halo
+    constexpr int GR = (TW + 2 + 3) / 4;        // 4-pixel groups per halo row (the last one partly beyond the halo: stored as read)
+    constexpr int NXB = HH * GR * 16;           // (halo row, pixel group, channel quad) blocks
     constexpr int NXI = (NXB + 255) / 256;
+    constexpr int STAGE = 64 * DP + 64 * XP;    // halves per stage: dzT [64 co][DP], then xT [64 ci][XP]
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    op_t* dzT = (op_t*)lds;                     // [64 co][DP]
-    op_t* xT = dzT + 64 * DP;                   // [3][64 ci][XP]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    op_t* L = (op_t*)lds;
+    const int tid = threadIdx.x;
+    const bool loader = tid >= 256;
+    const int lt = tid & 255, lane = tid & 63, wave = (tid >> 6) & 3;
     const int r = lane & 31, h = lane >> 5;
     const int cb = wave & 1, ib = wave >> 1;    // 32-wide co / ci block of this wave inside the 64 x 64 block
 
@@ -68,85 +76,113 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo16_kernel(WgH16Params p) 
     const int co0 = (pair / p.ci_tiles) * 64, ci0 = (pair % p.ci_tiles) * 64;
     const int64_t t_begin = (int64_t)split * p.chunk;
     const int64_t t_end = t_begin + p.chunk < p.ntiles ? t_begin + p.chunk : p.ntiles;
+    const int nt = (int)(t_end - t_begin);
+    const int tpi = p.tiles_y * p.tiles_x;
+
+    if (loader) {
+        const int pg = lt & 15, cq = lt >> 4;   // dZ: 4-pixel group, channel quad of this thread
+        f32x4 dv[4], xv[NXI][4];
+        auto load_tile = [&](int tile) {        // all loads of a tile in flight together
+            const int n = tile / tpi;
+            const int rem = tile - n * tpi;
+            const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+            const int y0 = ty * TH, x0 = tx * TW;
+            const float* dzn = p.dz + (int64_t)n * p.H * p.W * p.Cout + co0 + cq * 4;
+            const float* xn = p.x + (int64_t)n * p.H * p.W * p.Cin + ci0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int tp = pg * 4 + q;
+                const int y = y0 + tp / TW, x = x0 + tp % TW;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (y < p.H && x < p.W) v = *(const f32x4*)(dzn + (unsigned)((y * p.W + x) * p.Cout));
+                dv[q] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < NXI; ++i) {
+                const int b = lt + 256 * i;
+                const int xq = b & 15, g = (b >> 4) % GR, hy = (b >> 4) / GR;
+                const int y = y0 - 1 + hy;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int hx = g * 4 + q;
+                    const int x = x0 - 1 + hx;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (b < NXB && hx < TW + 2 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
+                        v = *(const f32x4*)(xn + (unsigned)((y * p.W + x) * p.Cin + xq * 4));
+                    xv[i][q] = v;
+                }
+            }
+        };
+        auto store_tile = [&](op_t* st) {       // convert, transpose: four 8-byte column pieces per 4 x 4 block
+            op_t* dzT = st;
+            op_t* xT = st + 64 * DP;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const op4 v = {(op_t)dv[0][k], (op_t)dv[1][k], (op_t)dv[2][k], (op_t)dv[3][k]};
+                *(op4*)(dzT + (cq * 4 + k) * DP + pg * 4) = v;
+            }
+#pragma unroll
+            for (int i = 0; i < NXI; ++i) {
+                const int b = lt + 256 * i;
+                if (b >= NXB) continue;
+                const int xq = b & 15, g = (b >> 4) % GR, hy = (b >> 4) / GR;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const op4 v = {(op_t)xv[i][0][k], (op_t)xv[i][1][k], (op_t)xv[i][2][k], (op_t)xv[i][3][k]};
+                    *(op4*)(xT + (xq * 4 + k) * XP + hy * RP + g * 4) = v;
+                }
+            }
+        };
+        if (nt > 0) {
+            load_tile((int)t_begin);
+            store_tile(L);
+            if (nt > 1) load_tile((int)t_begin + 1);
+        }
+        __syncthreads();
+        for (int s = 0; s < nt; ++s) {
+            if (s + 1 < nt) store_tile(L + ((s + 1) & 1) * STAGE);      // the stage the matrix waves left at the previous barrier
+            if (s + 2 < nt) load_tile((int)t_begin + s + 2);
+            __syncthreads();
+        }
+        return;
+    }
 
     f32x16 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-
-    const int tpi = p.tiles_y * p.tiles_x;
-    const int pg = tid & 15, cq = tid >> 4;     // dZ: 4-pixel group, channel quad of this thread
-    const op_t* ap = dzT + (cb * 32 + r) * DP + 8 * h;
-    const op_t* bp = xT + (ib * 32 + r) * XP + (TW == 16 ? 8 * h : TW * h);
-
-    for (int tile = (int)t_begin; tile < (int)t_end; ++tile) {
-        const int n = tile / tpi;
-        const int rem = tile - n * tpi;
-        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
-        const int y0 = ty * TH, x0 = tx * TW;
-        const float* dzn = p.dz + (int64_t)n * p.H * p.W * p.Cout + co0 + cq * 4;
-        const float* xn = p.x + (int64_t)n * p.H * p.W * p.Cin + ci0;
-
-        // ---- fetch (all loads of the tile in flight together), convert, transpose ----
-        f32x4 dv[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int tp = pg * 4 + q;
-            const int y = y0 + tp / TW, x = x0 + tp % TW;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (y < p.H && x < p.W) v = *(const f32x4*)(dzn + (unsigned)((y * p.W + x) * p.Cout));
-            dv[q] = v;
-        }
-        f32x4 xv[NXI][4];
-#pragma unroll
-        for (int i = 0; i < NXI; ++i) {
-            const int b = tid + 256 * i;
-            const int xq = b & 15, g = (b >> 4) % XG, c = (b >> 4) / XG;
-            const int hy = (g * 4) / TW, j0 = (g * 4) % TW;
-            const int y = y0 - 1 + hy;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int x = x0 - 1 + j0 + q + c;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (b < NXB && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
-                    v = *(const f32x4*)(xn + (unsigned)((y * p.W + x) * p.Cin + xq * 4));
-                xv[i][q] = v;
-            }
-        }
-        __syncthreads();                        // the previous tile's fragments have all been read
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    __syncthreads();
+    for (int s = 0; s < nt; ++s) {
+        const op_t* st = L + (s & 1) * STAGE;
+        const op_t* ap = st + (cb * 32 + r) * DP + 8 * h;
+        // lane half h: pixels 8 h .. 8 h + 7 of tile row k (TW = 16), or the whole tile row 2 k + h (TW = 8)
+        const op_t* bp = st + 64 * DP + (ib * 32 + r) * XP + (TW == 16 ? 8 * h : RP * h);
+        // 4 K-steps of 16 pixels x 9 taps.  A = dZ^T[co][16 k + 8 h ..]; per ky one aligned 16-byte piece of X^T + the next dword,
+        // from which the three kx fragments are formed in registers
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const op4 v = {(op_t)dv[0][k], (op_t)dv[1][k], (op_t)dv[2][k], (op_t)dv[3][k]};
-            *(op4*)(dzT + (cq * 4 + k) * DP + pg * 4) = v;
-        }
+            const op8 a = *(const op8*)(ap + k * 16);
+            u32x4 c0[3];
+            unsigned c1[3];
 #pragma unroll
-        for (int i = 0; i < NXI; ++i) {
-            const int b = tid + 256 * i;
-            if (b >= NXB) continue;
-            const int xq = b & 15, g = (b >> 4) % XG, c = (b >> 4) / XG;
+            for (int ky = 0; ky < 3; ++ky) {
+                const int row = TW == 16 ? k + ky : 2 * k + ky;
+                c0[ky] = *(const u32x4*)(bp + row * RP);
+                c1[ky] = *(const unsigned*)(bp + row * RP + 8);
+            }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const op4 v = {(op_t)xv[i][0][k], (op_t)xv[i][1][k], (op_t)xv[i][2][k], (op_t)xv[i][3][k]};
-                *(op4*)(xT + (c * 64 + xq * 4 + k) * XP + g * 4) = v;
+            for (int ky = 0; ky < 3; ++ky) {
+                const u32x4 b1 = {__builtin_amdgcn_alignbit(c0[ky][1], c0[ky][0], 16), __builtin_amdgcn_alignbit(c0[ky][2], c0[ky][1], 16),
+                                  __builtin_amdgcn_alignbit(c0[ky][3], c0[ky][2], 16), __builtin_amdgcn_alignbit(c1[ky], c0[ky][3], 16)};
+                const u32x4 b2 = {c0[ky][1], c0[ky][2], c0[ky][3], c1[ky]};
+                acc[ky * 3 + 0] = Op16<F16>::mfma(a, __builtin_bit_cast(op8, c0[ky]), acc[ky * 3 + 0]);
+                acc[ky * 3 + 1] = Op16<F16>::mfma(a, __builtin_bit_cast(op8, b1), acc[ky * 3 + 1]);
+                acc[ky * 3 + 2] = Op16<F16>::mfma(a, __builtin_bit_cast(op8, b2), acc[ky * 3 + 2]);
             }
         }
         __syncthreads();
-
-        // ---- 4 K-steps of 16 pixels x 9 taps.  Lane (r, h): A = dZ^T[co][16 s + 8 h ..], B_tap = X^T copy kx, row shifted by ky ----
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const op8 a = *(const op8*)(ap + s * 16);
-            op8 b[9];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int ky = t / 3, kx = t - 3 * ky;
-                const int row = TW == 16 ? s + ky : 2 * s + ky;          // (TW == 8: the lane half adds its own row, folded into bp)
-                b[t] = *(const op8*)(bp + kx * 64 * XP + row * TW);
-            }
-#pragma unroll
-            for (int t = 0; t < 9; ++t) acc[t] = Op16<F16>::mfma(a, b[t], acc[t]);
-        }
     }
 
     // D[row = co][col = ci]: reg e of lane (r, h) = co (e & 3) + 8 (e >> 2) + 4 h, ci r
@@ -161,8 +197,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo16_kernel(WgH16Params p) 
 }
 
 static int halo16_splits(int64_t ntiles, int npairs) {
-    // two workgroups per CU in one round of equal work; every split adds one slab (written once, read once by the reduction)
-    static const int target = getenv("SSAD_WGRAD_HALO16_WGS") ? atoi(getenv("SSAD_WGRAD_HALO16_WGS")) : 512;
+    // one workgroup per CU in one round of equal work; every split adds one slab (written once, read once by the reduction)
+    static const int target = getenv("SSAD_WGRAD_HALO16_WGS") ? atoi(getenv("SSAD_WGRAD_HALO16_WGS")) : 256;
     int64_t s = (target + npairs - 1) / npairs;
     if (s > ntiles / 4) s = ntiles / 4;
     if (s < 1) s = 1;
@@ -204,13 +240,25 @@ extern "C" int ssad_conv_wgrad3x3_halo16(const float* dz, const float* x, float*
     const unsigned grid = (unsigned)(p.npairs * splits);
     hipStream_t st = (hipStream_t)stream;
     if (TW == 16) {
-        constexpr int bytes = (64 * (64 + 8) + 3 * 64 * (6 * 16 + 8)) * 2;
-        if (f16) hipLaunchKernelGGL((wgrad3x3_halo16_kernel<4, 16, true>), dim3(grid), dim3(256), bytes, st, p);
-        else hipLaunchKernelGGL((wgrad3x3_halo16_kernel<4, 16, false>), dim3(grid), dim3(256), bytes, st, p);
+        constexpr int bytes = 2 * (64 * (64 + 8) + 64 * (6 * 24 + 8)) * 2;
+        static bool set = false;
+        if (!set) {
+            SSAD_SET_DYN_LDS((wgrad3x3_halo16_kernel<4, 16, true>), bytes);
+            SSAD_SET_DYN_LDS((wgrad3x3_halo16_kernel<4, 16, false>), bytes);
+            set = true;
+        }
+        if (f16) hipLaunchKernelGGL((wgrad3x3_halo16_kernel<4, 16, true>), dim3(grid), dim3(512), bytes, st, p);
+        else hipLaunchKernelGGL((wgrad3x3_halo16_kernel<4, 16, false>), dim3(grid), dim3(512), bytes, st, p);
     } else {
-        constexpr int bytes = (64 * (64 + 8) + 3 * 64 * (10 * 8 + 8)) * 2;
-        if (f16) hipLaunchKernelGGL((wgrad3x3_halo16_kernel<8, 8, true>), dim3(grid), dim3(256), bytes, st, p);
-        else hipLaunchKernelGGL((wgrad3x3_halo16_kernel<8, 8, false>), dim3(grid), dim3(256), bytes, st, p);
+        constexpr int bytes = 2 * (64 * (64 + 8) + 64 * (10 * 16 + 8)) * 2;
+        static bool set = false;
+        if (!set) {
+            SSAD_SET_DYN_LDS((wgrad3x3_halo16_kernel<8, 8, true>), bytes);
+            SSAD_SET_DYN_LDS((wgrad3x3_halo16_kernel<8, 8, false>), bytes);
+            set = true;
+        }
+        if (f16) hipLaunchKernelGGL((wgrad3x3_halo16_kernel<8, 8, true>), dim3(grid), dim3(512), bytes, st, p);
+        else hipLaunchKernelGGL((wgrad3x3_halo16_kernel<8, 8, false>), dim3(grid), dim3(512), bytes, st, p);
     }
     SSAD_CHECK_LAUNCH();
     return 0;
