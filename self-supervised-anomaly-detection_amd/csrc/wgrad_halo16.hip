@@ -49,7 +49,12 @@ template <> struct Op16<true> {
 
 // 512 threads: waves 0-3 run the matrix instructions, waves 4-7 only stage (fetch -> convert -> transposed LDS stores), one tile
 // ahead in LDS (two stages) and one more in registers.  With MFMAs this short a tile is 0.5 us of matrix work against 2-4 us of
-// memory latency: a workgroup that does both in turn spends its life waiting (first version of this kernel: 8 us per tile).
+// memory latency: a workgroup that does both in turn spends its life waiting (first version of this kernel: 8 us per tile per
+// workgroup, 210-265 us per layer; this form 115-140 us).  What bounds it now is instruction issue: every SIMD carries one matrix wave
+// (0.83 us per tile, 0.48 of it MFMAs) and one staging wave (0.5-1 us), and a wave that streams MFMAs keeps the SIMD's issue to
+// itself, so the two add up (measured by switching either side off: 82 us matrix waves alone, 93-129 us staging waves alone, of which
+// 29 us are the slab epilogue and its reduction).  Tried on top, no gain: a second register set so that loads are issued two
+// barriers ahead, XCD-contiguous numbering of the blocks that walk the same tiles, fragment reads one K-step ahead (slower).
 template <int TH, int TW, bool F16>
 __global__ __launch_bounds__(512, 1) void wgrad3x3_halo16_kernel(WgH16Params p) {
     using op_t = typename Op16<F16>::t;
@@ -82,38 +87,55 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_halo16_kernel(WgH16Params p) 
     if (loader) {
         const int pg = lt & 15, cq = lt >> 4;   // dZ: 4-pixel group, channel quad of this thread
         f32x4 dv[4], xv[NXI][4];
-        auto load_tile = [&](int tile) {        // all loads of a tile in flight together
-            const int n = tile / tpi;
-            const int rem = tile - n * tpi;
-            const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
-            const int y0 = ty * TH, x0 = tx * TW;
-            const float* dzn = p.dz + (int64_t)n * p.H * p.W * p.Cout + co0 + cq * 4;
-            const float* xn = p.x + (int64_t)n * p.H * p.W * p.Cin + ci0;
+        // Everything about a thread's pieces that does not depend on the tile is computed once: position inside the tile / halo and the
+        // offset from the tile's first pixel.  Tiles are taken in order, so (n, ty, tx) advance by counting -- the staging waves' own
+        // instruction count is what bounds this kernel once the loads are far enough ahead.
+        const int dzy = (pg * 4) / TW, dzx = (pg * 4) % TW;
+        const unsigned dz_off = (unsigned)((dzy * p.W + dzx) * p.Cout + cq * 4);
+        int xhy[NXI], xhx[NXI];
+        unsigned x_off[NXI];
+        bool x_on[NXI];
+#pragma unroll
+        for (int i = 0; i < NXI; ++i) {
+            const int b = lt + 256 * i;
+            const int xq = b & 15, g = (b >> 4) % GR;
+            xhy[i] = (b >> 4) / GR;
+            xhx[i] = g * 4;
+            x_on[i] = b < NXB;
+            x_off[i] = (unsigned)((xhy[i] * p.W + xhx[i]) * p.Cin + xq * 4);
+        }
+        int ld_n = (int)(t_begin / tpi), ld_ty, ld_tx;
+        {
+            const int rem = (int)(t_begin - (int64_t)ld_n * tpi);
+            ld_ty = rem / p.tiles_x;
+            ld_tx = rem - ld_ty * p.tiles_x;
+        }
+        auto load_tile = [&]() {                 // the next tile of this workgroup: all its loads in flight together
+            const int y0 = ld_ty * TH, x0 = ld_tx * TW;
+            const float* dzn = p.dz + ((int64_t)ld_n * p.H * p.W + (int64_t)y0 * p.W + x0) * p.Cout + co0;
+            // first halo pixel (y0 - 1, x0 - 1): outside the image on border tiles -- never dereferenced there
+            const float* xn = p.x + ((int64_t)ld_n * p.H * p.W + (int64_t)(y0 - 1) * p.W + (x0 - 1)) * p.Cin + ci0;
+            const bool dy_ok = y0 + dzy < p.H;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int tp = pg * 4 + q;
-                const int y = y0 + tp / TW, x = x0 + tp % TW;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (y < p.H && x < p.W) v = *(const f32x4*)(dzn + (unsigned)((y * p.W + x) * p.Cout));
+                if (dy_ok && x0 + dzx + q < p.W) v = *(const f32x4*)(dzn + dz_off + (unsigned)(q * p.Cout));
                 dv[q] = v;
             }
 #pragma unroll
             for (int i = 0; i < NXI; ++i) {
-                const int b = lt + 256 * i;
-                const int xq = b & 15, g = (b >> 4) % GR, hy = (b >> 4) / GR;
-                const int y = y0 - 1 + hy;
+                const bool row_ok = x_on[i] && (unsigned)(y0 - 1 + xhy[i]) < (unsigned)p.H;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int hx = g * 4 + q;
-                    const int x = x0 - 1 + hx;
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (b < NXB && hx < TW + 2 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
-                        v = *(const f32x4*)(xn + (unsigned)((y * p.W + x) * p.Cin + xq * 4));
+                    if (row_ok && xhx[i] + q < TW + 2 && (unsigned)(x0 - 1 + xhx[i] + q) < (unsigned)p.W)
+                        v = *(const f32x4*)(xn + x_off[i] + (unsigned)(q * p.Cin));
                     xv[i][q] = v;
                 }
             }
+            if (++ld_tx == p.tiles_x) { ld_tx = 0; if (++ld_ty == p.tiles_y) { ld_ty = 0; ++ld_n; } }
         };
-        auto store_tile = [&](op_t* st) {       // convert, transpose: four 8-byte column pieces per 4 x 4 block
+        auto store_tile = [&](op_t* st) {        // convert, transpose: four 8-byte column pieces per 4 x 4 block
             op_t* dzT = st;
             op_t* xT = st + 64 * DP;
 #pragma unroll
@@ -134,14 +156,14 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_halo16_kernel(WgH16Params p) 
             }
         };
         if (nt > 0) {
-            load_tile((int)t_begin);
+            load_tile();
             store_tile(L);
-            if (nt > 1) load_tile((int)t_begin + 1);
+            if (nt > 1) load_tile();
         }
         __syncthreads();
         for (int s = 0; s < nt; ++s) {
             if (s + 1 < nt) store_tile(L + ((s + 1) & 1) * STAGE);      // the stage the matrix waves left at the previous barrier
-            if (s + 2 < nt) load_tile((int)t_begin + s + 2);
+            if (s + 2 < nt) load_tile();
             __syncthreads();
         }
         return;
