@@ -470,14 +470,25 @@ def main():
                 res["train_extra_" + name] = round(world * per_rank * max(args.steps, 10) / dt, 2)
             trainer.eng.bf16 = training.precision_mode(prec)
         del trainer
+    # the training step objects hold reference cycles (closures over the engine): collect them NOW, so that their hipGraphs and
+    # private memory pools are released here and not by a garbage-collector pass in the middle of the timed scoring passes
+    # (a hipFree waits for the device: measured 387 ms per pass instead of 375 in the first process on a fresh box)
+    import gc
+    gc.collect()
     torch.cuda.empty_cache()
     if args.phase in ("both", "score"):
         model.eval(); model.enable_patch_level_mode()
         det = AnomalyDetector(patch_level=True, batch=per_rank, num_patches=841)
         det.fit_bank(bank)
         ops.PROFILE = None
-        for _ in range(max(args.warmup, 1)):
+        for i in range(max(args.warmup, 1)):
+            if i == max(args.warmup, 1) - 1:
+                # the last warm-up pass runs exactly what the timed passes run, HIP events around every launch included: in the first
+                # process on a fresh box the event path is otherwise executed -- and paged in from the image -- for the first time
+                # inside the timed region (measured: 387.8 ms per pass in the first process of a box, 375.4 in every later one)
+                ops.PROFILE = []
             score_batch(model, det, x, args.size)
+        ops.drain_profile()
         ops.PROFILE = []           # scoring is ~270 launches of ~1.5 ms: the events ride inside the timed region
         res["score_s"] = timed(lambda: score_batch(model, det, x, args.size), args.steps, 0)
         prof["score"] = ops.drain_profile()
