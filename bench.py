@@ -226,11 +226,17 @@ def end_to_end(args):
             ck = os.path.join(tmp, "out32") + "/best_model.ckpt"
             tools.inference(ck, root + "bottle/", "bottle", mvtec_inference=True, patch_localization=True)      # warm-up (plans, lazy init)
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            r = tools.inference(ck, root + "bottle/", "bottle", mvtec_inference=True, patch_localization=True)
-            up = tools.upsample(r.anomaly_maps, args.size)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
+            import gc
+            gc.collect()               # the training runs above left cycles behind; their frees would wait for the device inside the clock
+            gc.disable()
+            try:
+                t0 = time.perf_counter()
+                r = tools.inference(ck, root + "bottle/", "bottle", mvtec_inference=True, patch_localization=True)
+                up = tools.upsample(r.anomaly_maps, args.size)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            finally:
+                gc.enable()
         # tools.Evaluator on the upsampled maps: device-resident maps take the hand-written sort / scan kernels (csrc/auroc.hip), host
         # maps the reference's sklearn / numpy route -- both timed once, same scores
         def evaluate(maps):
