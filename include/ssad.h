@@ -217,6 +217,13 @@ int ssad_conv_wgrad3x3_halo(const float* dz, const float* x, float* slab, int sp
 /* 3x3 / stride 2 / pad 1 (the first convolution of layer2-4): dz [N][Ho][Wo][Cout], x [N][H][W][Cin], Ho = (H - 1) / 2 + 1. */
 int ssad_conv_wgrad3x3s2_halo(const float* dz, const float* x, float* slab, int splits, int64_t N, int Ho, int Wo, int H, int W,
                               int Cin, int Cout, void* stream);
+/* Stem conv 7x7 / 2 of the precision-16 training step (csrc/stem16.hip): fp16 (f16 != 0) or bf16 operands, fp32 accumulation; the
+ * 16-bit counterpart of ssad_stem_fwd_stats for whole images -- resnet.conv1 + bn1 statistics under fp16 autocast
+ * (pl.Trainer(precision=16), src/self_supervised/tools.py:263; models.py:224).  wk16: 14 * 64 * 16 halves from ssad_pack_stem_weight16;
+ * workspace: ssad_stem_stats_rows() * 128 doubles. */
+int ssad_pack_stem_weight16(const float* w_oihw, void* wk16, int f16, void* stream);
+int ssad_stem_fwd_stats16(const float* img, int B, int H, int W, const void* wk16, float* out, float eps, float momentum, float* mean,
+                          float* invstd, float* running_mean, float* running_var, double* workspace, int f16, void* stream);
 /* The same halo-tile weight gradient with 16-bit OPERANDS (fp32 tensors in memory, rounded to fp16 -- f16 != 0 -- or bf16 while
  * staged, fp32 accumulation; csrc/wgrad_halo16.hip): the conv2d weight gradient of the reference's fp16-autocast training
  * (pl.Trainer(precision=16), src/self_supervised/tools.py:263, :270, :303) for the 3 x 3 / stride 1 / pad 1 layers.  Same slab contract:

@@ -46,13 +46,36 @@ class _Linear(torch.autograd.Function):
         return dyr @ bf(w), dyr.t() @ bf(x)
 
 
-def emulate_bf16(model, fp32_stem=True):
+class _ConvFwd16(torch.autograd.Function):
+    """conv1 of the HIP path since round 4: the FORWARD runs on bf16-rounded operands (csrc/stem16.hip), its weight gradient on the
+    fp32 image and fp32 dz (csrc/stem_wgrad.hip is the fp32-MFMA kernel in both precisions); the image needs no gradient."""
+    @staticmethod
+    def forward(ctx, x, w, stride, pad):
+        ctx.save_for_backward(x, w)
+        ctx.sp = (stride, pad)
+        return F.conv2d(bf(x), bf(w), None, stride, pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad = ctx.sp
+        wr = w.detach().requires_grad_()
+        with torch.enable_grad():
+            y = F.conv2d(x.detach(), wr, None, stride, pad)
+        gw, = torch.autograd.grad(y, wr, dy)
+        return None, gw, None, None
+
+
+def emulate_bf16(model, fp32_stem="wgrad"):
     """Patches every Conv2d / Linear of ``model`` in place to compute on bf16-rounded operands (bias stays fp32).
-    fp32_stem: the 3-channel conv1 stays fp32, as in the HIP path (its image-space kernels are fp32 MFMA in both
-    precisions: 2 % of the step, and the raw pixels keep full precision)."""
+    fp32_stem: what the 3-channel conv1 does -- "wgrad" (the HIP path since round 4): forward on rounded operands, weight gradient in
+    fp32; True (rounds 1-3): everything fp32; False: rounded like every other conv."""
     for m in model.modules():
         if isinstance(m, nn.Conv2d):
-            if fp32_stem and m.in_channels == 3:
+            if fp32_stem is True and m.in_channels == 3:
+                continue
+            if fp32_stem == "wgrad" and m.in_channels == 3:
+                m.forward = (lambda mod: lambda x: _ConvFwd16.apply(x, mod.weight, mod.stride[0], mod.padding[0]))(m)
                 continue
             m.forward = (lambda mod: lambda x: _Conv.apply(x, mod.weight, mod.stride[0], mod.padding[0]))(m)
         elif isinstance(m, nn.Linear):

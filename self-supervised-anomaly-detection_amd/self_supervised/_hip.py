@@ -75,6 +75,8 @@ SIGNATURES = {
     "ssad_wgrad3x3_halo_ok": [_c_i, _c_i, _c_i, _c_i, _c_i, _c_i],
     "ssad_wgrad3x3_halo_splits": [_c_l, _c_i, _c_i, _c_i, _c_i],
     "ssad_conv_wgrad3x3_halo": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_pack_stem_weight16": [_c_fp, _c_fp, _c_i, _c_fp],
+    "ssad_stem_fwd_stats16": [_c_fp, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_f, _c_f, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_fp],
     "ssad_wgrad3x3_halo16_ok": [_c_i, _c_i, _c_i, _c_i, _c_i, _c_i],
     "ssad_wgrad3x3_halo16_splits": [_c_l, _c_i, _c_i, _c_i, _c_i],
     "ssad_conv_wgrad3x3_halo16": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],

@@ -124,6 +124,25 @@ def stem_fwd_stats(img, wk, eps, momentum, running_mean, running_var):
     return out, mean, invstd
 
 
+def stem_fwd_stats16(img, w_oihw, eps, momentum, running_mean, running_var, mode):
+    """The training stem conv with fp16 (mode 2) or bf16 (mode 1) operands and fp32 accumulation (csrc/stem16.hip):
+    -> (z [B][Ho][Wo][64] fp32, mean, invstd), statistics from the accumulators as in stem_fwd_stats."""
+    b, c, h, w = img.shape
+    assert c == 3 and tuple(w_oihw.shape) == (64, 3, 7, 7) and int(mode) in (1, 2)
+    lib = _hip.lib()
+    wk = torch.empty(14 * 64 * 16, device=img.device, dtype=torch.float16 if int(mode) == 2 else torch.bfloat16)
+    _hip.check(lib.ssad_pack_stem_weight16(_hip.ptr(w_oihw), wk.data_ptr(), int(int(mode) == 2), _hip.stream()))
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    out = _new((b, ho, wo, 64), img)
+    mean, invstd = _new((64,), img), _new((64,), img)
+    ws = torch.empty(lib.ssad_stem_stats_rows() * 128, device=img.device, dtype=torch.float64)
+    _run(_kname("stem_conv7x7", mode), 2.0 * b * ho * wo * 64 * 147, 4.0 * (b * 3 * h * w + b * ho * wo * 64),
+         lambda: lib.ssad_stem_fwd_stats16(_hip.ptr(img), b, h, w, wk.data_ptr(), _hip.ptr(out), eps, momentum, _hip.ptr(mean),
+                                           _hip.ptr(invstd), _hip.ptr(running_mean, True), _hip.ptr(running_var, True),
+                                           ws.data_ptr(), int(int(mode) == 2), _hip.stream()))
+    return out, mean, invstd
+
+
 def pack_stem_weight_folded(w):
     assert tuple(w.shape) == (64, 3, 7, 7)
     out = _new((24, 2, 64), w)

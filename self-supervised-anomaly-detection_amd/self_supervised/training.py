@@ -137,7 +137,7 @@ class _Affine:
         return w if self.is_conv else w.view(w.shape[0], 1, 1, w.shape[1])
 
     def _stem_fwd(self, img, w):
-        """conv1 straight from the NCHW image (fp32 MFMA also under precision=16); train or eval BatchNorm + ReLU."""
+        """conv1 straight from the NCHW image (the unfused fp32-MFMA form; the training step takes fwd_pool); train or eval BatchNorm + ReLU."""
         bn = self.bn
         self.x, self.res_used = img, False
         if bn.training:
@@ -168,7 +168,12 @@ class _Affine:
             return ops.maxpool3x3s2_fwd_idx(self._stem_fwd(img, self.weight()))
         self.x, self.res_used = img, False
         mom = 0.1 if bn.momentum is None else bn.momentum
-        z, self.mean, self.invstd = ops.stem_fwd_stats(img, self.weight(), bn.eps, mom, bn.running_mean, bn.running_var)
+        if self.eng.bf16 in (1, 2) and self.eng.sw_stem16:
+            # precision 16 / 'bf16': conv1 on the 16-bit matrix instructions (csrc/stem16.hip), as autocast runs it
+            z, self.mean, self.invstd = ops.stem_fwd_stats16(img, self.lin.weight.detach().contiguous(), bn.eps, mom, bn.running_mean,
+                                                             bn.running_var, self.eng.bf16)
+        else:
+            z, self.mean, self.invstd = ops.stem_fwd_stats(img, self.weight(), bn.eps, mom, bn.running_mean, bn.running_var)
         with torch.no_grad():
             self.eng.count_batch(bn)
         a = self.eng.arena
@@ -427,10 +432,11 @@ class TrainEngine:
         self.sw_c64 = os.environ.get("SSAD_C64", "1") != "0"
         self.sw_relu_mask = os.environ.get("SSAD_RELU_MASK", "1") != "0"
         self.sw_wgrad_halo = os.environ.get("SSAD_WGRAD_HALO", "1") != "0"
+        self.sw_stem16 = os.environ.get("SSAD_STEM16", "1") != "0"
 
     def switches(self):
         """Everything besides shapes that decides which launches a step consists of (hipGraph plan key)."""
-        return (self.bf16, self.param_grads, self.sw_c64, self.sw_relu_mask, self.sw_wgrad_halo, self._side_on,
+        return (self.bf16, self.param_grads, self.sw_c64, self.sw_relu_mask, self.sw_wgrad_halo, self.sw_stem16, self._side_on,
                 os.environ.get("SSAD_WGRAD_HALO", "1") != "0", torch.is_grad_enabled())
 
     # ---- second stream for the weight gradients ----

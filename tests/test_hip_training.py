@@ -772,6 +772,26 @@ def test_f16_operand_kernels(dev):
         assert rel_err(dw.view(cout, k, k, cin).permute(0, 3, 1, 2), gw) < 2e-5
 
 
+def test_stem_conv_with_16_bit_operands(dev):
+    """csrc/stem16.hip (conv1 of the precision-16 step): fp32 math on fp16- (bf16-) rounded image and weights, sizes that are ragged
+    against the 8 x 32 output tile, BatchNorm statistics and running statistics from the raw output as the fp32 kernel takes them."""
+    from self_supervised import ops
+    for (b, h, w) in [(2, 64, 64), (3, 50, 74), (1, 256, 256), (5, 33, 31)]:
+        g = torch.Generator().manual_seed(b * 100 + h)
+        img = torch.randn(b, 3, h, w, generator=g) * 1.2
+        wt = torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5
+        for mode, rnd in ((2, _h), (1, lambda t: t.to(torch.bfloat16).float())):
+            want = F.conv2d(rnd(img), rnd(wt), None, 2, 3)
+            rm, rv = torch.zeros(64, device=dev), torch.ones(64, device=dev)
+            z, mean, invstd = ops.stem_fwd_stats16(img.to(dev), wt.to(dev), 1e-5, 0.1, rm, rv, mode)
+            assert rel_err(z.permute(0, 3, 1, 2), want) < 2e-5, (b, h, w, mode)
+            zc = z.detach().cpu().double().reshape(-1, 64)
+            m, v = zc.mean(0), zc.var(0, unbiased=False)
+            assert (mean.cpu().double() - m).abs().max() < 1e-5 and rel_err(invstd, (v + 1e-5).rsqrt()) < 1e-5
+            n = zc.shape[0]
+            assert rel_err(rm, 0.1 * m) < 1e-4 and rel_err(rv, 0.9 + 0.1 * v * n / max(n - 1, 1)) < 1e-4
+
+
 def test_halo_wgrad_with_16_bit_operands(dev):
     """csrc/wgrad_halo16.hip (3x3 / stride 1 / pad 1 weight gradients of the precision-16 step): fp32 math on fp16- (bf16-) rounded
     operands, on maps that are ragged against both tile shapes (4 x 16 for widths above 8, 8 x 8 below), one and several (co, ci)
