@@ -188,7 +188,7 @@ extern "C" int ssad_stem_fwd_stats16(const float* img, int B, int H, int W, cons
                                      float* mean, float* invstd, float* running_mean, float* running_var, double* workspace, int f16,
                                      void* stream) {
     SSAD_CHECK_ARG(img && wk16 && out && mean && invstd && workspace, "null pointer");
-    SSAD_CHECK_ARG(B > 0 && H > 0 && W > 0, "empty shape");
+    SSAD_CHECK_ARG(B > 0 && H >= 64 && W >= 64, "whole images of at least 64 x 64 (smaller ones are resized first: ssad_stem_fwd_stats)");
     Stem16Params p;
     p.img = img; p.wk16 = wk16; p.out = out; p.stats = workspace; p.B = B; p.H = H; p.W = W;
     p.Ho = (H - 1) / 2 + 1; p.Wo = (W - 1) / 2 + 1;

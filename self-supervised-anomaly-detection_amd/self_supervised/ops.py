@@ -129,6 +129,7 @@ def stem_fwd_stats16(img, w_oihw, eps, momentum, running_mean, running_var, mode
     -> (z [B][Ho][Wo][64] fp32, mean, invstd), statistics from the accumulators as in stem_fwd_stats."""
     b, c, h, w = img.shape
     assert c == 3 and tuple(w_oihw.shape) == (64, 3, 7, 7) and int(mode) in (1, 2)
+    assert h >= 64 and w >= 64, "images below 64 x 64 are resized first (models.py:217-219): that is the fp32 stem's loader"
     lib = _hip.lib()
     wk = torch.empty(14 * 64 * 16, device=img.device, dtype=torch.float16 if int(mode) == 2 else torch.bfloat16)
     _hip.check(lib.ssad_pack_stem_weight16(_hip.ptr(w_oihw), wk.data_ptr(), int(int(mode) == 2), _hip.stream()))

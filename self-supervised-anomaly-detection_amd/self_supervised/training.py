@@ -168,7 +168,8 @@ class _Affine:
             return ops.maxpool3x3s2_fwd_idx(self._stem_fwd(img, self.weight()))
         self.x, self.res_used = img, False
         mom = 0.1 if bn.momentum is None else bn.momentum
-        if self.eng.bf16 in (1, 2) and self.eng.sw_stem16:
+        if self.eng.bf16 in (1, 2) and self.eng.sw_stem16 and img.shape[2] >= 64 and img.shape[3] >= 64:
+            # (smaller images are first resized to 64 x 64, models.py:217-219: the fp32 stem's loader does that, this kernel does not)
             # precision 16 / 'bf16': conv1 on the 16-bit matrix instructions (csrc/stem16.hip), as autocast runs it
             z, self.mean, self.invstd = ops.stem_fwd_stats16(img, self.lin.weight.detach().contiguous(), bn.eps, mom, bn.running_mean,
                                                              bn.running_var, self.eng.bf16)

@@ -776,7 +776,7 @@ def test_stem_conv_with_16_bit_operands(dev):
     """csrc/stem16.hip (conv1 of the precision-16 step): fp32 math on fp16- (bf16-) rounded image and weights, sizes that are ragged
     against the 8 x 32 output tile, BatchNorm statistics and running statistics from the raw output as the fp32 kernel takes them."""
     from self_supervised import ops
-    for (b, h, w) in [(2, 64, 64), (3, 50, 74), (1, 256, 256), (5, 33, 31)]:
+    for (b, h, w) in [(2, 64, 64), (3, 70, 74), (1, 256, 256), (5, 65, 97)]:
         g = torch.Generator().manual_seed(b * 100 + h)
         img = torch.randn(b, 3, h, w, generator=g) * 1.2
         wt = torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5
