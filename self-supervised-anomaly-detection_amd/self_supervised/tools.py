@@ -230,6 +230,8 @@ def _predict_mvtec_streamed(model: PeraNet, dataset, device, indices, group: int
     n = len(indices)
     out = ModelOutputsContainer()
     if n == 0:
+        if prefetch is not None:
+            prefetch.close()
         return out, None
     w_img, h_img = dataset.imsize
     pre = prefetch if prefetch is not None else _MVTecPrefetch(dataset, indices, threads)
