@@ -199,6 +199,13 @@ int ssad_conv3x3_c64(const float* in, const float* w_ohwi, float* out, const flo
                      const float* tr_invstd, const float* tr_gamma, const float* tr_beta, float* emit, int64_t N, int H, int W,
                      double* stats_ws, float eps, float momentum, float* mean, float* invstd, float* running_mean,
                      float* running_var, void* stream);
+/* The same with op = 1 / 2: bf16 / fp16 OPERANDS (fp32 tensors, rounded while staged; fp32 accumulation, statistics, transform and
+ * emit) -- the layer1 convolutions of the reference's fp16-autocast training (pl.Trainer(precision=16), tools.py:263); op = 0 is
+ * ssad_conv3x3_c64. */
+int ssad_conv3x3_c64_op(const float* in, const float* w_ohwi, float* out, const float* residual, const uint8_t* res_mask,
+                        const float* tr_mean, const float* tr_invstd, const float* tr_gamma, const float* tr_beta, float* emit, int64_t N,
+                        int H, int W, double* stats_ws, float eps, float momentum, float* mean, float* invstd, float* running_mean,
+                        float* running_var, int op, void* stream);
 /* Inference form of the halo-tile convolution (frozen BatchNorm folded into scale / shift):
  * out = act(conv3x3(in) * scale[co] + shift[co] + residual), 64 -> 64 channels, stride 1, pad 1, exact fp32 MFMA.
  * in_hwnc / out_hwnc / res_hwnc != 0: the input / the output / the residual is position-major [H][W][N][64] (the

@@ -72,11 +72,36 @@ struct C64Params {
     int stagger;              // start delay of the workgroups in the second wave slot of their CU, in units of s_sleep(127)
 };
 
-template <bool EVAL>
+// OP: 0 = exact fp32 (v_mfma_f32_32x32x2_f32); 1 / 2 = bf16 / fp16 OPERANDS, fp32 accumulation (v_mfma_f32_32x32x16_*): the layer1
+// convolutions of the precision-16 step (pl.Trainer(precision=16), tools.py:263).  Tensors stay fp32 in memory; the halo and the
+// weight slice are rounded while they are staged (the input transform and `emit` run in fp32 before the rounding), pixels and filter
+// rows are 72 halves apart in LDS (144 B: conflict-free b128 fragment reads), 8 MFMAs per tap instead of 128.  Accumulators have the
+// fp32 kernel's layout, so every epilogue below is shared.
+template <int OP> struct C64Op { using t = float; using v4 = f32x4; using v8 = f32x4; };
+template <> struct C64Op<1> {
+    using t = __bf16; using v4 = bf16x4; using v8 = bf16x8;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct C64Op<2> {
+    using t = _Float16; using v4 = f16x4; using v8 = f16x8;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+constexpr int LDP16 = C + 8;                        // halves per pixel / filter row of the 16-bit forms
+constexpr int ROWP16 = HW * LDP16 + 8;              // halves per halo row
+constexpr int HALO16_H = HH * ROWP16, WT16_H = C * LDP16;
+constexpr int LDS_BYTES16 = ((HALO16_H + WT16_H) * 2 > 128 * LDP * 4 ? (HALO16_H + WT16_H) * 2 : 128 * LDP * 4);   // >= the LDS epilogue tile
+
+template <bool EVAL, int OP = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
+    static_assert(!(EVAL && OP), "the 16-bit forms are training-only");
+    using op_t = typename C64Op<OP>::t;
+    using op4 = typename C64Op<OP>::v4;
+    using op8 = typename C64Op<OP>::v8;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* halo = lds;
     float* Bs = lds + HALO_F;
+    op_t* halo16 = (op_t*)lds;                      // OP != 0: [HH][ROWP16] halves, then the tap's [64 co][LDP16] slice
+    op_t* Bs16 = halo16 + HALO16_H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
 
@@ -145,13 +170,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
             }
         }
     }
+    auto cvt4 = [](const f32x4& v) { op4 o = {(op_t)v[0], (op_t)v[1], (op_t)v[2], (op_t)v[3]}; return o; };
 #pragma unroll
     for (int q = 0; q < NPASS; ++q) {
         const int hp = q * 16 + p0;
-        if (hp < HH * HW) *(f32x4*)(halo + (hp / HW) * ROWP + (hp % HW) * LDP + c4 * 4) = hv[q];
+        if (hp < HH * HW) {
+            if (OP) *(op4*)(halo16 + (hp / HW) * ROWP16 + (hp % HW) * LDP16 + c4 * 4) = cvt4(hv[q]);
+            else *(f32x4*)(halo + (hp / HW) * ROWP + (hp % HW) * LDP + c4 * 4) = hv[q];
+        }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *(f32x4*)(Bs + ((tid >> 4) + 16 * i) * LDP + c4 * 4) = wv[i];
+    for (int i = 0; i < 4; ++i) {
+        if (OP) *(op4*)(Bs16 + ((tid >> 4) + 16 * i) * LDP16 + c4 * 4) = cvt4(wv[i]);
+        else *(f32x4*)(Bs + ((tid >> 4) + 16 * i) * LDP + c4 * 4) = wv[i];
+    }
     C64_STAMP(5);                                   // loads landed, LDS writes done (the stamp waits for them)
     __syncthreads();
     C64_STAMP(1);
@@ -174,6 +206,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
         if (t < 8 && !(C64_ABL & 1)) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) wv[i] = *(const f32x4*)(wrow + (int64_t)i * 16 * 9 * C + (t + 1) * C);
+        }
+        if constexpr (OP != 0) {
+            // 4 chunks of 16 channels x 2 output-channel halves: lane (r, h) feeds pixel r / filter row r, channels 16 kk + 8 h .. + 7
+            const op_t* At16 = halo16 + (2 * wave + (r >> 4) + ky) * ROWP16 + ((r & 15) + kx) * LDP16 + h * 8;
+            const op_t* Bb16 = Bs16 + r * LDP16 + h * 8;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const op8 a16 = *(const op8*)(At16 + kk * 16);
+                const op8 b0 = *(const op8*)(Bb16 + kk * 16), b1 = *(const op8*)(Bb16 + 32 * LDP16 + kk * 16);
+                acc[0] = C64Op<OP>::mfma(a16, b0, acc[0]);
+                acc[1] = C64Op<OP>::mfma(a16, b1, acc[1]);
+            }
+            __syncthreads();                         // every wave is done with this tap's weights
+            if (t < 8) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *(op4*)(Bs16 + ((tid >> 4) + 16 * i) * LDP16 + c4 * 4) = cvt4(wv[i]);
+                __syncthreads();
+            }
+            continue;
         }
         const float* At = Ab + ky * ROWP + kx * LDP;
         f32x4 a[2], b[2][2];
@@ -340,7 +391,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
     C64_STAMP(3);
     if (!EVAL && p.stats) {
         // lane halves -> one value per channel per wave, then the four waves in a fixed order through LDS
-        double* S = (double*)Bs;                     // [4 waves][2][64]; the weight buffer is free (barrier above)
+        double* S = OP ? (double*)Bs16 : (double*)Bs;      // [4 waves][2][64]; the weight buffer is free (barrier above)
+        if (OP) __syncthreads();                     // ... but in the 16-bit layout it lies inside the LDS epilogue's tile
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             s0[j] += __shfl_xor(s0[j], 32);
@@ -379,11 +431,13 @@ extern "C" int64_t ssad_conv3x3_c64_stats_rows(int64_t N, int H, int W) {
 // `emit`, if given, receives T(in): the activation the weight-gradient kernel of this layer needs).
 // stats_ws != NULL: train-mode BatchNorm statistics of the output (ssad_conv3x3_c64_stats_rows(N, H, W) * 2 * 64 doubles
 // of workspace), finalised exactly as ssad_conv_igemm_fwd_stats does.
-extern "C" int ssad_conv3x3_c64(const float* in, const float* w_ohwi, float* out, const float* residual, const uint8_t* res_mask, const float* tr_mean,
-                                const float* tr_invstd, const float* tr_gamma, const float* tr_beta, float* emit, int64_t N,
-                                int H, int W, double* stats_ws, float eps, float momentum, float* mean, float* invstd,
-                                float* running_mean, float* running_var, void* stream) {
+// op: 0 exact fp32, 1 bf16 operands, 2 fp16 operands (fp32 accumulation; csrc comment at the kernel)
+extern "C" int ssad_conv3x3_c64_op(const float* in, const float* w_ohwi, float* out, const float* residual, const uint8_t* res_mask,
+                                   const float* tr_mean, const float* tr_invstd, const float* tr_gamma, const float* tr_beta, float* emit,
+                                   int64_t N, int H, int W, double* stats_ws, float eps, float momentum, float* mean, float* invstd,
+                                   float* running_mean, float* running_var, int op, void* stream) {
     SSAD_CHECK_ARG(in && w_ohwi && out && N > 0 && H > 0 && W > 0, "bad argument");
+    SSAD_CHECK_ARG(op >= 0 && op <= 2, "op: 0 fp32, 1 bf16, 2 fp16");
     SSAD_CHECK_ARG(!tr_mean || (tr_invstd && tr_gamma && tr_beta), "input transform needs mean, invstd, gamma, beta");
     SSAD_CHECK_ARG(!emit || tr_mean, "emit without an input transform");
     SSAD_CHECK_ARG(!stats_ws || (mean && invstd), "statistics need mean / invstd outputs");
@@ -404,12 +458,22 @@ extern "C" int ssad_conv3x3_c64(const float* in, const float* w_ohwi, float* out
         SSAD_SET_DYN_LDS(conv3x3_c64_kernel<false>, lds_bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv3x3_c64_kernel<false>, dim3((unsigned)nwg), dim3(256), lds_bytes, (hipStream_t)stream, p);
+    if (op == 2) hipLaunchKernelGGL((conv3x3_c64_kernel<false, 2>), dim3((unsigned)nwg), dim3(256), LDS_BYTES16, (hipStream_t)stream, p);
+    else if (op == 1) hipLaunchKernelGGL((conv3x3_c64_kernel<false, 1>), dim3((unsigned)nwg), dim3(256), LDS_BYTES16, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(conv3x3_c64_kernel<false>, dim3((unsigned)nwg), dim3(256), lds_bytes, (hipStream_t)stream, p);
     SSAD_CHECK_LAUNCH();
     if (stats_ws)
         return ssad_bn_finalize_partials(stats_ws, (int)nwg, N * H * W, C, eps, momentum, mean, invstd, running_mean,
                                          running_var, stream);
     return 0;
+}
+
+extern "C" int ssad_conv3x3_c64(const float* in, const float* w_ohwi, float* out, const float* residual, const uint8_t* res_mask, const float* tr_mean,
+                                const float* tr_invstd, const float* tr_gamma, const float* tr_beta, float* emit, int64_t N,
+                                int H, int W, double* stats_ws, float eps, float momentum, float* mean, float* invstd,
+                                float* running_mean, float* running_var, void* stream) {
+    return ssad_conv3x3_c64_op(in, w_ohwi, out, residual, res_mask, tr_mean, tr_invstd, tr_gamma, tr_beta, emit, N, H, W, stats_ws, eps,
+                               momentum, mean, invstd, running_mean, running_var, 0, stream);
 }
 
 // Inference form (frozen BatchNorm folded into scale / shift): out = act(conv3x3(in) * scale[co] + shift[co] + residual),

@@ -66,6 +66,8 @@ SIGNATURES = {
     "ssad_conv3x3_c64_stats_rows": [_c_l, _c_i, _c_i],
     "ssad_conv3x3_c64": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp, _c_f, _c_f,
                          _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
+    "ssad_conv3x3_c64_op": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp, _c_f, _c_f,
+                         _c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_fp],
     "ssad_conv3x3_c64_eval": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
     "ssad_bn_apply_fwd_mask": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp],
     "ssad_bn_bwd_reduce_mask": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_fp, _c_fp],

@@ -248,7 +248,7 @@ def conv_fwd_stats(x, w_ohwi, eps, momentum, running_mean, running_var, stride=1
     return out, mean, invstd
 
 
-def conv3x3_c64(x, w_ohwi, residual=None, transform=None, emit=False, stats=None, res_mask=None):
+def conv3x3_c64(x, w_ohwi, residual=None, transform=None, emit=False, stats=None, res_mask=None, bf16=0):
     """Halo-tile 3x3 / stride 1 / pad 1 convolution, 64 -> 64 channels (layer1 forward and input-gradient convs).
     x NHWC [N][H][W][64], w OHWI [64][3][3][64].  transform = (mean, invstd, gamma, beta): the input is taken through
     relu(bn(x)) while it is staged (emit=True also returns that activation).  stats = (eps, momentum, running_mean,
@@ -267,12 +267,14 @@ def conv3x3_c64(x, w_ohwi, residual=None, transform=None, emit=False, stats=None
         mean, invstd = _new((64,), x), _new((64,), x)
         ws = torch.empty(lib.ssad_conv3x3_c64_stats_rows(n, h, w) * 128, device=x.device, dtype=torch.float64)
     nb = 4.0 * (x.numel() + out.numel() * (2 if residual is not None else 1) + (out.numel() if emit else 0) + w_ohwi.numel())
-    _run("conv_c64_f32", 2.0 * out.numel() * 9 * 64, nb,
-         lambda: lib.ssad_conv3x3_c64(_hip.ptr(x), _hip.ptr(w_ohwi), _hip.ptr(out), _hip.ptr(residual, True),
-                                      res_mask.data_ptr() if res_mask is not None else None, _hip.ptr(tr[0], True),
-                                      _hip.ptr(tr[1], True), _hip.ptr(tr[2], True), _hip.ptr(tr[3], True), _hip.ptr(em, True),
-                                      n, h, w, ws.data_ptr() if ws is not None else None, eps, mom, _hip.ptr(mean, True),
-                                      _hip.ptr(invstd, True), _hip.ptr(rm, True), _hip.ptr(rv, True), _hip.stream()))
+    op = int(bf16)
+    assert op in (0, 1, 2), "conv3x3_c64: exact fp32, or bf16 (1) / fp16 (2) operands"
+    _run(_kname("conv_c64", op), 2.0 * out.numel() * 9 * 64, nb,
+         lambda: lib.ssad_conv3x3_c64_op(_hip.ptr(x), _hip.ptr(w_ohwi), _hip.ptr(out), _hip.ptr(residual, True),
+                                         res_mask.data_ptr() if res_mask is not None else None, _hip.ptr(tr[0], True),
+                                         _hip.ptr(tr[1], True), _hip.ptr(tr[2], True), _hip.ptr(tr[3], True), _hip.ptr(em, True),
+                                         n, h, w, ws.data_ptr() if ws is not None else None, eps, mom, _hip.ptr(mean, True),
+                                         _hip.ptr(invstd, True), _hip.ptr(rm, True), _hip.ptr(rv, True), op, _hip.stream()))
     res = [out]
     if emit:
         res.append(em)

@@ -202,7 +202,7 @@ class _Affine:
         l, bn = self.lin, self.bn
         return (self.is_conv and not self.stem and l.kernel_size == (3, 3) and self.stride == 1 and self.pad == 1
                 and l.in_channels == 64 and l.out_channels == 64 and l.bias is None and bn is not None and bn.training
-                and not self.eng.bf16 and self.eng.sw_c64)
+                and (not self.eng.bf16 or (self.eng.bf16 in (1, 2) and self.eng.sw_c64_16)) and self.eng.sw_c64)
 
     def fwd_raw_c64(self, x, producer=None):
         """conv + batch statistics only: returns the raw z of this layer and leaves its BatchNorm (+ ReLU) to the consumer.
@@ -213,16 +213,17 @@ class _Affine:
         st = (bn.eps, mom, bn.running_mean, bn.running_var)
         self.x_shape = tuple(x.shape)
         if producer is None:
-            z, self.mean, self.invstd = ops.conv3x3_c64(x, a.w(self.lin.weight), stats=st)
+            z, self.mean, self.invstd = ops.conv3x3_c64(x, a.w(self.lin.weight), stats=st, bf16=self.eng.bf16)
             self.x = x
         else:
             pb = producer.bn
             tr = (producer.mean, producer.invstd, a.w(pb.weight), a.w(pb.bias))
             need_x = self.lin.weight.requires_grad and self.eng.param_grads and torch.is_grad_enabled()
             if need_x:
-                z, self.x, self.mean, self.invstd = ops.conv3x3_c64(x, a.w(self.lin.weight), transform=tr, emit=True, stats=st)
+                z, self.x, self.mean, self.invstd = ops.conv3x3_c64(x, a.w(self.lin.weight), transform=tr, emit=True, stats=st,
+                                                                    bf16=self.eng.bf16)
             else:
-                z, self.mean, self.invstd = ops.conv3x3_c64(x, a.w(self.lin.weight), transform=tr, stats=st)
+                z, self.mean, self.invstd = ops.conv3x3_c64(x, a.w(self.lin.weight), transform=tr, stats=st, bf16=self.eng.bf16)
                 self.x = None
         with torch.no_grad():
             self.eng.count_batch(bn)
@@ -375,7 +376,7 @@ class _Affine:
                 wt = torch.zeros((padc,) + tuple(w.shape[1:]), device=dz.device)
                 wt[:cout] = w
             if self.c64_ok() and dz.dim() == 4:
-                dx = ops.conv3x3_c64(dzz, self.eng.flipped(self.lin, wt), residual=dx_residual, res_mask=dx_res_mask)
+                dx = ops.conv3x3_c64(dzz, self.eng.flipped(self.lin, wt), residual=dx_residual, res_mask=dx_res_mask, bf16=bf)
             else:
                 wf = self.eng.flipped(self.lin, wt) if wt is w else ops.flip_transpose_weight(wt)
                 dx = ops.conv_dgrad(dzz, wf, self.x_shape, self.stride, self.pad, dx_residual, bf, res_mask=dx_res_mask)
@@ -434,10 +435,11 @@ class TrainEngine:
         self.sw_relu_mask = os.environ.get("SSAD_RELU_MASK", "1") != "0"
         self.sw_wgrad_halo = os.environ.get("SSAD_WGRAD_HALO", "1") != "0"
         self.sw_stem16 = os.environ.get("SSAD_STEM16", "1") != "0"
+        self.sw_c64_16 = os.environ.get("SSAD_C64_16", "1") != "0"
 
     def switches(self):
         """Everything besides shapes that decides which launches a step consists of (hipGraph plan key)."""
-        return (self.bf16, self.param_grads, self.sw_c64, self.sw_relu_mask, self.sw_wgrad_halo, self.sw_stem16, self._side_on,
+        return (self.bf16, self.param_grads, self.sw_c64, self.sw_relu_mask, self.sw_wgrad_halo, self.sw_stem16, self.sw_c64_16, self._side_on,
                 os.environ.get("SSAD_WGRAD_HALO", "1") != "0", torch.is_grad_enabled())
 
     # ---- second stream for the weight gradients ----

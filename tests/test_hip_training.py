@@ -772,6 +772,44 @@ def test_f16_operand_kernels(dev):
         assert rel_err(dw.view(cout, k, k, cin).permute(0, 3, 1, 2), gw) < 2e-5
 
 
+def test_halo_conv_c64_with_16_bit_operands(dev):
+    """csrc/conv_c64.hip, OP = 1 / 2 (layer1 convolutions of the precision-16 step): fp32 math on bf16- / fp16-rounded operands; the input
+    transform (BatchNorm + ReLU of the producer) and the emitted activation stay fp32 and are rounded after; residual, statistics and
+    the input-gradient use (flipped filter) as in the fp32 kernel; ragged tiles."""
+    from self_supervised import ops
+    for (n, h, w) in [(3, 16, 16), (2, 13, 21), (5, 64, 64)]:
+        g = torch.Generator().manual_seed(n * 10 + h)
+        x = torch.randn(n, 64, h, w, generator=g)
+        wt = torch.randn(64, 64, 3, 3, generator=g) / 24.0
+        res = torch.randn(n, 64, h, w, generator=g)
+        mean, var = torch.randn(64, generator=g) * 0.1, torch.rand(64, generator=g) + 0.5
+        gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+        invstd = (var + 1e-5).rsqrt()
+        nh = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().to(dev)
+        w_ohwi = ops.repack_oihw_to_ohwi(wt.to(dev))
+        xd, rd = nh(x), nh(res)
+        for mode, rnd in ((2, _h), (1, lambda t: t.to(torch.bfloat16).float())):
+            want = F.conv2d(rnd(x), rnd(wt), None, 1, 1)
+            got = ops.conv3x3_c64(xd, w_ohwi, bf16=mode)
+            assert rel_err(got.permute(0, 3, 1, 2), want) < 2e-5, (n, h, w, mode)
+            got = ops.conv3x3_c64(xd, w_ohwi, residual=rd, bf16=mode)
+            assert rel_err(got.permute(0, 3, 1, 2), want + res) < 2e-5
+            act = torch.relu((x - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1) * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1))
+            rm, rv = torch.zeros(64, device=dev), torch.ones(64, device=dev)
+            z, em, m2, i2 = ops.conv3x3_c64(xd, w_ohwi, transform=tuple(t.to(dev) for t in (mean, invstd, gamma, beta)), emit=True,
+                                            stats=(1e-5, 0.1, rm, rv), bf16=mode)
+            assert rel_err(em.permute(0, 3, 1, 2), act) < 1e-6                      # emitted in fp32, before the rounding
+            want_t = F.conv2d(rnd(em.permute(0, 3, 1, 2).cpu()), rnd(wt), None, 1, 1)   # (rounded from the kernel's own fp32 activation)
+            assert rel_err(z.permute(0, 3, 1, 2), want_t) < 2e-5
+            zc = z.detach().cpu().double().reshape(-1, 64)
+            assert (m2.cpu().double() - zc.mean(0)).abs().max() < 1e-5 and rel_err(i2, (zc.var(0, unbiased=False) + 1e-5).rsqrt()) < 1e-5
+            # input gradient of the same layer: the flipped filter through the same kernel
+            xr = rnd(x).requires_grad_()
+            gx, = torch.autograd.grad(F.conv2d(xr, rnd(wt), None, 1, 1), xr, rnd(res))
+            dx = ops.conv3x3_c64(rd, ops.flip_transpose_weight(w_ohwi), bf16=mode)
+            assert rel_err(dx.permute(0, 3, 1, 2), gx) < 2e-5
+
+
 def test_stem_conv_with_16_bit_operands(dev):
     """csrc/stem16.hip (conv1 of the precision-16 step): fp32 math on fp16- (bf16-) rounded image and weights, sizes that are ragged
     against the 8 x 32 output tile, BatchNorm statistics and running statistics from the raw output as the fp32 kernel takes them."""
