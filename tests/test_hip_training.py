@@ -902,6 +902,32 @@ def test_loss_scaler_state_machine(dev):
     assert torch.allclose(p2.cpu(), torch.full((10,), 1 - 0.1 * (2.0 + 0.5)))
 
 
+def test_precision16_step_on_images_below_and_above_64(dev, seeded_sd):
+    """The 16-bit kernels of the precision-16 step choose themselves by shape: 32 x 32 images are resized to 64 x 64 by the fp32 stem's
+    loader (models.py:217-219; the 16-bit stem takes whole images from 64 x 64 up), 96 x 72 ones take the 16-bit stem and ragged halo
+    tiles.  Eager step, captured step, replayed step: the same finite loss going down, and the gradient of the 16-bit step close to the
+    exact one (a 16-bit stem that mis-sized its output made the fp32 stem weight gradient read past its input: round 4)."""
+    from self_supervised import training
+    from oracle import weights as ow
+    for size in ((32, 32), (96, 72)):
+        g = torch.Generator().manual_seed(size[0])
+        x = torch.randn(8, 3, *size, generator=g).to(dev)
+        y = ow.synthetic_labels(8, seed=3).to(dev)
+        grads = {}
+        for prec in (32, 16):
+            _, m = _pair(seeded_sd, dev)
+            m.unfreeze()
+            step = training.DataParallelStep(m, lr=0.01, world_size=1, precision=prec)
+            losses = [float(step.step(x, y)[0])]
+            grads[prec] = step.eng.arena.g.detach().clone()            # the first step's gradient: same weights in both precisions
+            losses += [float(step.step(x, y)[0]) for _ in range(3)]
+            torch.cuda.synchronize()
+            assert all(np.isfinite(l) for l in losses) and losses[-1] < losses[0], (size, prec, losses)
+        g16 = grads[16] / max(float(grads[16].abs().max()), 1e-30)      # (the 16-bit step's gradient carries the loss scale)
+        cos = torch.nn.functional.cosine_similarity(g16, grads[32], dim=0).item()
+        assert cos > 0.7, (size, cos)         # fp16 operands through 20 layers of batch-8 BatchNorm: direction, not digits
+
+
 def test_f16_training_step_vs_autocast_oracle(dev, seeded_sd):
     """Trainer(precision=16) = fp16 operands + loss scaling, against the reference's own arithmetic: the oracle under
     torch.autocast(dtype=float16) with a scaled loss (what pl.Trainer(precision=16) runs, tools.py:263).  Autocast also
