@@ -165,15 +165,19 @@ int ssad_bn_small_bwd(const float* dy, const float* z, const float* mean, const 
 int ssad_linear_small_max_rows(void);
 int ssad_linear_wgrad_small(const float* dy, const float* x, float* dw, int64_t M, int Cin, int Cout, int accumulate, void* stream);
 /* Replaces autograd's conv2d/linear weight-gradient.  Two launches: partial tiles per pixel split into
- * slab[splits][Cout][KH*KW*Cin], then a fixed-order sum written as OIHW (to_oihw=1, checkpoint layout) or OHWI. */
+ * slab[splits][Cout][KH*KW*Cin], then a fixed-order sum written as OIHW (to_oihw=1, checkpoint layout) or OHWI.
+ * Guard convention (round 5): wherever an entry point reads a SECOND tensor over extents it derives from the first one's (dy from
+ * x's N, H, W and the filter geometry; dz from the image size; the pooled gradient from z's size), the caller also states how many
+ * elements that second buffer holds (`dy_elems`, `dz_elems`, `dpool_elems`); a count that does not match the derived extents is an
+ * error return, not an out-of-bounds read. */
 int ssad_wgrad_splits(int64_t M, int Cin, int Cout, int KH, int KW);
 int ssad_wgrad_splits_bf16(int64_t M, int Cin, int Cout, int KH, int KW);   /* for ssad_conv_wgrad_bf16 / _x3 */
 int ssad_conv_wgrad(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin, int Cout,
-                    int KH, int KW, int stride, int pad, void* stream);
+                    int KH, int KW, int stride, int pad, int64_t dy_elems, void* stream);
 int ssad_conv_wgrad_x3(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin, int Cout,
-                       int KH, int KW, int stride, int pad, void* stream);   /* split-bf16 products, see ssad_conv_igemm_fwd_x3 */
+                       int KH, int KW, int stride, int pad, int64_t dy_elems, void* stream);   /* split-bf16 products, see ssad_conv_igemm_fwd_x3 */
 int ssad_conv_wgrad_x6(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin, int Cout,
-                       int KH, int KW, int stride, int pad, void* stream);   /* three-way split, see ssad_conv_igemm_fwd_x6 */
+                       int KH, int KW, int stride, int pad, int64_t dy_elems, void* stream);   /* three-way split, see ssad_conv_igemm_fwd_x6 */
 int ssad_wgrad_reduce(const float* slab, float* dw, int splits, int Cout, int Kpad, int KH, int KW, int Cin, int to_oihw,
                       int accumulate, void* stream);
 /* bf16-operand forms of the three MFMA entry points above (fp32 tensors in HBM; operands rounded to bf16 while staging,
@@ -185,7 +189,7 @@ int ssad_conv_igemm_fwd_bf16(const float* in, const float* w_ohwi, float* out, c
 int ssad_conv_igemm_dgrad_bf16(const float* dy, const float* w_flipT, float* dx, const float* residual, int64_t N, int Hy,
                                int Wy, int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride, int pad, void* stream);
 int ssad_conv_wgrad_bf16(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin, int Cout,
-                         int KH, int KW, int stride, int pad, void* stream);
+                         int KH, int KW, int stride, int pad, int64_t dy_elems, void* stream);
 /* Halo-tile direct convolution for the 64 -> 64 channel 3x3 / stride 1 / pad 1 layers (torchvision BasicBlock conv3x3 of
  * ResNet-18 layer1, models.py:224 of the reference under trainer.fit, and their input gradients -- call it with
  * ssad_flip_transpose_weight(w) and dy): out = conv(T(in)) (+ residual), NHWC fp32, OHWI weights, exact fp32 MFMA.
@@ -220,10 +224,10 @@ int ssad_conv3x3_c64_eval(const float* in, const float* w_ohwi, float* out, cons
 int ssad_wgrad3x3_halo_ok(int Cin, int Cout, int KH, int KW, int stride, int pad);   /* 0 no, 1 stride-1 form, 2 stride-2 form */
 int ssad_wgrad3x3_halo_splits(int64_t N, int H, int W, int Cin, int Cout);            /* H, W: size of dz (the conv's OUTPUT) */
 int ssad_conv_wgrad3x3_halo(const float* dz, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin, int Cout,
-                            void* stream);
+                            int64_t dz_elems, void* stream);
 /* 3x3 / stride 2 / pad 1 (the first convolution of layer2-4): dz [N][Ho][Wo][Cout], x [N][H][W][Cin], Ho = (H - 1) / 2 + 1. */
 int ssad_conv_wgrad3x3s2_halo(const float* dz, const float* x, float* slab, int splits, int64_t N, int Ho, int Wo, int H, int W,
-                              int Cin, int Cout, void* stream);
+                              int Cin, int Cout, int64_t dz_elems, void* stream);
 /* Stem conv 7x7 / 2 of the precision-16 training step (csrc/stem16.hip): fp16 (f16 != 0) or bf16 operands, fp32 accumulation; the
  * 16-bit counterpart of ssad_stem_fwd_stats for whole images -- resnet.conv1 + bn1 statistics under fp16 autocast
  * (pl.Trainer(precision=16), src/self_supervised/tools.py:263; models.py:224).  wk16: 14 * 64 * 16 halves from ssad_pack_stem_weight16;
@@ -238,7 +242,7 @@ int ssad_stem_fwd_stats16(const float* img, int B, int H, int W, const void* wk1
 int ssad_wgrad3x3_halo16_ok(int Cin, int Cout, int KH, int KW, int stride, int pad);
 int ssad_wgrad3x3_halo16_splits(int64_t N, int H, int W, int Cin, int Cout);
 int ssad_conv_wgrad3x3_halo16(const float* dz, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin, int Cout,
-                              int f16, void* stream);
+                              int f16, int64_t dz_elems, void* stream);
 /* fp16-operand forms: the reference trains under fp16 autocast (pl.Trainer(precision=16), src/self_supervised/tools.py:263,
  * :296), i.e. its Conv2d / Linear products take fp16 operands and accumulate in fp32.  Same contract as the _bf16 forms
  * with v_mfma_f32_32x32x16_f16 (11-bit significands); the slab of ssad_conv_wgrad_f16 is sized by ssad_wgrad_splits_bf16. */
@@ -248,7 +252,7 @@ int ssad_conv_igemm_fwd_f16(const float* in, const float* w_ohwi, float* out, co
 int ssad_conv_igemm_dgrad_f16(const float* dy, const float* w_flipT, float* dx, const float* residual, int64_t N, int Hy,
                               int Wy, int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride, int pad, void* stream);
 int ssad_conv_wgrad_f16(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin, int Cout,
-                        int KH, int KW, int stride, int pad, void* stream);
+                        int KH, int KW, int stride, int pad, int64_t dy_elems, void* stream);
 /* Stem in training: im2col rows of 160 floats (147 taps + zero pad, nearest resize fused) so that conv1 forward and
  * its weight gradient run on the generic MFMA kernels.  Replaces conv1 of torchvision resnet18 under autograd. */
 int ssad_stem_im2col(const float* img, float* col, int64_t B, int H, int W, int Hv, int Wv, void* stream);
@@ -257,8 +261,8 @@ int ssad_stem_im2col(const float* img, float* col, int64_t B, int H, int W, int 
  * 64x64 go through the same nearest resize).  dw receives 64*7*7*3 floats, OHWI or (to_oihw) OIHW, optionally
  * accumulated.  workspace: ssad_stem_wgrad_workspace(B, H, W) floats (per-workgroup slabs, summed in a fixed order). */
 int64_t ssad_stem_wgrad_workspace(int B, int H, int W);
-int ssad_stem_wgrad(const float* img, const float* dz, float* dw, int B, int H, int W, int to_oihw, int accumulate,
-                    float* workspace, void* stream);
+int ssad_stem_wgrad(const float* img, const float* dz, float* dw, int B, int H, int W, int64_t dz_elems, int to_oihw,
+                    int accumulate, float* workspace, void* stream);
 int ssad_pack_stem_weight_2d(const float* w_oihw, float* out, void* stream);
 /* Replaces nn.BatchNorm2d / nn.BatchNorm1d in training mode (models.py:65-95 + torchvision BasicBlock):
  * batch statistics over R rows (biased variance for normalisation, unbiased for running_var, momentum),
@@ -307,7 +311,7 @@ int ssad_bn_apply_bwd_zmask(const float* dy, const float* z, const float* mean, 
                             const float* beta, const float* dbeta, const float* dgamma, float* dz, int64_t R, int C,
                             void* stream);
 /* Replaces the backward of nn.MaxPool2d(3,2,1) and of adaptive_avg_pool2d + cat (models.py:224-245). */
-int ssad_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int64_t N, int H, int W, int C, void* stream);
+int ssad_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int64_t N, int H, int W, int C, int64_t dy_elems, void* stream);
 /* Same pair with the argmax recorded by the forward pass (one byte per output element: window slot dy*3+dx of the
  * first maximum), so backward compares <= 4 indices per input element instead of rescanning 4 windows. */
 int ssad_maxpool3x3s2_fwd_idx(const float* in, float* out, uint8_t* idx, int64_t N, int H, int W, int C, void* stream);
@@ -321,8 +325,9 @@ int ssad_bn_relu_maxpool_fwd(const float* z, const float* mean, const float* inv
                              float* out, uint8_t* idx, int64_t N, int H, int W, int C, void* stream);
 int ssad_pool_bn_relu_bwd(const uint8_t* idx, const float* dpool, const float* z, const float* mean, const float* invstd,
                           const float* gamma, const float* beta, float* dbeta, float* dgamma, float* dz, int64_t N, int H,
-                          int W, int C, double* workspace, void* stream);
-int ssad_maxpool3x3s2_bwd_idx(const uint8_t* idx, const float* dy, float* dx, int64_t N, int H, int W, int C, void* stream);
+                          int W, int C, int64_t dpool_elems, double* workspace, void* stream);
+int ssad_maxpool3x3s2_bwd_idx(const uint8_t* idx, const float* dy, float* dx, int64_t N, int H, int W, int C, int64_t dy_elems,
+                              void* stream);
 int ssad_gap_bwd(const float* dpooled, float* dy, int64_t N, int HW, int C, int stride, int offset, int accumulate,
                  void* stream);
 /* Replaces F.cross_entropy + torchmetrics accuracy (models.py:261-262) and their backward: loss_acc[0] = mean NLL,
@@ -446,6 +451,58 @@ int ssad_resize_bicubic_u8(const uint8_t* in, uint8_t* tmp, uint8_t* out, int B,
 int64_t ssad_obj_mask_workspace(int B, int H, int W);
 int ssad_obj_mask(const uint8_t* rgb, uint8_t* mask, uint8_t* edges, int B, int H, int W, const double* gauss_w_host, int radius,
                   double low, double high, void* workspace, void* stream);
+
+/* ---- half-tensor forms of the precision-16 training step ----
+ * pl.Trainer(precision=16) (src/self_supervised/tools.py:263, :296) runs the reference's training_step (models.py:256-277) under
+ * torch.autocast(float16): every conv / linear / BatchNorm output of the trunk is an fp16 tensor in memory and so is its gradient.
+ * The `_h` entry points below are the SAME kernels as their fp32-tensor namesakes with the activation tensors (void*: N H W C
+ * halves) read and written as halves; arithmetic, BatchNorm statistics (those of the stored halves), parameters and parameter
+ * gradients stay fp32.  Same call sites, same argument meaning. */
+/* one rounded copy of the fp32 master arena per step (autocast's weight cast): src, dst 16-byte aligned */
+int ssad_cvt_f32_f16(const float* src, void* dst, int64_t n, void* stream);
+/* ssad_flip_transpose_batch writing halves (dgrad operands) */
+int ssad_flip_transpose_batch_h(const float* src, void* dst, const int64_t* desc, int n, void* stream);
+/* resnet.conv1 with fp16 operands, z stored as halves [B][Ho][Wo][64] (ssad_stem_fwd_stats16) */
+int ssad_stem_fwd_stats16_h(const float* img, int B, int H, int W, const void* wk16, void* out, float eps, float momentum,
+                            float* mean, float* invstd, float* running_mean, float* running_var, double* workspace, void* stream);
+int ssad_bn_relu_maxpool_fwd_h(const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta, void* out,
+                               uint8_t* idx, int64_t N, int H, int W, int C, void* stream);
+/* conv + train-mode BatchNorm statistics, dgrad: in / out / residual AND the weights (w_ohwi, w_flipT) are halves
+ * (ssad_conv_igemm_fwd_stats with bf16 = 2, ssad_conv_igemm_dgrad_f16) */
+int ssad_conv_igemm_fwd_stats_h(const void* in, const void* w_ohwi, void* out, int64_t N, int H, int W, int Cin, int Cout, int KH,
+                                int KW, int stride, int pad, float eps, float momentum, float* mean, float* invstd,
+                                float* running_mean, float* running_var, double* workspace, void* stream);
+int ssad_conv_igemm_dgrad_h(const void* dy, const void* w_flipT, void* dx, const void* residual, int64_t N, int Hy, int Wy, int Cout,
+                            int Hx, int Wx, int Cin, int KH, int KW, int stride, int pad, void* stream);
+/* ssad_conv3x3_c64_op with op = 2 and in / out / residual / emit as halves (the weights are the fp32 OHWI master copy) */
+int ssad_conv3x3_c64_h(const void* in, const float* w_ohwi, void* out, const void* residual, const float* tr_mean,
+                       const float* tr_invstd, const float* tr_gamma, const float* tr_beta, void* emit, int64_t N, int H, int W,
+                       double* stats_ws, float eps, float momentum, float* mean, float* invstd, float* running_mean,
+                       float* running_var, void* stream);
+int ssad_bn_stats_h(const void* z, int64_t R, int C, float eps, float momentum, float* mean, float* invstd, float* running_mean,
+                    float* running_var, double* workspace, void* stream);
+int ssad_bn_apply_fwd_h(const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                        const void* residual, void* y, int64_t R, int C, int relu, void* stream);
+int ssad_gap_fwd_h(const void* in, float* out, int64_t N, int HW, int C, int out_stride, int out_offset, void* stream);
+int ssad_gap_bwd_h(const float* dpooled, void* dy, int64_t N, int HW, int C, int stride, int offset, int accumulate, void* stream);
+int ssad_bn_bwd_reduce_h(const void* dy, const void* yact, const void* z, const float* mean, const float* invstd, float* dbeta,
+                         float* dgamma, int64_t R, int C, double* workspace, void* stream);
+int ssad_bn_bwd_reduce_zmask_h(const void* dy, const void* z, const float* mean, const float* invstd, const float* gamma,
+                               const float* beta, float* dbeta, float* dgamma, int64_t R, int C, double* workspace, void* stream);
+int ssad_bn_apply_bwd_h(const void* dy, const void* yact, const void* z, const float* mean, const float* invstd, const float* gamma,
+                        const float* dbeta, const float* dgamma, void* dz, void* dres, int64_t R, int C, int eval_mode, void* stream);
+int ssad_bn_apply_bwd_zmask_h(const void* dy, const void* z, const float* mean, const float* invstd, const float* gamma,
+                              const float* beta, const float* dbeta, const float* dgamma, void* dz, int64_t R, int C, void* stream);
+int ssad_pool_bn_relu_bwd_h(const uint8_t* idx, const void* dpool, const void* z, const float* mean, const float* invstd,
+                            const float* gamma, const float* beta, float* dbeta, float* dgamma, void* dz, int64_t N, int H, int W,
+                            int C, int64_t dpool_elems, double* workspace, void* stream);
+/* weight gradients from half tensors (fp32 slabs, then ssad_wgrad_reduce, as the fp32-tensor forms) */
+int ssad_conv_wgrad3x3_halo16_h(const void* dz, const void* x, float* slab, int splits, int64_t N, int H, int W, int Cin, int Cout,
+                                int64_t dz_elems, void* stream);
+int ssad_conv_wgrad_f16_h(const void* dy, const void* x, float* slab, int splits, int64_t N, int H, int W, int Cin, int Cout, int KH,
+                          int KW, int stride, int pad, int64_t dy_elems, void* stream);
+int ssad_stem_wgrad_h(const float* img, const void* dz, float* dw, int B, int H, int W, int64_t dz_elems, int to_oihw, int accumulate,
+                      float* workspace, void* stream);
 
 #ifdef __cplusplus
 }

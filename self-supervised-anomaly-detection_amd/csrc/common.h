@@ -54,6 +54,25 @@ int ssad_linear_small_launch(const float* a, const float* b, float* y, const flo
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Storage type of an activation tensor: float, or _Float16 for the precision-16 step whose tensors live in HBM as halves (what
+// torch.autocast stores under the reference's pl.Trainer(precision=16), tools.py:263).  Arithmetic is fp32 either way: four
+// consecutive elements are read as / written from an f32x4 (16-byte or 8-byte access).
+typedef _Float16 hf;
+template <typename T> __device__ __forceinline__ f32x4 ld4(const T* p);
+template <> __device__ __forceinline__ f32x4 ld4<float>(const float* p) { return *(const f32x4*)p; }
+template <> __device__ __forceinline__ f32x4 ld4<hf>(const hf* p) {
+    const f16x4 v = *(const f16x4*)p;
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, f32x4 v);
+template <> __device__ __forceinline__ void st4<float>(float* p, f32x4 v) { *(f32x4*)p = v; }
+template <> __device__ __forceinline__ void st4<hf>(hf* p, f32x4 v) {
+    *(f16x4*)p = f16x4{(hf)v[0], (hf)v[1], (hf)v[2], (hf)v[3]};
+}
+// the value a tensor of type T holds after storing v (statistics of a half tensor are those of the stored halves)
+template <typename T> __device__ __forceinline__ float stored(float v) { return v; }
+template <> __device__ __forceinline__ float stored<hf>(float v) { return (float)(hf)v; }
+
 // v_mfma_f32_32x32x2_f32: lane l feeds A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];
 // D[row = (reg&3) + 8*(reg>>2) + 4*(l>>5)][col = l&31].  Exact f32 fma chain in k order.
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {

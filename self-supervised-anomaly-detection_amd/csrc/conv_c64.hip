@@ -19,6 +19,7 @@
 // the reference, under trainer.fit) and its input gradient.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 // Ablation switches for tools/micro/c64_ablate.hip (where the time goes); always 0 in the library build.
 #ifndef C64_ABL
@@ -91,9 +92,13 @@ constexpr int ROWP16 = HW * LDP16 + 8;              // halves per halo row
 constexpr int HALO16_H = HH * ROWP16, WT16_H = C * LDP16;
 constexpr int LDS_BYTES16 = ((HALO16_H + WT16_H) * 2 > 128 * LDP * 4 ? (HALO16_H + WT16_H) * 2 : 128 * LDP * 4);   // >= the LDS epilogue tile
 
-template <bool EVAL, int OP = 0>
+// TI = hf (OP == 2 only): in, out, residual and emit are stored as halves -- the precision-16 step with its tensors as autocast keeps
+// them; 8-byte accesses, the output rounded once, statistics of the stored halves, always the LDS epilogue (8-byte row pieces).
+template <bool EVAL, int OP = 0, typename TI = float>
 __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
     static_assert(!(EVAL && OP), "the 16-bit forms are training-only");
+    static_assert(std::is_same<TI, float>::value || OP == 2, "half tensors go with fp16 operands");
+    constexpr bool HIO = !std::is_same<TI, float>::value;
     using op_t = typename C64Op<OP>::t;
     using op4 = typename C64Op<OP>::v4;
     using op8 = typename C64Op<OP>::v8;
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
     const int n = bid / (p.tiles_x * p.tiles_y);
     const int y0 = ty * TH, x0 = tx * TW;
     const int64_t in_ps = EVAL ? p.in_ps : (int64_t)C;
-    const float* img = p.in + (EVAL ? (int64_t)n * p.in_ss : (int64_t)n * p.H * p.W * C);
+    const TI* img = (const TI*)p.in + (EVAL ? (int64_t)n * p.in_ss : (int64_t)n * p.H * p.W * C);
 
     // ---- halo fill: thread -> channel quad c4, pixels q*16 + (tid >> 4) ----
     const int c4 = tid & 15, p0 = tid >> 4;
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
         const int y = y0 - 1 + hy, x = x0 - 1 + hx;
         hin[q] = hp < HH * HW && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (hin[q] && !(C64_ABL & 8)) v = *(const f32x4*)(img + ((int64_t)y * p.W + x) * in_ps + c4 * 4);
+        if (hin[q] && !(C64_ABL & 8)) v = ld4(img + ((int64_t)y * p.W + x) * in_ps + c4 * 4);
         hv[q] = v;
     }
     // first weight slice while the halo loads are in flight: thread -> rows (tid >> 4) + 16 i, chunk c4
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
                 const int hp = q * 16 + p0;
                 const int hy = hp / HW, hx = hp - hy * HW;
                 if (hy >= 1 && hy <= TH && hx >= 1 && hx <= TW)
-                    *(f32x4*)(p.emit + ((int64_t)n * p.H * p.W + (int64_t)(y0 - 1 + hy) * p.W + (x0 - 1 + hx)) * C + c4 * 4) = hv[q];
+                    st4((TI*)p.emit + ((int64_t)n * p.H * p.W + (int64_t)(y0 - 1 + hy) * p.W + (x0 - 1 + hx)) * C + c4 * 4, hv[q]);
             }
         }
     }
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
     // workgroup's matrix stream cannot hide (profiles/r03_igemm_phases.md).  Training instantiation only: 5.37 -> 5.17 ms per step
     // over its 8 launches; the inference form (16 x 16 maps of 15 979+ patches per launch) lost 2 % with 4-byte stores and keeps
     // the LDS epilogue's 16-byte ones. ----
-    if (C64_DIRECT_EPI && !EVAL && y0 + TH <= p.H && x0 + TW <= p.W) {
+    if (C64_DIRECT_EPI && !EVAL && !HIO && y0 + TH <= p.H && x0 + TW <= p.W) {
         const int64_t ops_ = EVAL ? p.out_ps : (int64_t)C, rps_ = EVAL ? p.res_ps : (int64_t)C;
         const int64_t obase = (EVAL ? (int64_t)n * p.out_ss : (int64_t)n * p.H * p.W * C) + ((int64_t)(y0 + 2 * wave) * p.W + x0 + 4 * h) * ops_ + r;
         const int64_t rbase = (EVAL ? (int64_t)n * p.res_ss : (int64_t)n * p.H * p.W * C) + ((int64_t)(y0 + 2 * wave) * p.W + x0 + 4 * h) * rps_ + r;
@@ -342,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
         const bool ok = y < p.H && x < p.W;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const float v = acc[j][e];
+            const float v = (p.stats && !p.residual) ? stored<TI>(acc[j][e]) : acc[j][e];      // statistics of what is stored
             if (!EVAL && p.stats && ok) { s0[j] += (double)v; s1[j] += (double)v * (double)v; }
             Ct[(wave * 32 + m) * LDP + j * 32 + r] = v;
         }
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
             else o[q] = ok ? (((int64_t)n * p.H + y) * p.W + x) * C + c4 * 4 : -1;
             f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
             if (EVAL) rs[q] = (ok && p.residual) ? *(const f32x4*)(p.residual + (int64_t)n * p.res_ss + ((int64_t)y * p.W + x) * p.res_ps + c4 * 4) : z4;
-            else rs[q] = (ok && p.residual) ? *(const f32x4*)(p.residual + o[q]) : z4;
+            else rs[q] = (ok && p.residual) ? ld4((const TI*)p.residual + o[q]) : z4;
             if (!EVAL && ok && p.res_mask) {
                 const unsigned mk = p.res_mask[o[q] >> 2];
 #pragma unroll
@@ -384,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
                     v[k] += rs[q][k];
                 }
             }
-            if (o[q] >= 0) *(f32x4*)(p.out + o[q]) = v;
+            if (o[q] >= 0) st4((TI*)p.out + o[q], v);
         }
     }
     }
@@ -432,12 +437,13 @@ extern "C" int64_t ssad_conv3x3_c64_stats_rows(int64_t N, int H, int W) {
 // stats_ws != NULL: train-mode BatchNorm statistics of the output (ssad_conv3x3_c64_stats_rows(N, H, W) * 2 * 64 doubles
 // of workspace), finalised exactly as ssad_conv_igemm_fwd_stats does.
 // op: 0 exact fp32, 1 bf16 operands, 2 fp16 operands (fp32 accumulation; csrc comment at the kernel)
-extern "C" int ssad_conv3x3_c64_op(const float* in, const float* w_ohwi, float* out, const float* residual, const uint8_t* res_mask,
-                                   const float* tr_mean, const float* tr_invstd, const float* tr_gamma, const float* tr_beta, float* emit,
-                                   int64_t N, int H, int W, double* stats_ws, float eps, float momentum, float* mean, float* invstd,
-                                   float* running_mean, float* running_var, int op, void* stream) {
+static int conv3x3_c64_impl(const float* in, const float* w_ohwi, float* out, const float* residual, const uint8_t* res_mask,
+                            const float* tr_mean, const float* tr_invstd, const float* tr_gamma, const float* tr_beta, float* emit,
+                            int64_t N, int H, int W, double* stats_ws, float eps, float momentum, float* mean, float* invstd,
+                            float* running_mean, float* running_var, int op, int half_io, void* stream) {
     SSAD_CHECK_ARG(in && w_ohwi && out && N > 0 && H > 0 && W > 0, "bad argument");
     SSAD_CHECK_ARG(op >= 0 && op <= 2, "op: 0 fp32, 1 bf16, 2 fp16");
+    SSAD_CHECK_ARG(!half_io || (op == 2 && !res_mask), "half tensors: fp16 operands, no residual mask");
     SSAD_CHECK_ARG(!tr_mean || (tr_invstd && tr_gamma && tr_beta), "input transform needs mean, invstd, gamma, beta");
     SSAD_CHECK_ARG(!emit || tr_mean, "emit without an input transform");
     SSAD_CHECK_ARG(!stats_ws || (mean && invstd), "statistics need mean / invstd outputs");
@@ -458,7 +464,8 @@ extern "C" int ssad_conv3x3_c64_op(const float* in, const float* w_ohwi, float* 
         SSAD_SET_DYN_LDS(conv3x3_c64_kernel<false>, lds_bytes);
         attr_set = true;
     }
-    if (op == 2) hipLaunchKernelGGL((conv3x3_c64_kernel<false, 2>), dim3((unsigned)nwg), dim3(256), LDS_BYTES16, (hipStream_t)stream, p);
+    if (half_io) hipLaunchKernelGGL((conv3x3_c64_kernel<false, 2, hf>), dim3((unsigned)nwg), dim3(256), LDS_BYTES16, (hipStream_t)stream, p);
+    else if (op == 2) hipLaunchKernelGGL((conv3x3_c64_kernel<false, 2>), dim3((unsigned)nwg), dim3(256), LDS_BYTES16, (hipStream_t)stream, p);
     else if (op == 1) hipLaunchKernelGGL((conv3x3_c64_kernel<false, 1>), dim3((unsigned)nwg), dim3(256), LDS_BYTES16, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(conv3x3_c64_kernel<false>, dim3((unsigned)nwg), dim3(256), lds_bytes, (hipStream_t)stream, p);
     SSAD_CHECK_LAUNCH();
@@ -466,6 +473,24 @@ extern "C" int ssad_conv3x3_c64_op(const float* in, const float* w_ohwi, float* 
         return ssad_bn_finalize_partials(stats_ws, (int)nwg, N * H * W, C, eps, momentum, mean, invstd, running_mean,
                                          running_var, stream);
     return 0;
+}
+
+extern "C" int ssad_conv3x3_c64_op(const float* in, const float* w_ohwi, float* out, const float* residual, const uint8_t* res_mask,
+                                   const float* tr_mean, const float* tr_invstd, const float* tr_gamma, const float* tr_beta, float* emit,
+                                   int64_t N, int H, int W, double* stats_ws, float eps, float momentum, float* mean, float* invstd,
+                                   float* running_mean, float* running_var, int op, void* stream) {
+    return conv3x3_c64_impl(in, w_ohwi, out, residual, res_mask, tr_mean, tr_invstd, tr_gamma, tr_beta, emit, N, H, W, stats_ws, eps,
+                            momentum, mean, invstd, running_mean, running_var, op, 0, stream);
+}
+
+// in / out / residual / emit stored as halves, fp16 operands (the weights stay the fp32 OHWI master copy, rounded while staged):
+// layer1 of the precision-16 step with half tensors
+extern "C" int ssad_conv3x3_c64_h(const void* in, const float* w_ohwi, void* out, const void* residual,
+                                  const float* tr_mean, const float* tr_invstd, const float* tr_gamma, const float* tr_beta, void* emit,
+                                  int64_t N, int H, int W, double* stats_ws, float eps, float momentum, float* mean, float* invstd,
+                                  float* running_mean, float* running_var, void* stream) {
+    return conv3x3_c64_impl((const float*)in, w_ohwi, (float*)out, (const float*)residual, nullptr, tr_mean, tr_invstd, tr_gamma, tr_beta,
+                            (float*)emit, N, H, W, stats_ws, eps, momentum, mean, invstd, running_mean, running_var, 2, 1, stream);
 }
 
 extern "C" int ssad_conv3x3_c64(const float* in, const float* w_ohwi, float* out, const float* residual, const uint8_t* res_mask, const float* tr_mean,

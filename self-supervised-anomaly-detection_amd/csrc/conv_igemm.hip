@@ -98,14 +98,20 @@ struct ConvParams {
 //        6 = three-way split hi + mid + lo (24 significant bits, rows [BK hi | BK mid | BK lo]) and the six products
 //        of weight >= 2^-18 (hh, hm, mh, hl, lh, mm): what is dropped is ~2^-25 of the product, i.e. fp32-faithful
 //        products at 6/16 of the fp32-MFMA time ("bf16x6").
-template <int BM, int BN, int TM, int TN, int BK, int TS, bool POS, bool DB = true, int BF = 0>
+// IO   : true = the activation tensors (in, out, residual) AND the weights are stored as halves (fp16 operands only, BF == 2): the
+//        precision-16 training step with its tensors as torch.autocast keeps them.  A 16-byte piece is then 8 consecutive k, staged
+//        without conversion; outputs are rounded once, in the epilogue; BatchNorm statistics are those of the stored halves.
+template <int BM, int BN, int TM, int TN, int BK, int TS, bool POS, bool DB = true, int BF = 0, bool IO = false>
 __global__ __launch_bounds__((BM / (32 * TM)) * (BN / (32 * TN)) * 64, TM * TN >= 8 ? 1 : 2)
 void conv_igemm_f32_kernel(ConvParams p) {
+    static_assert(!IO || BF == 2, "half tensors go with fp16 operands");
+    using io_t = std::conditional_t<IO, hf, float>;
+    constexpr int PE = IO ? 8 : 4;  // elements per 16-byte piece
     constexpr int NT = (BM / (32 * TM)) * (BN / (32 * TN)) * 64;   // threads: one wave per (32 TM) x (32 TN) sub-tile
     // LDS row stride in elements (f32: 144 / 80 bytes; bf16: 80 / 48 bytes; bf16x3: hi and lo halves, the f32 bytes)
     constexpr int LDK = BF == 6 ? 3 * BK + 8 : (BF == 3 ? 2 * BK + 8 : (BF ? BK + 8 : BK + 4));
     constexpr int ESZ = BF ? 2 : 4;
-    constexpr int CPR = BK / 4;     // 16-byte chunks per staged row
+    constexpr int CPR = BK / PE;    // 16-byte chunks per staged row
     constexpr int RPP = NT / CPR;   // rows staged per pass
     constexpr int WN = BN / (32 * TN);
     constexpr int AR = BM / RPP;    // 16-byte chunks of A staged per thread per K-step
@@ -130,7 +136,9 @@ void conv_igemm_f32_kernel(ConvParams p) {
     const int ntaps = p.KH * p.KW;
     const int64_t in_sp = p.hwnc ? p.N * p.Cin : (int64_t)p.Cin;                       // floats between pixels
     const int64_t in_sn = p.hwnc ? (int64_t)p.Cin : (int64_t)p.H * p.W * p.Cin;        // floats between samples
-    const float* zero = g_zero_page;
+    const io_t* zero = (const io_t*)g_zero_page;
+    const io_t* const tin = (const io_t*)p.in;
+    const io_t* const twt = (const io_t*)p.wt;
 
     // ---- row geometry ----
     int64_t m0;                 // first flattened row (normal) / first sample (POS)
@@ -231,7 +239,7 @@ void conv_igemm_f32_kernel(ConvParams p) {
     };
 
     // ---- per-thread staging rows (fixed across the K loop): base pointer at tap (0,0) + in-bounds tap mask ----
-    const float* a_ptr[AR];
+    const io_t* a_ptr[AR];
     unsigned a_mask[AR];
     int a_iy[AR], a_ix[AR];                 // only live in the TS == 2 instantiation
 #pragma unroll
@@ -269,13 +277,13 @@ void conv_igemm_f32_kernel(ConvParams p) {
             mk &= tapmask;
         }
         a_mask[i] = (IGEMM_ABL & 2) ? 0u : mk;      // ablation 2: every activation piece comes from the zero page (no HBM latency)
-        a_ptr[i] = TS > 1 ? p.in + n * in_sn + sc * 4 : p.in + n * in_sn + ((int64_t)iy0 * p.W + ix0) * in_sp + sc * 4;
+        a_ptr[i] = TS > 1 ? tin + n * in_sn + sc * PE : tin + n * in_sn + ((int64_t)iy0 * p.W + ix0) * in_sp + sc * PE;
     }
-    const float* b_ptr[BR];
+    const io_t* b_ptr[BR];
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
         const int co = n0 + sr + RPP * i;
-        b_ptr[i] = co < p.Cout ? p.wt + (int64_t)co * p.K + sc * 4 : nullptr;
+        b_ptr[i] = co < p.Cout ? twt + (int64_t)co * p.K + sc * PE : nullptr;
     }
 
     f32x16 acc[TM][TN];
@@ -313,7 +321,7 @@ void conv_igemm_f32_kernel(ConvParams p) {
     auto load_piece = [&](int q, int set = 0) {         // one 16-byte piece: q < AR activation rows, then the BR weight rows
 #if IGEMM_ABL & 64      // timing experiment only (results are garbage): global -> LDS directly, no VGPR staging, no ds_write
         {
-            const float* src;
+            const io_t* src;
             if (q < AR) {
                 const bool ok = (a_mask[q] >> ld_ptap) & 1u;
                 src = ok ? a_ptr[q] + ld_koff : zero;
@@ -328,11 +336,11 @@ void conv_igemm_f32_kernel(ConvParams p) {
 #endif
         if (q < AR) {
             const bool ok = (a_mask[q] >> ld_ptap) & 1u;
-            const float* src = a_ptr[q] + ld_koff;
+            const io_t* src = a_ptr[q] + ld_koff;
             if (TS > 1) src += ((int64_t)((a_iy[q] + ld_pky) / TS) * p.W + (a_ix[q] + ld_pkx) / TS) * in_sp;
-            ra2[set][q] = *(const f32x4*)(ok ? src : zero);
+            ra2[set][q] = *(const f32x4*)(const void*)(ok ? src : zero);
         } else {
-            rb2[set][q - AR] = *(const f32x4*)(b_ptr[q - AR] ? b_ptr[q - AR] + ld_woff : zero);
+            rb2[set][q - AR] = *(const f32x4*)(const void*)(b_ptr[q - AR] ? b_ptr[q - AR] + ld_woff : zero);
         }
     };
     auto load_step = [&]() {
@@ -377,6 +385,15 @@ void conv_igemm_f32_kernel(ConvParams p) {
             for (int i = 0; i < AR; ++i) split(ra[i], As + (sr + RPP * i) * LDK);
 #pragma unroll
             for (int i = 0; i < BR; ++i) split(rb[i], Bs + (sr + RPP * i) * LDK);
+            return;
+        }
+        if (BF == 2 && IO) {                 // the pieces are halves already: eight k per 16-byte store
+            _Float16* As = (_Float16*)buf;
+            _Float16* Bs = As + BM * LDK;
+#pragma unroll
+            for (int i = 0; i < AR; ++i) *(f32x4*)(void*)(As + (sr + RPP * i) * LDK + sc * 8) = ra[i];
+#pragma unroll
+            for (int i = 0; i < BR; ++i) *(f32x4*)(void*)(Bs + (sr + RPP * i) * LDK + sc * 8) = rb[i];
             return;
         }
         if (BF == 2) {
@@ -674,7 +691,7 @@ void conv_igemm_f32_kernel(ConvParams p) {
     }
     // whole tiles only (every row and column of the tile exists: all but the last row / column tile of a launch), so that the
     // path is straight-line code without a single per-lane predicate; ragged tiles take the LDS epilogue below
-    if (IGEMM_EPI && TS == 1 && limit >= BM && n0 + BN <= p.Cout) {
+    if (IGEMM_EPI && !IO && TS == 1 && limit >= BM && n0 + BN <= p.Cout) {
         const int64_t pitch = RS * p.Cout;          // floats between consecutive tile rows (workgroup-uniform)
         const int lrow0 = wm * 32 * TM + 4 * h;     // this lane's tile row for e = 0, i = 0
         const int colb = n0 + wn * 32 * TN + r;     // ... and its column for j = 0
@@ -761,7 +778,7 @@ void conv_igemm_f32_kernel(ConvParams p) {
     // between a prologue and an epilogue (one to four filter taps): the LDS-transpose epilogue (~10 k cycles alone, 33-40 k beside a
     // streaming partner) was a tenth to a third of such a workgroup. ----
     if constexpr (TS > 1) {
-        if (IGEMM_EPI && !p.stats && Mc - m0 >= BM && n0 + BN <= p.Cout && !p.scale && !p.shift && !p.relu) {
+        if (IGEMM_EPI && !IO && !p.stats && Mc - m0 >= BM && n0 + BN <= p.Cout && !p.scale && !p.shift && !p.relu) {
             int64_t* rowoff = (int64_t*)lds;                    // the stages are dead: the K loop ended on a barrier
             for (int lr = tid; lr < BM; lr += NT) {
                 int64_t n;
@@ -836,7 +853,7 @@ void conv_igemm_f32_kernel(ConvParams p) {
         __syncthreads();
         if (p.stats) {
             for (int rw = 0; rw < RS; ++rw) {
-                const double v = (double)C[(ssl * RS + rw) * LDC + scol];
+                const double v = (double)stored<io_t>(C[(ssl * RS + rw) * LDC + scol]);
                 st0 += v;
                 st1 += v * v;
             }
@@ -860,7 +877,8 @@ void conv_igemm_f32_kernel(ConvParams p) {
                 ok = ok && row < p.M;
             }
             o[q] = ok ? row * p.Cout + col : -1;
-            res[q] = *(const f32x4*)((aligned && ok && p.residual) ? p.residual + o[q] : zero);
+            if (IO) res[q] = (aligned && ok && p.residual) ? ld4((const hf*)p.residual + o[q]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            else res[q] = *(const f32x4*)((aligned && ok && p.residual) ? p.residual + o[q] : g_zero_page);
             if (aligned && ok && p.res_mask) {
                 const unsigned mk = p.res_mask[o[q] >> 2];
 #pragma unroll
@@ -876,7 +894,10 @@ void conv_igemm_f32_kernel(ConvParams p) {
                     float x = v[k] * s4[k] + t4[k] + res[q][k];
                     v[k] = p.relu ? fmaxf(x, 0.f) : x;
                 }
-                if (o[q] >= 0) *(f32x4*)(p.out + o[q]) = v;
+                if (o[q] >= 0) {
+                    if (IO) st4((hf*)p.out + o[q], v);
+                    else *(f32x4*)(p.out + o[q]) = v;
+                }
             } else if (o[q] >= 0) {
                 for (int k = 0; k < 4 && col + k < p.Cout; ++k) {
                     float x = v[k] * (p.scale ? p.scale[col + k] : 1.f) + (p.shift ? p.shift[col + k] : 0.f);
@@ -939,7 +960,7 @@ static void sort_positions(ConvParams& p, int sample_groups) {
     }
 }
 
-template <int BM, int BN, int TM, int TN, int BK, int TS, bool POS, bool DB = true, int BF = 0>
+template <int BM, int BN, int TM, int TN, int BK, int TS, bool POS, bool DB = true, int BF = 0, bool IO = false>
 int launch(const ConvParams& p, hipStream_t st) {
     constexpr int stage_bytes = (DB ? 2 : 1) * (BM + BN) *
                                 (BF == 6 ? (3 * BK + 8) * 2 : (BF == 3 ? (2 * BK + 8) * 2 : (BF ? (BK + 8) * 2 : (BK + 4) * 4)));
@@ -951,7 +972,7 @@ int launch(const ConvParams& p, hipStream_t st) {
     const int lds_bytes = lds_min + lds_pad;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_f32_kernel<BM, BN, TM, TN, BK, TS, POS, DB, BF>,
+        (void)hipFuncSetAttribute((const void*)conv_igemm_f32_kernel<BM, BN, TM, TN, BK, TS, POS, DB, BF, IO>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         attr_set = true;
     }
@@ -983,16 +1004,16 @@ int launch(const ConvParams& p, hipStream_t st) {
         q.cls_start[4] = (int)gx;
     }
     dim3 grid((unsigned)gx, (unsigned)((p.Cout + BN - 1) / BN));
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, TM, TN, BK, TS, POS, DB, BF>), grid,
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, TM, TN, BK, TS, POS, DB, BF, IO>), grid,
                        dim3((BM / (32 * TM)) * (BN / (32 * TN)) * 64), lds_bytes, st, q);
     return (int)gx;
 }
 
 // every dispatch returns the number of row workgroups launched (= rows of the statistics partials)
-template <int TS, int BF = 1>
+template <int TS, int BF = 1, bool IO = false>
 int dispatch_bf16(const ConvParams& p, hipStream_t st) {
-    if (p.Cout <= 64) return launch<256, 64, 2, 2, 32, TS, false, true, BF>(p, st);
-    return launch<128, 128, 2, 2, 32, TS, false, true, BF>(p, st);
+    if (p.Cout <= 64) return launch<256, 64, 2, 2, 32, TS, false, true, BF, IO>(p, st);
+    return launch<128, 128, 2, 2, 32, TS, false, true, BF, IO>(p, st);
 }
 
 // three-way split ("bf16x6"): rows are 1.5x the fp32 bytes.  Measured: one LDS stage with BK = 32 (53 KB, three
@@ -1078,8 +1099,9 @@ int dispatch(const ConvParams& p, hipStream_t st) {
 
 int conv_fwd_impl(const float* in, const float* w_ohwi, float* out, const float* scale, const float* shift,
                   const float* residual, int relu, int64_t N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
-                  int pad, int hwnc, void* stream, int bf16 = 0, double* stats = nullptr, int* stat_rows = nullptr) {
+                  int pad, int hwnc, void* stream, int bf16 = 0, double* stats = nullptr, int* stat_rows = nullptr, int io16 = 0) {
     SSAD_CHECK_ARG(in && w_ohwi && out, "null pointer");
+    SSAD_CHECK_ARG(!io16 || (bf16 == 2 && !hwnc && Cout % 4 == 0), "half tensors: fp16 operands, NHWC, Cout % 4 == 0");
     SSAD_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "empty shape");
     if (!bf16 && !hwnc && KH == 1 && KW == 1 && H == 1 && W == 1 && stride == 1 && pad == 0 &&
         ssad_linear_small_ok(in, w_ohwi, N, Cin))          // a linear layer over a training batch's few rows
@@ -1112,7 +1134,7 @@ int conv_fwd_impl(const float* in, const float* w_ohwi, float* out, const float*
         rows = posmajor ? dispatch_x3<1, true>(p, st) : dispatch_x3<1, false>(p, st);
     } else if (bf16) {
         SSAD_CHECK_ARG(!hwnc, "16-bit operands: NHWC only");
-        rows = bf16 == 2 ? dispatch_bf16<1, 2>(p, st) : dispatch_bf16<1, 1>(p, st);
+        rows = io16 ? dispatch_bf16<1, 2, true>(p, st) : bf16 == 2 ? dispatch_bf16<1, 2>(p, st) : dispatch_bf16<1, 1>(p, st);
     } else if (posmajor) rows = dispatch<1, true>(p, st);
     else rows = dispatch<1, false>(p, st);
     if (stat_rows) *stat_rows = rows;
@@ -1213,8 +1235,9 @@ extern "C" int ssad_conv_igemm_tile(int64_t N, int H, int W, int Cin, int Cout, 
 // same gather-GEMM with k = (ky', kx', co), numerator row = iy - (KH-1-pad) + ky'.
 static int dgrad_impl(const float* dy, const float* w_flipT, float* dx, const float* residual, int64_t N,
                                      int Hy, int Wy, int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride,
-                                     int pad, void* stream, int bf16, const uint8_t* res_mask = nullptr) {
+                                     int pad, void* stream, int bf16, const uint8_t* res_mask = nullptr, int io16 = 0) {
     SSAD_CHECK_ARG(dy && w_flipT && dx, "null pointer");
+    SSAD_CHECK_ARG(!io16 || (bf16 == 2 && !res_mask && Cin % 4 == 0), "half tensors: fp16 operands, no residual mask, Cin % 4 == 0");
     SSAD_CHECK_ARG(N > 0 && Hy > 0 && Wy > 0 && Hx > 0 && Wx > 0 && Cin > 0 && Cout > 0, "empty shape");
     if (!bf16 && !res_mask && KH == 1 && KW == 1 && Hy == 1 && Wy == 1 && Hx == 1 && Wx == 1 && stride == 1 && pad == 0 &&
         ssad_linear_small_ok(dy, w_flipT, N, Cout))        // dx[M][Cin] = dy[M][Cout] . w_flipT[Cin][Cout]^T
@@ -1241,6 +1264,9 @@ static int dgrad_impl(const float* dy, const float* w_flipT, float* dx, const fl
     } else if (bf16 == 3) {
         if (stride == 1) dispatch_x3<1, false>(p, st);
         else dispatch_x3<2, false>(p, st);
+    } else if (bf16 == 2 && io16) {
+        if (stride == 1) dispatch_bf16<1, 2, true>(p, st);
+        else dispatch_bf16<2, 2, true>(p, st);
     } else if (bf16 == 2) {
         if (stride == 1) dispatch_bf16<1, 2>(p, st);
         else dispatch_bf16<2, 2>(p, st);
@@ -1290,4 +1316,28 @@ extern "C" int ssad_conv_igemm_dgrad_x3(const float* dy, const float* w_flipT, f
                                         int Hy, int Wy, int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride,
                                         int pad, void* stream) {
     return dgrad_impl(dy, w_flipT, dx, residual, N, Hy, Wy, Cout, Hx, Wx, Cin, KH, KW, stride, pad, stream, 3);
+}
+
+// ---- half-tensor forms (precision-16 training step with its activations AND a per-step copy of the weights stored as halves, as
+// torch.autocast keeps them under pl.Trainer(precision=16), tools.py:263): fp16 operands straight from memory, fp32 accumulation,
+// the output rounded once.  Same call sites as ssad_conv_igemm_fwd_stats / ssad_conv_igemm_dgrad. ----
+extern "C" int ssad_conv_igemm_fwd_stats_h(const void* in, const void* w_ohwi, void* out, int64_t N, int H, int W, int Cin,
+                                           int Cout, int KH, int KW, int stride, int pad, float eps, float momentum,
+                                           float* mean, float* invstd, float* running_mean, float* running_var,
+                                           double* workspace, void* stream) {
+    SSAD_CHECK_ARG(mean && invstd && workspace, "null pointer");
+    int rows = 0;
+    int rc = conv_fwd_impl((const float*)in, (const float*)w_ohwi, (float*)out, nullptr, nullptr, nullptr, 0, N, H, W, Cin, Cout, KH, KW,
+                           stride, pad, 0, stream, 2, workspace, &rows, 1);
+    if (rc) return rc;
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    return ssad_bn_finalize_partials(workspace, rows, N * Ho * Wo, Cout, eps, momentum, mean, invstd, running_mean,
+                                     running_var, stream);
+}
+
+extern "C" int ssad_conv_igemm_dgrad_h(const void* dy, const void* w_flipT, void* dx, const void* residual, int64_t N,
+                                       int Hy, int Wy, int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride,
+                                       int pad, void* stream) {
+    return dgrad_impl((const float*)dy, (const float*)w_flipT, (float*)dx, (const float*)residual, N, Hy, Wy, Cout, Hx, Wx, Cin, KH, KW,
+                      stride, pad, stream, 2, nullptr, 1);
 }

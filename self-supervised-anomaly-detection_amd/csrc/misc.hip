@@ -60,16 +60,17 @@ __global__ void gap_kernel(const float* __restrict__ in, float* __restrict__ out
 
 // Few samples, large maps (training batches): one workgroup per (sample, 64-channel slab); 16 pixel lanes x 16 float4
 // channel lanes, lane sums added in a fixed order through LDS.
-__global__ __launch_bounds__(256) void gap_wide_kernel(const float* __restrict__ in, float* __restrict__ out, int HW, int C,
+template <typename T>
+__global__ __launch_bounds__(256) void gap_wide_kernel(const T* __restrict__ in, float* __restrict__ out, int HW, int C,
                                                        int out_stride, int out_offset) {
     __shared__ f32x4 part[16][16];
     const int cq = threadIdx.x & 15, pg = threadIdx.x >> 4;
     const int64_t n = blockIdx.x;
     const int c0 = blockIdx.y * 64 + cq * 4;
-    const float* p = in + n * HW * C + c0;
+    const T* p = in + n * HW * C + c0;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     for (int k = pg; k < HW; k += 16) {
-        const f32x4 v = *(const f32x4*)(p + (int64_t)k * C);
+        const f32x4 v = ld4(p + (int64_t)k * C);
         s += v;
     }
     part[pg][cq] = s;
@@ -296,11 +297,21 @@ extern "C" int ssad_gap_fwd(const float* in, float* out, int64_t N, int HW, int 
     SSAD_CHECK_ARG(in && out && N > 0 && HW > 0 && C > 0, "bad argument");
     SSAD_CHECK_ARG(out_offset >= 0 && out_offset + C <= out_stride, "slice does not fit the output row");
     if (!hwnc && C % 64 == 0 && HW >= 64 && N * C < 256 * 1024)
-        hipLaunchKernelGGL(gap_wide_kernel, dim3((unsigned)N, C / 64), dim3(256), 0, (hipStream_t)stream, in, out, HW, C,
+        hipLaunchKernelGGL(gap_wide_kernel<float>, dim3((unsigned)N, C / 64), dim3(256), 0, (hipStream_t)stream, in, out, HW, C,
                            out_stride, out_offset);
     else
         hipLaunchKernelGGL(gap_kernel, dim3((unsigned)cdiv64(N * C, 256)), dim3(256), 0, (hipStream_t)stream, in, out, N, HW, C,
                            out_stride, out_offset, hwnc);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+// in stored as halves [N][HW][C] (C % 64 == 0: the precision-16 training trunk), out fp32 as above
+extern "C" int ssad_gap_fwd_h(const void* in, float* out, int64_t N, int HW, int C, int out_stride, int out_offset, void* stream) {
+    SSAD_CHECK_ARG(in && out && N > 0 && HW > 0 && C > 0 && C % 64 == 0, "bad argument (C % 64)");
+    SSAD_CHECK_ARG(out_offset >= 0 && out_offset + C <= out_stride, "slice does not fit the output row");
+    hipLaunchKernelGGL(gap_wide_kernel<hf>, dim3((unsigned)N, C / 64), dim3(256), 0, (hipStream_t)stream, (const hf*)in, out, HW, C,
+                       out_stride, out_offset);
     SSAD_CHECK_LAUNCH();
     return 0;
 }

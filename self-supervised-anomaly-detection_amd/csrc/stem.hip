@@ -337,7 +337,8 @@ __global__ void pack_stem_weight_kernel(const float* __restrict__ w, float* __re
 // between conv1/bn1/relu and the pool never exists in HBM.
 struct PoolBN { const float* mean; const float* invstd; const float* gamma; const float* beta; };
 
-__global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restrict__ out, uint8_t* __restrict__ idx,
+template <typename T>
+__global__ void maxpool3x3s2_kernel(const T* __restrict__ in, T* __restrict__ out, uint8_t* __restrict__ idx,
                                     int64_t total4, int H, int W, int C4, int Ho, int Wo, int64_t N, int hwnc, PoolBN bn) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total4) return;
@@ -372,17 +373,19 @@ __global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restr
             int x = ox * 2 - 1 + dx;
             if ((unsigned)x >= (unsigned)W) continue;
             const int64_t ip = hwnc ? ((int64_t)y * W + x) * N + n : (n * H + y) * W + x;
-            f32x4 v = ((const f32x4*)in)[ip * C4 + c4];
+            f32x4 v = ld4(in + 4 * (ip * C4 + c4));
             if (bn.mean) {
+                // (half tensors: the BatchNorm output is itself a stored half under autocast, so candidates are compared -- and tie --
+                // as halves)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = fmaxf((v[k] - mu[k]) * is[k] * ga[k] + be[k], 0.f);
+                for (int k = 0; k < 4; ++k) v[k] = stored<T>(fmaxf((v[k] - mu[k]) * is[k] * ga[k] + be[k], 0.f));
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (v[k] > m[k]) { m[k] = v[k]; am[k] = dy * 3 + dx; }
         }
     }
-    ((f32x4*)out)[i] = m;
+    st4(out + 4 * i, m);
     if (idx) ((uint32_t*)idx)[i] = (uint32_t)am[0] | ((uint32_t)am[1] << 8) | ((uint32_t)am[2] << 16) | ((uint32_t)am[3] << 24);
 }
 
@@ -484,14 +487,15 @@ extern "C" int ssad_stem_patch_pool_fwd(const float* img, int B, int H, int W, i
     return 0;
 }
 
-static int maxpool_fwd_impl(const float* in, float* out, uint8_t* idx, int64_t N, int H, int W, int C, int hwnc, void* stream,
+template <typename T>
+static int maxpool_fwd_impl(const T* in, T* out, uint8_t* idx, int64_t N, int H, int W, int C, int hwnc, void* stream,
                             PoolBN bn = PoolBN{nullptr, nullptr, nullptr, nullptr}) {
     SSAD_CHECK_ARG(in && out, "null pointer");
     SSAD_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "bad shape (C % 4)");
     int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     int64_t total4 = N * Ho * Wo * (C / 4);
     SSAD_CHECK_ARG(cdiv64(total4, 256) < (int64_t)2147483647, "too large");
-    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((unsigned)cdiv64(total4, 256)), dim3(256), 0, (hipStream_t)stream, in, out, idx,
+    hipLaunchKernelGGL(maxpool3x3s2_kernel<T>, dim3((unsigned)cdiv64(total4, 256)), dim3(256), 0, (hipStream_t)stream, in, out, idx,
                        total4, H, W, C / 4, Ho, Wo, N, hwnc, bn);
     SSAD_CHECK_LAUNCH();
     return 0;
@@ -503,16 +507,24 @@ extern "C" int ssad_bn_relu_maxpool_fwd(const float* z, const float* mean, const
                                         const float* beta, float* out, uint8_t* idx, int64_t N, int H, int W, int C,
                                         void* stream) {
     SSAD_CHECK_ARG(mean && invstd && gamma && beta && idx, "null pointer");
-    return maxpool_fwd_impl(z, out, idx, N, H, W, C, 0, stream, PoolBN{mean, invstd, gamma, beta});
+    return maxpool_fwd_impl<float>(z, out, idx, N, H, W, C, 0, stream, PoolBN{mean, invstd, gamma, beta});
+}
+
+// the same over tensors stored as halves (precision-16 step: z, the pooled map)
+extern "C" int ssad_bn_relu_maxpool_fwd_h(const void* z, const float* mean, const float* invstd, const float* gamma,
+                                          const float* beta, void* out, uint8_t* idx, int64_t N, int H, int W, int C,
+                                          void* stream) {
+    SSAD_CHECK_ARG(mean && invstd && gamma && beta && idx, "null pointer");
+    return maxpool_fwd_impl<hf>((const hf*)z, (hf*)out, idx, N, H, W, C, 0, stream, PoolBN{mean, invstd, gamma, beta});
 }
 
 extern "C" int ssad_maxpool3x3s2_fwd(const float* in, float* out, int64_t N, int H, int W, int C, int hwnc, void* stream) {
-    return maxpool_fwd_impl(in, out, nullptr, N, H, W, C, hwnc, stream);
+    return maxpool_fwd_impl<float>(in, out, nullptr, N, H, W, C, hwnc, stream);
 }
 
 // Training forward: also records, per output element, which of the 9 window slots held the first maximum
 // (one byte each, [N][Ho][Wo][C]); ssad_maxpool3x3s2_bwd_idx routes gradients with it.
 extern "C" int ssad_maxpool3x3s2_fwd_idx(const float* in, float* out, uint8_t* idx, int64_t N, int H, int W, int C, void* stream) {
     SSAD_CHECK_ARG(idx, "null index buffer");
-    return maxpool_fwd_impl(in, out, idx, N, H, W, C, 0, stream);
+    return maxpool_fwd_impl<float>(in, out, idx, N, H, W, C, 0, stream);
 }

@@ -23,7 +23,7 @@ constexpr int W_H = 14 * 64 * 16;            // halves
 struct Stem16Params {
     const float* img;     // [B][3][H][W]
     const void* wk16;     // [7][2][64][16] halves
-    float* out;           // [B][Ho][Wo][64]
+    void* out;            // [B][Ho][Wo][64] floats, or halves (TO = hf: the precision-16 step keeps its activations as halves)
     double* stats;        // [gridDim.x][2][64]
     int B, H, W, Ho, Wo, tiles_y, tiles_x;
     int64_t total_tiles;
@@ -39,8 +39,9 @@ template <> struct Op16<true> {
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
 
-template <bool F16>
+template <bool F16, typename TO = float>
 __global__ __launch_bounds__(256, 2) void stem_conv7x7_16_kernel(Stem16Params p) {
+    TO* const outp = (TO*)p.out;
     using op_t = typename Op16<F16>::t;
     using op4 = typename Op16<F16>::v4;
     using op8 = typename Op16<F16>::v8;
@@ -131,9 +132,10 @@ __global__ __launch_bounds__(256, 2) void stem_conv7x7_16_kernel(Stem16Params p)
                 for (int e = 0; e < 16; ++e) {
                     const int ox = tx0 + (e & 3) + 8 * (e >> 2) + 4 * h;
                     if (ox < p.Wo) {
-                        fs += acc[i][j][e]; fq += acc[i][j][e] * acc[i][j][e];
+                        const float v = stored<TO>(acc[i][j][e]);          // statistics of what is stored
+                        fs += v; fq += v * v;
                         const int64_t pix = (n * p.Ho + oy) * p.Wo + ox;
-                        p.out[pix * 64 + j * 32 + r] = acc[i][j][e];
+                        outp[pix * 64 + j * 32 + r] = (TO)v;
                     }
                 }
                 st0[j] += (double)fs; st1[j] += (double)fq;
@@ -184,9 +186,9 @@ extern "C" int ssad_pack_stem_weight16(const float* w_oihw, void* wk16, int f16,
 
 // The 16-bit-operand form of ssad_stem_fwd_stats (whole images, no patch windows): z [B][Ho][Wo][64] fp32, mean / invstd / running
 // statistics of bn1; workspace: ssad_stem_stats_rows() * 128 doubles.
-extern "C" int ssad_stem_fwd_stats16(const float* img, int B, int H, int W, const void* wk16, float* out, float eps, float momentum,
-                                     float* mean, float* invstd, float* running_mean, float* running_var, double* workspace, int f16,
-                                     void* stream) {
+static int stem_fwd_stats16_impl(const float* img, int B, int H, int W, const void* wk16, void* out, int out_half, float eps, float momentum,
+                                 float* mean, float* invstd, float* running_mean, float* running_var, double* workspace, int f16,
+                                 void* stream) {
     SSAD_CHECK_ARG(img && wk16 && out && mean && invstd && workspace, "null pointer");
     SSAD_CHECK_ARG(B > 0 && H >= 64 && W >= 64, "whole images of at least 64 x 64 (smaller ones are resized first: ssad_stem_fwd_stats)");
     Stem16Params p;
@@ -196,9 +198,25 @@ extern "C" int ssad_stem_fwd_stats16(const float* img, int B, int H, int W, cons
     p.total_tiles = (int64_t)B * p.tiles_y * p.tiles_x;
     constexpr int lds_bytes = (W_H + IN_H) * 2;
     const int64_t grid = p.total_tiles < S16_MAX_GRID ? p.total_tiles : S16_MAX_GRID;
-    if (f16) hipLaunchKernelGGL(stem_conv7x7_16_kernel<true>, dim3((unsigned)grid), dim3(256), lds_bytes, (hipStream_t)stream, p);
+    if (out_half) {
+        SSAD_CHECK_ARG(f16, "half output goes with fp16 operands");
+        hipLaunchKernelGGL((stem_conv7x7_16_kernel<true, hf>), dim3((unsigned)grid), dim3(256), lds_bytes, (hipStream_t)stream, p);
+    } else if (f16) hipLaunchKernelGGL(stem_conv7x7_16_kernel<true>, dim3((unsigned)grid), dim3(256), lds_bytes, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(stem_conv7x7_16_kernel<false>, dim3((unsigned)grid), dim3(256), lds_bytes, (hipStream_t)stream, p);
     SSAD_CHECK_LAUNCH();
     return ssad_bn_finalize_partials(workspace, (int)grid, (int64_t)B * p.Ho * p.Wo, 64, eps, momentum, mean, invstd, running_mean,
                                      running_var, stream);
+}
+
+extern "C" int ssad_stem_fwd_stats16(const float* img, int B, int H, int W, const void* wk16, float* out, float eps, float momentum,
+                                     float* mean, float* invstd, float* running_mean, float* running_var, double* workspace, int f16,
+                                     void* stream) {
+    return stem_fwd_stats16_impl(img, B, H, W, wk16, out, 0, eps, momentum, mean, invstd, running_mean, running_var, workspace, f16, stream);
+}
+
+// fp16 operands and z stored as halves [B][Ho][Wo][64]; the statistics are those of the stored halves
+extern "C" int ssad_stem_fwd_stats16_h(const float* img, int B, int H, int W, const void* wk16, void* out, float eps, float momentum,
+                                       float* mean, float* invstd, float* running_mean, float* running_var, double* workspace,
+                                       void* stream) {
+    return stem_fwd_stats16_impl(img, B, H, W, wk16, out, 1, eps, momentum, mean, invstd, running_mean, running_var, workspace, 1, stream);
 }

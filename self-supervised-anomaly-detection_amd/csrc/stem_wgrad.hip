@@ -22,13 +22,15 @@ constexpr int KPAD = KT * 32;
 
 struct StemWgradParams {
     const float* img;
-    const float* dz;
+    const void* dz;       // floats, or halves (TZ = hf)
     float* slab;
     int B, H, W, Hv, Wv, Ho, Wo, tiles_y, tiles_x;
     int64_t total_tiles;
 };
 
+template <typename TZ>
 __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemWgradParams p) {
+    const TZ* const dzp = (const TZ*)p.dz;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* dys = lds;                    // [128 px][64 co]
     float* tin = lds + DY_FLOATS;        // [IH][IW][3]
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemWgradParams p) {
             const int px = i >> 4, c4 = i & 15;
             const int oy = ty0 + (px >> 5), ox = tx0 + (px & 31);
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (oy < p.Ho && ox < p.Wo) v = *(const f32x4*)(p.dz + ((n * p.Ho + oy) * p.Wo + ox) * 64 + c4 * 4);
+            if (oy < p.Ho && ox < p.Wo) v = ld4(dzp + ((n * p.Ho + oy) * p.Wo + ox) * 64 + c4 * 4);
             dzv[q] = v;
         }
         // input tile (virtual, i.e. after the nearest resize of models.py:217-219 when the image is below 64x64)
@@ -154,8 +156,8 @@ extern "C" int64_t ssad_stem_wgrad_workspace(int B, int H, int W) {
     return (int64_t)stem_wgrad_blocks(tiles) * 64 * KPAD;
 }
 
-extern "C" int ssad_stem_wgrad(const float* img, const float* dz, float* dw, int B, int H, int W, int to_oihw, int accumulate,
-                               float* workspace, void* stream) {
+static int stem_wgrad_impl(const float* img, const void* dz, int dz_half, float* dw, int B, int H, int W, int64_t dz_elems, int to_oihw,
+                           int accumulate, float* workspace, void* stream) {
     SSAD_CHECK_ARG(img && dz && dw && workspace, "null pointer");
     SSAD_CHECK_ARG(B > 0 && H > 0 && W > 0, "empty shape");
     StemWgradParams p;
@@ -168,8 +170,23 @@ extern "C" int ssad_stem_wgrad(const float* img, const float* dz, float* dw, int
     p.tiles_y = (p.Ho + TH - 1) / TH;
     p.tiles_x = (p.Wo + TW - 1) / TW;
     p.total_tiles = (int64_t)B * p.tiles_y * p.tiles_x;
+    // dz is read over B x Ho x Wo x 64 as derived from the IMAGE's extents (round 4: a half-size dz from a stem variant that skipped the
+    // nearest resize was read out of bounds here): the caller states what its buffer holds
+    SSAD_CHECK_ARG(dz_elems == (int64_t)B * p.Ho * p.Wo * 64, "dz does not hold B x Ho x Wo x 64 elements for these images");
     const int nblk = stem_wgrad_blocks(p.total_tiles);
-    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nblk), dim3(256), (DY_FLOATS + IN_FLOATS) * 4, (hipStream_t)stream, p);
+    if (dz_half) hipLaunchKernelGGL(stem_wgrad_kernel<hf>, dim3(nblk), dim3(256), (DY_FLOATS + IN_FLOATS) * 4, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(stem_wgrad_kernel<float>, dim3(nblk), dim3(256), (DY_FLOATS + IN_FLOATS) * 4, (hipStream_t)stream, p);
     SSAD_CHECK_LAUNCH();
     return ssad_wgrad_reduce(workspace, dw, nblk, 64, KPAD, 7, 7, 3, to_oihw, accumulate, stream);
+}
+
+extern "C" int ssad_stem_wgrad(const float* img, const float* dz, float* dw, int B, int H, int W, int64_t dz_elems, int to_oihw,
+                               int accumulate, float* workspace, void* stream) {
+    return stem_wgrad_impl(img, dz, 0, dw, B, H, W, dz_elems, to_oihw, accumulate, workspace, stream);
+}
+
+// dz stored as halves (precision-16 step); products and sums in fp32 as above
+extern "C" int ssad_stem_wgrad_h(const float* img, const void* dz, float* dw, int B, int H, int W, int64_t dz_elems, int to_oihw,
+                                 int accumulate, float* workspace, void* stream) {
+    return stem_wgrad_impl(img, dz, 1, dw, B, H, W, dz_elems, to_oihw, accumulate, workspace, stream);
 }

@@ -9,6 +9,7 @@
 // statistics and BN gradients are deterministic and free of E[x^2]-E[x]^2 cancellation.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -30,8 +31,8 @@ static inline ColReduce col_geom(int C) {
 //         sign of (z - mean) * invstd * gamma + beta recomputed from z -- one tensor less to read
 //         or mask4: one byte per channel quad, bit k = "the ReLU output of channel 4q+k was positive" (written by the forward
 //         BatchNorm apply: 1/16 of the bytes of the activation it stands for)
-template <int MODE>
-__global__ void col_reduce_kernel(const float* __restrict__ a, const float* __restrict__ yact, const float* __restrict__ z,
+template <int MODE, typename T = float>
+__global__ void col_reduce_kernel(const T* __restrict__ a, const T* __restrict__ yact, const T* __restrict__ z,
                                   const float* __restrict__ mean, const float* __restrict__ invstd,
                                   const float* __restrict__ zmask_gamma, const float* __restrict__ zmask_beta,
                                   double* __restrict__ partial, int64_t R, int C, int TC, int RL, int rows_per_block,
@@ -57,10 +58,10 @@ __global__ void col_reduce_kernel(const float* __restrict__ a, const float* __re
             for (int u = 0; u < U; ++u) {
                 const int64_t rw = row + (int64_t)u * RL;
                 const int64_t o = (rw < re ? rw : rb + ty) * C4 + cq;       // clamp: tail rows re-read a valid row ...
-                v[u] = ((const f32x4*)a)[o];
-                if (MODE == 1 && yact) ya[u] = ((const f32x4*)yact)[o];
+                v[u] = ld4(a + 4 * o);
+                if (MODE == 1 && yact) ya[u] = ld4(yact + 4 * o);
                 if (MODE == 1 && mask4) mk[u] = mask4[o];
-                if (MODE == 1 && z) zz[u] = ((const f32x4*)z)[o];
+                if (MODE == 1 && z) zz[u] = ld4(z + 4 * o);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -157,19 +158,20 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
 }
 
 // y = (z - mean) * invstd * gamma + beta (+ res) (relu)
-__global__ void bn_apply_fwd_kernel(const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ invstd,
+template <typename T>
+__global__ void bn_apply_fwd_kernel(const T* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                    const float* __restrict__ res, float* __restrict__ y, int64_t total4, int C4, int relu,
+                                    const T* __restrict__ res, T* __restrict__ y, int64_t total4, int C4, int relu,
                                     uint8_t* __restrict__ mask4 = nullptr) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
         const int cq = (int)(i % C4);
         const f32x4 mu = ((const f32x4*)mean)[cq], is = ((const f32x4*)invstd)[cq];
         const f32x4 g = ((const f32x4*)gamma)[cq], b = ((const f32x4*)beta)[cq];
-        f32x4 v = ((const f32x4*)z)[i];
+        f32x4 v = ld4(z + 4 * i);
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = (v[k] - mu[k]) * is[k] * g[k] + b[k];
         if (res) {
-            const f32x4 rr = ((const f32x4*)res)[i];
+            const f32x4 rr = ld4(res + 4 * i);
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] += rr[k];
         }
@@ -178,24 +180,25 @@ __global__ void bn_apply_fwd_kernel(const float* __restrict__ z, const float* __
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
         }
-        ((f32x4*)y)[i] = v;
+        st4(y + 4 * i, v);
     }
 }
 
 // g = dy * (yact > 0); dz = gamma*invstd*(g - dbeta/R - xhat*dgamma/R)  [train]   or  g*gamma*invstd  [eval];
 // optionally dres = g (gradient of the identity branch of a residual block)
-__global__ void bn_apply_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ yact, const float* __restrict__ z,
+template <typename T>
+__global__ void bn_apply_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ yact, const T* __restrict__ z,
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ gamma, const float* __restrict__ dbeta,
-                                    const float* __restrict__ dgamma, float* __restrict__ dz, float* __restrict__ dres,
+                                    const float* __restrict__ dgamma, T* __restrict__ dz, T* __restrict__ dres,
                                     int64_t total4, int C4, float invR, int eval_mode, const float* __restrict__ zmask_beta,
                                     const uint8_t* __restrict__ mask4 = nullptr) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
         const int cq = (int)(i % C4);
         const f32x4 mu = ((const f32x4*)mean)[cq], is = ((const f32x4*)invstd)[cq], ga = ((const f32x4*)gamma)[cq];
-        f32x4 g = ((const f32x4*)dy)[i];
+        f32x4 g = ld4(dy + 4 * i);
         if (yact) {
-            const f32x4 ya = ((const f32x4*)yact)[i];
+            const f32x4 ya = ld4(yact + 4 * i);
 #pragma unroll
             for (int k = 0; k < 4; ++k) g[k] = ya[k] > 0.f ? g[k] : 0.f;
         } else if (mask4) {
@@ -204,25 +207,25 @@ __global__ void bn_apply_bwd_kernel(const float* __restrict__ dy, const float* _
             for (int k = 0; k < 4; ++k) g[k] = (mk >> k) & 1u ? g[k] : 0.f;
         } else if (zmask_beta) {                 // ReLU mask recomputed from z (layer without residual)
             const f32x4 zb = ((const f32x4*)zmask_beta)[cq];
-            const f32x4 zm = ((const f32x4*)z)[i];
+            const f32x4 zm = ld4(z + 4 * i);
 #pragma unroll
             for (int k = 0; k < 4; ++k) g[k] = (zm[k] - mu[k]) * is[k] * ga[k] + zb[k] > 0.f ? g[k] : 0.f;
         }
-        if (dres) ((f32x4*)dres)[i] = g;
+        if (dres) st4(dres + 4 * i, g);
         f32x4 o;
         if (eval_mode) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) o[k] = g[k] * ga[k] * is[k];
         } else {
             const f32x4 db = ((const f32x4*)dbeta)[cq], dg = ((const f32x4*)dgamma)[cq];
-            const f32x4 zz = ((const f32x4*)z)[i];
+            const f32x4 zz = ld4(z + 4 * i);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float xh = (zz[k] - mu[k]) * is[k];
                 o[k] = ga[k] * is[k] * (g[k] - db[k] * invR - xh * dg[k] * invR);
             }
         }
-        ((f32x4*)dz)[i] = o;
+        st4(dz + 4 * i, o);
     }
 }
 
@@ -330,12 +333,12 @@ __device__ __forceinline__ f32x4 pool_grad(const uint8_t* __restrict__ idx, cons
 // look-ups, not the streaming of z, set the pace of the one-pixel form (1.19 ms per step at 3.2 TB/s -> see DESIGN.md).
 // Block (a, b) = pixels (2a .. 2a+1, 2b .. 2b+1); cell (oy, ox) covers pixels 2oy-1 .. 2oy+1, so the block's pixels are covered by
 // cells oy in {a, a+1}, ox in {b, b+1} only; slot of pixel (y, x) in cell (oy, ox) = (y - 2oy + 1) * 3 + (x - 2ox + 1).
-template <int APPLY>
-__global__ __launch_bounds__(256) void pool_bn_bwd_kernel(const uint8_t* __restrict__ idx, const float* __restrict__ dpool,
-                                                          const float* __restrict__ z, const float* __restrict__ mean,
+template <int APPLY, typename T = float>
+__global__ __launch_bounds__(256) void pool_bn_bwd_kernel(const uint8_t* __restrict__ idx, const T* __restrict__ dpool,
+                                                          const T* __restrict__ z, const float* __restrict__ mean,
                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, const float* __restrict__ dbeta,
-                                                          const float* __restrict__ dgamma, float* __restrict__ dz,
+                                                          const float* __restrict__ dgamma, T* __restrict__ dz,
                                                           double* __restrict__ partial, int64_t R, int H, int W, int C,
                                                           int Ho, int Wo, int64_t rows_per_block) {
     __shared__ double sh[2][256][4];
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_kernel(const uint8_t* __restr
                 const bool ok = oy < Ho && ox < Wo;
                 const int64_t o = ((n * Ho + (ok ? oy : 0)) * Wo + (ok ? ox : 0)) * C4 + c4;
                 pk[dy][dx] = ok ? ((const uint32_t*)idx)[o] : 0xffffffffu;        // slot 255 never matches
-                gq[dy][dx] = ((const f32x4*)dpool)[o];
+                gq[dy][dx] = ld4(dpool + 4 * o);
             }
 #pragma unroll
         for (int py = 0; py < 2; ++py)
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_kernel(const uint8_t* __restr
                         for (int k = 0; k < 4; ++k) g[k] += ((pk[dy][dx] >> (8 * k)) & 0xffu) == slot ? gq[dy][dx][k] : 0.f;
                     }
                 const int64_t row = (n * H + y) * W + x;
-                const f32x4 zz = ((const f32x4*)z)[row * C4 + c4];
+                const f32x4 zz = ld4(z + 4 * (row * C4 + c4));
                 f32x4 xh;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -400,7 +403,7 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_kernel(const uint8_t* __restr
                     f32x4 o;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) o[k] = ga[k] * is[k] * (g[k] - db[k] * invR - xh[k] * dg[k] * invR);
-                    ((f32x4*)dz)[row * C4 + c4] = o;
+                    st4(dz + 4 * (row * C4 + c4), o);
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) { s0[k] += (double)g[k]; s1[k] += (double)g[k] * (double)xh[k]; }
@@ -432,7 +435,8 @@ __global__ void gap_bwd_kernel(const float* __restrict__ dpooled, float* __restr
     const float g = dpooled[n * stride + off + c] / (float)HW;
     dy[i] = accumulate ? dy[i] + g : g;
 }
-__global__ void gap_bwd4_kernel(const float* __restrict__ dpooled, float* __restrict__ dy, int64_t total4, int HW, int C4,
+template <typename T>
+__global__ void gap_bwd4_kernel(const float* __restrict__ dpooled, T* __restrict__ dy, int64_t total4, int HW, int C4,
                                 int stride, int off, int accumulate) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total4) return;
@@ -440,8 +444,8 @@ __global__ void gap_bwd4_kernel(const float* __restrict__ dpooled, float* __rest
     const int64_t n = i / ((int64_t)HW * C4);
     const float* gp = dpooled + n * stride + off + c4 * 4;
     f32x4 g = {gp[0] / (float)HW, gp[1] / (float)HW, gp[2] / (float)HW, gp[3] / (float)HW};
-    f32x4* d = (f32x4*)dy + i;
-    *d = accumulate ? *d + g : g;
+    T* d = dy + 4 * i;
+    st4(d, accumulate ? ld4(d) + g : g);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -506,7 +510,8 @@ struct FlipTable {
 };
 // One workgroup = one 32 x 32 (o, i) tile of one tap: read coalesced along i, written coalesced along o through LDS (the
 // one-thread-per-element form read with a stride of O floats: 96 us per step for 45 MB, 0.9 TB/s).
-__global__ __launch_bounds__(256) void flip_transpose_batch_kernel(const float* __restrict__ src, float* __restrict__ dst, FlipTable t) {
+template <typename TO>
+__global__ __launch_bounds__(256) void flip_transpose_batch_kernel(const float* __restrict__ src, TO* __restrict__ dst, FlipTable t) {
     __shared__ float tile[32][33];
     int k = 0;
     while (k + 1 < t.n && (int64_t)blockIdx.x >= t.e[k + 1][6]) ++k;
@@ -517,7 +522,7 @@ __global__ __launch_bounds__(256) void flip_transpose_batch_kernel(const float* 
     const int to = l % ot;
     const int tap = l / ot;                                   // destination tap (ky', kx'); the source tap is the mirrored one
     const float* w = src + t.e[k][0];
-    float* out = dst + t.e[k][1];
+    TO* out = dst + t.e[k][1];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -528,7 +533,7 @@ __global__ __launch_bounds__(256) void flip_transpose_batch_kernel(const float* 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int i = ti * 32 + ty + 8 * r, o = to * 32 + tx;
-        if (o < O && i < I) out[((int64_t)i * T + tap) * O + o] = tile[tx][ty + 8 * r];
+        if (o < O && i < I) out[((int64_t)i * T + tap) * O + o] = (TO)tile[tx][ty + 8 * r];
     }
 }
 
@@ -654,7 +659,8 @@ extern "C" int64_t ssad_colreduce_workspace(int64_t R, int C) {
     return col_blocks(R, g) * 2 * C;
 }
 
-static int launch_col_reduce(int mode, const float* a, const float* yact, const float* z, const float* mean,
+template <typename T>
+static int launch_col_reduce(int mode, const T* a, const T* yact, const T* z, const float* mean,
                              const float* invstd, double* ws, int64_t R, int C, int* nblk_out, hipStream_t st,
                              const float* zg = nullptr, const float* zb = nullptr, const uint8_t* mask4 = nullptr) {
     ColReduce g = col_geom(C);
@@ -664,10 +670,10 @@ static int launch_col_reduce(int mode, const float* a, const float* yact, const 
     int gx = (C / 4 + g.TC - 1) / g.TC;
     dim3 grid(gx, (unsigned)nblk);
     if (mode == 0)
-        hipLaunchKernelGGL(col_reduce_kernel<0>, grid, dim3(256), 0, st, a, yact, z, mean, invstd, zg, zb, ws, R, C, g.TC, g.RL, rows_per_block,
+        hipLaunchKernelGGL((col_reduce_kernel<0, T>), grid, dim3(256), 0, st, a, yact, z, mean, invstd, zg, zb, ws, R, C, g.TC, g.RL, rows_per_block,
                            (const uint8_t*)nullptr);
     else
-        hipLaunchKernelGGL(col_reduce_kernel<1>, grid, dim3(256), 0, st, a, yact, z, mean, invstd, zg, zb, ws, R, C, g.TC, g.RL, rows_per_block,
+        hipLaunchKernelGGL((col_reduce_kernel<1, T>), grid, dim3(256), 0, st, a, yact, z, mean, invstd, zg, zb, ws, R, C, g.TC, g.RL, rows_per_block,
                            mask4);
     *nblk_out = (int)nblk;
     return 0;
@@ -681,25 +687,49 @@ int ssad_bn_finalize_partials(const double* partial, int nblk, int64_t R, int C,
     return 0;
 }
 
-extern "C" int ssad_bn_stats(const float* z, int64_t R, int C, float eps, float momentum, float* mean, float* invstd,
-                             float* running_mean, float* running_var, double* workspace, void* stream) {
+template <typename T>
+static int bn_stats_impl(const T* z, int64_t R, int C, float eps, float momentum, float* mean, float* invstd,
+                         float* running_mean, float* running_var, double* workspace, void* stream) {
     SSAD_CHECK_ARG(z && mean && invstd && workspace && R > 0 && C > 0 && C % 4 == 0, "bad argument");
     int nblk;
-    launch_col_reduce(0, z, nullptr, nullptr, nullptr, nullptr, workspace, R, C, &nblk, (hipStream_t)stream);
+    launch_col_reduce<T>(0, z, nullptr, nullptr, nullptr, nullptr, workspace, R, C, &nblk, (hipStream_t)stream);
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, workspace, nblk, R, C,
                        eps, momentum, mean, invstd, running_mean, running_var);
     SSAD_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int ssad_bn_apply_fwd(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                                 const float* residual, float* y, int64_t R, int C, int relu, void* stream) {
+extern "C" int ssad_bn_stats(const float* z, int64_t R, int C, float eps, float momentum, float* mean, float* invstd,
+                             float* running_mean, float* running_var, double* workspace, void* stream) {
+    return bn_stats_impl<float>(z, R, C, eps, momentum, mean, invstd, running_mean, running_var, workspace, stream);
+}
+
+// ..._h: the same kernels over tensors stored as halves (arithmetic, statistics, parameters and their gradients stay fp32): the
+// precision-16 training step, whose activations live in HBM as torch.autocast stores them (tools.py:263 of the reference)
+extern "C" int ssad_bn_stats_h(const void* z, int64_t R, int C, float eps, float momentum, float* mean, float* invstd,
+                               float* running_mean, float* running_var, double* workspace, void* stream) {
+    return bn_stats_impl<hf>((const hf*)z, R, C, eps, momentum, mean, invstd, running_mean, running_var, workspace, stream);
+}
+
+template <typename T>
+static int bn_apply_fwd_impl(const T* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                             const T* residual, T* y, int64_t R, int C, int relu, void* stream) {
     SSAD_CHECK_ARG(z && mean && invstd && gamma && beta && y && R > 0 && C > 0 && C % 4 == 0, "bad argument");
     const int64_t total4 = R * (C / 4);
-    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, z, mean, invstd, gamma,
+    hipLaunchKernelGGL(bn_apply_fwd_kernel<T>, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, z, mean, invstd, gamma,
                        beta, residual, y, total4, C / 4, relu, (uint8_t*)nullptr);
     SSAD_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int ssad_bn_apply_fwd(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                 const float* residual, float* y, int64_t R, int C, int relu, void* stream) {
+    return bn_apply_fwd_impl<float>(z, mean, invstd, gamma, beta, residual, y, R, C, relu, stream);
+}
+
+extern "C" int ssad_bn_apply_fwd_h(const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                   const void* residual, void* y, int64_t R, int C, int relu, void* stream) {
+    return bn_apply_fwd_impl<hf>((const hf*)z, mean, invstd, gamma, beta, (const hf*)residual, (hf*)y, R, C, relu, stream);
 }
 
 // The same apply, also leaving the ReLU's active set as a nibble mask (one byte per channel quad, bit k = output of channel
@@ -708,7 +738,7 @@ extern "C" int ssad_bn_apply_fwd_mask(const float* z, const float* mean, const f
                                       const float* residual, float* y, uint8_t* mask4, int64_t R, int C, int relu, void* stream) {
     SSAD_CHECK_ARG(z && mean && invstd && gamma && beta && y && mask4 && R > 0 && C > 0 && C % 4 == 0, "bad argument");
     const int64_t total4 = R * (C / 4);
-    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, z, mean, invstd, gamma,
+    hipLaunchKernelGGL(bn_apply_fwd_kernel<float>, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, z, mean, invstd, gamma,
                        beta, residual, y, total4, C / 4, relu, mask4);
     SSAD_CHECK_LAUNCH();
     return 0;
@@ -743,19 +773,22 @@ __global__ __launch_bounds__(256) void col_sum_tiny_kernel(const float* __restri
 }
 
 // dbeta/dgamma over rows of g = dy*(yact>0); with z == NULL only dbeta (= column sums: Linear bias gradient).
-static int bn_bwd_reduce_impl(const float* dy, const float* yact, const float* z, const float* mean, const float* invstd,
+template <typename T>
+static int bn_bwd_reduce_impl(const T* dy, const T* yact, const T* z, const float* mean, const float* invstd,
                               float* dbeta, float* dgamma, int64_t R, int C, double* workspace, void* stream,
                               const float* zg, const float* zb, const uint8_t* mask4 = nullptr) {
     SSAD_CHECK_ARG(dy && workspace && R > 0 && C > 0 && C % 4 == 0, "bad argument");
     SSAD_CHECK_ARG(!z || (mean && invstd), "z needs mean/invstd");
     SSAD_CHECK_ARG(!zg || (z && zb && !yact), "mask-from-z needs z, gamma, beta and no yact");
-    if (!z && !yact && !mask4 && dbeta && R <= 4096 && (C == 4 || C == 8 || C == 16 || C == 32)) {     // plain column sums, tiny
-        hipLaunchKernelGGL(col_sum_tiny_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, dy, dbeta, (int)R, C);
-        SSAD_CHECK_LAUNCH();
-        return 0;
+    if constexpr (std::is_same<T, float>::value) {
+        if (!z && !yact && !mask4 && dbeta && R <= 4096 && (C == 4 || C == 8 || C == 16 || C == 32)) {     // plain column sums, tiny
+            hipLaunchKernelGGL(col_sum_tiny_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, dy, dbeta, (int)R, C);
+            SSAD_CHECK_LAUNCH();
+            return 0;
+        }
     }
     int nblk;
-    launch_col_reduce(1, dy, yact, z, mean, invstd, workspace, R, C, &nblk, (hipStream_t)stream, zg, zb, mask4);
+    launch_col_reduce<T>(1, dy, yact, z, mean, invstd, workspace, R, C, &nblk, (hipStream_t)stream, zg, zb, mask4);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, workspace, nblk, C, dbeta,
                        z ? dgamma : nullptr);
     SSAD_CHECK_LAUNCH();
@@ -764,7 +797,13 @@ static int bn_bwd_reduce_impl(const float* dy, const float* yact, const float* z
 
 extern "C" int ssad_bn_bwd_reduce(const float* dy, const float* yact, const float* z, const float* mean, const float* invstd,
                                   float* dbeta, float* dgamma, int64_t R, int C, double* workspace, void* stream) {
-    return bn_bwd_reduce_impl(dy, yact, z, mean, invstd, dbeta, dgamma, R, C, workspace, stream, nullptr, nullptr);
+    return bn_bwd_reduce_impl<float>(dy, yact, z, mean, invstd, dbeta, dgamma, R, C, workspace, stream, nullptr, nullptr);
+}
+
+extern "C" int ssad_bn_bwd_reduce_h(const void* dy, const void* yact, const void* z, const float* mean, const float* invstd,
+                                    float* dbeta, float* dgamma, int64_t R, int C, double* workspace, void* stream) {
+    return bn_bwd_reduce_impl<hf>((const hf*)dy, (const hf*)yact, (const hf*)z, mean, invstd, dbeta, dgamma, R, C, workspace, stream,
+                                  nullptr, nullptr);
 }
 
 // Same reductions with the ReLU mask recomputed from z: mask = (z - mean) * invstd * gamma + beta > 0 (a BN + ReLU with no
@@ -773,17 +812,25 @@ extern "C" int ssad_bn_bwd_reduce_zmask(const float* dy, const float* z, const f
                                         const float* gamma, const float* beta, float* dbeta, float* dgamma, int64_t R, int C,
                                         double* workspace, void* stream) {
     SSAD_CHECK_ARG(gamma && beta, "null gamma/beta");
-    return bn_bwd_reduce_impl(dy, nullptr, z, mean, invstd, dbeta, dgamma, R, C, workspace, stream, gamma, beta);
+    return bn_bwd_reduce_impl<float>(dy, nullptr, z, mean, invstd, dbeta, dgamma, R, C, workspace, stream, gamma, beta);
 }
 
-static int bn_apply_bwd_impl(const float* dy, const float* yact, const float* z, const float* mean, const float* invstd,
-                                 const float* gamma, const float* dbeta, const float* dgamma, float* dz, float* dres,
+extern "C" int ssad_bn_bwd_reduce_zmask_h(const void* dy, const void* z, const float* mean, const float* invstd,
+                                          const float* gamma, const float* beta, float* dbeta, float* dgamma, int64_t R, int C,
+                                          double* workspace, void* stream) {
+    SSAD_CHECK_ARG(gamma && beta, "null gamma/beta");
+    return bn_bwd_reduce_impl<hf>((const hf*)dy, nullptr, (const hf*)z, mean, invstd, dbeta, dgamma, R, C, workspace, stream, gamma, beta);
+}
+
+template <typename T>
+static int bn_apply_bwd_impl(const T* dy, const T* yact, const T* z, const float* mean, const float* invstd,
+                                 const float* gamma, const float* dbeta, const float* dgamma, T* dz, T* dres,
                                  int64_t R, int C, int eval_mode, void* stream, const float* zmask_beta,
                                  const uint8_t* mask4 = nullptr) {
     SSAD_CHECK_ARG(dy && mean && invstd && gamma && dz && R > 0 && C > 0 && C % 4 == 0, "bad argument");
     SSAD_CHECK_ARG(eval_mode || (z && dbeta && dgamma), "train-mode backward needs z, dbeta, dgamma");
     const int64_t total4 = R * (C / 4);
-    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, dy, yact, z, mean, invstd,
+    hipLaunchKernelGGL(bn_apply_bwd_kernel<T>, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, dy, yact, z, mean, invstd,
                        gamma, dbeta, dgamma, dz, dres, total4, C / 4, 1.f / (float)R, eval_mode, zmask_beta, mask4);
     SSAD_CHECK_LAUNCH();
     return 0;
@@ -792,14 +839,29 @@ static int bn_apply_bwd_impl(const float* dy, const float* yact, const float* z,
 extern "C" int ssad_bn_apply_bwd(const float* dy, const float* yact, const float* z, const float* mean, const float* invstd,
                                  const float* gamma, const float* dbeta, const float* dgamma, float* dz, float* dres,
                                  int64_t R, int C, int eval_mode, void* stream) {
-    return bn_apply_bwd_impl(dy, yact, z, mean, invstd, gamma, dbeta, dgamma, dz, dres, R, C, eval_mode, stream, nullptr);
+    return bn_apply_bwd_impl<float>(dy, yact, z, mean, invstd, gamma, dbeta, dgamma, dz, dres, R, C, eval_mode, stream, nullptr);
+}
+
+extern "C" int ssad_bn_apply_bwd_h(const void* dy, const void* yact, const void* z, const float* mean, const float* invstd,
+                                   const float* gamma, const float* dbeta, const float* dgamma, void* dz, void* dres,
+                                   int64_t R, int C, int eval_mode, void* stream) {
+    return bn_apply_bwd_impl<hf>((const hf*)dy, (const hf*)yact, (const hf*)z, mean, invstd, gamma, dbeta, dgamma, (hf*)dz, (hf*)dres,
+                                 R, C, eval_mode, stream, nullptr);
 }
 
 extern "C" int ssad_bn_apply_bwd_zmask(const float* dy, const float* z, const float* mean, const float* invstd,
                                        const float* gamma, const float* beta, const float* dbeta, const float* dgamma, float* dz,
                                        int64_t R, int C, void* stream) {
     SSAD_CHECK_ARG(z && beta, "mask-from-z needs z and beta");
-    return bn_apply_bwd_impl(dy, nullptr, z, mean, invstd, gamma, dbeta, dgamma, dz, nullptr, R, C, 0, stream, beta);
+    return bn_apply_bwd_impl<float>(dy, nullptr, z, mean, invstd, gamma, dbeta, dgamma, dz, nullptr, R, C, 0, stream, beta);
+}
+
+extern "C" int ssad_bn_apply_bwd_zmask_h(const void* dy, const void* z, const float* mean, const float* invstd,
+                                         const float* gamma, const float* beta, const float* dbeta, const float* dgamma, void* dz,
+                                         int64_t R, int C, void* stream) {
+    SSAD_CHECK_ARG(z && beta, "mask-from-z needs z and beta");
+    return bn_apply_bwd_impl<hf>((const hf*)dy, nullptr, (const hf*)z, mean, invstd, gamma, dbeta, dgamma, (hf*)dz, nullptr, R, C, 0,
+                                 stream, beta);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -936,9 +998,11 @@ extern "C" int ssad_bn_small_bwd(const float* dy, const float* z, const float* m
     return 0;
 }
 
-extern "C" int ssad_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int64_t N, int H, int W, int C, void* stream) {
+extern "C" int ssad_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int64_t N, int H, int W, int C, int64_t dy_elems,
+                                     void* stream) {
     SSAD_CHECK_ARG(x && dy && dx && N > 0 && H > 0 && W > 0 && C > 0, "bad argument");
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    SSAD_CHECK_ARG(dy_elems == N * Ho * Wo * C, "dy does not hold N x Ho x Wo x C elements for this x");
     SSAD_CHECK_ARG(C % 4 == 0, "C must be a multiple of 4");
     const int64_t total = N * H * W * (C / 4);
     SSAD_CHECK_ARG(cdiv64(total, 256) < (int64_t)2147483647, "too large");
@@ -949,9 +1013,10 @@ extern "C" int ssad_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx,
 }
 
 extern "C" int ssad_maxpool3x3s2_bwd_idx(const uint8_t* idx, const float* dy, float* dx, int64_t N, int H, int W, int C,
-                                        void* stream) {
+                                        int64_t dy_elems, void* stream) {
     SSAD_CHECK_ARG(idx && dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "bad argument");
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    SSAD_CHECK_ARG(dy_elems == N * Ho * Wo * C, "dy / idx do not hold N x Ho x Wo x C elements for this dx");
     const int64_t total = N * H * W * (C / 4);
     SSAD_CHECK_ARG(cdiv64(total, 256) < (int64_t)2147483647, "too large");
     hipLaunchKernelGGL(maxpool_bwd_idx_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, idx, dy, dx,
@@ -963,12 +1028,14 @@ extern "C" int ssad_maxpool3x3s2_bwd_idx(const uint8_t* idx, const float* dy, fl
 // Stem head of the backward pass: dz (gradient of the raw conv1 output) and the BatchNorm parameter gradients from the
 // POOLED gradient, the argmax slots and z -- max-pool backward, the ReLU mask and both BatchNorm passes without ever
 // storing the gradient of the 128x128 activation.  workspace: ssad_colreduce_workspace(N*H*W, C) doubles.
-extern "C" int ssad_pool_bn_relu_bwd(const uint8_t* idx, const float* dpool, const float* z, const float* mean,
-                                     const float* invstd, const float* gamma, const float* beta, float* dbeta, float* dgamma,
-                                     float* dz, int64_t N, int H, int W, int C, double* workspace, void* stream) {
+template <typename T>
+static int pool_bn_relu_bwd_impl(const uint8_t* idx, const T* dpool, const T* z, const float* mean,
+                                 const float* invstd, const float* gamma, const float* beta, float* dbeta, float* dgamma,
+                                 T* dz, int64_t N, int H, int W, int C, int64_t dpool_elems, double* workspace, void* stream) {
     SSAD_CHECK_ARG(idx && dpool && z && mean && invstd && gamma && beta && dbeta && dgamma && dz && workspace, "null pointer");
     SSAD_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0, "bad shape");
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    SSAD_CHECK_ARG(dpool_elems == N * Ho * Wo * C, "dpool / idx do not hold N x Ho x Wo x C elements for this z");
     const int64_t R = N * H * W;
     const int RL = 256 / (C / 4);
     const int64_t NB = N * ((H + 1) / 2) * ((W + 1) / 2);          // 2 x 2 pixel blocks: the unit a thread works on
@@ -976,13 +1043,26 @@ extern "C" int ssad_pool_bn_relu_bwd(const uint8_t* idx, const float* dpool, con
     if (nblk > 2048) nblk = 2048;
     const int64_t rows_per_block = cdiv64(NB, nblk);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(pool_bn_bwd_kernel<0>, dim3((unsigned)nblk), dim3(256), 0, st, idx, dpool, z, mean, invstd, gamma, beta,
-                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr, workspace, R, H, W, C, Ho, Wo, rows_per_block);
+    hipLaunchKernelGGL((pool_bn_bwd_kernel<0, T>), dim3((unsigned)nblk), dim3(256), 0, st, idx, dpool, z, mean, invstd, gamma, beta,
+                       (const float*)nullptr, (const float*)nullptr, (T*)nullptr, workspace, R, H, W, C, Ho, Wo, rows_per_block);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, workspace, (int)nblk, C, dbeta, dgamma);
-    hipLaunchKernelGGL(pool_bn_bwd_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, st, idx, dpool, z, mean, invstd, gamma, beta,
+    hipLaunchKernelGGL((pool_bn_bwd_kernel<1, T>), dim3((unsigned)nblk), dim3(256), 0, st, idx, dpool, z, mean, invstd, gamma, beta,
                        dbeta, dgamma, dz, (double*)nullptr, R, H, W, C, Ho, Wo, rows_per_block);
     SSAD_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int ssad_pool_bn_relu_bwd(const uint8_t* idx, const float* dpool, const float* z, const float* mean,
+                                     const float* invstd, const float* gamma, const float* beta, float* dbeta, float* dgamma,
+                                     float* dz, int64_t N, int H, int W, int C, int64_t dpool_elems, double* workspace, void* stream) {
+    return pool_bn_relu_bwd_impl<float>(idx, dpool, z, mean, invstd, gamma, beta, dbeta, dgamma, dz, N, H, W, C, dpool_elems, workspace, stream);
+}
+
+extern "C" int ssad_pool_bn_relu_bwd_h(const uint8_t* idx, const void* dpool, const void* z, const float* mean,
+                                       const float* invstd, const float* gamma, const float* beta, float* dbeta, float* dgamma,
+                                       void* dz, int64_t N, int H, int W, int C, int64_t dpool_elems, double* workspace, void* stream) {
+    return pool_bn_relu_bwd_impl<hf>(idx, (const hf*)dpool, (const hf*)z, mean, invstd, gamma, beta, dbeta, dgamma, (hf*)dz, N, H, W, C,
+                                     dpool_elems, workspace, stream);
 }
 
 extern "C" int ssad_gap_bwd(const float* dpooled, float* dy, int64_t N, int HW, int C, int stride, int offset, int accumulate,
@@ -990,11 +1070,21 @@ extern "C" int ssad_gap_bwd(const float* dpooled, float* dy, int64_t N, int HW, 
     SSAD_CHECK_ARG(dpooled && dy && N > 0 && HW > 0 && C > 0 && offset >= 0 && offset + C <= stride, "bad argument");
     const int64_t total = N * HW * C;
     if (C % 4 == 0 && ((uintptr_t)dy & 15) == 0)
-        hipLaunchKernelGGL(gap_bwd4_kernel, dim3((unsigned)cdiv64(total / 4, 256)), dim3(256), 0, (hipStream_t)stream, dpooled, dy,
+        hipLaunchKernelGGL(gap_bwd4_kernel<float>, dim3((unsigned)cdiv64(total / 4, 256)), dim3(256), 0, (hipStream_t)stream, dpooled, dy,
                            total / 4, HW, C / 4, stride, offset, accumulate);
     else
         hipLaunchKernelGGL(gap_bwd_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, dpooled, dy, total,
                            HW, C, stride, offset, accumulate);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ssad_gap_bwd_h(const float* dpooled, void* dy, int64_t N, int HW, int C, int stride, int offset, int accumulate,
+                              void* stream) {
+    SSAD_CHECK_ARG(dpooled && dy && N > 0 && HW > 0 && C > 0 && C % 4 == 0 && offset >= 0 && offset + C <= stride, "bad argument");
+    const int64_t total = N * HW * C;
+    hipLaunchKernelGGL(gap_bwd4_kernel<hf>, dim3((unsigned)cdiv64(total / 4, 256)), dim3(256), 0, (hipStream_t)stream, dpooled, (hf*)dy,
+                       total / 4, HW, C / 4, stride, offset, accumulate);
     SSAD_CHECK_LAUNCH();
     return 0;
 }
@@ -1088,20 +1178,40 @@ extern "C" int ssad_bn_bwd_reduce_mask(const float* dy, const uint8_t* mask4, co
                                        const float* invstd, float* dbeta, float* dgamma, int64_t R, int C, double* workspace,
                                        void* stream) {
     SSAD_CHECK_ARG(z, "z required");
-    return bn_bwd_reduce_impl(dy, nullptr, z, mean, invstd, dbeta, dgamma, R, C, workspace, stream, nullptr, nullptr, mask4);
+    return bn_bwd_reduce_impl<float>(dy, nullptr, z, mean, invstd, dbeta, dgamma, R, C, workspace, stream, nullptr, nullptr, mask4);
 }
 
 extern "C" int ssad_bn_apply_bwd_mask(const float* dy, const uint8_t* mask4, const float* z, const float* mean, const float* invstd,
                                       const float* gamma, const float* dbeta, const float* dgamma, float* dz, int64_t R, int C,
                                       void* stream) {
-    return bn_apply_bwd_impl(dy, nullptr, z, mean, invstd, gamma, dbeta, dgamma, dz, nullptr, R, C, 0, stream, nullptr, mask4);
+    return bn_apply_bwd_impl<float>(dy, nullptr, z, mean, invstd, gamma, dbeta, dgamma, dz, nullptr, R, C, 0, stream, nullptr, mask4);
 }
 
 
 // ssad_flip_transpose_weight for n filters at once: desc[k] = {src offset, dst offset, O, I, KH, KW} (floats, host
 // memory), sources inside `src`, results inside `dst`.  One launch per 32 filters (the kernel's table travels as a launch
 // argument): PeraNet() with its default head is one launch, a deeper latent_space_layers two or more.
-extern "C" int ssad_flip_transpose_batch(const float* src, float* dst, const int64_t* desc, int n, void* stream) {
+// fp32 -> half copy of a parameter arena (8 elements per thread; n % 8 == 0 or the tail is done element-wise)
+__global__ void cvt_f32_f16_kernel(const float* __restrict__ src, hf* __restrict__ dst, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i + 8 <= n) {
+        const f32x4 a = *(const f32x4*)(src + i), b = *(const f32x4*)(src + i + 4);
+        *(f16x8*)(dst + i) = f16x8{(hf)a[0], (hf)a[1], (hf)a[2], (hf)a[3], (hf)b[0], (hf)b[1], (hf)b[2], (hf)b[3]};
+    } else {
+        for (int64_t k = i; k < n; ++k) dst[k] = (hf)src[k];
+    }
+}
+
+// The precision-16 step with half tensors reads its weights as halves: one rounded copy of the (fp32 master) arena per step, as
+// torch.autocast makes one per use (cast cache) under pl.Trainer(precision=16), tools.py:263.  src, dst 16-byte aligned.
+extern "C" int ssad_cvt_f32_f16(const float* src, void* dst, int64_t n, void* stream) {
+    SSAD_CHECK_ARG(src && dst && n > 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "bad argument");
+    hipLaunchKernelGGL(cvt_f32_f16_kernel, dim3((unsigned)cdiv64(cdiv64(n, 8), 256)), dim3(256), 0, (hipStream_t)stream, src, (hf*)dst, n);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+static int flip_transpose_batch_impl(const float* src, void* dst, int dst_half, const int64_t* desc, int n, void* stream) {
     SSAD_CHECK_ARG(src && dst && desc && n > 0, "bad argument");
     for (int k = 0; k < n; ++k)
         SSAD_CHECK_ARG(desc[6 * k + 2] > 0 && desc[6 * k + 3] > 0 && desc[6 * k + 4] > 0 && desc[6 * k + 5] > 0, "bad filter shape");
@@ -1116,8 +1226,18 @@ extern "C" int ssad_flip_transpose_batch(const float* src, float* dst, const int
         }
         t.total = acc;
         SSAD_CHECK_ARG(acc < (int64_t)2147483647, "too many tiles");
-        hipLaunchKernelGGL(flip_transpose_batch_kernel, dim3((unsigned)acc), dim3(256), 0, (hipStream_t)stream, src, dst, t);
+        if (dst_half) hipLaunchKernelGGL(flip_transpose_batch_kernel<hf>, dim3((unsigned)acc), dim3(256), 0, (hipStream_t)stream, src, (hf*)dst, t);
+        else hipLaunchKernelGGL(flip_transpose_batch_kernel<float>, dim3((unsigned)acc), dim3(256), 0, (hipStream_t)stream, src, (float*)dst, t);
         SSAD_CHECK_LAUNCH();
     }
     return 0;
+}
+
+extern "C" int ssad_flip_transpose_batch(const float* src, float* dst, const int64_t* desc, int n, void* stream) {
+    return flip_transpose_batch_impl(src, dst, 0, desc, n, stream);
+}
+
+// the flipped filters written as halves (dgrad operands of the precision-16 step with half tensors)
+extern "C" int ssad_flip_transpose_batch_h(const float* src, void* dst, const int64_t* desc, int n, void* stream) {
+    return flip_transpose_batch_impl(src, dst, 1, desc, n, stream);
 }

@@ -206,7 +206,8 @@ template <> struct OpType<true> {
 // WS: wave-specialised like wgrad_f32_kernel (4 MFMA waves + 4 loader waves): with MFMAs 16x shorter than the fp32 ones
 // the loads, converts and transposed LDS stores dominate a 4-wave step.
 // F16: fp16 operands (v_mfma_f32_32x32x16_f16) instead of bf16 -- the reference's fp16 autocast (tools.py:263); NS = 1 only.
-template <int BT, int NS = 1, bool WS = false, bool F16 = false>
+// TI = hf: dy and x are stored as halves (the precision-16 step with half tensors): 8-byte loads, no conversion of value
+template <int BT, int NS = 1, bool WS = false, bool F16 = false, typename TI = float>
 __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void wgrad_bf16_kernel(WgradParams p) {
     using op_t = typename OpType<F16>::t;
     using op4 = typename OpType<F16>::v4;
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void wgrad_bf16_kernel(
     const int64_t m_begin = (int64_t)split * p.chunk;
     const int64_t m_end = m_begin + p.chunk < p.M ? m_begin + p.chunk : p.M;
     const int HoWo = p.Ho * p.Wo;
-    const float* zero = g_wzero;
+    const TI* zero = (const TI*)g_wzero;
 
     const int pg = lt & 7, c4 = lt >> 3;        // pixel group (4 pixels), channel quad
     const bool stager = c4 < BT / 4 && (!WS || loader);
@@ -263,8 +264,8 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void wgrad_bf16_kernel(
     }
     const int dn = PK / HoWo, rp = PK - dn * HoWo;
     const int dyy = rp / p.Wo, dxx = rp - dyy * p.Wo;
-    const float* ybase = p.dy + co0 + c4 * 4;
-    const float* xbase = p.x + ci0 + c4 * 4;
+    const TI* ybase = (const TI*)p.dy + co0 + c4 * 4;
+    const TI* xbase = (const TI*)p.x + ci0 + c4 * 4;
 
     f32x4 ry[4], rx[4];
     auto load_step = [&]() {
@@ -274,8 +275,8 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void wgrad_bf16_kernel(
             const bool live = m1 + q < m_end;
             const int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
             const bool inb = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            ry[q] = *(const f32x4*)((live && co_ok) ? ybase + (m1 + q) * p.Cout : zero);
-            rx[q] = *(const f32x4*)((live && inb && ci_ok) ? xbase + (((int64_t)n * p.H + iy) * p.W + ix) * p.Cin : zero);
+            ry[q] = ld4((live && co_ok) ? ybase + (m1 + q) * p.Cout : zero);
+            rx[q] = ld4((live && inb && ci_ok) ? xbase + (((int64_t)n * p.H + iy) * p.W + ix) * p.Cin : zero);
             if (++ox >= p.Wo) { ox = 0; if (++oy >= p.Ho) { oy = 0; ++n; } }
         }
         m1 += PK;
@@ -555,7 +556,8 @@ extern "C" int ssad_wgrad_splits_bf16(int64_t M, int Cin, int Cout, int KH, int 
 }
 
 static int wgrad_impl(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin,
-                               int Cout, int KH, int KW, int stride, int pad, void* stream, int bf16) {
+                               int Cout, int KH, int KW, int stride, int pad, int64_t dy_elems, void* stream, int bf16, int half_in = 0) {
+    SSAD_CHECK_ARG(!half_in || bf16 == 2, "half tensors go with fp16 operands");
     SSAD_CHECK_ARG(dy && x && slab, "null pointer");
     SSAD_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0, "bad shape");
     SSAD_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0, "channel counts must be multiples of 4");
@@ -567,6 +569,8 @@ static int wgrad_impl(const float* dy, const float* x, float* slab, int splits, 
     p.Wo = (W + 2 * pad - KW) / stride + 1;
     SSAD_CHECK_ARG(p.Ho > 0 && p.Wo > 0, "empty output");
     p.M = N * p.Ho * p.Wo;
+    // dy is read over N x Ho x Wo x Cout as derived from x's extents: the caller states what its buffer holds
+    SSAD_CHECK_ARG(dy_elems == p.M * Cout, "dy does not hold N x Ho x Wo x Cout elements for this x / filter geometry");
     int64_t chunk = (p.M + splits - 1) / splits;
     p.chunk = (chunk + PK - 1) / PK * PK;
     const int BT = (Cin <= 64 || Cout <= 64) ? 64 : 128;   // a 128-wide tile would be half empty
@@ -590,6 +594,9 @@ static int wgrad_impl(const float* dy, const float* x, float* slab, int splits, 
             }
             hipLaunchKernelGGL((wgrad_bf16_kernel<128, 2, true>), grid, dim3(512), 2 * 2 * 128 * (2 * PK + 8) * 2, st, p);
         }
+    } else if (bf16 == 2 && half_in) {
+        if (BT == 64) hipLaunchKernelGGL((wgrad_bf16_kernel<64, 1, true, true, hf>), grid, dim3(512), 2 * 2 * 64 * (PK + 8) * 2, st, p);
+        else hipLaunchKernelGGL((wgrad_bf16_kernel<128, 1, true, true, hf>), grid, dim3(512), 2 * 2 * 128 * (PK + 8) * 2, st, p);
     } else if (bf16 == 2) {
         if (BT == 64) hipLaunchKernelGGL((wgrad_bf16_kernel<64, 1, true, true>), grid, dim3(512), 2 * 2 * 64 * (PK + 8) * 2, st, p);
         else hipLaunchKernelGGL((wgrad_bf16_kernel<128, 1, true, true>), grid, dim3(512), 2 * 2 * 128 * (PK + 8) * 2, st, p);
@@ -612,32 +619,38 @@ static int wgrad_impl(const float* dy, const float* x, float* slab, int splits, 
 }
 
 extern "C" int ssad_conv_wgrad(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin,
-                               int Cout, int KH, int KW, int stride, int pad, void* stream) {
-    return wgrad_impl(dy, x, slab, splits, N, H, W, Cin, Cout, KH, KW, stride, pad, stream, 0);
+                               int Cout, int KH, int KW, int stride, int pad, int64_t dy_elems, void* stream) {
+    return wgrad_impl(dy, x, slab, splits, N, H, W, Cin, Cout, KH, KW, stride, pad, dy_elems, stream, 0);
 }
 
 // bf16-operand form (fp32 tensors, fp32 accumulate and slabs): Trainer(precision=16).
 extern "C" int ssad_conv_wgrad_bf16(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin,
-                                    int Cout, int KH, int KW, int stride, int pad, void* stream) {
-    return wgrad_impl(dy, x, slab, splits, N, H, W, Cin, Cout, KH, KW, stride, pad, stream, 1);
+                                    int Cout, int KH, int KW, int stride, int pad, int64_t dy_elems, void* stream) {
+    return wgrad_impl(dy, x, slab, splits, N, H, W, Cin, Cout, KH, KW, stride, pad, dy_elems, stream, 1);
 }
 
 // fp16-operand form (the reference's fp16 autocast, tools.py:263); slab sizing as for the bf16 kernel (ssad_wgrad_splits_bf16).
 extern "C" int ssad_conv_wgrad_f16(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin,
-                                   int Cout, int KH, int KW, int stride, int pad, void* stream) {
-    return wgrad_impl(dy, x, slab, splits, N, H, W, Cin, Cout, KH, KW, stride, pad, stream, 2);
+                                   int Cout, int KH, int KW, int stride, int pad, int64_t dy_elems, void* stream) {
+    return wgrad_impl(dy, x, slab, splits, N, H, W, Cin, Cout, KH, KW, stride, pad, dy_elems, stream, 2);
+}
+
+// dy and x stored as halves (precision-16 step with half tensors)
+extern "C" int ssad_conv_wgrad_f16_h(const void* dy, const void* x, float* slab, int splits, int64_t N, int H, int W, int Cin,
+                                     int Cout, int KH, int KW, int stride, int pad, int64_t dy_elems, void* stream) {
+    return wgrad_impl((const float*)dy, (const float*)x, slab, splits, N, H, W, Cin, Cout, KH, KW, stride, pad, dy_elems, stream, 2, 1);
 }
 
 // split-bf16 ("bf16x3") form: fp32-class accuracy from the bf16 matrix cores (use ssad_wgrad_splits_bf16 for the slab).
 // three-way split ("bf16x6"): fp32-faithful products.
 extern "C" int ssad_conv_wgrad_x6(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin,
-                                  int Cout, int KH, int KW, int stride, int pad, void* stream) {
-    return wgrad_impl(dy, x, slab, splits, N, H, W, Cin, Cout, KH, KW, stride, pad, stream, 6);
+                                  int Cout, int KH, int KW, int stride, int pad, int64_t dy_elems, void* stream) {
+    return wgrad_impl(dy, x, slab, splits, N, H, W, Cin, Cout, KH, KW, stride, pad, dy_elems, stream, 6);
 }
 
 extern "C" int ssad_conv_wgrad_x3(const float* dy, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin,
-                                  int Cout, int KH, int KW, int stride, int pad, void* stream) {
-    return wgrad_impl(dy, x, slab, splits, N, H, W, Cin, Cout, KH, KW, stride, pad, stream, 3);
+                                  int Cout, int KH, int KW, int stride, int pad, int64_t dy_elems, void* stream) {
+    return wgrad_impl(dy, x, slab, splits, N, H, W, Cin, Cout, KH, KW, stride, pad, dy_elems, stream, 3);
 }
 
 extern "C" int ssad_wgrad_reduce(const float* slab, float* dw, int splits, int Cout, int Kpad, int KH, int KW, int Cin,

@@ -196,8 +196,9 @@ extern "C" int ssad_wgrad3x3_halo_splits(int64_t N, int H, int W, int Cin, int C
 }
 
 static int halo_launch(const float* dz, const float* x, float* slab, int splits, int64_t N, int H, int W, int Hx, int Wx, int Cin,
-                       int Cout, int S, void* stream) {
+                       int Cout, int S, int64_t dz_elems, void* stream) {
     SSAD_CHECK_ARG(dz && x && slab && N > 0 && H > 0 && W > 0, "bad argument");
+    SSAD_CHECK_ARG(dz_elems == N * H * W * Cout, "dz does not hold N x H x W x Cout elements");
     SSAD_CHECK_ARG(Cin % 64 == 0 && Cout % 64 == 0, "channel counts must be multiples of 64");
     SSAD_CHECK_ARG((int64_t)Hx * Wx * Cin < (int64_t)1 << 32 && (int64_t)H * W * Cout < (int64_t)1 << 32 &&
                    N * (int64_t)((H + 3) / 4) * ((W + 7) / 8) < (int64_t)1 << 31, "offsets inside an image are 32-bit, tile numbers int");
@@ -242,14 +243,14 @@ static int halo_launch(const float* dz, const float* x, float* slab, int splits,
 // dz NHWC [N][H][W][Cout], x NHWC [N][H][W][Cin] (3x3, stride 1, pad 1) -> slab[splits][Cout][9 * Cin] with splits =
 // ssad_wgrad3x3_halo_splits(...); follow with ssad_wgrad_reduce(slab, dw, splits, Cout, 9 * Cin, 3, 3, Cin, ...).
 extern "C" int ssad_conv_wgrad3x3_halo(const float* dz, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin,
-                                       int Cout, void* stream) {
-    return halo_launch(dz, x, slab, splits, N, H, W, H, W, Cin, Cout, 1, stream);
+                                       int Cout, int64_t dz_elems, void* stream) {
+    return halo_launch(dz, x, slab, splits, N, H, W, H, W, Cin, Cout, 1, dz_elems, stream);
 }
 
 // The stride-2 form (ssad_wgrad3x3_halo_ok() == 2): dz NHWC [N][Ho][Wo][Cout] with Ho = (H - 1) / 2 + 1, x NHWC [N][H][W][Cin];
 // splits = ssad_wgrad3x3_halo_splits(N, Ho, Wo, Cin, Cout).
 extern "C" int ssad_conv_wgrad3x3s2_halo(const float* dz, const float* x, float* slab, int splits, int64_t N, int Ho, int Wo, int H,
-                                         int W, int Cin, int Cout, void* stream) {
+                                         int W, int Cin, int Cout, int64_t dz_elems, void* stream) {
     SSAD_CHECK_ARG(Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1, "dz / x sizes disagree for stride 2, pad 1");
-    return halo_launch(dz, x, slab, splits, N, Ho, Wo, H, W, Cin, Cout, 2, stream);
+    return halo_launch(dz, x, slab, splits, N, Ho, Wo, H, W, Cin, Cout, 2, dz_elems, stream);
 }

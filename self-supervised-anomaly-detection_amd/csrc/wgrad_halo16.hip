@@ -29,8 +29,8 @@
 namespace {
 
 struct WgH16Params {
-    const float* dz;     // [N][H][W][Cout]
-    const float* x;      // [N][H][W][Cin]
+    const void* dz;      // [N][H][W][Cout]  floats, or halves (TI = hf: the precision-16 step with half tensors)
+    const void* x;       // [N][H][W][Cin]
     float* slab;         // [splits][Cout][9 * Cin]
     int N, H, W, Cin, Cout;
     int tiles_y, tiles_x, ci_tiles, npairs, splits;
@@ -55,7 +55,7 @@ template <> struct Op16<true> {
 // itself, so the two add up (measured by switching either side off: 82 us matrix waves alone, 93-129 us staging waves alone, of which
 // 29 us are the slab epilogue and its reduction).  Tried on top, no gain: a second register set so that loads are issued two
 // barriers ahead, XCD-contiguous numbering of the blocks that walk the same tiles, fragment reads one K-step ahead (slower).
-template <int TH, int TW, bool F16>
+template <int TH, int TW, bool F16, typename TI = float>
 __global__ __launch_bounds__(512, 1) void wgrad3x3_halo16_kernel(WgH16Params p) {
     using op_t = typename Op16<F16>::t;
     using op4 = typename Op16<F16>::v4;
@@ -112,14 +112,14 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_halo16_kernel(WgH16Params p) 
         }
         auto load_tile = [&]() {                 // the next tile of this workgroup: all its loads in flight together
             const int y0 = ld_ty * TH, x0 = ld_tx * TW;
-            const float* dzn = p.dz + ((int64_t)ld_n * p.H * p.W + (int64_t)y0 * p.W + x0) * p.Cout + co0;
+            const TI* dzn = (const TI*)p.dz + ((int64_t)ld_n * p.H * p.W + (int64_t)y0 * p.W + x0) * p.Cout + co0;
             // first halo pixel (y0 - 1, x0 - 1): outside the image on border tiles -- never dereferenced there
-            const float* xn = p.x + ((int64_t)ld_n * p.H * p.W + (int64_t)(y0 - 1) * p.W + (x0 - 1)) * p.Cin + ci0;
+            const TI* xn = (const TI*)p.x + ((int64_t)ld_n * p.H * p.W + (int64_t)(y0 - 1) * p.W + (x0 - 1)) * p.Cin + ci0;
             const bool dy_ok = y0 + dzy < p.H;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (dy_ok && x0 + dzx + q < p.W) v = *(const f32x4*)(dzn + dz_off + (unsigned)(q * p.Cout));
+                if (dy_ok && x0 + dzx + q < p.W) v = ld4(dzn + dz_off + (unsigned)(q * p.Cout));
                 dv[q] = v;
             }
 #pragma unroll
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_halo16_kernel(WgH16Params p) 
                 for (int q = 0; q < 4; ++q) {
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
                     if (row_ok && xhx[i] + q < TW + 2 && (unsigned)(x0 - 1 + xhx[i] + q) < (unsigned)p.W)
-                        v = *(const f32x4*)(xn + x_off[i] + (unsigned)(q * p.Cin));
+                        v = ld4(xn + x_off[i] + (unsigned)(q * p.Cin));
                     xv[i][q] = v;
                 }
             }
@@ -244,9 +244,10 @@ extern "C" int ssad_wgrad3x3_halo16_splits(int64_t N, int H, int W, int Cin, int
 // dz NHWC [N][H][W][Cout], x NHWC [N][H][W][Cin] (3x3, stride 1, pad 1), both fp32 in memory and rounded to fp16 (f16 != 0) or
 // bf16 while staged -> slab[splits][Cout][9 * Cin] fp32 with splits = ssad_wgrad3x3_halo16_splits(...); follow with
 // ssad_wgrad_reduce(slab, dw, splits, Cout, 9 * Cin, 3, 3, Cin, ...).
-extern "C" int ssad_conv_wgrad3x3_halo16(const float* dz, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin,
-                                         int Cout, int f16, void* stream) {
+static int wgrad3x3_halo16_impl(const void* dz, const void* x, int half_in, float* slab, int splits, int64_t N, int H, int W, int Cin,
+                                int Cout, int f16, int64_t dz_elems, void* stream) {
     SSAD_CHECK_ARG(dz && x && slab && N > 0 && H > 0 && W > 0, "bad argument");
+    SSAD_CHECK_ARG(dz_elems == N * H * W * Cout, "dz does not hold N x H x W x Cout elements");
     SSAD_CHECK_ARG(Cin % 64 == 0 && Cout % 64 == 0, "channel counts must be multiples of 64");
     SSAD_CHECK_ARG((int64_t)H * W * Cin < (int64_t)1 << 32 && (int64_t)H * W * Cout < (int64_t)1 << 32 &&
                    N * (int64_t)((H + 3) / 4) * ((W + 7) / 8) < (int64_t)1 << 31, "offsets inside an image are 32-bit, tile numbers int");
@@ -267,9 +268,11 @@ extern "C" int ssad_conv_wgrad3x3_halo16(const float* dz, const float* x, float*
         if (!set) {
             SSAD_SET_DYN_LDS((wgrad3x3_halo16_kernel<4, 16, true>), bytes);
             SSAD_SET_DYN_LDS((wgrad3x3_halo16_kernel<4, 16, false>), bytes);
+            SSAD_SET_DYN_LDS((wgrad3x3_halo16_kernel<4, 16, true, hf>), bytes);
             set = true;
         }
-        if (f16) hipLaunchKernelGGL((wgrad3x3_halo16_kernel<4, 16, true>), dim3(grid), dim3(512), bytes, st, p);
+        if (half_in) hipLaunchKernelGGL((wgrad3x3_halo16_kernel<4, 16, true, hf>), dim3(grid), dim3(512), bytes, st, p);
+        else if (f16) hipLaunchKernelGGL((wgrad3x3_halo16_kernel<4, 16, true>), dim3(grid), dim3(512), bytes, st, p);
         else hipLaunchKernelGGL((wgrad3x3_halo16_kernel<4, 16, false>), dim3(grid), dim3(512), bytes, st, p);
     } else {
         constexpr int bytes = 2 * (64 * (64 + 8) + 64 * (10 * 16 + 8)) * 2;
@@ -277,11 +280,24 @@ extern "C" int ssad_conv_wgrad3x3_halo16(const float* dz, const float* x, float*
         if (!set) {
             SSAD_SET_DYN_LDS((wgrad3x3_halo16_kernel<8, 8, true>), bytes);
             SSAD_SET_DYN_LDS((wgrad3x3_halo16_kernel<8, 8, false>), bytes);
+            SSAD_SET_DYN_LDS((wgrad3x3_halo16_kernel<8, 8, true, hf>), bytes);
             set = true;
         }
-        if (f16) hipLaunchKernelGGL((wgrad3x3_halo16_kernel<8, 8, true>), dim3(grid), dim3(512), bytes, st, p);
+        if (half_in) hipLaunchKernelGGL((wgrad3x3_halo16_kernel<8, 8, true, hf>), dim3(grid), dim3(512), bytes, st, p);
+        else if (f16) hipLaunchKernelGGL((wgrad3x3_halo16_kernel<8, 8, true>), dim3(grid), dim3(512), bytes, st, p);
         else hipLaunchKernelGGL((wgrad3x3_halo16_kernel<8, 8, false>), dim3(grid), dim3(512), bytes, st, p);
     }
     SSAD_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int ssad_conv_wgrad3x3_halo16(const float* dz, const float* x, float* slab, int splits, int64_t N, int H, int W, int Cin,
+                                         int Cout, int f16, int64_t dz_elems, void* stream) {
+    return wgrad3x3_halo16_impl(dz, x, 0, slab, splits, N, H, W, Cin, Cout, f16, dz_elems, stream);
+}
+
+// dz and x stored as halves (fp16 operands without a conversion); slabs and their reduction as above
+extern "C" int ssad_conv_wgrad3x3_halo16_h(const void* dz, const void* x, float* slab, int splits, int64_t N, int H, int W, int Cin,
+                                           int Cout, int64_t dz_elems, void* stream) {
+    return wgrad3x3_halo16_impl(dz, x, 1, slab, splits, N, H, W, Cin, Cout, 1, dz_elems, stream);
 }

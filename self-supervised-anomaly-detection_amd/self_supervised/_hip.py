@@ -49,7 +49,7 @@ SIGNATURES = {
     "ssad_linear_wgrad_small": [_c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_fp],
     "ssad_wgrad_splits": [_c_l, _c_i, _c_i, _c_i, _c_i],
     "ssad_wgrad_splits_bf16": [_c_l, _c_i, _c_i, _c_i, _c_i],
-    "ssad_conv_wgrad": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_conv_wgrad": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_l, _c_fp],
     "ssad_conv_igemm_fwd_bf16": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
                                  _c_i, _c_i, _c_fp],
     "ssad_conv_igemm_fwd_x3": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
@@ -62,7 +62,7 @@ SIGNATURES = {
                                  _c_i, _c_fp],
     "ssad_conv_igemm_dgrad_bf16": [_c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
                                    _c_i, _c_fp],
-    "ssad_conv_wgrad_bf16": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_conv_wgrad_bf16": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_l, _c_fp],
     "ssad_conv3x3_c64_stats_rows": [_c_l, _c_i, _c_i],
     "ssad_conv3x3_c64": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp, _c_f, _c_f,
                          _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
@@ -76,24 +76,24 @@ SIGNATURES = {
                                      _c_i, _c_fp],
     "ssad_wgrad3x3_halo_ok": [_c_i, _c_i, _c_i, _c_i, _c_i, _c_i],
     "ssad_wgrad3x3_halo_splits": [_c_l, _c_i, _c_i, _c_i, _c_i],
-    "ssad_conv_wgrad3x3_halo": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_conv_wgrad3x3_halo": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_l, _c_fp],
     "ssad_pack_stem_weight16": [_c_fp, _c_fp, _c_i, _c_fp],
     "ssad_stem_fwd_stats16": [_c_fp, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_f, _c_f, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_fp],
     "ssad_wgrad3x3_halo16_ok": [_c_i, _c_i, _c_i, _c_i, _c_i, _c_i],
     "ssad_wgrad3x3_halo16_splits": [_c_l, _c_i, _c_i, _c_i, _c_i],
-    "ssad_conv_wgrad3x3_halo16": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
-    "ssad_conv_wgrad3x3s2_halo": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_conv_wgrad3x3_halo16": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_l, _c_fp],
+    "ssad_conv_wgrad3x3s2_halo": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_l, _c_fp],
     "ssad_conv_igemm_fwd_f16": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
                                 _c_i, _c_i, _c_fp],
     "ssad_conv_igemm_dgrad_f16": [_c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
                                   _c_i, _c_fp],
-    "ssad_conv_wgrad_f16": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_conv_wgrad_f16": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_l, _c_fp],
     "ssad_sgd_step_dev": [_c_fp, _c_fp, _c_fp, _c_l, _c_fp, _c_fp, _c_fp],
     "ssad_scale_by_loss_scale": [_c_fp, _c_l, _c_fp, _c_fp],
     "ssad_check_finite": [_c_fp, _c_l, _c_fp, _c_fp],
     "ssad_loss_scaler_update": [_c_fp, _c_f, _c_f, _c_i, _c_fp],
-    "ssad_conv_wgrad_x3": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
-    "ssad_conv_wgrad_x6": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_conv_wgrad_x3": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_l, _c_fp],
+    "ssad_conv_wgrad_x6": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_l, _c_fp],
     "ssad_wgrad_reduce": [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
     "ssad_stem_im2col": [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_fp],
     "ssad_pack_stem_weight_2d": [_c_fp, _c_fp, _c_fp],
@@ -103,19 +103,19 @@ SIGNATURES = {
     "ssad_bn_bwd_reduce": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_fp, _c_fp],
     "ssad_bn_relu_maxpool_fwd": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_fp],
     "ssad_pool_bn_relu_bwd": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i,
-                              _c_fp, _c_fp],
+                              _c_l, _c_fp, _c_fp],
     "ssad_gradcam_map": [_c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_fp],
     "ssad_stem_wgrad_workspace": [_c_i, _c_i, _c_i],
-    "ssad_stem_wgrad": [_c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp],
+    "ssad_stem_wgrad": [_c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_l, _c_i, _c_i, _c_fp, _c_fp],
     "ssad_conv_stats_workspace": [_c_l, _c_i, _c_i, _c_i],
     "ssad_conv_igemm_fwd_stats": [_c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
                                   _c_f, _c_f, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
     "ssad_bn_bwd_reduce_zmask": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_fp, _c_fp],
     "ssad_bn_apply_bwd_zmask": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_fp],
     "ssad_bn_apply_bwd": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp],
-    "ssad_maxpool3x3s2_bwd": [_c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_maxpool3x3s2_bwd": [_c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_l, _c_fp],
     "ssad_maxpool3x3s2_fwd_idx": [_c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_fp],
-    "ssad_maxpool3x3s2_bwd_idx": [_c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_maxpool3x3s2_bwd_idx": [_c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_l, _c_fp],
     "ssad_gap_bwd": [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
     "ssad_softmax_ce": [_c_fp, _c_fp, _c_i, _c_i, _c_fp, _c_fp, _c_i, _c_f, _c_fp],
     "ssad_sgd_step": [_c_fp, _c_fp, _c_fp, _c_l, _c_f, _c_f, _c_f, _c_f, _c_fp],
@@ -138,6 +138,29 @@ SIGNATURES = {
     "ssad_resize_bicubic_u8": [_c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_i, _c_fp, _c_fp, _c_i, _c_fp],
     "ssad_u8hwc_to_f32chw_norm": [_c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
                                   _c_fp],
+    # half-tensor forms of the precision-16 training step (include/ssad.h, last section)
+    "ssad_cvt_f32_f16": [_c_fp, _c_fp, _c_l, _c_fp],
+    "ssad_flip_transpose_batch_h": [_c_fp, _c_fp, ctypes.POINTER(ctypes.c_int64), _c_i, _c_fp],
+    "ssad_stem_fwd_stats16_h": [_c_fp, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_f, _c_f, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
+    "ssad_bn_relu_maxpool_fwd_h": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_conv_igemm_fwd_stats_h": [_c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
+                                    _c_f, _c_f, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
+    "ssad_conv_igemm_dgrad_h": [_c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_conv3x3_c64_h": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp, _c_f, _c_f,
+                           _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
+    "ssad_bn_stats_h": [_c_fp, _c_l, _c_i, _c_f, _c_f, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
+    "ssad_bn_apply_fwd_h": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp],
+    "ssad_gap_fwd_h": [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_gap_bwd_h": [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_bn_bwd_reduce_h": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_fp, _c_fp],
+    "ssad_bn_bwd_reduce_zmask_h": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_fp, _c_fp],
+    "ssad_bn_apply_bwd_h": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp],
+    "ssad_bn_apply_bwd_zmask_h": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_fp],
+    "ssad_pool_bn_relu_bwd_h": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i,
+                                _c_l, _c_fp, _c_fp],
+    "ssad_conv_wgrad3x3_halo16_h": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_l, _c_fp],
+    "ssad_conv_wgrad_f16_h": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_l, _c_fp],
+    "ssad_stem_wgrad_h": [_c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_l, _c_i, _c_i, _c_fp, _c_fp],
 }
 RESTYPES = {"ssad_conv3x3_c64_stats_rows": _c_l, "ssad_colreduce_workspace": _c_l, "ssad_conv_stats_workspace": _c_l, "ssad_stem_wgrad_workspace": _c_l, "ssad_auroc_workspace": _c_l, "ssad_obj_mask_workspace": _c_l, "ssad_pro_curve_workspace": _c_l,
             "ssad_best_f1_workspace": _c_l}
@@ -185,8 +208,13 @@ def ptr(t, allow_none=False, dtype=torch.float32):
         raise HipExtensionError("null tensor")
     if not (t.is_cuda and t.dtype == dtype and t.is_contiguous()):
         raise HipExtensionError(
-            f"expected a contiguous fp32 ROCm tensor, got device={t.device} dtype={t.dtype} contiguous={t.is_contiguous()}")
+            f"expected a contiguous {dtype} ROCm tensor, got device={t.device} dtype={t.dtype} contiguous={t.is_contiguous()}")
     return t.data_ptr()
+
+
+def hptr(t, allow_none=False):
+    """Device pointer of a contiguous half tensor (the activations of the precision-16 step)."""
+    return ptr(t, allow_none, torch.float16)
 
 
 def stream():

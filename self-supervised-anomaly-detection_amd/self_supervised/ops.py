@@ -13,6 +13,20 @@ def _new(shape, like):
     return torch.empty(shape, device=like.device, dtype=torch.float32)
 
 
+def _newh(shape, like):
+    """A half tensor: the activations of the precision-16 step are stored as torch.autocast stores them."""
+    return torch.empty(shape, device=like.device, dtype=torch.float16)
+
+
+def _is_h(t):
+    return t is not None and t.dtype == torch.float16
+
+
+def _p(t, allow_none=False):
+    """Device pointer of a contiguous fp32 OR half tensor (the `_h` entry points take void*)."""
+    return _hip.ptr(t, allow_none, torch.float16 if _is_h(t) else torch.float32)
+
+
 def _run(kernel, flops, nbytes, rc_fn, exec_flops=None, tile=None):
     """Launch through the C ABI; when PROFILE is on, bracket the launch with events on the launch stream.
     flops = ALGORITHMIC FLOPs of the op; exec_flops = the FLOPs the kernel really issues to the matrix cores when that
@@ -124,9 +138,10 @@ def stem_fwd_stats(img, wk, eps, momentum, running_mean, running_var):
     return out, mean, invstd
 
 
-def stem_fwd_stats16(img, w_oihw, eps, momentum, running_mean, running_var, mode):
+def stem_fwd_stats16(img, w_oihw, eps, momentum, running_mean, running_var, mode, out_half=False):
     """The training stem conv with fp16 (mode 2) or bf16 (mode 1) operands and fp32 accumulation (csrc/stem16.hip):
-    -> (z [B][Ho][Wo][64] fp32, mean, invstd), statistics from the accumulators as in stem_fwd_stats."""
+    -> (z [B][Ho][Wo][64] fp32, mean, invstd), statistics from the accumulators as in stem_fwd_stats.
+    out_half (mode 2): z is stored as halves and the statistics are those of the stored halves."""
     b, c, h, w = img.shape
     assert c == 3 and tuple(w_oihw.shape) == (64, 3, 7, 7) and int(mode) in (1, 2)
     assert h >= 64 and w >= 64, "images below 64 x 64 are resized first (models.py:217-219): that is the fp32 stem's loader"
@@ -134,9 +149,17 @@ def stem_fwd_stats16(img, w_oihw, eps, momentum, running_mean, running_var, mode
     wk = torch.empty(14 * 64 * 16, device=img.device, dtype=torch.float16 if int(mode) == 2 else torch.bfloat16)
     _hip.check(lib.ssad_pack_stem_weight16(_hip.ptr(w_oihw), wk.data_ptr(), int(int(mode) == 2), _hip.stream()))
     ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
-    out = _new((b, ho, wo, 64), img)
     mean, invstd = _new((64,), img), _new((64,), img)
     ws = torch.empty(lib.ssad_stem_stats_rows() * 128, device=img.device, dtype=torch.float64)
+    if out_half:
+        assert int(mode) == 2
+        out = _newh((b, ho, wo, 64), img)
+        _run("stem_conv7x7_h16", 2.0 * b * ho * wo * 64 * 147, 4.0 * b * 3 * h * w + 2.0 * b * ho * wo * 64,
+             lambda: lib.ssad_stem_fwd_stats16_h(_hip.ptr(img), b, h, w, wk.data_ptr(), out.data_ptr(), eps, momentum, _hip.ptr(mean),
+                                                 _hip.ptr(invstd), _hip.ptr(running_mean, True), _hip.ptr(running_var, True),
+                                                 ws.data_ptr(), _hip.stream()))
+        return out, mean, invstd
+    out = _new((b, ho, wo, 64), img)
     _run(_kname("stem_conv7x7", mode), 2.0 * b * ho * wo * 64 * 147, 4.0 * (b * 3 * h * w + b * ho * wo * 64),
          lambda: lib.ssad_stem_fwd_stats16(_hip.ptr(img), b, h, w, wk.data_ptr(), _hip.ptr(out), eps, momentum, _hip.ptr(mean),
                                            _hip.ptr(invstd), _hip.ptr(running_mean, True), _hip.ptr(running_var, True),
@@ -234,10 +257,19 @@ def conv_fwd_stats(x, w_ohwi, eps, momentum, running_mean, running_var, stride=1
     cout, kh, kw, cin2 = w_ohwi.shape
     assert cin == cin2
     ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
-    out = _new((n, ho, wo, cout), x)
     mean, invstd = _new((cout,), x), _new((cout,), x)
     lib = _hip.lib()
     ws = torch.empty(lib.ssad_conv_stats_workspace(n, ho, wo, cout), device=x.device, dtype=torch.float64)
+    if _is_h(x):                 # precision-16 step with half tensors: x, the weights and z are halves
+        assert _is_h(w_ohwi) and bf16 == 2
+        out = _newh((n, ho, wo, cout), x)
+        _run("conv_igemm_h16", 2.0 * out.numel() * kh * kw * cin, 2.0 * (x.numel() + out.numel() + w_ohwi.numel()),
+             lambda: lib.ssad_conv_igemm_fwd_stats_h(x.data_ptr(), w_ohwi.data_ptr(), out.data_ptr(), n, h, w, cin, cout, kh, kw,
+                                                     stride, pad, eps, momentum, _hip.ptr(mean), _hip.ptr(invstd),
+                                                     _hip.ptr(running_mean, True), _hip.ptr(running_var, True), ws.data_ptr(),
+                                                     _hip.stream()))
+        return out, mean, invstd
+    out = _new((n, ho, wo, cout), x)
     nb = 4.0 * (x.numel() + out.numel() + w_ohwi.numel())
     _run(_kname("conv_igemm", bf16), 2.0 * out.numel() * kh * kw * cin, nb,
          lambda: lib.ssad_conv_igemm_fwd_stats(_hip.ptr(x), _hip.ptr(w_ohwi), _hip.ptr(out), n, h, w, cin, cout, kh, kw,
@@ -256,7 +288,9 @@ def conv3x3_c64(x, w_ohwi, residual=None, transform=None, emit=False, stats=None
     n, h, w, c = x.shape
     assert c == 64 and tuple(w_ohwi.shape) == (64, 3, 3, 64)
     lib = _hip.lib()
-    out = _new((n, h, w, 64), x)
+    half = _is_h(x)
+    assert residual is None or tuple(residual.shape) == (n, h, w, 64), "residual must have the output's shape"
+    out = _newh((n, h, w, 64), x) if half else _new((n, h, w, 64), x)
     em = torch.empty_like(x) if emit else None
     tr = transform if transform is not None else (None, None, None, None)
     mean = invstd = ws = None
@@ -269,12 +303,20 @@ def conv3x3_c64(x, w_ohwi, residual=None, transform=None, emit=False, stats=None
     nb = 4.0 * (x.numel() + out.numel() * (2 if residual is not None else 1) + (out.numel() if emit else 0) + w_ohwi.numel())
     op = int(bf16)
     assert op in (0, 1, 2), "conv3x3_c64: exact fp32, or bf16 (1) / fp16 (2) operands"
-    _run(_kname("conv_c64", op), 2.0 * out.numel() * 9 * 64, nb,
-         lambda: lib.ssad_conv3x3_c64_op(_hip.ptr(x), _hip.ptr(w_ohwi), _hip.ptr(out), _hip.ptr(residual, True),
-                                         res_mask.data_ptr() if res_mask is not None else None, _hip.ptr(tr[0], True),
-                                         _hip.ptr(tr[1], True), _hip.ptr(tr[2], True), _hip.ptr(tr[3], True), _hip.ptr(em, True),
-                                         n, h, w, ws.data_ptr() if ws is not None else None, eps, mom, _hip.ptr(mean, True),
-                                         _hip.ptr(invstd, True), _hip.ptr(rm, True), _hip.ptr(rv, True), op, _hip.stream()))
+    if half:
+        assert op == 2 and res_mask is None and (residual is None or _is_h(residual))
+        _run("conv_c64_h16", 2.0 * out.numel() * 9 * 64, nb / 2 + 2.0 * w_ohwi.numel(),
+             lambda: lib.ssad_conv3x3_c64_h(x.data_ptr(), _hip.ptr(w_ohwi), out.data_ptr(), _p(residual, True), _hip.ptr(tr[0], True),
+                                            _hip.ptr(tr[1], True), _hip.ptr(tr[2], True), _hip.ptr(tr[3], True), _p(em, True),
+                                            n, h, w, ws.data_ptr() if ws is not None else None, eps, mom, _hip.ptr(mean, True),
+                                            _hip.ptr(invstd, True), _hip.ptr(rm, True), _hip.ptr(rv, True), _hip.stream()))
+    else:
+        _run(_kname("conv_c64", op), 2.0 * out.numel() * 9 * 64, nb,
+             lambda: lib.ssad_conv3x3_c64_op(_hip.ptr(x), _hip.ptr(w_ohwi), _hip.ptr(out), _hip.ptr(residual, True),
+                                             res_mask.data_ptr() if res_mask is not None else None, _hip.ptr(tr[0], True),
+                                             _hip.ptr(tr[1], True), _hip.ptr(tr[2], True), _hip.ptr(tr[3], True), _hip.ptr(em, True),
+                                             n, h, w, ws.data_ptr() if ws is not None else None, eps, mom, _hip.ptr(mean, True),
+                                             _hip.ptr(invstd, True), _hip.ptr(rm, True), _hip.ptr(rv, True), op, _hip.stream()))
     res = [out]
     if emit:
         res.append(em)
@@ -328,6 +370,11 @@ def gap_fwd(x, out, offset, hwnc=False):
         h, w, n, c = x.shape
     else:
         n, h, w, c = x.shape
+    if _is_h(x):
+        assert not hwnc
+        _run("gap_h16", 0.0, 2.0 * x.numel() + 4.0 * n * c,
+             lambda: _hip.lib().ssad_gap_fwd_h(x.data_ptr(), _hip.ptr(out), n, h * w, c, out.shape[1], offset, _hip.stream()))
+        return out
     _run("gap", 0.0, 4.0 * (x.numel() + n * c),
          lambda: _hip.lib().ssad_gap_fwd(_hip.ptr(x), _hip.ptr(out), n, h * w, c, out.shape[1], offset, int(hwnc),
                                          _hip.stream()))
@@ -454,6 +501,16 @@ def conv_dgrad(dy, w_flipT, x_shape, stride, pad, residual=None, bf16=False, res
     """dy NHWC [N][Hy][Wy][Cout]; w_flipT [Cin][KH][KW][Cout] -> dx NHWC of x_shape (+ residual [under res_mask])."""
     n, hy, wy, cout = dy.shape
     cin, kh, kw, _ = w_flipT.shape
+    assert residual is None or tuple(residual.shape) == tuple(x_shape), "residual must have dx's shape"
+    assert tuple(x_shape) == (n, x_shape[1], x_shape[2], cin) and w_flipT.shape[-1] == cout
+    if _is_h(dy):
+        assert _is_h(w_flipT) and bf16 == 2 and res_mask is None and (residual is None or _is_h(residual))
+        dx = _newh(tuple(x_shape), dy)
+        _run("conv_igemm_h16", 2.0 * dx.numel() * kh * kw * cout / (stride * stride),
+             2.0 * (dy.numel() + dx.numel() * (2 if residual is not None else 1) + w_flipT.numel()),
+             lambda: _hip.lib().ssad_conv_igemm_dgrad_h(dy.data_ptr(), w_flipT.data_ptr(), dx.data_ptr(), _p(residual, True), n, hy, wy,
+                                                        cout, x_shape[1], x_shape[2], cin, kh, kw, stride, pad, _hip.stream()))
+        return dx
     dx = _new(tuple(x_shape), dy)
     if res_mask is not None:
         assert not bf16 and residual is not None
@@ -485,8 +542,29 @@ def conv_wgrad(dy, x, dw_out, kh, kw, stride, pad, kreal=None, to_oihw=False, ac
     cout = dy.shape[-1]
     m = dy.numel() // cout
     lib = _hip.lib()
+    assert tuple(dy.shape[:-1]) == (n, (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1), \
+        f"dy {tuple(dy.shape)} is not the output of a {kh} x {kw} / stride {stride} / pad {pad} conv over x {tuple(x.shape)}"
     if bf16 == 6 and not force_x6:
         bf16 = False            # (see below)
+    if _is_h(dy):
+        # precision-16 step with half tensors: the same two 16-bit kernels, their operands read as the halves they are stored as
+        assert _is_h(x) and bf16 == 2 and kreal is None
+        if lib.ssad_wgrad3x3_halo16_ok(cin, cout, kh, kw, stride, pad):
+            splits = lib.ssad_wgrad3x3_halo16_splits(n, h, w, cin, cout)
+            slab = _new((splits, cout, 9 * cin), dy)
+            _run("wgrad_h16", 2.0 * m * cout * 9 * cin, 2.0 * (dy.numel() + x.numel()) + 4.0 * slab.numel(),
+                 lambda: lib.ssad_conv_wgrad3x3_halo16_h(dy.data_ptr(), x.data_ptr(), _hip.ptr(slab), splits, n, h, w, cin, cout,
+                                                         dy.numel(), _hip.stream()))
+        else:
+            splits = lib.ssad_wgrad_splits_bf16(m, cin, cout, kh, kw)
+            slab = _new((splits, cout, kh * kw * cin), dy)
+            _run("wgrad_h16", 2.0 * m * cout * kh * kw * cin, 2.0 * (dy.numel() + x.numel()) * kh * kw + 4.0 * slab.numel(),
+                 lambda: lib.ssad_conv_wgrad_f16_h(dy.data_ptr(), x.data_ptr(), _hip.ptr(slab), splits, n, h, w, cin, cout, kh, kw,
+                                                   stride, pad, dy.numel(), _hip.stream()))
+        _run("wgrad_reduce", 0.0, 4.0 * slab.numel(),
+             lambda: lib.ssad_wgrad_reduce(_hip.ptr(slab), _hip.ptr(dw_out), splits, cout, kh * kw * cin, kh, kw, cin, int(to_oihw),
+                                           int(accumulate), _hip.stream()))
+        return dw_out
     if (not bf16 and kreal is None and kh == 1 and kw == 1 and h == 1 and w == 1 and m <= lib.ssad_linear_small_max_rows()):
         # linear layer over a training batch's rows: one launch straight into the gradient (OIHW == OHWI for 1 x 1)
         _run("wgrad_f32", 2.0 * m * cout * cin, 4.0 * (dy.numel() + x.numel() + cout * cin),
@@ -503,10 +581,10 @@ def conv_wgrad(dy, x, dw_out, kh, kw, stride, pad, kreal=None, to_oihw=False, ac
         slab = _new((splits, cout, 9 * cin), dy)
         if halo == 1:
             fn = lambda: lib.ssad_conv_wgrad3x3_halo(_hip.ptr(dy), _hip.ptr(x), _hip.ptr(slab), splits, n, h, w, cin, cout,
-                                                     _hip.stream())
+                                                     dy.numel(), _hip.stream())
         else:
             fn = lambda: lib.ssad_conv_wgrad3x3s2_halo(_hip.ptr(dy), _hip.ptr(x), _hip.ptr(slab), splits, n, ho, wo, h, w, cin,
-                                                       cout, _hip.stream())
+                                                       cout, dy.numel(), _hip.stream())
         _run("wgrad_f32", 2.0 * m * cout * 9 * cin, 4.0 * (dy.numel() + x.numel() + slab.numel()), fn)
         _run("wgrad_reduce", 0.0, 4.0 * slab.numel(),
              lambda: lib.ssad_wgrad_reduce(_hip.ptr(slab), _hip.ptr(dw_out), splits, cout, 9 * cin, 3, 3, cin, int(to_oihw),
@@ -519,7 +597,7 @@ def conv_wgrad(dy, x, dw_out, kh, kw, stride, pad, kreal=None, to_oihw=False, ac
         slab = _new((splits, cout, 9 * cin), dy)
         _run(_kname("wgrad", bf16), 2.0 * m * cout * 9 * cin, 4.0 * (dy.numel() + x.numel() + slab.numel()),
              lambda: lib.ssad_conv_wgrad3x3_halo16(_hip.ptr(dy), _hip.ptr(x), _hip.ptr(slab), splits, n, h, w, cin, cout,
-                                                   int(bf16 == 2), _hip.stream()))
+                                                   int(bf16 == 2), dy.numel(), _hip.stream()))
         _run("wgrad_reduce", 0.0, 4.0 * slab.numel(),
              lambda: lib.ssad_wgrad_reduce(_hip.ptr(slab), _hip.ptr(dw_out), splits, cout, 9 * cin, 3, 3, cin, int(to_oihw),
                                            int(accumulate), _hip.stream()))
@@ -535,7 +613,8 @@ def conv_wgrad(dy, x, dw_out, kh, kw, stride, pad, kreal=None, to_oihw=False, ac
           _hip.lib().ssad_conv_wgrad_bf16 if bf16 else _hip.lib().ssad_conv_wgrad)
     _run(_kname("wgrad", bf16), 2.0 * m * cout * kh * kw * cin,
          4.0 * (dy.numel() * kh * kw + x.numel() * kh * kw + slab.numel()),
-         lambda: fn(_hip.ptr(dy), _hip.ptr(x), _hip.ptr(slab), splits, n, h, w, cin, cout, kh, kw, stride, pad, _hip.stream()))
+         lambda: fn(_hip.ptr(dy), _hip.ptr(x), _hip.ptr(slab), splits, n, h, w, cin, cout, kh, kw, stride, pad, dy.numel(),
+                    _hip.stream()))
     rkh, rkw, rcin = kreal if kreal else (kh, kw, cin)
     _run("wgrad_reduce", 0.0, 4.0 * slab.numel(),
          lambda: _hip.lib().ssad_wgrad_reduce(_hip.ptr(slab), _hip.ptr(dw_out), splits, cout, kh * kw * cin, rkh, rkw, rcin,
@@ -546,11 +625,17 @@ def conv_wgrad(dy, x, dw_out, kh, kw, stride, pad, kreal=None, to_oihw=False, ac
 def stem_wgrad(img, dz, dw_out, to_oihw=False, accumulate=False):
     """Weight gradient of the stem conv from the NCHW image and dz [B][Ho][Wo][64] -> dw_out (64*147 floats)."""
     b, c, h, w = img.shape
-    assert c == 3 and dz.shape[0] == b and dz.shape[-1] == 64
+    _, _, _, ho, wo = stem_geometry(h, w, 0, 0)
+    assert c == 3 and tuple(dz.shape) == (b, ho, wo, 64), f"dz {tuple(dz.shape)} does not belong to images {tuple(img.shape)}"
     lib = _hip.lib()
     ws = torch.empty(lib.ssad_stem_wgrad_workspace(b, h, w), device=img.device, dtype=torch.float32)
+    if _is_h(dz):
+        _run("stem_wgrad_h16", 2.0 * dz.numel() * 147, 2.0 * dz.numel() + 4.0 * img.numel() * 1.6,
+             lambda: lib.ssad_stem_wgrad_h(_hip.ptr(img), dz.data_ptr(), _hip.ptr(dw_out), b, h, w, dz.numel(), int(to_oihw), int(accumulate),
+                                           _hip.ptr(ws), _hip.stream()))
+        return dw_out
     _run("stem_wgrad", 2.0 * dz.numel() * 147, 4.0 * (dz.numel() + img.numel() * 1.6),
-         lambda: lib.ssad_stem_wgrad(_hip.ptr(img), _hip.ptr(dz), _hip.ptr(dw_out), b, h, w, int(to_oihw), int(accumulate),
+         lambda: lib.ssad_stem_wgrad(_hip.ptr(img), _hip.ptr(dz), _hip.ptr(dw_out), b, h, w, dz.numel(), int(to_oihw), int(accumulate),
                                      _hip.ptr(ws), _hip.stream()))
     return dw_out
 
@@ -579,8 +664,9 @@ def bn_stats(z, c, eps, momentum, running_mean, running_var):
     r = z.numel() // c
     mean, invstd = _new((c,), z), _new((c,), z)
     ws = _colreduce_ws(r, c, z)
-    _run("bn_stats", 0.0, 4.0 * z.numel(),
-         lambda: _hip.lib().ssad_bn_stats(_hip.ptr(z), r, c, eps, momentum, _hip.ptr(mean), _hip.ptr(invstd),
+    fn = _hip.lib().ssad_bn_stats_h if _is_h(z) else _hip.lib().ssad_bn_stats
+    _run("bn_stats", 0.0, z.element_size() * z.numel(),
+         lambda: fn(_p(z), r, c, eps, momentum, _hip.ptr(mean), _hip.ptr(invstd),
                                           _hip.ptr(running_mean, True), _hip.ptr(running_var, True), ws.data_ptr(),
                                           _hip.stream()))
     return mean, invstd
@@ -617,18 +703,22 @@ def bn_small_bwd(dy, z, mean, invstd, gamma, zmask_beta, dbeta, dgamma, dbias=No
 def bn_apply_fwd(z, mean, invstd, gamma, beta, residual, relu):
     c = mean.numel()
     y = torch.empty_like(z)
-    _run("bn_apply_fwd", 0.0, 4.0 * z.numel() * (3 if residual is not None else 2),
-         lambda: _hip.lib().ssad_bn_apply_fwd(_hip.ptr(z), _hip.ptr(mean), _hip.ptr(invstd), _hip.ptr(gamma), _hip.ptr(beta),
-                                              _hip.ptr(residual, True), _hip.ptr(y), z.numel() // c, c, int(relu),
-                                              _hip.stream()))
+    assert residual is None or (residual.dtype == z.dtype and residual.shape == z.shape), "residual must have z's shape"
+    assert z.shape[-1] == c
+    fn = _hip.lib().ssad_bn_apply_fwd_h if _is_h(z) else _hip.lib().ssad_bn_apply_fwd
+    _run("bn_apply_fwd_h16" if _is_h(z) else "bn_apply_fwd", 0.0, z.element_size() * z.numel() * (3 if residual is not None else 2),
+         lambda: fn(_p(z), _hip.ptr(mean), _hip.ptr(invstd), _hip.ptr(gamma), _hip.ptr(beta),
+                    _p(residual, True), _p(y), z.numel() // c, c, int(relu), _hip.stream()))
     return y
 
 
 def bn_bwd_reduce(dy, yact, z, mean, invstd, dbeta, dgamma, c):
     r = dy.numel() // c
     ws = _colreduce_ws(r, c, dy)
-    _run("bn_bwd_reduce", 0.0, 4.0 * dy.numel() * (1 + (yact is not None) + (z is not None)),
-         lambda: _hip.lib().ssad_bn_bwd_reduce(_hip.ptr(dy), _hip.ptr(yact, True), _hip.ptr(z, True), _hip.ptr(mean, True),
+    assert all(t is None or (t.dtype == dy.dtype and t.shape == dy.shape) for t in (yact, z)), "dy, yact, z must share one shape"
+    fn = _hip.lib().ssad_bn_bwd_reduce_h if _is_h(dy) else _hip.lib().ssad_bn_bwd_reduce
+    _run("bn_bwd_reduce_h16" if _is_h(dy) else "bn_bwd_reduce", 0.0, dy.element_size() * dy.numel() * (1 + (yact is not None) + (z is not None)),
+         lambda: fn(_p(dy), _p(yact, True), _p(z, True), _hip.ptr(mean, True),
                                                _hip.ptr(invstd, True), _hip.ptr(dbeta, True), _hip.ptr(dgamma, True), r, c,
                                                ws.data_ptr(), _hip.stream()))
 
@@ -637,11 +727,13 @@ def bn_apply_bwd(dy, yact, z, mean, invstd, gamma, dbeta, dgamma, want_dres, eva
     c = mean.numel()
     dz = torch.empty_like(dy)
     dres = torch.empty_like(dy) if want_dres else None
-    _run("bn_apply_bwd", 0.0, 4.0 * dy.numel() * (3 + (yact is not None) + want_dres),
-         lambda: _hip.lib().ssad_bn_apply_bwd(_hip.ptr(dy), _hip.ptr(yact, True), _hip.ptr(z, True), _hip.ptr(mean),
-                                              _hip.ptr(invstd), _hip.ptr(gamma), _hip.ptr(dbeta, True), _hip.ptr(dgamma, True),
-                                              _hip.ptr(dz), _hip.ptr(dres, True), dy.numel() // c, c, int(eval_mode),
-                                              _hip.stream()))
+    assert all(t is None or (t.dtype == dy.dtype and t.shape == dy.shape) for t in (yact, z)), "dy, yact, z must share one shape"
+    assert dy.shape[-1] == c
+    fn = _hip.lib().ssad_bn_apply_bwd_h if _is_h(dy) else _hip.lib().ssad_bn_apply_bwd
+    _run("bn_apply_bwd_h16" if _is_h(dy) else "bn_apply_bwd", 0.0, dy.element_size() * dy.numel() * (3 + (yact is not None) + want_dres),
+         lambda: fn(_p(dy), _p(yact, True), _p(z, True), _hip.ptr(mean),
+                    _hip.ptr(invstd), _hip.ptr(gamma), _hip.ptr(dbeta, True), _hip.ptr(dgamma, True),
+                    _p(dz), _p(dres, True), dy.numel() // c, c, int(eval_mode), _hip.stream()))
     return dz, dres
 
 
@@ -651,15 +743,18 @@ def bn_bwd_zmask(dy, z, mean, invstd, gamma, beta, dbeta, dgamma):
     r = dy.numel() // c
     ws = _colreduce_ws(r, c, dy)
     lib = _hip.lib()
-    _run("bn_bwd_reduce", 0.0, 8.0 * dy.numel(),
-         lambda: lib.ssad_bn_bwd_reduce_zmask(_hip.ptr(dy), _hip.ptr(z), _hip.ptr(mean), _hip.ptr(invstd), _hip.ptr(gamma),
-                                              _hip.ptr(beta), _hip.ptr(dbeta), _hip.ptr(dgamma), r, c, ws.data_ptr(),
-                                              _hip.stream()))
+    assert z.dtype == dy.dtype and z.shape == dy.shape, "dy and z must share one shape"
+    half = _is_h(dy)
+    es = dy.element_size()
+    f_red = lib.ssad_bn_bwd_reduce_zmask_h if half else lib.ssad_bn_bwd_reduce_zmask
+    f_app = lib.ssad_bn_apply_bwd_zmask_h if half else lib.ssad_bn_apply_bwd_zmask
+    _run("bn_bwd_reduce_h16" if half else "bn_bwd_reduce", 0.0, 2.0 * es * dy.numel(),
+         lambda: f_red(_p(dy), _p(z), _hip.ptr(mean), _hip.ptr(invstd), _hip.ptr(gamma),
+                       _hip.ptr(beta), _hip.ptr(dbeta), _hip.ptr(dgamma), r, c, ws.data_ptr(), _hip.stream()))
     dz = torch.empty_like(dy)
-    _run("bn_apply_bwd", 0.0, 12.0 * dy.numel(),
-         lambda: lib.ssad_bn_apply_bwd_zmask(_hip.ptr(dy), _hip.ptr(z), _hip.ptr(mean), _hip.ptr(invstd), _hip.ptr(gamma),
-                                             _hip.ptr(beta), _hip.ptr(dbeta), _hip.ptr(dgamma), _hip.ptr(dz), r, c,
-                                             _hip.stream()))
+    _run("bn_apply_bwd_h16" if half else "bn_apply_bwd", 0.0, 3.0 * es * dy.numel(),
+         lambda: f_app(_p(dy), _p(z), _hip.ptr(mean), _hip.ptr(invstd), _hip.ptr(gamma),
+                       _hip.ptr(beta), _hip.ptr(dbeta), _hip.ptr(dgamma), _p(dz), r, c, _hip.stream()))
     return dz
 
 
@@ -667,8 +762,14 @@ def bn_relu_maxpool_fwd(z, mean, invstd, gamma, beta):
     """Training stem tail: pooled = maxpool3x3s2(relu(bn(z))) + argmax slots, without storing the activation."""
     n, h, w, c = z.shape
     ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
-    out = _new((n, ho, wo, c), z)
     idx = torch.empty((n, ho, wo, c), device=z.device, dtype=torch.uint8)
+    if _is_h(z):
+        out = _newh((n, ho, wo, c), z)
+        _run("maxpool3x3s2_h16", 0.0, 2.0 * (z.numel() + out.numel()) + idx.numel(),
+             lambda: _hip.lib().ssad_bn_relu_maxpool_fwd_h(z.data_ptr(), _hip.ptr(mean), _hip.ptr(invstd), _hip.ptr(gamma),
+                                                           _hip.ptr(beta), out.data_ptr(), idx.data_ptr(), n, h, w, c, _hip.stream()))
+        return out, idx
+    out = _new((n, ho, wo, c), z)
     _run("maxpool3x3s2", 0.0, 4.0 * (z.numel() + out.numel()) + idx.numel(),
          lambda: _hip.lib().ssad_bn_relu_maxpool_fwd(_hip.ptr(z), _hip.ptr(mean), _hip.ptr(invstd), _hip.ptr(gamma),
                                                      _hip.ptr(beta), _hip.ptr(out), idx.data_ptr(), n, h, w, c, _hip.stream()))
@@ -678,12 +779,21 @@ def bn_relu_maxpool_fwd(z, mean, invstd, gamma, beta):
 def pool_bn_relu_bwd(idx, dpool, z, mean, invstd, gamma, beta, dbeta, dgamma):
     """Training stem head of the backward pass: (idx, dpool, z) -> dz, filling dbeta / dgamma."""
     n, h, w, c = z.shape
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    assert tuple(dpool.shape) == (n, ho, wo, c) and tuple(idx.shape) == (n, ho, wo, c) and dpool.dtype == z.dtype, \
+        f"pooled gradient {tuple(dpool.shape)} / slots {tuple(idx.shape)} do not belong to z {tuple(z.shape)}"
     dz = torch.empty_like(z)
     ws = _colreduce_ws(n * h * w, c, z)
+    if _is_h(z):
+        _run("pool_bn_bwd_h16", 0.0, 2.0 * (3 * z.numel() + 2 * dpool.numel()),
+             lambda: _hip.lib().ssad_pool_bn_relu_bwd_h(idx.data_ptr(), dpool.data_ptr(), z.data_ptr(), _hip.ptr(mean), _hip.ptr(invstd),
+                                                        _hip.ptr(gamma), _hip.ptr(beta), _hip.ptr(dbeta), _hip.ptr(dgamma),
+                                                        dz.data_ptr(), n, h, w, c, dpool.numel(), ws.data_ptr(), _hip.stream()))
+        return dz
     _run("pool_bn_bwd", 0.0, 4.0 * (3 * z.numel() + 2 * dpool.numel()),
          lambda: _hip.lib().ssad_pool_bn_relu_bwd(idx.data_ptr(), _hip.ptr(dpool), _hip.ptr(z), _hip.ptr(mean), _hip.ptr(invstd),
                                                   _hip.ptr(gamma), _hip.ptr(beta), _hip.ptr(dbeta), _hip.ptr(dgamma),
-                                                  _hip.ptr(dz), n, h, w, c, ws.data_ptr(), _hip.stream()))
+                                                  _hip.ptr(dz), n, h, w, c, dpool.numel(), ws.data_ptr(), _hip.stream()))
     return dz
 
 
@@ -691,7 +801,7 @@ def maxpool3x3s2_bwd(x, dy):
     n, h, w, c = x.shape
     dx = torch.empty_like(x)
     _run("maxpool_bwd", 0.0, 4.0 * (2 * x.numel() + dy.numel()),
-         lambda: _hip.lib().ssad_maxpool3x3s2_bwd(_hip.ptr(x), _hip.ptr(dy), _hip.ptr(dx), n, h, w, c, _hip.stream()))
+         lambda: _hip.lib().ssad_maxpool3x3s2_bwd(_hip.ptr(x), _hip.ptr(dy), _hip.ptr(dx), n, h, w, c, dy.numel(), _hip.stream()))
     return dx
 
 
@@ -707,14 +817,21 @@ def maxpool3x3s2_fwd_idx(x):
 
 def maxpool3x3s2_bwd_idx(idx, dy, x_shape):
     n, h, w, c = x_shape
+    assert tuple(dy.shape) == (n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c) and idx.shape == dy.shape, "dy / idx do not belong to x_shape"
     dx = _new(tuple(x_shape), dy)
     _run("maxpool_bwd", 0.0, 4.0 * (dx.numel() + dy.numel()) + idx.numel(),
-         lambda: _hip.lib().ssad_maxpool3x3s2_bwd_idx(idx.data_ptr(), _hip.ptr(dy), _hip.ptr(dx), n, h, w, c, _hip.stream()))
+         lambda: _hip.lib().ssad_maxpool3x3s2_bwd_idx(idx.data_ptr(), _hip.ptr(dy), _hip.ptr(dx), n, h, w, c, dy.numel(),
+                                                      _hip.stream()))
     return dx
 
 
 def gap_bwd(dpooled, dy, offset, accumulate):
     n, h, w, c = dy.shape
+    if _is_h(dy):
+        _run("gap_bwd_h16", 0.0, 2.0 * dy.numel() * (2 if accumulate else 1),
+             lambda: _hip.lib().ssad_gap_bwd_h(_hip.ptr(dpooled), dy.data_ptr(), n, h * w, c, dpooled.shape[1], offset,
+                                               int(accumulate), _hip.stream()))
+        return dy
     _run("gap_bwd", 0.0, 4.0 * dy.numel() * (2 if accumulate else 1),
          lambda: _hip.lib().ssad_gap_bwd(_hip.ptr(dpooled), _hip.ptr(dy), n, h * w, c, dpooled.shape[1], offset,
                                          int(accumulate), _hip.stream()))
@@ -785,3 +902,11 @@ def bn_bwd_mask(dy, mask, z, mean, invstd, gamma, dbeta, dgamma):
          lambda: lib.ssad_bn_apply_bwd_mask(_hip.ptr(dy), mp, _hip.ptr(z), _hip.ptr(mean), _hip.ptr(invstd), _hip.ptr(gamma),
                                             _hip.ptr(dbeta), _hip.ptr(dgamma), _hip.ptr(dz), r, c, _hip.stream()))
     return dz
+
+
+def cvt_f32_f16(src, dst):
+    """One rounded (half) copy of a flat fp32 arena: the weights the half-tensor kernels of the precision-16 step read."""
+    assert src.dtype == torch.float32 and dst.dtype == torch.float16 and src.numel() == dst.numel()
+    _run("cvt_f32_f16", 0.0, 6.0 * src.numel(),
+         lambda: _hip.lib().ssad_cvt_f32_f16(_hip.ptr(src), dst.data_ptr(), src.numel(), _hip.stream()))
+    return dst

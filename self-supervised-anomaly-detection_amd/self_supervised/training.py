@@ -93,6 +93,18 @@ class ParamArena:
         off, n = self.offset[id(p)]
         return self.g[off:off + n]
 
+    def refresh_half(self):
+        """Round the whole arena to halves once (start of a precision-16 step with half tensors): the copy its conv kernels read."""
+        if getattr(self, "p16", None) is None:
+            self.p16 = torch.empty(self.total, device=self.p.device, dtype=torch.float16)
+        ops.cvt_f32_f16(self.p, self.p16)
+
+    def w16(self, p):
+        """Kernel view (OHWI) of a conv weight inside the half copy of the arena."""
+        off, n = self.offset[id(p)]
+        o, c, kh, kw = p.shape
+        return self.p16[off:off + n].view(o, kh, kw, c)
+
     def sync_grads(self):
         """Compatibility path (PyTorch Lightning / set_to_none): make the arena hold whatever ``p.grad`` holds."""
         for p in self.params:
@@ -172,7 +184,7 @@ class _Affine:
             # (smaller images are first resized to 64 x 64, models.py:217-219: the fp32 stem's loader does that, this kernel does not)
             # precision 16 / 'bf16': conv1 on the 16-bit matrix instructions (csrc/stem16.hip), as autocast runs it
             z, self.mean, self.invstd = ops.stem_fwd_stats16(img, self.lin.weight.detach().contiguous(), bn.eps, mom, bn.running_mean,
-                                                             bn.running_var, self.eng.bf16)
+                                                             bn.running_var, self.eng.bf16, out_half=self.eng.h16)
         else:
             z, self.mean, self.invstd = ops.stem_fwd_stats(img, self.weight(), bn.eps, mom, bn.running_mean, bn.running_var)
         with torch.no_grad():
@@ -254,6 +266,9 @@ class _Affine:
         self.mask = None
         bias = getattr(self.lin, "bias", None)
         bf = self.eng.bf16
+        if x.dtype == torch.float16:             # precision-16 step with half tensors: the rounded copy of the weights
+            assert self.is_conv and bn is not None and bn.training and bias is None
+            w = a.w16(self.lin.weight)
         if bn is None:
             y = ops.conv_fwd(x, w, None, a.w(bias) if bias is not None else None, None, self.relu, self.stride, self.pad, bf)
             self.z = self.y = None
@@ -375,8 +390,11 @@ class _Affine:
                 dzz[..., :cout] = dz
                 wt = torch.zeros((padc,) + tuple(w.shape[1:]), device=dz.device)
                 wt[:cout] = w
+            half = dz.dtype == torch.float16
             if self.c64_ok() and dz.dim() == 4:
                 dx = ops.conv3x3_c64(dzz, self.eng.flipped(self.lin, wt), residual=dx_residual, res_mask=dx_res_mask, bf16=bf)
+            elif half:
+                dx = ops.conv_dgrad(dzz, self.eng.flipped(self.lin, wt, half=True), self.x_shape, self.stride, self.pad, dx_residual, bf)
             else:
                 wf = self.eng.flipped(self.lin, wt) if wt is w else ops.flip_transpose_weight(wt)
                 dx = ops.conv_dgrad(dzz, wf, self.x_shape, self.stride, self.pad, dx_residual, bf, res_mask=dx_res_mask)
@@ -436,10 +454,15 @@ class TrainEngine:
         self.sw_wgrad_halo = os.environ.get("SSAD_WGRAD_HALO", "1") != "0"
         self.sw_stem16 = os.environ.get("SSAD_STEM16", "1") != "0"
         self.sw_c64_16 = os.environ.get("SSAD_C64_16", "1") != "0"
+        # precision 16: the trunk's activations (and their gradients) live in HBM as halves, as torch.autocast stores them
+        # (SSAD_ACT16=0: fp32 tensors with operands rounded while staged -- rounds 2-4)
+        self.sw_act16 = os.environ.get("SSAD_ACT16", "1") != "0"
+        self.h16 = False              # decided per forward (trunk BatchNorms in training mode, whole images of >= 64 x 64)
+        self._flip16_view, self._flip16_ready = {}, False
 
     def switches(self):
         """Everything besides shapes that decides which launches a step consists of (hipGraph plan key)."""
-        return (self.bf16, self.param_grads, self.sw_c64, self.sw_relu_mask, self.sw_wgrad_halo, self.sw_stem16, self.sw_c64_16, self._side_on,
+        return (self.bf16, self.param_grads, self.sw_c64, self.sw_relu_mask, self.sw_wgrad_halo, self.sw_stem16, self.sw_c64_16, self.sw_act16, self._side_on,
                 os.environ.get("SSAD_WGRAD_HALO", "1") != "0", torch.is_grad_enabled())
 
     # ---- second stream for the weight gradients ----
@@ -468,9 +491,34 @@ class TrainEngine:
         """num_batches_tracked += 1 for every train-mode BatchNorm of the step, in ONE multi-tensor launch (end of forward)."""
         self._nbt.append(bn.num_batches_tracked)
 
-    def flipped(self, lin, w):
+    def _flipped_half(self, lin):
+        """The same table over the block convs only, written as halves (precision-16 step with half tensors)."""
+        key = id(lin.weight)
+        if self._flip16_ready:
+            return self._flip16_view[key]
+        if not self._flip16_view:
+            import ctypes
+            a, desc, off, shapes = self.arena, [], 0, {}
+            for layer in [d[k] for d in self.blocks for k in ("c1", "c2", "ds") if d[k] is not None]:
+                p = layer.lin.weight
+                o, c, kh, kw = p.shape
+                desc += [a.offset[id(p)][0], off, o, c, kh, kw]
+                shapes[id(p)] = (off, (c, kh, kw, o))
+                off += p.numel()
+            self._flip16_buf = torch.empty(off, device=a.p.device, dtype=torch.float16)
+            self._flip16_desc = (ctypes.c_int64 * len(desc))(*desc)
+            self._flip16_n = len(desc) // 6
+            self._flip16_view = {k: self._flip16_buf[o:o + s[0] * s[1] * s[2] * s[3]].view(s) for k, (o, s) in shapes.items()}
+        _hip.check(_hip.lib().ssad_flip_transpose_batch_h(_hip.ptr(self.arena.p), self._flip16_buf.data_ptr(), self._flip16_desc,
+                                                          self._flip16_n, _hip.stream()))
+        self._flip16_ready = True
+        return self._flip16_view[key]
+
+    def flipped(self, lin, w, half=False):
         """dgrad operand of a conv layer (ssad_flip_transpose_weight of its OHWI weight).  All block convs are flipped by one
         launch per step (the first request after a forward), not one launch per layer."""
+        if half:
+            return self._flipped_half(lin)
         key = id(lin.weight)
         if self._flip_ready and key in self._flip_view:
             return self._flip_view[key]
@@ -514,7 +562,11 @@ class TrainEngine:
         m = self.model
         b, _, h, w = x.shape
         self.trunk_grad = any(p.requires_grad for p in m.feature_extractor.parameters())
-        self._nbt, self._flip_ready = [], False
+        self._nbt, self._flip_ready, self._flip16_ready = [], False, False
+        self.h16 = bool(self.bf16 == 2 and self.sw_act16 and self.sw_stem16 and h >= 64 and w >= 64 and self.param_grads and
+                        all(mod.training for mod in m.feature_extractor.modules() if isinstance(mod, BN_TYPES)))
+        if self.h16:
+            self.arena.refresh_half()
         a, self.pool_idx = self.stem.fwd_pool(x.contiguous())
         if not self.trunk_grad:
             self.stem.x = None
@@ -575,7 +627,7 @@ class TrainEngine:
             self._drop_tape()
             return
         dpooled = d.view(b, -1).contiguous()
-        dy = torch.empty(self.last_shape, device=dpooled.device, dtype=torch.float32)
+        dy = torch.empty(self.last_shape, device=dpooled.device, dtype=torch.float16 if self.h16 else torch.float32)
         ops.gap_bwd(dpooled, dy, self.gap_off["layer4"], accumulate=False)
         for i in range(len(self.blocks) - 1, -1, -1):
             blk = self.blocks[i]
@@ -1058,18 +1110,33 @@ class DataParallelStep:
         ok_local = True
         if self.use_graph:
             key = self._plan_key(x, y)
+            # Phase 1, no collective inside: every rank records its plan (the recorder notes the buckets, it does not reduce them).
+            plan = None
             try:
                 plan = self._capture(x, y, key)
-                self._replay(plan, x, y)
-                torch.cuda.synchronize(dev)
+            except Exception as e:           # noqa: BLE001  (a capture the runtime refuses is a reason to run eagerly, not to stop)
+                rep["capture_error"] = f"{type(e).__name__}: {e}"
+                self._plans.pop(key, None)
+            # Phase 2: ONE collective decision.  A rank that failed to capture must not meet ranks that go on to issue the replay's
+            # per-bucket all-reduces with a different collective (mismatched RCCL collectives hang or corrupt): either every rank
+            # replays, or none does and all of them fall back together.
+            captured_everywhere = all_ranks_true(plan is not None, dev, self.pg)
+            rep["captured_on_every_rank"] = captured_everywhere
+            ok_local = False
+            if captured_everywhere:
+                try:
+                    self._replay(plan, x, y)
+                    torch.cuda.synchronize(dev)
+                except Exception as e:
+                    # part of the collective sequence may be out already: no fallback can realign the ranks from here
+                    raise RuntimeError("self-check: the replayed step failed after its collectives had started; "
+                                       "aborting the job (run with SSAD_GRAPH=0 for eager launches)") from e
                 replay = state()
                 ok_local = bool(torch.equal(eager, replay))
                 rep["replicas_agree_replay"] = ranks_agree(shared(), self.pg)
                 rep["graph_segments"] = sum(1 for o in plan["ops"] if o[0] == "graph")
-            except Exception as e:           # noqa: BLE001  (a capture the runtime refuses is a reason to run eagerly, not to stop)
-                ok_local = False
-                rep["capture_error"] = f"{type(e).__name__}: {e}"
-                rep["replicas_agree_replay"] = ranks_agree(shared(), self.pg) and False          # (keeps the collective sequence aligned)
+            else:
+                rep["replicas_agree_replay"] = False
                 self._plans.pop(key, None)
             self._restore(snap)
             rep["graph_equals_eager"] = all_ranks_true(ok_local, dev, self.pg)

@@ -112,6 +112,25 @@ def case_selfcheck(res):
     torch.cuda.synchronize()
     res["faulty_plans"] = len(bad._plans)
     res["faulty_weights_equal"] = allsame(bad.eng.arena.p)[0]
+    # a capture the runtime refuses on ONE rank only: no rank may go on to replay (its per-bucket all-reduces would meet the
+    # other rank's different collective); both fall back to eager launches together and keep training
+    m3 = PeraNet(); m3.load_state_dict(ow.seeded_state_dict(9)); m3.to(dev).train(); m3.unfreeze()
+    half = training.DataParallelStep(m3, lr=0.03, world_size=world)
+    orig_cap = half._capture
+
+    def one_sided_capture(xx, yy, key):
+        if rank == 1:
+            raise RuntimeError("injected: capture refused on rank 1")
+        return orig_cap(xx, yy, key)
+    half._capture = one_sided_capture
+    rep3 = half.self_check(x, y)
+    half._capture = orig_cap
+    res["one_sided"] = rep3
+    res["one_sided_use_graph"] = bool(half.use_graph)
+    for _ in range(3):
+        half.step(x, y)
+    torch.cuda.synchronize()
+    res["one_sided_weights_equal"] = allsame(half.eng.arena.p)[0]
 
 
 def case_rccl1(res):

@@ -50,6 +50,9 @@ def test_two_rank_self_check(tmp_path):
     assert f["replicas_agree_eager"] and not f["graph_equals_eager"] and not f["replicas_agree_replay"], r
     assert f["launch_mode"].startswith("eager (self-check") and not r["faulty_use_graph"] and r["faulty_plans"] == 0, r
     assert r["faulty_weights_equal"], r
+    o = r["one_sided"]                      # capture failed on rank 1 only: a collective decision, nobody replays
+    assert not o["captured_on_every_rank"] and not o["graph_equals_eager"] and not o["replicas_agree_replay"], r
+    assert o["launch_mode"].startswith("eager (self-check") and not r["one_sided_use_graph"] and r["one_sided_weights_equal"], r
 
 
 def test_two_rank_tools_training(tmp_path):

@@ -1,0 +1,264 @@
+"""Half-tensor forms of the precision-16 training step (`_h` entry points of include/ssad.h).
+
+pl.Trainer(precision=16) (tools.py:263 of the reference) keeps every trunk activation and its gradient as an fp16 tensor.  Each `_h`
+kernel is the SAME kernel as its fp32-tensor namesake with the tensors read / written as halves, so on inputs that are
+representable as halves the two must agree to the last bit once the fp32-tensor result is rounded -- that identity is what is
+tested here, kernel by kernel; the arithmetic itself is pinned by the fp32-tensor tests (test_hip_training.py) against torch."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _r(t):
+    """Round to fp16 and back: a value a half tensor can hold."""
+    return t.half().float()
+
+
+def _bn_params(c, g, dev):
+    mean, invstd = (torch.randn(c, generator=g) * 0.2).to(dev), (torch.rand(c, generator=g) + 0.5).to(dev)
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).to(dev), (torch.randn(c, generator=g) * 0.3).to(dev)
+    return mean, invstd, gamma, beta
+
+
+def test_weight_copies(dev):
+    from self_supervised import _hip, ops
+    import ctypes
+    g = torch.Generator().manual_seed(1)
+    src = torch.randn(1000 * 8 + 5, generator=g).to(dev)
+    dst = torch.empty(src.numel(), device=dev, dtype=torch.float16)
+    ops.cvt_f32_f16(src, dst)
+    assert torch.equal(dst, src.half())
+    # two filters of one arena, flipped as halves == the fp32 flip, rounded
+    w1, w2 = torch.randn(96, 3, 3, 64, generator=g), torch.randn(128, 1, 1, 64, generator=g)
+    arena = torch.cat([w1.flatten(), w2.flatten()]).to(dev)
+    desc = [0, 0, 96, 64, 3, 3, w1.numel(), w1.numel(), 128, 64, 1, 1]
+    out = torch.empty(arena.numel(), device=dev, dtype=torch.float16)
+    _hip.check(_hip.lib().ssad_flip_transpose_batch_h(_hip.ptr(arena), out.data_ptr(), (ctypes.c_int64 * 12)(*desc), 2, _hip.stream()))
+    f1 = ops.flip_transpose_weight(w1.to(dev)).half()
+    f2 = ops.flip_transpose_weight(w2.to(dev)).half()
+    assert torch.equal(out[:w1.numel()].view(f1.shape), f1) and torch.equal(out[w1.numel():].view(f2.shape), f2)
+
+
+@pytest.mark.parametrize("shape", [(3, 8, 8, 64, 64, 3, 1, 1), (2, 9, 9, 64, 128, 3, 2, 1), (4, 6, 6, 128, 256, 3, 1, 1),
+                                   (2, 8, 8, 64, 128, 1, 2, 0), (64, 32, 32, 128, 128, 3, 1, 1), (5, 7, 5, 256, 512, 3, 2, 1)])
+def test_conv_igemm_half_tensors(dev, shape):
+    """conv + statistics, input gradient (+ residual), weight gradient: half tensors == the fp16-operand kernels on fp32 tensors
+    holding the same (half-representable) values, rounded once; ragged tiles, both strides, a >= 500-workgroup grid."""
+    from self_supervised import ops
+    n, h, w, cin, cout, k, s, p = shape
+    g = torch.Generator().manual_seed(n * 13 + k + cin)
+    x = _r(torch.randn(n, h, w, cin, generator=g)).to(dev)
+    wt = _r(torch.randn(cout, k, k, cin, generator=g) / (cin * k * k) ** 0.5).to(dev)
+    rm1, rv1 = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)
+    rm2, rv2 = rm1.clone(), rv1.clone()
+    z32, m32, i32 = ops.conv_fwd_stats(x, wt, 1e-5, 0.1, rm1, rv1, s, p, bf16=2)
+    zh, mh, ih = ops.conv_fwd_stats(x.half(), wt.half(), 1e-5, 0.1, rm2, rv2, s, p, bf16=2)
+    assert zh.dtype == torch.float16 and torch.equal(zh, z32.half())
+    # statistics are those of the STORED halves
+    zc = zh.double().reshape(-1, cout)
+    assert (mh.double() - zc.mean(0)).abs().max().item() < 1e-5 * max(1.0, zc.abs().max().item())
+    assert ((ih.double() - (zc.var(0, unbiased=False) + 1e-5).rsqrt()).abs() / ih.double()).max().item() < 1e-5
+    assert (mh - m32).abs().max().item() < 2e-3 and ((ih - i32).abs() / i32).max().item() < 2e-3
+    # input gradient
+    dy = _r(torch.randn(z32.shape, generator=g)).to(dev)
+    res = _r(torch.randn(x.shape, generator=g)).to(dev)
+    wf = ops.flip_transpose_weight(wt)
+    dx32 = ops.conv_dgrad(dy, wf, x.shape, s, p, res, bf16=2)
+    dxh = ops.conv_dgrad(dy.half(), wf.half(), x.shape, s, p, res.half(), bf16=2)
+    assert dxh.dtype == torch.float16 and torch.equal(dxh, dx32.half())
+    dxh = ops.conv_dgrad(dy.half(), wf.half(), x.shape, s, p, None, bf16=2)
+    assert torch.equal(dxh, ops.conv_dgrad(dy, wf, x.shape, s, p, None, bf16=2).half())
+    # weight gradient (fp32 either way)
+    dw32 = torch.empty(cout * k * k * cin, device=dev)
+    dwh = torch.empty_like(dw32)
+    ops.conv_wgrad(dy, x, dw32, k, k, s, p, bf16=2)
+    ops.conv_wgrad(dy.half(), x.half(), dwh, k, k, s, p, bf16=2)
+    assert torch.equal(dwh, dw32)
+
+
+@pytest.mark.parametrize("shape", [(3, 16, 16), (2, 13, 21), (5, 64, 64)])
+def test_conv_c64_half_tensors(dev, shape):
+    """Halo-tile 64 -> 64 conv with half tensors: plain, residual, producer BatchNorm + ReLU on load with the emitted activation and the
+    output statistics; as input gradient; ragged tiles."""
+    from self_supervised import ops
+    n, h, w = shape
+    g = torch.Generator().manual_seed(n * 10 + h)
+    x = _r(torch.randn(n, h, w, 64, generator=g)).to(dev)
+    wt = (torch.randn(64, 3, 3, 64, generator=g) / 24.0).to(dev)          # fp32 master weights, rounded while staged in both forms
+    res = _r(torch.randn(n, h, w, 64, generator=g)).to(dev)
+    assert torch.equal(ops.conv3x3_c64(x.half(), wt, bf16=2), ops.conv3x3_c64(x, wt, bf16=2).half())
+    assert torch.equal(ops.conv3x3_c64(x.half(), wt, residual=res.half(), bf16=2), ops.conv3x3_c64(x, wt, residual=res, bf16=2).half())
+    tr = _bn_params(64, g, dev)
+    rm1, rv1 = torch.zeros(64, device=dev), torch.ones(64, device=dev)
+    rm2, rv2 = rm1.clone(), rv1.clone()
+    z32, e32, m32, i32 = ops.conv3x3_c64(x, wt, transform=tr, emit=True, stats=(1e-5, 0.1, rm1, rv1), bf16=2)
+    zh, eh, mh, ih = ops.conv3x3_c64(x.half(), wt, transform=tr, emit=True, stats=(1e-5, 0.1, rm2, rv2), bf16=2)
+    assert torch.equal(eh, e32.half()) and torch.equal(zh, z32.half())
+    zc = zh.double().reshape(-1, 64)
+    assert (mh.double() - zc.mean(0)).abs().max().item() < 1e-5 * max(1.0, zc.abs().max().item())
+    assert ((ih.double() - (zc.var(0, unbiased=False) + 1e-5).rsqrt()).abs() / ih.double()).max().item() < 1e-5
+    assert (rm2 - rm1).abs().max().item() < 1e-3
+
+
+def test_elementwise_half_tensors(dev):
+    """BatchNorm apply / backward reductions / backward apply, global average pooling both ways: half tensors == the fp32-tensor
+    kernels on the same values, outputs rounded once, parameter gradients equal."""
+    from self_supervised import ops
+    for (n, h, w, c) in [(3, 8, 8, 64), (2, 5, 7, 128), (33, 4, 4, 512)]:
+        g = torch.Generator().manual_seed(n + c)
+        z = _r(torch.randn(n, h, w, c, generator=g)).to(dev)
+        res = _r(torch.randn(n, h, w, c, generator=g)).to(dev)
+        dy = _r(torch.randn(n, h, w, c, generator=g)).to(dev)
+        mean, invstd, gamma, beta = _bn_params(c, g, dev)
+        for r_, relu in ((None, True), (res, True), (res, False), (None, False)):
+            y32 = ops.bn_apply_fwd(z, mean, invstd, gamma, beta, r_, relu)
+            yh = ops.bn_apply_fwd(z.half(), mean, invstd, gamma, beta, None if r_ is None else r_.half(), relu)
+            assert yh.dtype == torch.float16 and torch.equal(yh, y32.half())
+        m1, i1 = ops.bn_stats(z, c, 1e-5, 0.1, None, None)
+        m2, i2 = ops.bn_stats(z.half(), c, 1e-5, 0.1, None, None)
+        assert torch.equal(m1, m2) and torch.equal(i1, i2)
+        # backward with the mask from the stored activation (residual block) ...
+        yact = ops.bn_apply_fwd(z, mean, invstd, gamma, beta, res, True).half().float()
+        db1, dg1, db2, dg2 = (torch.empty(c, device=dev) for _ in range(4))
+        ops.bn_bwd_reduce(dy, yact, z, mean, invstd, db1, dg1, c)
+        ops.bn_bwd_reduce(dy.half(), yact.half(), z.half(), mean, invstd, db2, dg2, c)
+        assert torch.equal(db1, db2) and torch.equal(dg1, dg2)
+        dz32, dr32 = ops.bn_apply_bwd(dy, yact, z, mean, invstd, gamma, db1, dg1, True)
+        dzh, drh = ops.bn_apply_bwd(dy.half(), yact.half(), z.half(), mean, invstd, gamma, db1, dg1, True)
+        assert torch.equal(dzh, dz32.half()) and torch.equal(drh, dr32.half())
+        # ... and with the mask recomputed from z
+        dz32 = ops.bn_bwd_zmask(dy, z, mean, invstd, gamma, beta, db1, dg1)
+        dzh = ops.bn_bwd_zmask(dy.half(), z.half(), mean, invstd, gamma, beta, db2, dg2)
+        assert torch.equal(db1, db2) and torch.equal(dg1, dg2) and torch.equal(dzh, dz32.half())
+        # global average pooling
+        if c % 64 == 0:
+            p1, p2 = torch.zeros(n, c + 64, device=dev), torch.zeros(n, c + 64, device=dev)
+            ops.gap_fwd(z, p1, 64)
+            ops.gap_fwd(z.half(), p2, 64)
+            assert (p1 - p2).abs().max().item() <= 1e-6 * max(1.0, p1.abs().max().item())
+        dp = torch.randn(n, c + 64, generator=g).to(dev)
+        d1, d2 = dy.clone(), dy.half()
+        ops.gap_bwd(dp, d1, 64, True)
+        ops.gap_bwd(dp, d2, 64, True)
+        assert torch.equal(d2, d1.half())
+        ops.gap_bwd(dp, d1, 64, False)
+        ops.gap_bwd(dp, d2, 64, False)
+        assert torch.equal(d2, d1.half())
+
+
+def test_stem_half_tensors(dev):
+    """conv1 (fp16 operands) with z stored as halves, BatchNorm + ReLU + max-pool over it, their fused backward and the stem weight
+    gradient from a half dz."""
+    from self_supervised import ops
+    from oracle import weights as ow
+    for (b, hw) in [(3, 64), (2, 96)]:
+        g = torch.Generator().manual_seed(b * 7 + hw)
+        img = ow.synthetic_images(b, hw, seed=40 + b).to(dev)
+        w = (torch.randn(64, 3, 7, 7, generator=g) / 12.0).to(dev)
+        rm1, rv1 = torch.zeros(64, device=dev), torch.ones(64, device=dev)
+        rm2, rv2 = rm1.clone(), rv1.clone()
+        z32, m32, i32 = ops.stem_fwd_stats16(img, w, 1e-5, 0.1, rm1, rv1, 2)
+        zh, mh, ih = ops.stem_fwd_stats16(img, w, 1e-5, 0.1, rm2, rv2, 2, out_half=True)
+        assert zh.dtype == torch.float16 and torch.equal(zh, z32.half())
+        zc = zh.double().reshape(-1, 64)
+        assert (mh.double() - zc.mean(0)).abs().max().item() < 1e-5 * max(1.0, zc.abs().max().item())
+        assert ((ih.double() - (zc.var(0, unbiased=False) + 1e-5).rsqrt()).abs() / ih.double()).max().item() < 1e-5
+        gamma, beta = (torch.rand(64, generator=g) + 0.5).to(dev), (torch.randn(64, generator=g) * 0.3).to(dev)
+        # pooling compares the BatchNorm outputs AS HALVES (autocast's BatchNorm output is a half tensor): the fp32 pooling kernel over
+        # that rounded activation is the statement
+        zf = zh.float()
+        act = ops.bn_apply_fwd(zf, mh, ih, gamma, beta, None, True).half().float()
+        want, widx = ops.maxpool3x3s2_fwd_idx(act)
+        got, gidx = ops.bn_relu_maxpool_fwd(zh, mh, ih, gamma, beta)
+        assert got.dtype == torch.float16 and torch.equal(got, want.half()) and torch.equal(gidx, widx)
+        # fused backward: pooled gradient -> dz, dbeta, dgamma
+        dpool = _r(torch.randn(got.shape, generator=g)).to(dev)
+        db1, dg1, db2, dg2 = (torch.empty(64, device=dev) for _ in range(4))
+        dz32 = ops.pool_bn_relu_bwd(gidx, dpool, zf, mh, ih, gamma, beta, db1, dg1)
+        dzh = ops.pool_bn_relu_bwd(gidx, dpool.half(), zh, mh, ih, gamma, beta, db2, dg2)
+        assert torch.equal(db1, db2) and torch.equal(dg1, dg2) and torch.equal(dzh, dz32.half())
+        dw1, dw2 = torch.empty(64 * 147, device=dev), torch.empty(64 * 147, device=dev)
+        ops.stem_wgrad(img, dzh.float(), dw1)
+        ops.stem_wgrad(img, dzh, dw2)
+        assert torch.equal(dw1, dw2)
+
+
+def test_wrong_extents_raise(dev):
+    """include/ssad.h: "return non-zero ... Never aborts".  Every entry point that reads a second tensor over extents derived from
+    the first one's takes that buffer's element count; a count that does not fit is an error return (HipExtensionError through the
+    binding) -- not an out-of-bounds read (round 4: a half-size dz reached ssad_stem_wgrad).  One case per guarded entry, through the C
+    ABI itself; the tensor wrappers refuse the same shapes before they get that far."""
+    from self_supervised import _hip, ops
+    from self_supervised._hip import HipExtensionError
+    lib, st = _hip.lib(), _hip.stream()
+    f = lambda *shape: torch.zeros(shape, device=dev)
+    h_ = lambda *shape: torch.zeros(shape, device=dev, dtype=torch.float16)
+    P = _hip.ptr
+    img, dw = f(2, 3, 64, 64), f(64 * 147)
+    ws = f(int(lib.ssad_stem_wgrad_workspace(2, 64, 64)))
+    dz_small = f(2, 16, 16, 64)                       # belongs to 32 x 32 images
+    with pytest.raises(HipExtensionError, match="dz does not hold"):
+        _hip.check(lib.ssad_stem_wgrad(P(img), P(dz_small), P(dw), 2, 64, 64, dz_small.numel(), 0, 0, P(ws), st))
+    with pytest.raises(HipExtensionError, match="dz does not hold"):
+        _hip.check(lib.ssad_stem_wgrad_h(P(img), h_(2, 16, 16, 64).data_ptr(), P(dw), 2, 64, 64, dz_small.numel(), 0, 0, P(ws), st))
+    with pytest.raises(AssertionError):
+        ops.stem_wgrad(img, dz_small, dw)
+    # pooled gradient / slots of the wrong map size
+    z, dpool = f(2, 32, 32, 64), f(2, 8, 8, 64)
+    idx = torch.zeros(2, 8, 8, 64, device=dev, dtype=torch.uint8)
+    v = [f(64) for _ in range(6)]
+    wsd = torch.zeros(int(lib.ssad_colreduce_workspace(2 * 32 * 32, 64)), device=dev, dtype=torch.float64)
+    with pytest.raises(HipExtensionError, match="dpool"):
+        _hip.check(lib.ssad_pool_bn_relu_bwd(idx.data_ptr(), P(dpool), P(z), P(v[0]), P(v[1]), P(v[2]), P(v[3]), P(v[4]), P(v[5]),
+                                             P(torch.empty_like(z)), 2, 32, 32, 64, dpool.numel(), wsd.data_ptr(), st))
+    with pytest.raises(HipExtensionError, match="dpool"):
+        _hip.check(lib.ssad_pool_bn_relu_bwd_h(idx.data_ptr(), dpool.half().data_ptr(), z.half().data_ptr(), P(v[0]), P(v[1]), P(v[2]),
+                                               P(v[3]), P(v[4]), P(v[5]), torch.empty_like(z).half().data_ptr(), 2, 32, 32, 64,
+                                               dpool.numel(), wsd.data_ptr(), st))
+    with pytest.raises(AssertionError):
+        ops.pool_bn_relu_bwd(idx, dpool, z, v[0], v[1], v[2], v[3], v[4], v[5])
+    with pytest.raises(HipExtensionError, match="dy"):
+        _hip.check(lib.ssad_maxpool3x3s2_bwd_idx(idx.data_ptr(), P(dpool), P(torch.empty_like(z)), 2, 32, 32, 64, dpool.numel(), st))
+    with pytest.raises(HipExtensionError, match="dy"):
+        _hip.check(lib.ssad_maxpool3x3s2_bwd(P(z), P(dpool), P(torch.empty_like(z)), 2, 32, 32, 64, dpool.numel(), st))
+    with pytest.raises(AssertionError):
+        ops.maxpool3x3s2_bwd_idx(idx, dpool, z.shape)
+    # weight gradients: dy of the wrong map size for x and the filter geometry
+    x, dy_bad = f(2, 8, 8, 64), f(2, 4, 4, 64)        # a stride-1 3 x 3 / pad 1 conv over 8 x 8 gives 8 x 8
+    slab = f(64, 64, 9 * 64)
+    for fn in (lib.ssad_conv_wgrad, lib.ssad_conv_wgrad_bf16, lib.ssad_conv_wgrad_f16, lib.ssad_conv_wgrad_x3, lib.ssad_conv_wgrad_x6):
+        with pytest.raises(HipExtensionError, match="dy does not hold"):
+            _hip.check(fn(P(dy_bad), P(x), P(slab), 1, 2, 8, 8, 64, 64, 3, 3, 1, 1, dy_bad.numel(), st))
+    with pytest.raises(HipExtensionError, match="dy does not hold"):
+        _hip.check(lib.ssad_conv_wgrad_f16_h(dy_bad.half().data_ptr(), x.half().data_ptr(), P(slab), 1, 2, 8, 8, 64, 64, 3, 3, 1, 1,
+                                             dy_bad.numel(), st))
+    sp = lib.ssad_wgrad3x3_halo_splits(2, 8, 8, 64, 64)
+    with pytest.raises(HipExtensionError, match="dz does not hold"):
+        _hip.check(lib.ssad_conv_wgrad3x3_halo(P(dy_bad), P(x), P(slab), sp, 2, 8, 8, 64, 64, dy_bad.numel(), st))
+    with pytest.raises(HipExtensionError, match="dz does not hold"):
+        _hip.check(lib.ssad_conv_wgrad3x3s2_halo(P(f(2, 2, 2, 64)), P(x), P(slab), lib.ssad_wgrad3x3_halo_splits(2, 4, 4, 64, 64), 2, 4, 4,
+                                                 8, 8, 64, 64, 2 * 2 * 2 * 64, st))
+    sp16 = lib.ssad_wgrad3x3_halo16_splits(2, 8, 8, 64, 64)
+    with pytest.raises(HipExtensionError, match="dz does not hold"):
+        _hip.check(lib.ssad_conv_wgrad3x3_halo16(P(dy_bad), P(x), P(slab), sp16, 2, 8, 8, 64, 64, 1, dy_bad.numel(), st))
+    with pytest.raises(HipExtensionError, match="dz does not hold"):
+        _hip.check(lib.ssad_conv_wgrad3x3_halo16_h(dy_bad.half().data_ptr(), x.half().data_ptr(), P(slab), sp16, 2, 8, 8, 64, 64,
+                                                   dy_bad.numel(), st))
+    with pytest.raises(AssertionError):
+        ops.conv_wgrad(dy_bad, x, f(64 * 9 * 64), 3, 3, 1, 1)
+    # tensors that must share one shape: the wrappers say so
+    with pytest.raises(AssertionError):
+        ops.bn_apply_bwd(f(2, 8, 8, 64), None, f(2, 4, 4, 64), v[0], v[1], v[2], v[3], v[4], False)
+    with pytest.raises(AssertionError):
+        ops.bn_apply_fwd(f(2, 8, 8, 64), v[0], v[1], v[2], v[3], f(2, 4, 4, 64), True)
+    with pytest.raises(AssertionError):
+        ops.conv_dgrad(f(2, 8, 8, 64), f(64, 3, 3, 64), (2, 8, 8, 64), 1, 1, residual=f(2, 4, 4, 64))
+    torch.cuda.synchronize()

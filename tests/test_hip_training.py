@@ -857,7 +857,7 @@ def test_halo_wgrad_with_16_bit_operands(dev):
             splits = lib.ssad_wgrad_splits_bf16(m, cin, cout, 3, 3)
             slab = torch.empty((splits, cout, 9 * cin), device=dev)
             fn = lib.ssad_conv_wgrad_f16 if mode == 2 else lib.ssad_conv_wgrad_bf16
-            _hip.check(fn(_hip.ptr(dyd), _hip.ptr(xd), _hip.ptr(slab), splits, n, h, w, cin, cout, 3, 3, 1, 1, _hip.stream()))
+            _hip.check(fn(_hip.ptr(dyd), _hip.ptr(xd), _hip.ptr(slab), splits, n, h, w, cin, cout, 3, 3, 1, 1, dyd.numel(), _hip.stream()))
             old = torch.empty_like(dw)
             _hip.check(lib.ssad_wgrad_reduce(_hip.ptr(slab), _hip.ptr(old), splits, cout, 9 * cin, 3, 3, cin, 0, 0, _hip.stream()))
             assert rel_err(dw, old) < 2e-6, (n, h, w, cin, cout, mode)
