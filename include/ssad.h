@@ -496,6 +496,17 @@ int ssad_bn_apply_bwd_zmask_h(const void* dy, const void* z, const float* mean, 
 int ssad_pool_bn_relu_bwd_h(const uint8_t* idx, const void* dpool, const void* z, const float* mean, const float* invstd,
                             const float* gamma, const float* beta, float* dbeta, float* dgamma, void* dz, int64_t N, int H, int W,
                             int C, int64_t dpool_elems, double* workspace, void* stream);
+/* 3x3 / stride 1 / pad 1 convolution over half tensors (csrc/conv16.hip): the BasicBlock conv3x3 layers of the trunk (models.py:224
+ * under pl.Trainer(precision=16)) forward and -- with the flipped filter -- their input gradients.  Halo-tile form with persistent
+ * workgroups: the input tile of 64 channels is staged once for its nine taps, optionally through relu(bn(x)) of the producing layer
+ * (tr_*: that layer's batch statistics and affine parameters; `emit` then receives the transformed activation for this layer's weight
+ * gradient), weight slices two steps ahead, accumulators stored straight from registers.  w_ohwi: halves [Cout][3][3][Cin].
+ * stats_ws: ssad_conv3x3_h_stats_rows(...) * 2 * Cout doubles -> mean / invstd / running statistics of the stored output. */
+int ssad_conv3x3_h_ok(int Cin, int Cout);
+int64_t ssad_conv3x3_h_stats_rows(int64_t N, int H, int W, int Cout);
+int ssad_conv3x3_h(const void* in, const void* w_ohwi, void* out, const void* residual, const float* tr_mean, const float* tr_invstd,
+                   const float* tr_gamma, const float* tr_beta, void* emit, int64_t N, int H, int W, int Cin, int Cout, double* stats_ws,
+                   float eps, float momentum, float* mean, float* invstd, float* running_mean, float* running_var, void* stream);
 /* weight gradients from half tensors (fp32 slabs, then ssad_wgrad_reduce, as the fp32-tensor forms) */
 int ssad_conv_wgrad3x3_halo16_h(const void* dz, const void* x, float* slab, int splits, int64_t N, int H, int W, int Cin, int Cout,
                                 int64_t dz_elems, void* stream);

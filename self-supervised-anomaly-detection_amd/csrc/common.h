@@ -69,6 +69,10 @@ template <> __device__ __forceinline__ void st4<float>(float* p, f32x4 v) { *(f3
 template <> __device__ __forceinline__ void st4<hf>(hf* p, f32x4 v) {
     *(f16x4*)p = f16x4{(hf)v[0], (hf)v[1], (hf)v[2], (hf)v[3]};
 }
+// four consecutive elements in their storage type (no conversion): what a kernel stages when its operands are the stored halves
+template <typename T> struct Raw4 { using t = f32x4; };
+template <> struct Raw4<hf> { using t = f16x4; };
+template <typename T> __device__ __forceinline__ typename Raw4<T>::t ldraw4(const T* p) { return *(const typename Raw4<T>::t*)p; }
 // the value a tensor of type T holds after storing v (statistics of a half tensor are those of the stored halves)
 template <typename T> __device__ __forceinline__ float stored(float v) { return v; }
 template <> __device__ __forceinline__ float stored<hf>(float v) { return (float)(hf)v; }

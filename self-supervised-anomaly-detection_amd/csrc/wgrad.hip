@@ -267,7 +267,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void wgrad_bf16_kernel(
     const TI* ybase = (const TI*)p.dy + co0 + c4 * 4;
     const TI* xbase = (const TI*)p.x + ci0 + c4 * 4;
 
-    f32x4 ry[4], rx[4];
+    typename Raw4<TI>::t ry[4], rx[4];          // fp32 tensors: floats, rounded in store_step; half tensors: the stored halves
     auto load_step = [&]() {
         int n = rn, oy = roy, ox = rox;
 #pragma unroll
@@ -275,8 +275,8 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void wgrad_bf16_kernel(
             const bool live = m1 + q < m_end;
             const int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
             const bool inb = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            ry[q] = ld4((live && co_ok) ? ybase + (m1 + q) * p.Cout : zero);
-            rx[q] = ld4((live && inb && ci_ok) ? xbase + (((int64_t)n * p.H + iy) * p.W + ix) * p.Cin : zero);
+            ry[q] = ldraw4((live && co_ok) ? ybase + (m1 + q) * p.Cout : zero);
+            rx[q] = ldraw4((live && inb && ci_ok) ? xbase + (((int64_t)n * p.H + iy) * p.W + ix) * p.Cin : zero);
             if (++ox >= p.Wo) { ox = 0; if (++oy >= p.Ho) { oy = 0; ++n; } }
         }
         m1 += PK;

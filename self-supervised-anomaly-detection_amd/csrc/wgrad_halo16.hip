@@ -86,7 +86,9 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_halo16_kernel(WgH16Params p) 
 
     if (loader) {
         const int pg = lt & 15, cq = lt >> 4;   // dZ: 4-pixel group, channel quad of this thread
-        f32x4 dv[4], xv[NXI][4];
+        using raw4 = typename Raw4<TI>::t;          // fp32 tensors: four floats; half tensors: the four halves as stored
+        const raw4 zero4 = {0, 0, 0, 0};
+        raw4 dv[4], xv[NXI][4];
         // Everything about a thread's pieces that does not depend on the tile is computed once: position inside the tile / halo and the
         // offset from the tile's first pixel.  Tiles are taken in order, so (n, ty, tx) advance by counting -- the staging waves' own
         // instruction count is what bounds this kernel once the loads are far enough ahead.
@@ -118,8 +120,8 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_halo16_kernel(WgH16Params p) 
             const bool dy_ok = y0 + dzy < p.H;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (dy_ok && x0 + dzx + q < p.W) v = ld4(dzn + dz_off + (unsigned)(q * p.Cout));
+                raw4 v = zero4;
+                if (dy_ok && x0 + dzx + q < p.W) v = ldraw4(dzn + dz_off + (unsigned)(q * p.Cout));
                 dv[q] = v;
             }
 #pragma unroll
@@ -127,9 +129,9 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_halo16_kernel(WgH16Params p) 
                 const bool row_ok = x_on[i] && (unsigned)(y0 - 1 + xhy[i]) < (unsigned)p.H;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    raw4 v = zero4;
                     if (row_ok && xhx[i] + q < TW + 2 && (unsigned)(x0 - 1 + xhx[i] + q) < (unsigned)p.W)
-                        v = ld4(xn + x_off[i] + (unsigned)(q * p.Cin));
+                        v = ldraw4(xn + x_off[i] + (unsigned)(q * p.Cin));
                     xv[i][q] = v;
                 }
             }

@@ -325,6 +325,41 @@ def conv3x3_c64(x, w_ohwi, residual=None, transform=None, emit=False, stats=None
     return res[0] if len(res) == 1 else tuple(res)
 
 
+def conv3x3_h(x, w_ohwi, residual=None, transform=None, emit=False, stats=None):
+    """3x3 / stride 1 / pad 1 convolution over half tensors (csrc/conv16.hip): x NHWC [N][H][W][Cin] halves, w OHWI halves
+    [Cout][3][3][Cin] -> [N][H][W][Cout] halves (+ residual).  transform = (mean, invstd, gamma, beta) of the PRODUCING layer: x is
+    taken through relu(bn(x)) while it is staged (emit=True also returns that activation, for the weight gradient).  stats = (eps,
+    momentum, running_mean, running_var): also the train-mode BatchNorm statistics of the stored output.
+    Returns out[, emitted][, mean, invstd]."""
+    n, h, w, cin = x.shape
+    cout = w_ohwi.shape[0]
+    assert _is_h(x) and _is_h(w_ohwi) and tuple(w_ohwi.shape) == (cout, 3, 3, cin)
+    assert residual is None or (_is_h(residual) and tuple(residual.shape) == (n, h, w, cout)), "residual must have the output's shape"
+    lib = _hip.lib()
+    out = _newh((n, h, w, cout), x)
+    em = torch.empty_like(x) if emit else None
+    tr = transform if transform is not None else (None, None, None, None)
+    mean = invstd = ws = None
+    eps = mom = 0.0
+    rm = rv = None
+    if stats is not None:
+        eps, mom, rm, rv = stats
+        mean, invstd = _new((cout,), x), _new((cout,), x)
+        ws = torch.empty(lib.ssad_conv3x3_h_stats_rows(n, h, w, cout) * 2 * cout, device=x.device, dtype=torch.float64)
+    nb = 2.0 * (x.numel() + out.numel() * (2 if residual is not None else 1) + (x.numel() if emit else 0) + w_ohwi.numel())
+    _run("conv3x3_h16", 2.0 * out.numel() * 9 * cin, nb,
+         lambda: lib.ssad_conv3x3_h(x.data_ptr(), w_ohwi.data_ptr(), out.data_ptr(), _p(residual, True), _hip.ptr(tr[0], True),
+                                    _hip.ptr(tr[1], True), _hip.ptr(tr[2], True), _hip.ptr(tr[3], True), _p(em, True), n, h, w, cin, cout,
+                                    ws.data_ptr() if ws is not None else None, eps, mom, _hip.ptr(mean, True), _hip.ptr(invstd, True),
+                                    _hip.ptr(rm, True), _hip.ptr(rv, True), _hip.stream()))
+    res = [out]
+    if emit:
+        res.append(em)
+    if stats is not None:
+        res += [mean, invstd]
+    return res[0] if len(res) == 1 else tuple(res)
+
+
 def conv3x3_c64_eval(x, w_ohwi, scale=None, shift=None, residual=None, relu=False, in_hwnc=False, out_hwnc=False,
                      res_hwnc=None):
     """Halo-tile 3x3 / stride 1 / pad 1 convolution 64 -> 64 with the inference epilogue act(conv * scale + shift + residual).

@@ -242,6 +242,39 @@ class _Affine:
         self.z, self.y, self.res_used, self.mask = z, None, False, None
         return z
 
+    # ---- 3x3 / stride 1 / pad 1 layers of the precision-16 step with half tensors: halo-tile kernel of csrc/conv16.hip (persistent
+    # workgroups, BatchNorm + ReLU of the producing layer applied while the input tile is staged) ----
+    def conv16_ok(self):
+        l, bn = self.lin, self.bn
+        return (self.eng.h16 and self.eng.sw_conv16 and self.is_conv and not self.stem and l.kernel_size == (3, 3) and self.stride == 1
+                and self.pad == 1 and l.bias is None and bn is not None and bn.training
+                and bool(_hip.lib().ssad_conv3x3_h_ok(l.in_channels, l.out_channels)))
+
+    def fwd_raw16(self, x, producer=None):
+        """conv + batch statistics over half tensors: returns the raw z of this layer and leaves its BatchNorm (+ ReLU) to the
+        consumer (apply_bn, or the next layer's input staging).  producer: the _Affine whose RAW output `x` is."""
+        a, bn = self.eng.arena, self.bn
+        mom = 0.1 if bn.momentum is None else bn.momentum
+        st = (bn.eps, mom, bn.running_mean, bn.running_var)
+        self.x_shape = tuple(x.shape)
+        w = a.w16(self.lin.weight)
+        if producer is None:
+            z, self.mean, self.invstd = ops.conv3x3_h(x, w, stats=st)
+            self.x = x
+        else:
+            pb = producer.bn
+            tr = (producer.mean, producer.invstd, a.w(pb.weight), a.w(pb.bias))
+            need_x = self.lin.weight.requires_grad and self.eng.param_grads and torch.is_grad_enabled()
+            if need_x:
+                z, self.x, self.mean, self.invstd = ops.conv3x3_h(x, w, transform=tr, emit=True, stats=st)
+            else:
+                z, self.mean, self.invstd = ops.conv3x3_h(x, w, transform=tr, stats=st)
+                self.x = None
+        with torch.no_grad():
+            self.eng.count_batch(bn)
+        self.z, self.y, self.res_used, self.mask = z, None, False, None
+        return z
+
     def apply_bn(self, residual=None):
         """The BatchNorm (+ residual) (+ ReLU) of a layer whose raw output fwd_raw_c64 left in self.z."""
         a, bn = self.eng.arena, self.bn
@@ -255,8 +288,9 @@ class _Affine:
         self.y = y if self.relu else None
         return y
 
-    def fwd(self, x, residual=None):
-        """x NHWC (4-D; the stem takes the NCHW image).  Returns y NHWC."""
+    def fwd(self, x, residual=None, raw=False):
+        """x NHWC (4-D; the stem takes the NCHW image).  Returns y NHWC.  raw (train-mode BatchNorm + ReLU, no residual): return the
+        raw conv output z and leave the BatchNorm + ReLU to the consumer's input staging (fwd_raw16(producer=self))."""
         a, bn = self.eng.arena, self.bn
         w = self.weight()
         if self.stem:
@@ -295,6 +329,10 @@ class _Affine:
             with torch.no_grad():
                 self.eng.count_batch(bn)
             self.z = z
+            if raw:
+                assert residual is None and self.relu
+                self.y = None
+                return z
             if residual is not None and self.relu and self.eng.use_relu_mask():
                 y, self.mask = ops.bn_apply_fwd_mask(z, self.mean, self.invstd, a.w(bn.weight), a.w(bn.bias), residual, True)
                 self.y = None
@@ -391,7 +429,9 @@ class _Affine:
                 wt = torch.zeros((padc,) + tuple(w.shape[1:]), device=dz.device)
                 wt[:cout] = w
             half = dz.dtype == torch.float16
-            if self.c64_ok() and dz.dim() == 4:
+            if half and dz.dim() == 4 and self.conv16_ok():
+                dx = ops.conv3x3_h(dzz, self.eng.flipped(self.lin, wt, half=True), residual=dx_residual)
+            elif self.c64_ok() and dz.dim() == 4:
                 dx = ops.conv3x3_c64(dzz, self.eng.flipped(self.lin, wt), residual=dx_residual, res_mask=dx_res_mask, bf16=bf)
             elif half:
                 dx = ops.conv_dgrad(dzz, self.eng.flipped(self.lin, wt, half=True), self.x_shape, self.stride, self.pad, dx_residual, bf)
@@ -457,12 +497,13 @@ class TrainEngine:
         # precision 16: the trunk's activations (and their gradients) live in HBM as halves, as torch.autocast stores them
         # (SSAD_ACT16=0: fp32 tensors with operands rounded while staged -- rounds 2-4)
         self.sw_act16 = os.environ.get("SSAD_ACT16", "1") != "0"
+        self.sw_conv16 = os.environ.get("SSAD_CONV16", "1") != "0"
         self.h16 = False              # decided per forward (trunk BatchNorms in training mode, whole images of >= 64 x 64)
         self._flip16_view, self._flip16_ready = {}, False
 
     def switches(self):
         """Everything besides shapes that decides which launches a step consists of (hipGraph plan key)."""
-        return (self.bf16, self.param_grads, self.sw_c64, self.sw_relu_mask, self.sw_wgrad_halo, self.sw_stem16, self.sw_c64_16, self.sw_act16, self._side_on,
+        return (self.bf16, self.param_grads, self.sw_c64, self.sw_relu_mask, self.sw_wgrad_halo, self.sw_stem16, self.sw_c64_16, self.sw_act16, self.sw_conv16, self._side_on,
                 os.environ.get("SSAD_WGRAD_HALO", "1") != "0", torch.is_grad_enabled())
 
     # ---- second stream for the weight gradients ----
@@ -578,7 +619,12 @@ class TrainEngine:
             idt = a
             if d["ds"] is not None:
                 idt = d["ds"].fwd(a)
-            if d["ds"] is None and d["c1"].c64_ok() and d["c2"].c64_ok():
+            if self.h16 and d["c2"].conv16_ok():
+                # half tensors: conv2 (and conv1 where it has stride 1) on the halo-tile kernel; bn1 + ReLU inside conv2's input staging
+                z1 = d["c1"].fwd_raw16(a) if d["c1"].conv16_ok() else d["c1"].fwd(a, raw=True)
+                d["c2"].fwd_raw16(z1, producer=d["c1"])
+                a = d["c2"].apply_bn(residual=idt)
+            elif d["ds"] is None and d["c1"].c64_ok() and d["c2"].c64_ok():
                 z1 = d["c1"].fwd_raw_c64(a)                       # bn1 + ReLU happen inside conv2's input staging
                 d["c2"].fwd_raw_c64(z1, producer=d["c1"])
                 a = d["c2"].apply_bn(residual=idt)

@@ -108,6 +108,44 @@ def test_conv_c64_half_tensors(dev, shape):
     assert (rm2 - rm1).abs().max().item() < 1e-3
 
 
+@pytest.mark.parametrize("shape", [(3, 16, 16, 64, 64), (2, 13, 21, 64, 128), (5, 8, 8, 128, 256), (3, 5, 7, 256, 64), (7, 8, 8, 512, 512),
+                                   (40, 32, 32, 128, 128), (3, 64, 64, 64, 64), (600, 8, 8, 64, 64)])
+def test_conv3x3_h_halo_kernel(dev, shape):
+    """csrc/conv16.hip against the implicit GEMM over the same half tensors (same products, fp32 accumulation in a different order):
+    plain + statistics, residual (the input-gradient use), producer BatchNorm + ReLU on load with the emitted activation; 8 x 16 tiles
+    and the two-maps-per-tile form of maps up to 8 wide, ragged tiles, odd sub-tile counts, one and several channel slabs, persistent
+    workgroups that walk many tiles (the 600-map case: > 512 tiles)."""
+    from self_supervised import ops
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(n * 3 + h + cin)
+    x = torch.randn(n, h, w, cin, generator=g).half().to(dev)
+    wt = (torch.randn(cout, 3, 3, cin, generator=g) / (9 * cin) ** 0.5).half().to(dev)
+    res = torch.randn(n, h, w, cout, generator=g).half().to(dev)
+    rm1, rv1 = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)
+    rm2, rv2 = rm1.clone(), rv1.clone()
+    zi, mi, ii = ops.conv_fwd_stats(x, wt, 1e-5, 0.1, rm1, rv1, 1, 1, bf16=2)
+    z, m, i = ops.conv3x3_h(x, wt, stats=(1e-5, 0.1, rm2, rv2))
+    tol = lambda ref: 2e-3 * max(1.0, ref.float().abs().max().item())               # one half ulp of the largest value, twice
+    assert z.dtype == torch.float16 and (z.float() - zi.float()).abs().max().item() <= tol(zi)
+    zc = z.double().reshape(-1, cout)
+    assert (m.double() - zc.mean(0)).abs().max().item() < 1e-5 * max(1.0, zc.abs().max().item())
+    assert ((i.double() - (zc.var(0, unbiased=False) + 1e-5).rsqrt()).abs() / i.double()).max().item() < 1e-5
+    assert (rm2 - rm1).abs().max().item() < 2e-3 and (rv2 - rv1).abs().max().item() < 2e-3
+    # fp32 math on the same operands
+    want = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), wt.float().cpu().permute(0, 3, 1, 2), None, 1, 1).permute(0, 2, 3, 1)
+    assert (z.float().cpu() - want).abs().max().item() <= tol(want)
+    # residual
+    zr = ops.conv3x3_h(x, wt, residual=res)
+    assert (zr.float().cpu() - (want + res.float().cpu())).abs().max().item() <= tol(want + res.float().cpu())
+    # producer BatchNorm + ReLU on load == bn_apply_fwd over half tensors, then the plain kernel
+    tr = _bn_params(cin, g, dev)
+    act = ops.bn_apply_fwd(x, tr[0], tr[1], tr[2], tr[3], None, True)
+    z2, em, m2, i2 = ops.conv3x3_h(x, wt, transform=tr, emit=True, stats=(1e-5, 0.1, rm2, rv2))
+    assert torch.equal(em, act)                                                     # the same expression, rounded once
+    z3 = ops.conv3x3_h(act, wt)
+    assert torch.equal(z2, z3)
+
+
 def test_elementwise_half_tensors(dev):
     """BatchNorm apply / backward reductions / backward apply, global average pooling both ways: half tensors == the fp32-tensor
     kernels on the same values, outputs rounded once, parameter gradients equal."""
