@@ -9,6 +9,7 @@
 // ssad_wgrad_reduce's kernel adds the slabs in a fixed order (deterministic).
 #include "common.h"
 #include "ssad.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -142,6 +143,129 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemWgradParams p) {
         }
 }
 
+// ---- fp16 OPERANDS (precision-16 step with half tensors): the same tiling on v_mfma_f32_32x32x16_f16 ----
+// The fp32 kernel above is bound by its matrix instructions (78.9 GFLOP per batch-256 step on the fp32 MFMAs: 0.93 ms); under the
+// reference's pl.Trainer(precision=16) autocast runs conv1 -- forward (stem16.hip) and weight gradient -- on fp16 operands.  dz arrives
+// as halves and stays so in LDS ([pixel][co]); the image tile is rounded to halves while it is staged ([row][col][3]).  An MFMA
+// contracts over 16 pixels (half a tile row): lane (r, h) supplies, for output channel r / filter column k(r), the 8 pixels
+// px0 + 8 h .. + 7 -- eight 2-byte LDS reads at constant offsets per operand (one pixel apart: 128 B for dz, 12 B for the image), which
+// the compiler places straight into the register halves (ds_read_u16_d16 / _d16_hi: no packing).  2 x 5 accumulator tiles per wave as
+// above; 10 MFMAs per 7 x 8 operand reads.  Same slabs, same fixed-order reduction.
+__global__ __launch_bounds__(256, 2) void stem_wgrad16_kernel(StemWgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    hf* dys = (hf*)lds;                  // [128 px][64 co]
+    hf* tin = dys + DY_FLOATS;           // [IH][IW][3]
+    const hf* const dzp = (const hf*)p.dz;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    int koff[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        const int k = kt * 32 + r;
+        const int tap = k / 3, c = k - tap * 3, ky = tap / 7, kx = tap - ky * 7;
+        koff[kt] = k < 147 ? (ky * IW + kx) * 3 + c : 0;        // padded columns read something finite; never stored
+    }
+    f32x16 acc[2][KT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < KT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int tiles_per_sample = p.tiles_y * p.tiles_x;
+    const int64_t plane = (int64_t)p.H * p.W;
+    const bool direct = p.Hv == p.H && p.Wv == p.W;
+    constexpr int NDZ = DY_FLOATS / 8 / 256;                 // 4 16-byte pieces (8 halves) of dz per thread
+    constexpr int NIN = (IH * IW + 255) / 256;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 dzv[NDZ];
+    float pv[NIN][3];
+    auto fetch_tile = [&](int64_t t) {
+        const int64_t n = t / tiles_per_sample;
+        const int tt = (int)(t - n * tiles_per_sample);
+        const int ty0 = (tt / p.tiles_x) * TH, tx0 = (tt % p.tiles_x) * TW;
+        const float* src = p.img + n * 3 * plane;
+#pragma unroll
+        for (int q = 0; q < NDZ; ++q) {
+            const int i = tid + 256 * q;
+            const int px = i >> 3, c8 = i & 7;
+            const int oy = ty0 + (px >> 5), ox = tx0 + (px & 31);
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (oy < p.Ho && ox < p.Wo) v = *(const u32x4*)(dzp + ((n * p.Ho + oy) * p.Wo + ox) * 64 + c8 * 8);
+            dzv[q] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < NIN; ++q) {
+            const int i = tid + 256 * q;
+            const int iy = i / IW, ix = i - iy * IW;
+            const int vy = 2 * ty0 - 3 + iy, vx = 2 * tx0 - 3 + ix;
+            float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+            if (i < IH * IW && (unsigned)vy < (unsigned)p.Hv && (unsigned)vx < (unsigned)p.Wv) {
+                const int sy = direct ? vy : (vy * p.H) / p.Hv, sx = direct ? vx : (vx * p.W) / p.Wv;
+                const float* sp = src + (int64_t)sy * p.W + sx;
+                v0 = sp[0]; v1 = sp[plane]; v2 = sp[2 * plane];
+            }
+            pv[q][0] = v0; pv[q][1] = v1; pv[q][2] = v2;
+        }
+    };
+    if ((int64_t)blockIdx.x < p.total_tiles) fetch_tile(blockIdx.x);
+    for (int64_t t = blockIdx.x; t < p.total_tiles; t += gridDim.x) {
+        __syncthreads();                 // the previous tile's readers are done
+#pragma unroll
+        for (int q = 0; q < NDZ; ++q) ((u32x4*)dys)[tid + 256 * q] = dzv[q];
+#pragma unroll
+        for (int q = 0; q < NIN; ++q) {
+            const int i = tid + 256 * q;
+            if (i < IH * IW) {
+                hf* d = tin + i * 3;
+                d[0] = (hf)pv[q][0]; d[1] = (hf)pv[q][1]; d[2] = (hf)pv[q][2];
+            }
+        }
+        __syncthreads();
+        if (t + gridDim.x < p.total_tiles) fetch_tile(t + gridDim.x);
+
+        // wave w contracts pixel groups w, w + 4 (16 pixels = half a tile row each): lane half h takes pixels px0 + 8 h .. + 7
+#pragma unroll
+        for (int g = wave; g < TH * TW / 16; g += 4) {
+            const int px0 = g * 16 + 8 * h;
+            const hf* ap = dys + px0 * 64 + r;
+            const hf* bp = tin + (2 * (px0 >> 5) * IW + 2 * (px0 & 31)) * 3;
+            f16x8 a0, a1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a0[j] = ap[j * 64]; a1[j] = ap[j * 64 + 32]; }
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                f16x8 b;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b[j] = bp[koff[kt] + j * 6];
+                acc[0][kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b, acc[0][kt], 0, 0, 0);
+                acc[1][kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b, acc[1][kt], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- the four waves hold partial sums over disjoint pixels: add them through LDS, one 32x32 tile at a time ----
+    float* red = lds;                    // [4 waves][32][32]
+    float* out = p.slab + (int64_t)blockIdx.x * 64 * KPAD;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * 32 + r] = acc[i][kt][e];
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = tid + 256 * q, row = idx >> 5, col = idx & 31;
+                const float v = ((red[idx] + red[1024 + idx]) + red[2048 + idx]) + red[3072 + idx];
+                out[(i * 32 + row) * KPAD + kt * 32 + col] = v;
+            }
+        }
+}
+
 int stem_wgrad_blocks(int64_t total_tiles) {
     static const int target = getenv("SSAD_STEM_WGRAD_BLOCKS") ? atoi(getenv("SSAD_STEM_WGRAD_BLOCKS")) : 512;
     return (int)(total_tiles < target ? total_tiles : target);
@@ -174,7 +298,9 @@ static int stem_wgrad_impl(const float* img, const void* dz, int dz_half, float*
     // nearest resize was read out of bounds here): the caller states what its buffer holds
     SSAD_CHECK_ARG(dz_elems == (int64_t)B * p.Ho * p.Wo * 64, "dz does not hold B x Ho x Wo x 64 elements for these images");
     const int nblk = stem_wgrad_blocks(p.total_tiles);
-    if (dz_half) hipLaunchKernelGGL(stem_wgrad_kernel<hf>, dim3(nblk), dim3(256), (DY_FLOATS + IN_FLOATS) * 4, (hipStream_t)stream, p);
+    // dz_half: 1 = halves read into the fp32-MFMA kernel (exact products of the stored values); 2 = fp16 operands (image rounded)
+    if (dz_half == 2) hipLaunchKernelGGL(stem_wgrad16_kernel, dim3(nblk), dim3(256), (DY_FLOATS + IN_FLOATS) * 4, (hipStream_t)stream, p);
+    else if (dz_half) hipLaunchKernelGGL(stem_wgrad_kernel<hf>, dim3(nblk), dim3(256), (DY_FLOATS + IN_FLOATS) * 4, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(stem_wgrad_kernel<float>, dim3(nblk), dim3(256), (DY_FLOATS + IN_FLOATS) * 4, (hipStream_t)stream, p);
     SSAD_CHECK_LAUNCH();
     return ssad_wgrad_reduce(workspace, dw, nblk, 64, KPAD, 7, 7, 3, to_oihw, accumulate, stream);
@@ -188,5 +314,6 @@ extern "C" int ssad_stem_wgrad(const float* img, const float* dz, float* dw, int
 // dz stored as halves (precision-16 step); products and sums in fp32 as above
 extern "C" int ssad_stem_wgrad_h(const float* img, const void* dz, float* dw, int B, int H, int W, int64_t dz_elems, int to_oihw,
                                  int accumulate, float* workspace, void* stream) {
-    return stem_wgrad_impl(img, dz, 1, dw, B, H, W, dz_elems, to_oihw, accumulate, workspace, stream);
+    static const int f16 = getenv("SSAD_STEM_WGRAD16") ? atoi(getenv("SSAD_STEM_WGRAD16")) : 1;
+    return stem_wgrad_impl(img, dz, f16 ? 2 : 1, dw, B, H, W, dz_elems, to_oihw, accumulate, workspace, stream);
 }

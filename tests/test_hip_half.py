@@ -223,10 +223,12 @@ def test_stem_half_tensors(dev):
         dz32 = ops.pool_bn_relu_bwd(gidx, dpool, zf, mh, ih, gamma, beta, db1, dg1)
         dzh = ops.pool_bn_relu_bwd(gidx, dpool.half(), zh, mh, ih, gamma, beta, db2, dg2)
         assert torch.equal(db1, db2) and torch.equal(dg1, dg2) and torch.equal(dzh, dz32.half())
+        # conv1's weight gradient from the half dz on fp16 operands (the image rounded while staged, as autocast feeds it): the exact
+        # fp32 kernel over the same rounded values gives the same products in another summation order
         dw1, dw2 = torch.empty(64 * 147, device=dev), torch.empty(64 * 147, device=dev)
-        ops.stem_wgrad(img, dzh.float(), dw1)
+        ops.stem_wgrad(img.half().float(), dzh.float(), dw1)
         ops.stem_wgrad(img, dzh, dw2)
-        assert torch.equal(dw1, dw2)
+        assert (dw1 - dw2).abs().max().item() <= 2e-5 * dw1.abs().max().item()
 
 
 def test_wrong_extents_raise(dev):
