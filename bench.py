@@ -34,7 +34,14 @@ for p in (ROOT, PKG):
         sys.path.insert(0, p)
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA (the 2:1-sparsity headline is twice that and never used here)
 PEAK_HBM_GBPS = 8000.0
+# SURVEY s.8d: algorithmic bytes of U_train with BN / ReLU / add fused into conv epilogues, every conv reading its input once and writing its
+# output once: 3 x 33.55 MB per image with fp32 tensors (forward, input gradients, weight gradients) + 254 MB per step of optimizer
+# traffic (12.69 M parameters: p, g, m read, p, m written).  With the tensors stored as halves (the precision-16 step) the activation
+# part halves; parameters, their gradients and the optimizer stay fp32.
+U_TRAIN_ACT_MB_F32 = 3 * 33.554432
+OPTIMIZER_MB_PER_STEP = 253.83
 U_TRAIN_GFLOP = 14.22            # SURVEY s.8d: one 256x256 image through fwd + bwd + update
 U_MAP_GFLOP = 252.06             # SURVEY s.8d: one 256x256 image -> anomaly map
 
@@ -349,6 +356,10 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
 
+    # ranks started by an external torchrun get the IPC mode launch_ranks() sets (the host driver only supports dmabuf IPC: without it
+    # RCCL fails with hipIpcGetMemHandle: invalid argument) -- before torch is imported
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 
@@ -445,6 +456,21 @@ def main():
         res["launch_mode"] = trainer.launch_mode
         res["train_s"] = timed(lambda: trainer.step(x, y), args.steps, max(args.warmup, 2))
         res["train_graph_segments"] = sum(1 for p in trainer._plans.values() for o in p["ops"] if o[0] == "graph")
+        if world > 1:
+            # how much of the gradient all-reduce stays exposed: HIP events around the wait of every step (a few steps outside the
+            # timed region: event records are not free), and the bytes each rank puts on the wire per step
+            def comm_probe():
+                trainer.comm_events = []
+                for _ in range(max(3, min(args.steps, 10))):
+                    trainer.step(x, y)
+                torch.cuda.synchronize()
+                ms = [a.elapsed_time(b) for a, b in trainer.comm_events]
+                trainer.comm_events = None
+                t = torch.tensor([sum(ms) / max(len(ms), 1)], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                return {"comm_exposed_ms": round(t.item(), 4), "allreduce_bytes": int(trainer.allreduce_bytes()),
+                        "allreduce_messages": int(trainer.allreduce_messages())}
+            res["comm"] = optional("comm_probe", comm_probe)
         # per-kernel attribution: the same step launched eagerly with HIP events around every launch (a captured graph
         # cannot carry them); not part of the timed region above
         ops.PROFILE = []
@@ -470,6 +496,55 @@ def main():
             r = optional("partition", partition_extra)
             if r:
                 res["partition"] = r
+        def precision16_object():
+            """The reference's DEFAULT training precision (pl.Trainer(precision=16), tools.py:263, :296) as a first-class figure: the
+            step with fp16 operands, fp32 accumulation, dynamic loss scaling and -- since round 5 -- every trunk activation and its
+            gradient stored as halves, as torch.autocast stores them.  Its matrix work is a few per cent of the step (16-bit MFMAs);
+            what bounds it is bytes: `roofline` prices SURVEY 8d's algorithmic bytes (2-byte activations, fp32 parameters / optimizer)
+            against HBM, `mfma_frac` the algorithmic FLOPs against the dense fp16 MFMA peak."""
+            tx = training.DataParallelStep(model, lr=0.005, world_size=world, precision=16, graph=use_graph)
+            n = max(args.steps, 10)
+            dt = timed(lambda: tx.step(x, y), n, 4)               # eager step, capture, two replays, then the clock
+            ms = 1e3 * dt / n
+            ops.PROFILE = []
+            for _ in range(2):
+                tx.step(x, y)
+            pr = ops.drain_profile()
+            ops.PROFILE = None
+            by = {}
+            for r in pr:
+                e = by.setdefault(r["kernel"], [0.0, 0, 0.0, 0.0]); e[0] += r["ms"]; e[1] += 1; e[2] += r["flops"]; e[3] += r["bytes"]
+            act_mb = per_rank * U_TRAIN_ACT_MB_F32 / 2
+            alg_gb = (act_mb + OPTIMIZER_MB_PER_STEP) / 1e3
+            kern_gb = sum(r["bytes"] for r in pr) / 2 / 1e9
+            out16 = {
+                "arithmetic": "fp16 operands / fp32 accumulate (v_mfma_f32_32x32x16_f16), activations and their gradients stored as halves, "
+                              "fp32 master weights, statistics, loss and SGD, device-side GradScaler",
+                "half_tensors": bool(tx.eng.h16), "images_per_gpu": per_rank,
+                "train_images_per_sec": round(world * per_rank * n / dt, 2), "train_ms_per_step": round(ms, 3), "steps": n,
+                "roofline": {"bound": "hbm", "achieved": round(alg_gb / (ms * 1e-3), 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                             "frac": round(alg_gb / (ms * 1e-3) / PEAK_HBM_GBPS, 4), "traffic": None,
+                             "alg_GB_per_step": round(alg_gb, 3),
+                             "definition": f"SURVEY 8d: {per_rank} images x 3 x 33.55 MB / 2 (half activations: forward, input gradients, "
+                                           f"weight-gradient reads) + {OPTIMIZER_MB_PER_STEP} MB optimizer traffic, over the replayed step's wall time",
+                             "kernel_sum_GB_per_step": round(kern_gb, 3),
+                             "kernel_sum_note": "sum over the step's launches of each kernel's own operand bytes (in + out once): what this "
+                                                "kernel decomposition moves at least, un-fused BatchNorm passes included"},
+                "mfma_frac": round(world * per_rank * n / dt / world * U_TRAIN_GFLOP / 1e3 / PEAK_F16_MFMA_TFLOPS, 4),
+                "mfma_peak_TFLOPs": PEAK_F16_MFMA_TFLOPS,
+                "kernel_ms": {k: [round(v[0] / 2, 3), v[1] // 2, round(v[2] / max(v[0], 1e-9) / 1e9, 1), round(v[3] / max(v[0], 1e-9) / 1e6, 1)]
+                              for k, v in sorted(by.items())},
+                "kernel_ms_columns": "ms per step, launches per step, TFLOP/s, GB/s (algorithmic bytes of the kernel's operands)"}
+            del tx
+            return out16
+        # (N = 1 only by default: a second DataParallelStep brings a second capture stream, and with two of them a multi-rank replay
+        # was measured to stall on this runtime -- DESIGN s.6; `--extras precision16` forces it)
+        if args.train_precision == "32" and (world == 1 or "precision16" in extras):
+            extras = [e for e in extras if e != "precision16"]
+            r16 = optional("precision16", precision16_object)
+            if r16:
+                res["precision16"] = r16
+            trainer.eng.bf16 = training.precision_mode(prec)
         for name in extras:
             pmap = {"precision16": 16, "bf16": "bf16", "bf16x3": "bf16x3", "bf16x6": "bf16x6"}
             if name not in pmap:
@@ -544,12 +619,14 @@ def main():
         return
 
     mode = "strong" if strong_headline else "weak"
+    rehearsal = world > 1 and (backend != "nccl" or ndev < world)
+    hw = f"{world}xMI355X" if not rehearsal else f"{world} ranks sharing {max(ndev, 1)} GPU(s) over {backend} (REHEARSAL of the N > 1 code path, not a scaling figure)"
     out = {
         "metric": "train images/sec + anomaly-maps/sec, ResNet-18 256x256 bs256",
         "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "higher_is_better": True, "scaling": mode, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"ResNet-18 {args.size}x{args.size} bs{per_rank * world if strong_headline else per_rank} self-sup train + "
-                               f"anomaly map, {world}xMI355X, synthetic images (BASELINE configs[{1 if world == 1 else 2}])",
+                               f"anomaly map, {hw}, synthetic images (BASELINE configs[{1 if world == 1 else 2}])",
                    "images_per_gpu": per_rank, "global_batch": per_rank * world, "patches_per_image": 841, "bank_rows": 588,
                    "parallelism": f"dp{world} ({mode}: {per_rank} images per rank, global batch {per_rank * world}; bucketed gradient "
                                   f"all-reduce overlapped with backward)" if world > 1 else f"dp1 ({per_rank} images)",
@@ -565,6 +642,11 @@ def main():
         out["config"]["train_graph_segments"] = res["train_graph_segments"]
         if res.get("self_check"):
             out["self_check"] = res["self_check"]
+        if res.get("comm"):
+            out["comm"] = dict(res["comm"], note="comm_exposed_ms: HIP events around the wait for the bucketed all-reduce, max over ranks, "
+                                                 "mean over steps; allreduce_bytes: fp32 gradient bytes per rank per step")
+        if res.get("precision16"):
+            out["precision16"] = res["precision16"]
         tot_s += res["train_s"]
     if "partition" in res:
         out["batch32" if world == 1 else ("weak" if strong_headline else "strong")] = res["partition"]
@@ -654,6 +736,16 @@ def main():
                                    "the zero padding that the position-major kernel skips (skipped_tap_share).")
         if rf_score and rf_train:
             out["roofline_train"] = rf_train
+    # whole-pass fractions: the MFMA FLOPs every kernel of a pass issues over the pass's wall time (not only the dominant kernel's)
+    wp = {}
+    if "train" in prof and "train_s" in res:
+        xf = sum(r["exec_flops"] for r in prof["train"]) / prof_train_steps
+        wp["train"] = round(xf / (res["train_s"] / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+    if "score" in prof and "score_s" in res:
+        xf = sum(r["exec_flops"] for r in prof["score"]) / args.steps
+        wp["score"] = round(xf / (res["score_s"] / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+    if wp:
+        out["whole_pass_frac"] = dict(wp, note="executed MFMA FLOPs of ALL kernels of the pass / its wall time / the dense fp32-MFMA peak")
     if prof:
         # HBM-bound kernels: algorithmic bytes (each operand read once, each result written once) over their event time
         hbm = {}

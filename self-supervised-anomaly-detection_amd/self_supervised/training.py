@@ -993,6 +993,7 @@ class DataParallelStep:
         self._cap_stream = None
         self.launch_mode = "hipGraph segments" if self.use_graph else "eager"
         self.self_check_report = None
+        self.comm_events = None       # bench.py: a list -> (event, event) pairs around every wait for the gradient all-reduce
 
     # ---- pieces ----
     def _sync_hyper(self):
@@ -1018,7 +1019,11 @@ class DataParallelStep:
         if sc is not None:
             ops.scale_by_loss_scale(dlogits, sc)
         eng.backward(dlogits)
-        self.bucketer.wait()
+        if self.bucketer.recorder is None and self.bucketer.works:      # eager launches: the same (optionally timed) wait as a replay
+            self._wait_works(self.bucketer.works)
+            self.bucketer.works = []
+        else:
+            self.bucketer.wait()
         rng = a.trainable_ranges()
         if sc is not None:
             for s, e in rng:
@@ -1108,10 +1113,35 @@ class DataParallelStep:
             elif op[0] == "allreduce":
                 works.append(dist.all_reduce(g[op[1]:op[2]], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
             else:
-                for w in works:
-                    w.wait()
+                self._wait_works(works)
                 works = []
         return plan["out"]
+
+    def _wait_works(self, works):
+        """The compute stream waits for the outstanding all-reduces.  With ``comm_events`` set (bench.py's probe) the wait is bracketed by
+        HIP events on the compute stream: nothing else is queued between them, so their distance is the time the step stands still
+        for the exchange -- the part of the all-reduce that backward did NOT hide."""
+        ev = getattr(self, "comm_events", None)
+        if ev is None:
+            for w in works:
+                w.wait()
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for w in works:
+            w.wait()
+        e1.record()
+        ev.append((e0, e1))
+
+    def allreduce_bytes(self):
+        """Gradient bytes one rank hands to the all-reduce per step (fp32; the trainable arena ranges)."""
+        return 4 * sum(e - s for s, e in self.eng.arena.trainable_ranges())
+
+    def allreduce_messages(self):
+        plan = next(iter(self._plans.values()), None)
+        if plan is not None:
+            return sum(1 for o in plan["ops"] if o[0] == "allreduce")
+        return len(self.bucketer.launched)
 
     # ---- start-up self-check of a multi-rank job ----
     def _snapshot(self):
