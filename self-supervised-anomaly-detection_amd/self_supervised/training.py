@@ -483,7 +483,7 @@ class TrainEngine:
         # BatchNorm kernels.  Measured (round 2, bs256 / bs32): 36.33 vs 36.07 ms and 8.05 vs 7.51 ms per step -- every big
         # kernel already fills the chip, the second stream only adds dependencies -- so it is OFF by default.
         self._nbt = []
-        self._flip_view, self._flip_ready = {}, False
+        self._flip_ready = False
         self.side = None
         self._side_keep = []
         # environment switches are read ONCE here: a captured step (hipGraph plan) must never be replayed under a different
@@ -561,28 +561,30 @@ class TrainEngine:
         if half:
             return self._flipped_half(lin)
         key = id(lin.weight)
-        if self._flip_ready and key in self._flip_view:
-            return self._flip_view[key]
-        if not self._flip_view:                      # build the table once: every conv of the residual blocks, arena offsets
+        # the fp32 table holds every layer, or -- while the trunk runs on half tensors and takes its flipped filters from the half
+        # table -- the head only.  One table per mode, BOTH kept alive: a recorded step (hipGraph plan) holds the addresses of the
+        # table it was captured with
+        tabs = self.__dict__.setdefault("_flip_tables", {})
+        tab = tabs.get(self.h16)
+        if tab is None:                              # build the table once: arena offsets of every layer it covers
             import ctypes
-            a, desc, off = self.arena, [], 0
-            layers = [d[k] for d in self.blocks for k in ("c1", "c2", "ds") if d[k] is not None] + list(self.head) + [self.cls]
-            for layer in layers:                 # every block conv and (round 3) the head's and classifier's linear layers, as 1 x 1 filters
+            a, desc, off, shapes = self.arena, [], 0, {}
+            trunk = [] if self.h16 else [d[k] for d in self.blocks for k in ("c1", "c2", "ds") if d[k] is not None]
+            for layer in trunk + list(self.head) + [self.cls]:      # block convs; the head's and classifier's linear layers as 1 x 1 filters
                 p = layer.lin.weight
                 o, c, kh, kw = p.shape if p.dim() == 4 else (p.shape[0], p.shape[1], 1, 1)
                 desc += [a.offset[id(p)][0], off, o, c, kh, kw]
-                self._flip_view[id(p)] = (off, (c, kh, kw, o))
+                shapes[id(p)] = (off, (c, kh, kw, o))
                 off += p.numel()
-            self._flip_buf = torch.empty(off, device=a.p.device, dtype=torch.float32)
-            self._flip_desc = (ctypes.c_int64 * len(desc))(*desc)
-            self._flip_n = len(desc) // 6
-            self._flip_view = {k: self._flip_buf[o:o + s[0] * s[1] * s[2] * s[3]].view(s) for k, (o, s) in self._flip_view.items()}
-        if key not in self._flip_view:
+            buf = torch.empty(off, device=a.p.device, dtype=torch.float32)
+            tab = tabs[self.h16] = {"buf": buf, "desc": (ctypes.c_int64 * len(desc))(*desc), "n": len(desc) // 6,
+                                    "view": {k: buf[o:o + sh[0] * sh[1] * sh[2] * sh[3]].view(sh) for k, (o, sh) in shapes.items()}}
+        if key not in tab["view"]:
             return ops.flip_transpose_weight(w)
-        _hip.check(_hip.lib().ssad_flip_transpose_batch(_hip.ptr(self.arena.p), _hip.ptr(self._flip_buf), self._flip_desc, self._flip_n,
-                                                        _hip.stream()))
-        self._flip_ready = True
-        return self._flip_view[key]
+        if self._flip_ready is not tab:              # first request after a forward: one launch for the whole table
+            _hip.check(_hip.lib().ssad_flip_transpose_batch(_hip.ptr(self.arena.p), _hip.ptr(tab["buf"]), tab["desc"], tab["n"], _hip.stream()))
+            self._flip_ready = tab
+        return tab["view"][key]
 
     def use_relu_mask(self):
         """Residual blocks keep their final ReLU's active set as a nibble mask (exact fp32 path, gradients wanted)."""
