@@ -399,7 +399,9 @@ def sampler_pool(num_workers):
     if _POOL["exe"] is not None and _POOL["size"] >= num_workers:
         return _POOL["exe"]
     if _POOL["exe"] is not None:
-        _POOL["exe"].shutdown(wait=False, cancel_futures=True)
+        # grow: the old pool finishes what it was given (other live loaders may still hold its futures -- their speculative next-epoch
+        # batches -- and a cancelled future would surface as CancelledError in the middle of their epoch); its workers exit afterwards
+        _POOL["exe"].shutdown(wait=False)
     ctx = _worker_context(preload=("self_supervised.augment",))
     exe = ProcessPoolExecutor(num_workers, mp_context=ctx)
     with _hidden_main(ctx):

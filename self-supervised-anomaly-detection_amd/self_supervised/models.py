@@ -187,8 +187,11 @@ class PeraNet(_Base):
         with torch.device('meta'):
             model = cls(**hp)
         model.load_state_dict(ck['state_dict'], strict=True, assign=True)
-        for p in model.parameters():
-            p.requires_grad_(True)
+        # (assign=True keeps every parameter's requires_grad flag)  Nothing may be left on the meta device: a non-persistent buffer or
+        # a plain tensor attribute created in __init__ would otherwise fail at its first use, far from here
+        left = [n for n, t in list(model.named_parameters()) + list(model.named_buffers()) if t.is_meta]
+        if left:
+            raise RuntimeError(f"load_from_checkpoint: {left} are not in the checkpoint's state_dict (still on the meta device)")
         model.on_load_checkpoint(ck)
         return model
 

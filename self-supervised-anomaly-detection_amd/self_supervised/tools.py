@@ -48,7 +48,7 @@ class Evaluator:
             # maps still on the device (straight from tools.upsample): every sort-bound metric runs there (csrc/auroc.hip) --
             # on the host the three argsorts of a category's 6 M pixel scores take longer than training the category
             targets_dev = targets.to(scores.device)
-            threshold = mtr.best_f1_threshold_gpu(scores, targets_dev)
+            threshold = self._get_threshold(scores, targets_dev)         # one overridable hook for host and device maps
             if 'auroc' in self.evaluation_metrics:
                 print(' pixel auroc' if patch_level else '>>> image auroc')
                 self.scores.auroc = mtr.auroc_gpu(targets_dev, scores)
@@ -83,6 +83,11 @@ class Evaluator:
                 json.dump({k: (None if v is None else float(v)) for k, v in vars(self.scores).items()}, f)
 
     def _get_threshold(self, scores: Tensor, targets: Tensor):
+        """F1-optimal threshold (tools.py:131-146 of the reference); device tensors take the device kernels, same value.  A subclass
+        that overrides this is honoured on both routes.  (curves['roc'] is only filled for host maps: the device route returns the
+        area, not the curve.)"""
+        if scores.is_cuda:
+            return mtr.best_f1_threshold_gpu(scores, targets)
         return mtr.best_f1_threshold(scores, targets)
 
 
@@ -200,9 +205,20 @@ class _MVTecPrefetch:
             if gfile:                                        # 'good' images: Image.new(mode='1') = all zeros
                 self.gt8[j] = np.asarray(get_ground_truth(gfile, dataset.imsize).convert('L'))
         self.pool = ThreadPoolExecutor(threads or min(8, os.cpu_count() or 1))
-        self.futs = [self.pool.submit(load, j) for j in range(n)]
+        self._load, self.futs, self._next = load, [None] * n, 0
+        # a sliding window of decodes ahead of the consumer (a real MVTec category is 100-170 test images of 1024 x 1024: decoding them
+        # all at once would hold 0.3-0.5 GB of native-size arrays with no back-pressure from the GPU side)
+        self.window = int(os.environ.get("SSAD_PREFETCH_WINDOW", "96"))
+        self._submit_until(self.window)
+
+    def _submit_until(self, end):
+        end = min(end, len(self.futs))
+        while self._next < end:
+            self.futs[self._next] = self.pool.submit(self._load, self._next)
+            self._next += 1
 
     def wait(self, a, b):
+        self._submit_until(b + self.window)             # keep `window` images in flight beyond the group that is asked for
         for f in self.futs[a:b]:
             f.result()
 
@@ -257,31 +273,35 @@ def _predict_mvtec_streamed(model: PeraNet, dataset, device, indices, group: int
             logits_host[a * p:b * p].copy_(logits_dev[a * p:b * p])
         for t in (o_dev, x_dev):
             t.record_stream(side)
-    with torch.no_grad():
-        for a in range(0, n, group):
-            b = min(n, a + group)
-            pre.wait(a, b)
-            img_dev = gpu_io.to_rgb_batch(native[a:b], dataset.imsize, device)
-            native[a:b] = [None] * (b - a)
-            o_dev = torch.empty((b - a, 3, h_img, w_img), device=device, dtype=torch.float32)
-            x_dev = torch.empty_like(o_dev)
-            _hip.check(lib.ssad_u8hwc_to_f32chw_norm(img_dev.data_ptr(), o_dev.data_ptr(), x_dev.data_ptr(), b - a, h_img, w_img,
-                                                     mean, std, _hip.stream()))
-            pred = model(x_dev)
-            p = pred['latent_space'].shape[0] // (b - a)
-            if emb_dev is None:
-                d, c = pred['latent_space'].shape[1], pred['classifier'].shape[1]
-                emb_dev = torch.empty((n * p, d), device=device, dtype=torch.float32)
-                logits_dev = torch.empty((n * p, c), device=device, dtype=torch.float32)
-                emb_host, logits_host = torch.empty((n * p, d)), torch.empty((n * p, c))
-            emb_dev[a * p:b * p].copy_(pred['latent_space'])
-            logits_dev[a * p:b * p].copy_(pred['classifier'])
-            ev = torch.cuda.Event()
-            ev.record(main)
-            if pending is not None:
-                drain(pending)                          # the previous group's results travel while this group computes
-            pending = (a, b, o_dev, x_dev, ev, p)
-        drain(pending)
+    try:
+        with torch.no_grad():
+            for a in range(0, n, group):
+                b = min(n, a + group)
+                pre.wait(a, b)
+                img_dev = gpu_io.to_rgb_batch(native[a:b], dataset.imsize, device)
+                native[a:b] = [None] * (b - a)
+                o_dev = torch.empty((b - a, 3, h_img, w_img), device=device, dtype=torch.float32)
+                x_dev = torch.empty_like(o_dev)
+                _hip.check(lib.ssad_u8hwc_to_f32chw_norm(img_dev.data_ptr(), o_dev.data_ptr(), x_dev.data_ptr(), b - a, h_img, w_img,
+                                                         mean, std, _hip.stream()))
+                pred = model(x_dev)
+                p = pred['latent_space'].shape[0] // (b - a)
+                if emb_dev is None:
+                    d, c = pred['latent_space'].shape[1], pred['classifier'].shape[1]
+                    emb_dev = torch.empty((n * p, d), device=device, dtype=torch.float32)
+                    logits_dev = torch.empty((n * p, c), device=device, dtype=torch.float32)
+                    emb_host, logits_host = torch.empty((n * p, d)), torch.empty((n * p, c))
+                emb_dev[a * p:b * p].copy_(pred['latent_space'])
+                logits_dev[a * p:b * p].copy_(pred['classifier'])
+                ev = torch.cuda.Event()
+                ev.record(main)
+                if pending is not None:
+                    drain(pending)                          # the previous group's results travel while this group computes
+                pending = (a, b, o_dev, x_dev, ev, p)
+            drain(pending)
+    except BaseException:
+        pre.close(cancel=True)                           # a failing predict must not leave decode threads running until exit
+        raise
     pre.close()
     side.synchronize()
     gts = torch.from_numpy(gt8).float().div_(255.0).unsqueeze(1)

@@ -167,10 +167,22 @@ class _Affine:
                 self.mean = bn.running_mean
                 scale = (bn.weight * self.invstd).contiguous()
                 shift = (bn.bias - bn.running_mean * scale).contiguous()
-            y = ops.stem_fwd(img, w, scale, shift, relu=True)
-            self.z = None
+            if self._gamma_grad_under_eval_stats():
+                # eval-mode statistics but a TRAINABLE BatchNorm weight: its gradient needs the normalised input, so the conv output
+                # is kept and the affine map applied by the BatchNorm kernel (running statistics in the role of mean / invstd)
+                a = self.eng.arena
+                z = ops.stem_fwd(img, w, None, None, relu=False)
+                y = ops.bn_apply_fwd(z, self.mean, self.invstd.contiguous(), a.w(bn.weight), a.w(bn.bias), None, True)
+                self.z, self.eval_stats = z, True
+            else:
+                y = ops.stem_fwd(img, w, scale, shift, relu=True)
+                self.z = None
         self.y = y
         return y
+
+    def _gamma_grad_under_eval_stats(self):
+        bn = self.bn
+        return (bn is not None and not bn.training and bn.weight.requires_grad and self.eng.param_grads and torch.is_grad_enabled())
 
     def fwd_pool(self, img):
         """Stem + max-pool: (pooled NHWC, argmax slots).  With batch statistics the BatchNorm + ReLU run inside the
@@ -196,7 +208,7 @@ class _Affine:
     def bwd_pool(self, idx, dpool, a0_shape):
         """Backward of fwd_pool: fills the BatchNorm and conv1 gradients (no input gradient: the image)."""
         a, bn = self.eng.arena, self.bn
-        if self.z is None:                       # eval-mode statistics: unfused path
+        if self.z is None or getattr(self, "eval_stats", False):       # eval-mode statistics: unfused path
             self.bwd(ops.maxpool3x3s2_bwd_idx(idx, dpool, a0_shape), need_dx=False)
             return
         pg = self.eng.param_grads
@@ -298,6 +310,7 @@ class _Affine:
         self.x, self.res_used = x, residual is not None
         self.x_shape = tuple(x.shape)
         self.mask = None
+        self.eval_stats = False
         bias = getattr(self.lin, "bias", None)
         bf = self.eng.bf16
         if x.dtype == torch.float16:             # precision-16 step with half tensors: the rounded copy of the weights
@@ -346,6 +359,14 @@ class _Affine:
                 shift = bn.bias - bn.running_mean * scale
                 if bias is not None:
                     shift = shift + bias * scale
+            if self._gamma_grad_under_eval_stats():
+                # (as in _stem_fwd) frozen statistics, trainable affine parameters -- e.g. freeze_net(['backbone']) followed by
+                # un-freezing the BatchNorm weights only: keep z, apply the affine map with the running statistics
+                z = ops.conv_fwd(x, w, None, a.w(bias) if bias is not None else None, None, False, self.stride, self.pad, bf)
+                y = ops.bn_apply_fwd(z, self.mean, self.invstd.contiguous(), a.w(bn.weight), a.w(bn.bias), residual, self.relu)
+                self.z, self.eval_stats = z, True
+                self.y = y if self.relu else None
+                return y
             y = ops.conv_fwd(x, w, scale, shift.contiguous(), residual, self.relu, self.stride, self.pad, bf)
             self.z = None
         self.y = y if self.relu else None
@@ -364,7 +385,7 @@ class _Affine:
             dz = dy
         else:
             c = bn.num_features
-            train_stats = self.z is not None
+            train_stats = self.z is not None and not getattr(self, "eval_stats", False)
             pg = self.eng.param_grads
             wg, bg = bn.weight.requires_grad and pg, bn.bias.requires_grad and pg
             small_bias = None
@@ -393,9 +414,8 @@ class _Affine:
             elif train_stats or wg or bg:
                 dbeta = a.grad(bn.bias) if bg else torch.empty(c, device=dy.device)
                 dgamma = a.grad(bn.weight) if wg else torch.empty(c, device=dy.device)
-                zsrc = self.z if train_stats else None
-                if zsrc is None and wg:
-                    raise NotImplementedError("BatchNorm weight gradient with eval-mode statistics")
+                zsrc = self.z             # train-mode statistics, or eval-mode statistics with z kept for a trainable weight
+                assert zsrc is not None or not wg, "the forward keeps z whenever the BatchNorm weight is trainable"
                 ops.bn_bwd_reduce(dy, self.y, zsrc, self.mean, self.invstd, dbeta, dgamma, c)
                 dz, dres = ops.bn_apply_bwd(dy, self.y, self.z, self.mean, self.invstd, a.w(bn.weight), dbeta, dgamma,
                                             want_dres, eval_mode=not train_stats)

@@ -371,6 +371,32 @@ def test_frozen_backbone_stage(dev, seeded_sd):
             assert rel_err(p.grad, ref_params[name].grad, grad_floor(ref)) < 1e-3, name
 
 
+def test_trainable_batchnorm_weights_under_eval_statistics(dev, seeded_sd):
+    """BatchNorm layers of the trunk in eval mode (running statistics) while their affine parameters -- and everything else -- train:
+    the reference's autograd handles it (models.py:174-196 only toggles requires_grad; a user may un-freeze any subset), the engine
+    keeps z for such a layer and takes the weight gradient from the normalised input (round 4 raised NotImplementedError here)."""
+    from self_supervised import training
+    from oracle import weights as ow
+    from oracle.peranet import train_step
+    ref, m = _pair(seeded_sd, dev)
+    m.unfreeze()
+    for mod in list(ref.feature_extractor.modules()) + list(m.feature_extractor.modules()):
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.eval()
+    x, y = ow.synthetic_images(8, 64, seed=65), ow.synthetic_labels(8, seed=66)
+    loss_ref, _, _ = train_step(ref, x, y)
+    loss_ref.backward()
+    step = training.DataParallelStep(m, lr=0.01, world_size=1, graph=False)
+    la = step.step(x.to(dev), y.to(dev))
+    np.testing.assert_allclose(la[0].item(), loss_ref.item(), rtol=1e-5)
+    ref_params = dict(ref.named_parameters())
+    for name, p in m.named_parameters():
+        assert rel_err(p.grad, ref_params[name].grad, grad_floor(ref)) < 1e-3, name
+    for (n1, b1), (n2, b2) in zip(ref.named_buffers(), m.named_buffers()):          # running statistics untouched
+        if "feature_extractor" in n1 and "num_batches" not in n1:
+            assert torch.allclose(b1, b2.cpu()), n1
+
+
 def test_autograd_bridge(dev, seeded_sd):
     """loss.backward() on the tensor returned by training_step fills p.grad (PyTorch-Lightning-style use)."""
     from oracle import weights as ow
