@@ -18,11 +18,22 @@
 //     exchanges one value (DPP) and each lane writes one 4-byte pair of halves (64 contiguous bytes per half-wave row);
 //     BatchNorm statistics are those of the STORED halves, summed per lane in double across all tiles of the workgroup: one
 //     partial row per workgroup (<= 512 rows for the finalize kernel instead of one per tile).
+//
+// Where its time goes (round 5, tools/micro/conv16_ablate.hip, 256 x 32 x 32 x 128 -> 128, zero operands; 31 us = the fp16 MFMA floor):
+// 109-118 us as shipped; without the MFMAs 47-50; MFMAs + fragment reads + barriers alone 49 -- the phases ADD, the co-resident
+// workgroup does not fill the matrix stream's gaps (the finding of profiles/r03_igemm_phases.md for fp32 holds for 16-bit MFMAs);
+// without the weight-slice loads 70 (their L2 latency: three steps of prefetch and a per-workgroup tap rotation took 132 -> 81-109);
+// without the epilogue 71, and the epilogue WITHOUT ITS STORES costs the same as with them: it is ~1 500 VALU instructions per tile
+// (64-bit offsets, lane-pair selects, conversions for the statistics).  A version with 32-bit scalar offsets and statistics taken
+// from the packed halves was built: the register allocator then spills 30-100 VGPRs (64 accumulators + 48 weight + 24 halo
+// prefetch registers are live across the epilogue) and nothing is gained (115 us); dealing the weight pieces out between the MFMA
+// groups: 117 us.  Not kept.
 #include "common.h"
 #include <stdlib.h>
 
 // Ablation switches for tools/micro/conv16_ablate.hip (timing only, results are garbage); always 0 in the library build.
 //   1 = no weight-slice loads   2 = no halo loads   4 = no epilogue   8 = no MFMAs   16 = no fragment reads   32 = no step barriers
+//   64 = the epilogue without its global stores
 #ifndef CONV16_ABL
 #define CONV16_ABL 0
 #endif
@@ -361,7 +372,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h_kernel(Conv16Params p) {
                             v1 += (float)rv[1];
                         }
                         const h2 ov = {(hf)v0, (hf)v1};
-                        *(unsigned*)(p.out + o[e >> 1] + 32 * j) = __builtin_bit_cast(unsigned, ov);
+                        if (!(CONV16_ABL & 64) || v0 == 123.456f)       // ablation 64: the epilogue's arithmetic without its stores
+                            *(unsigned*)(p.out + o[e >> 1] + 32 * j) = __builtin_bit_cast(unsigned, ov);
                         if (p.stats) {              // this lane's own channel over both rows of the pair, as stored
                             const float s0 = (float)(hf)acc[i][j][e], s1 = (float)(hf)acc[i][j][e + 1];
                             fs[j] += s0 + s1;
