@@ -1249,6 +1249,18 @@ class DataParallelStep:
         self.self_check_report = rep
         return rep
 
+    def bind_inputs(self, x, y):
+        """-> (x, y) tensors a producer may fill IN PLACE for the next step: the recorded plan's own input buffers for this shape
+        (step(x, y) then replays without the device-to-device copy of the batch -- 201 MB per step at 256 x 3 x 256 x 256); the given
+        tensors themselves while no plan exists for the shape (eager launches, first steps)."""
+        plan = self._plans.get(self._plan_key(x, y)) if self.use_graph else None
+        if plan is None:
+            return x, y
+        if plan["x"].data_ptr() != x.data_ptr():
+            plan["x"].copy_(x)
+            plan["y"].copy_(y)
+        return plan["x"], plan["y"]
+
     def _plan_key(self, x, y):
         return (tuple(x.shape), tuple(y.shape), x.dtype, y.dtype, self.eng.switches(), tuple(self.eng.arena.trainable_ranges()),
                 tuple(bool(m.training) for m in self.model.modules() if isinstance(m, BN_TYPES)))

@@ -397,6 +397,33 @@ def test_trainable_batchnorm_weights_under_eval_statistics(dev, seeded_sd):
             assert torch.allclose(b1, b2.cpu()), n1
 
 
+def test_bound_step_inputs(dev, seeded_sd):
+    """DataParallelStep.bind_inputs: a producer fills the recorded step's own input buffers in place; replays from them equal replays
+    that copy the batch in, bit for bit."""
+    from self_supervised import training
+    from oracle import weights as ow
+    x, y = ow.synthetic_images(4, 64, seed=75).to(dev), ow.synthetic_labels(4, seed=76).to(dev)
+    x2 = ow.synthetic_images(4, 64, seed=77).to(dev)
+    outs = []
+    for bound in (False, True):
+        _, m = _pair(seeded_sd, dev)
+        m.unfreeze()
+        step = training.DataParallelStep(m, lr=0.01, world_size=1)
+        assert step.bind_inputs(x, y)[0] is x                       # no plan yet: the tensors themselves
+        for _ in range(3):
+            step.step(x, y)
+        if bound:
+            xb, yb = step.bind_inputs(x, y)
+            assert xb.data_ptr() != x.data_ptr() and torch.equal(xb, x)
+            xb.copy_(x2)                                            # the producer writes the next batch in place
+            step.step(xb, yb)
+        else:
+            step.step(x2, y)
+        torch.cuda.synchronize()
+        outs.append(step.eng.arena.p.clone())
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_autograd_bridge(dev, seeded_sd):
     """loss.backward() on the tensor returned by training_step fills p.grad (PyTorch-Lightning-style use)."""
     from oracle import weights as ow
