@@ -66,6 +66,7 @@ def parse_args():
     ap.add_argument("--no-wrn50", action="store_true", help="skip the BASELINE configs[3] (WideResNet-50 512x512 bs64) member of the N = 1 line")
     ap.add_argument("--no-partition-extra", action="store_true", help="skip the strong-partition / batch-32 extra line")
     ap.add_argument("--no-faithful", action="store_true", help="skip the bf16x6 (fp32-faithful split products) side measurement")
+    ap.add_argument("--no-precision16", action="store_true", help="skip the precision16 member (the reference's default precision) of the N = 1 line")
     ap.add_argument("--no-graph", action="store_true", help="launch the training step eagerly instead of replaying hipGraphs")
     ap.add_argument("--train-precision", choices=["32", "16", "bf16"], default="32",
                     help="32: exact fp32 MFMA (headline); 16: fp16 operands + loss scaling (the reference's Trainer(precision=16)); "
@@ -550,7 +551,7 @@ def main():
             return out16
         # (N = 1 only by default: a second DataParallelStep brings a second capture stream, and with two of them a multi-rank replay
         # was measured to stall on this runtime -- DESIGN s.6; `--extras precision16` forces it)
-        if args.train_precision == "32" and (world == 1 or "precision16" in extras):
+        if args.train_precision == "32" and not args.no_precision16 and (world == 1 or "precision16" in extras):
             extras = [e for e in extras if e != "precision16"]
             r16 = optional("precision16", precision16_object)
             if r16:

@@ -379,3 +379,43 @@ def label_mean_rgb(segments, image_array):
         msk = (segments == s).nonzero()
         out[msk] = image_array[msk].mean(axis=0)
     return out
+
+
+_SLIC_MEMO = {}
+
+
+def slic_superpixels_cached(image_array, n_segments=5, sigma=2, **kw):
+    """slic_superpixels with a memo: the labels of an image are a pure function of its pixels and the parameters, and the one caller
+    (the 'cable' pre-segmentation, datasets.py:201-206 of the reference) asks for the same first training image at every dataset
+    construction -- train, validation and every later run.  In-process dictionary, then a file under SSAD_CACHE_DIR (default
+    ~/.cache/ssad; SSAD_CACHE_DIR="" switches the files off) named by the SHA-1 of the pixels, the shape and the parameters: the
+    host k-means (0.1-0.3 s) then runs once per image ever, not once per construction."""
+    import hashlib
+    import os
+    arr = np.ascontiguousarray(image_array)
+    key = hashlib.sha1(arr.tobytes() + repr((arr.shape, str(arr.dtype), n_segments, sigma, sorted(kw.items()))).encode()).hexdigest()
+    if key in _SLIC_MEMO:
+        return _SLIC_MEMO[key].copy()
+    root = os.environ.get("SSAD_CACHE_DIR", os.path.join(os.path.expanduser("~"), ".cache", "ssad"))
+    path = os.path.join(root, f"slic_{key}.npy") if root else None
+    labels = None
+    if path and os.path.exists(path):
+        try:
+            labels = np.load(path)
+            if labels.shape != arr.shape[:2]:
+                labels = None
+        except Exception:          # noqa: BLE001  (a truncated cache file is recomputed, never trusted)
+            labels = None
+    if labels is None:
+        labels = slic_superpixels(arr, n_segments=n_segments, sigma=sigma, **kw)
+        if path:
+            try:
+                os.makedirs(root, exist_ok=True)
+                tmp = f"{path}.{os.getpid()}.tmp"
+                with open(tmp, "wb") as f:
+                    np.save(f, labels)
+                os.replace(tmp, path)          # atomic: concurrent ranks either see the whole file or none
+            except OSError:
+                pass
+    _SLIC_MEMO[key] = labels
+    return labels.copy()

@@ -21,7 +21,8 @@ from torch.utils.data import DataLoader, Dataset
 
 from . import constants
 from .dataset_generator import (check_color_similarity, check_valid_coordinates_by_container, generate_patch,
-                                get_random_coordinate, label_mean_rgb, obj_mask, paste_patch, rect2poly, slic_superpixels)
+                                get_random_coordinate, label_mean_rgb, obj_mask, paste_patch, rect2poly, slic_superpixels,
+                                slic_superpixels_cached)
 from .functional import (duplicate_filenames, get_all_subject_experiments, get_filenames, get_ground_truth,
                          get_ground_truth_filename, get_test_data_filenames)
 
@@ -183,7 +184,7 @@ class PretextTaskDataset(Dataset):
                 # datasets.py:201-206: SLIC super-pixels (5 segments, sigma 2, Lab) painted with their mean colours first
                 # (scikit-image is not a dependency here: dataset_generator.slic_superpixels restates it, pinned against the library)
                 arr = np.array(temp)
-                temp = Image.fromarray(label_mean_rgb(slic_superpixels(arr, n_segments=5, sigma=2), arr)).convert('RGB')
+                temp = Image.fromarray(label_mean_rgb(slic_superpixels_cached(arr, n_segments=5, sigma=2), arr)).convert('RGB')
             self.fixed_segmentation = obj_mask(temp)
 
     # -- one synthetic defect, PIL back-end --
