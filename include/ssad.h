@@ -507,6 +507,15 @@ int64_t ssad_conv3x3_h_stats_rows(int64_t N, int H, int W, int Cout);
 int ssad_conv3x3_h(const void* in, const void* w_ohwi, void* out, const void* residual, const float* tr_mean, const float* tr_invstd,
                    const float* tr_gamma, const float* tr_beta, void* emit, int64_t N, int H, int W, int Cin, int Cout, double* stats_ws,
                    float eps, float momentum, float* mean, float* invstd, float* running_mean, float* running_var, void* stream);
+/* Weight gradient of the 3 x 3 / pad 1 convolutions, stride 1 AND 2, over half tensors (csrc/wgrad16.hip): tiles go to LDS as they lie
+ * in memory and the [pixel][channel] -> [channel][pixel] transpose the matrix instruction needs happens in the fragment reads (eight
+ * 2-byte LDS reads per operand), so no staging waves, no conversion; same slab contract as ssad_conv_wgrad3x3_halo16:
+ * splits = ssad_wgrad3x3_g16_splits(N, Ho, Wo, Cin, Cout, stride), then ssad_wgrad_reduce(slab, dw, splits, Cout, 9 * Cin, 3, 3, Cin, ..).
+ * Replaces the conv2d weight-gradient node of every BasicBlock conv3x3 under pl.Trainer(precision=16) (tools.py:263, :270, :303). */
+int ssad_wgrad3x3_g16_ok(int Cin, int Cout, int KH, int KW, int stride, int pad);
+int ssad_wgrad3x3_g16_splits(int64_t N, int Ho, int Wo, int Cin, int Cout, int stride);
+int ssad_conv_wgrad3x3_g16_h(const void* dz, const void* x, float* slab, int splits, int64_t N, int Ho, int Wo, int H, int W, int Cin,
+                             int Cout, int stride, int64_t dz_elems, void* stream);
 /* weight gradients from half tensors (fp32 slabs, then ssad_wgrad_reduce, as the fp32-tensor forms) */
 int ssad_conv_wgrad3x3_halo16_h(const void* dz, const void* x, float* slab, int splits, int64_t N, int H, int W, int Cin, int Cout,
                                 int64_t dz_elems, void* stream);

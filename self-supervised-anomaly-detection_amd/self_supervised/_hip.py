@@ -162,6 +162,9 @@ SIGNATURES = {
     "ssad_bn_apply_bwd_zmask_h": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_fp],
     "ssad_pool_bn_relu_bwd_h": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i,
                                 _c_l, _c_fp, _c_fp],
+    "ssad_wgrad3x3_g16_ok": [_c_i, _c_i, _c_i, _c_i, _c_i, _c_i],
+    "ssad_wgrad3x3_g16_splits": [_c_l, _c_i, _c_i, _c_i, _c_i, _c_i],
+    "ssad_conv_wgrad3x3_g16_h": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_l, _c_fp],
     "ssad_conv_wgrad3x3_halo16_h": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_l, _c_fp],
     "ssad_conv_wgrad_f16_h": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_l, _c_fp],
     "ssad_stem_wgrad_h": [_c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_l, _c_i, _c_i, _c_fp, _c_fp],

@@ -584,7 +584,15 @@ def conv_wgrad(dy, x, dw_out, kh, kw, stride, pad, kreal=None, to_oihw=False, ac
     if _is_h(dy):
         # precision-16 step with half tensors: the same two 16-bit kernels, their operands read as the halves they are stored as
         assert _is_h(x) and bf16 == 2 and kreal is None
-        if lib.ssad_wgrad3x3_halo16_ok(cin, cout, kh, kw, stride, pad):
+        if lib.ssad_wgrad3x3_g16_ok(cin, cout, kh, kw, stride, pad):
+            # 3 x 3 / pad 1, stride 1 or 2: tiles staged as they lie in memory, transposed by the fragment reads (csrc/wgrad16.hip)
+            ho, wo = dy.shape[1], dy.shape[2]
+            splits = lib.ssad_wgrad3x3_g16_splits(n, ho, wo, cin, cout, stride)
+            slab = _new((splits, cout, 9 * cin), dy)
+            _run("wgrad_g16", 2.0 * m * cout * 9 * cin, 2.0 * (dy.numel() + x.numel()) + 4.0 * slab.numel(),
+                 lambda: lib.ssad_conv_wgrad3x3_g16_h(dy.data_ptr(), x.data_ptr(), _hip.ptr(slab), splits, n, ho, wo, h, w, cin, cout,
+                                                      stride, dy.numel(), _hip.stream()))
+        elif lib.ssad_wgrad3x3_halo16_ok(cin, cout, kh, kw, stride, pad):
             splits = lib.ssad_wgrad3x3_halo16_splits(n, h, w, cin, cout)
             slab = _new((splits, cout, 9 * cin), dy)
             _run("wgrad_h16", 2.0 * m * cout * 9 * cin, 2.0 * (dy.numel() + x.numel()) + 4.0 * slab.numel(),

@@ -81,7 +81,11 @@ def test_conv_igemm_half_tensors(dev, shape):
     dwh = torch.empty_like(dw32)
     ops.conv_wgrad(dy, x, dw32, k, k, s, p, bf16=2)
     ops.conv_wgrad(dy.half(), x.half(), dwh, k, k, s, p, bf16=2)
-    assert torch.equal(dwh, dw32)
+    # 1 x 1 layers: the same kernel reading halves (equal bits); 3 x 3 layers: csrc/wgrad16.hip -- the same products, another order
+    if k == 1:
+        assert torch.equal(dwh, dw32)
+    else:
+        assert (dwh - dw32).abs().max().item() <= 2e-5 * max(1.0, dw32.abs().max().item())
 
 
 @pytest.mark.parametrize("shape", [(3, 16, 16), (2, 13, 21), (5, 64, 64)])
@@ -144,6 +148,27 @@ def test_conv3x3_h_halo_kernel(dev, shape):
     assert torch.equal(em, act)                                                     # the same expression, rounded once
     z3 = ops.conv3x3_h(act, wt)
     assert torch.equal(z2, z3)
+
+
+@pytest.mark.parametrize("shape", [(3, 16, 16, 64, 64, 1), (2, 13, 21, 64, 128, 1), (5, 8, 8, 128, 64, 1), (3, 5, 7, 64, 64, 1),
+                                   (40, 32, 32, 128, 128, 1), (9, 64, 64, 64, 64, 1), (3, 32, 32, 64, 128, 2), (2, 13, 21, 64, 64, 2),
+                                   (5, 16, 16, 128, 256, 2), (40, 16, 16, 256, 512, 2), (3, 9, 9, 64, 64, 2)])
+def test_wgrad_gather16_kernel(dev, shape):
+    """csrc/wgrad16.hip (fragments gathered from [pixel][channel] tiles by 2-byte LDS reads) against fp32 math on the same half
+    operands: stride 1 and 2, 4 x 16 / 8 x 8 / 2 x 16 / 4 x 8 tiles, ragged tiles, odd maps, several (co, ci) blocks and splits."""
+    from self_supervised import ops
+    n, h, w, cin, cout, s_ = shape
+    g = torch.Generator().manual_seed(n * 5 + h + cin + s_)
+    x = torch.randn(n, h, w, cin, generator=g).half()
+    ho, wo = (h - 1) // s_ + 1, (w - 1) // s_ + 1
+    dy = torch.randn(n, ho, wo, cout, generator=g).half()
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(False)
+    wref = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    F.conv2d(xr, wref, None, s_, 1).backward(dy.float().permute(0, 3, 1, 2))
+    want = wref.grad.permute(0, 2, 3, 1).reshape(-1)                    # OHWI
+    dw = torch.empty(cout * 9 * cin, device=dev)
+    ops.conv_wgrad(dy.to(dev), x.to(dev), dw, 3, 3, s_, 1, bf16=2)
+    assert (dw.cpu() - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item()), shape
 
 
 def test_elementwise_half_tensors(dev):
