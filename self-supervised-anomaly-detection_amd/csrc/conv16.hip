@@ -14,10 +14,10 @@
 //     16 MFMAs per wave;
 //   * workgroups are persistent (at most two per CU) over (tile, chunk) pairs: the next pair's halo is in flight in registers
 //     during the nine steps of the current one, so a tile never waits for HBM;
-//   * the epilogue stores accumulators straight from registers: neighbouring lanes hold neighbouring channels, a lane pair
-//     exchanges one value (DPP) and each lane writes one 4-byte pair of halves (64 contiguous bytes per half-wave row);
-//     BatchNorm statistics are those of the STORED halves, summed per lane in double across all tiles of the workgroup: one
-//     partial row per workgroup (<= 512 rows for the finalize kernel instead of one per tile).
+//   * the epilogue stores accumulators straight from registers, every lane its own halves (a wave store covers whole 64-byte
+//     runs: 32 consecutive channels of one pixel per lane half); ragged tiles pair neighbouring lanes (one DPP move) and predicate
+//     per pixel.  BatchNorm statistics are those of the STORED halves, summed per lane in double across all tiles of the
+//     workgroup: one partial row per workgroup (<= 512 rows for the finalize kernel instead of one per tile).
 //
 // Where its time goes (round 5, tools/micro/conv16_ablate.hip, 256 x 32 x 32 x 128 -> 128, zero operands; 31 us = the fp16 MFMA floor):
 // 109-118 us as shipped; without the MFMAs 47-50; MFMAs + fragment reads + barriers alone 49 -- the phases ADD, the co-resident
@@ -27,7 +27,8 @@
 // (64-bit offsets, lane-pair selects, conversions for the statistics).  A version with 32-bit scalar offsets and statistics taken
 // from the packed halves was built: the register allocator then spills 30-100 VGPRs (64 accumulators + 48 weight + 24 halo
 // prefetch registers are live across the epilogue) and nothing is gained (115 us); dealing the weight pieces out between the MFMA
-// groups: 117 us.  Not kept.
+// groups: 117 us.  Not kept.  Kept: whole tiles store single halves per lane instead of exchanged pairs (no DPP move, no selects;
+// the same 64-byte runs): the 26 launches of a batch-256 step 3.29 -> 3.15 ms, same box, A / B.
 #include "common.h"
 #include <stdlib.h>
 
@@ -331,57 +332,54 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h_kernel(Conv16Params p) {
         // whole tiles (every pixel inside its map: all tiles of the ResNet-18 maps) take a path without a single per-pixel predicate
         const bool full = TW8 ? (p.W == 8 && ok0 && ok1 && ya + 8 <= p.H && yb + 8 <= p.H) : (ya + 8 <= p.H && xa + 16 <= p.W);
         if (full) {
-            typedef hf h2 __attribute__((ext_vector_type(2)));
+            // Every lane stores its own 16 x TN values of a tile as single halves: a wave's store still covers whole 64-byte runs
+            // (32 lanes = 32 consecutive channels of one pixel, the lane halves two pixels), exactly what the lane-pair exchange of
+            // the ragged path produces -- without its DPP move and three selects per pair.  Measured reason: this epilogue's VALU
+            // instructions, not its stores, were a third of the kernel (conv16_ablate, bits 4 / 64).
             const int64_t rowst = (int64_t)p.W * p.Cout;
-            // this lane's first pixel (register pair e = 0, i = 0): even lanes own row m, odd lanes row m + 1 = the next pixel
-            int64_t base;
-            if (TW8) base = (((int64_t)(wm ? n1 : n0) * p.H + (wm ? yb : ya)) * p.W + 4 * h + (even ? 0 : 1)) * p.Cout;
-            else base = (((int64_t)n0 * p.H + ya + wm * 4) * p.W + xa + 4 * h + (even ? 0 : 1)) * p.Cout;
-            base += co0 + wn * 32 * TN + (r & ~1);
+            int64_t base;                           // this lane's pixel for register 0 of tile i = 0, its channel of tile j = 0
+            if (TW8) base = (((int64_t)(wm ? n1 : n0) * p.H + (wm ? yb : ya)) * p.W + 4 * h) * p.Cout;
+            else base = (((int64_t)n0 * p.H + ya + wm * 4) * p.W + xa + 4 * h) * p.Cout;
+            base += co0 + wn * 32 * TN + r;
+            hf* const outp = p.out + base;
+            const hf* const resp = p.residual ? p.residual + base : nullptr;
             float fs[TN], fq[TN];
 #pragma unroll
             for (int j = 0; j < TN; ++j) fs[j] = fq[j] = 0.f;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                // pixel of register e for the lane half h = 0, even lane: TW16: row 2 i + (e >> 3), column 8 ((e >> 2) & 1) + (e & 3);
-                // TW8: row 4 i + (e >> 2), column e & 3
-                int64_t o[8];
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int e = 0; e < 16; e += 2)
-                    o[e >> 1] = TW8 ? base + (int64_t)(4 * i + (e >> 2)) * rowst + (int64_t)(e & 3) * p.Cout
-                                    : base + (int64_t)(2 * i + (e >> 3)) * rowst + (int64_t)(8 * ((e >> 2) & 1) + (e & 3)) * p.Cout;
-                unsigned rres[8][TN];
-                if (p.residual) {                   // every residual load of this half in flight before the first is used
+                for (int g = 0; g < 2; ++g) {
+                    // pixel of register e = 8 g + q (lane half h = 0): TW16: row 2 i + g, column 8 (q >> 2) + (q & 3); TW8: row
+                    // 4 i + 2 g + (q >> 2), column q & 3 -- wave-uniform offsets; eight registers at a time (register pressure)
+                    int64_t o[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        o[q] = TW8 ? (int64_t)(4 * i + 2 * g + (q >> 2)) * rowst + (int64_t)(q & 3) * p.Cout
+                                   : (int64_t)(2 * i + g) * rowst + (int64_t)(8 * (q >> 2) + (q & 3)) * p.Cout;
+                    hf rres[8][TN];
+                    if (p.residual) {               // the residual loads of these eight pixels in flight before the first is used
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) rres[q][j] = resp[o[q] + 32 * j];
+                    }
 #pragma unroll
                     for (int q = 0; q < 8; ++q)
 #pragma unroll
-                        for (int j = 0; j < TN; ++j) rres[q][j] = *(const unsigned*)(p.residual + o[q] + 32 * j);
-                }
-#pragma unroll
-                for (int e = 0; e < 16; e += 2) {
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        // lane pair (r, r ^ 1): the odd lane takes the even lane's register e + 1, the even lane the odd lane's register e
-                        const float give = even ? acc[i][j][e + 1] : acc[i][j][e];
-                        const float got = dpp_swap_pair(give);
-                        float v0 = even ? acc[i][j][e] : got;
-                        float v1 = even ? got : acc[i][j][e + 1];
-                        if (p.residual) {
-                            const h2 rv = __builtin_bit_cast(h2, rres[e >> 1][j]);
-                            v0 += (float)rv[0];
-                            v1 += (float)rv[1];
+                        for (int j = 0; j < TN; ++j) {
+                            float v = acc[i][j][8 * g + q];
+                            if (p.residual) v += (float)rres[q][j];
+                            const hf ov = (hf)v;
+                            if (!(CONV16_ABL & 64) || v == 123.456f)       // ablation 64: the epilogue's arithmetic without its stores
+                                outp[o[q] + 32 * j] = ov;
+                            if (p.stats) {          // statistics of what is stored
+                                const float sv = (float)ov;
+                                fs[j] += sv;
+                                fq[j] += sv * sv;
+                            }
                         }
-                        const h2 ov = {(hf)v0, (hf)v1};
-                        if (!(CONV16_ABL & 64) || v0 == 123.456f)       // ablation 64: the epilogue's arithmetic without its stores
-                            *(unsigned*)(p.out + o[e >> 1] + 32 * j) = __builtin_bit_cast(unsigned, ov);
-                        if (p.stats) {              // this lane's own channel over both rows of the pair, as stored
-                            const float s0 = (float)(hf)acc[i][j][e], s1 = (float)(hf)acc[i][j][e + 1];
-                            fs[j] += s0 + s1;
-                            fq[j] += s0 * s0 + s1 * s1;
-                        }
-                    }
                 }
-            }
             if (p.stats) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) { st0[j] += (double)fs[j]; st1[j] += (double)fq[j]; }
