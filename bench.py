@@ -526,6 +526,14 @@ def main():
             by = {}
             for r in pr:
                 e = by.setdefault(r["kernel"], [0.0, 0, 0.0, 0.0]); e[0] += r["ms"]; e[1] += 1; e[2] += r["flops"]; e[3] += r["bytes"]
+            tprof = None                   # PMC passes cannot run inside this process: the newest committed pass with this batch size
+            import glob
+            for tj in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_p16_traffic.json")), reverse=True):
+                tjd = json.load(open(tj))
+                if tjd.get("images_per_step") == per_rank:
+                    tprof = {"file": "profiles/" + os.path.basename(tj), "traffic_MB_per_step": tjd["traffic_MB_per_step"],
+                             "ratio_to_algorithmic": tjd.get("ratio_to_algorithmic"), "counters": tjd.get("correction")}
+                    break
             act_mb = per_rank * U_TRAIN_ACT_MB_F32 / 2
             alg_gb = (act_mb + OPTIMIZER_MB_PER_STEP) / 1e3
             kern_gb = sum(r["bytes"] for r in pr) / 2 / 1e9
@@ -535,7 +543,11 @@ def main():
                 "half_tensors": bool(tx.eng.h16), "images_per_gpu": per_rank,
                 "train_images_per_sec": round(world * per_rank * n / dt, 2), "train_ms_per_step": round(ms, 3), "steps": n,
                 "roofline": {"bound": "hbm", "achieved": round(alg_gb / (ms * 1e-3), 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                             "frac": round(alg_gb / (ms * 1e-3) / PEAK_HBM_GBPS, 4), "traffic": None,
+                             "frac": round(alg_gb / (ms * 1e-3) / PEAK_HBM_GBPS, 4),
+                             "traffic": round(tprof["traffic_MB_per_step"] * 1e6) if tprof else None,
+                             "traffic_unit": "fabric-side bytes per STEP, all kernels (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 PMC passes; "
+                                             "Infinity-Cache hits included)" if tprof else None,
+                             "traffic_profile": tprof,
                              "alg_GB_per_step": round(alg_gb, 3),
                              "definition": f"SURVEY 8d: {per_rank} images x 3 x 33.55 MB / 2 (half activations: forward, input gradients, "
                                            f"weight-gradient reads) + {OPTIMIZER_MB_PER_STEP} MB optimizer traffic, over the replayed step's wall time",

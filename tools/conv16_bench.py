@@ -41,4 +41,4 @@ for (hw, c) in [(64, 64), (32, 128), (16, 256), (8, 512)]:
     if c == 64:
         wf = w.float()
         t["c64_h stats"] = timeit(lambda: ops.conv3x3_c64(x, wf, stats=st, bf16=2))
-    print(f"{hw}x{hw}x{c}: {gf:.1f} GFLOP, {mb:.0f} MB in+out | " + " | ".join(f"{k} {v:.1f} us ({mb / v * 1e-3:.2f} TB/s)" for k, v in t.items()))
+    print(f"{hw}x{hw}x{c}: {gf:.1f} GFLOP, {mb:.0f} MB in+out | " + " | ".join(f"{k} {v:.1f} us ({mb / v:.2f} TB/s of in + out)" for k, v in t.items()))

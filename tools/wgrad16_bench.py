@@ -29,4 +29,4 @@ for (hw, cin, cout, s) in [(64, 64, 64, 1), (32, 128, 128, 1), (16, 256, 256, 1)
     dw = torch.empty(cout * 9 * cin, device=dev)
     t = timeit(lambda: ops.conv_wgrad(dy, x, dw, 3, 3, s, 1, bf16=2))
     gf = 2.0 * B * ho * ho * cin * cout * 9 / 1e9
-    print(f"{hw}x{hw} {cin}->{cout} s{s}: {t:.1f} us (wgrad + reduce), {gf / t * 1e-3:.0f} TFLOP/s")
+    print(f"{hw}x{hw} {cin}->{cout} s{s}: {t:.1f} us (wgrad + reduce), {gf / t * 1e3:.0f} TFLOP/s")
