@@ -69,6 +69,24 @@ template <> __device__ __forceinline__ void st4<float>(float* p, f32x4 v) { *(f3
 template <> __device__ __forceinline__ void st4<hf>(hf* p, f32x4 v) {
     *(f16x4*)p = f16x4{(hf)v[0], (hf)v[1], (hf)v[2], (hf)v[3]};
 }
+// One lane's share of a streaming (HBM-bound) kernel is ONE 16-byte access per tensor: four floats or eight halves (round 5: the half
+// instantiations first read 8 bytes per lane -- twice the instructions per byte -- and ran BELOW the fp32 kernels' byte rate).
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+template <typename T> struct Lane { static constexpr int E = 4; using vec = f32x4; };
+template <> struct Lane<hf> { static constexpr int E = 8; using vec = f32x8; };
+template <typename T> __device__ __forceinline__ typename Lane<T>::vec ldv(const T* p);
+template <> __device__ __forceinline__ f32x4 ldv<float>(const float* p) { return *(const f32x4*)p; }
+template <> __device__ __forceinline__ f32x8 ldv<hf>(const hf* p) { return __builtin_convertvector(*(const f16x8*)p, f32x8); }
+template <typename T> __device__ __forceinline__ void stv(T* p, typename Lane<T>::vec v);
+template <> __device__ __forceinline__ void stv<float>(float* p, f32x4 v) { *(f32x4*)p = v; }
+template <> __device__ __forceinline__ void stv<hf>(hf* p, f32x8 v) { *(f16x8*)p = __builtin_convertvector(v, f16x8); }
+// E consecutive per-channel parameters (fp32 either way), E = 4 or 8, index in units of E
+template <typename V> __device__ __forceinline__ V ldpar(const float* p, int i);
+template <> __device__ __forceinline__ f32x4 ldpar<f32x4>(const float* p, int i) { return ((const f32x4*)p)[i]; }
+template <> __device__ __forceinline__ f32x8 ldpar<f32x8>(const float* p, int i) {
+    const f32x4 a = ((const f32x4*)p)[2 * i], b = ((const f32x4*)p)[2 * i + 1];
+    return f32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
 // four consecutive elements in their storage type (no conversion): what a kernel stages when its operands are the stored halves
 template <typename T> struct Raw4 { using t = f32x4; };
 template <> struct Raw4<hf> { using t = f16x4; };

@@ -19,9 +19,12 @@ namespace {
 struct ColReduce {
     int TC, RL;
 };
-static inline ColReduce col_geom(int C) {
-    int TC = C / 4;
-    if (TC > 256) TC = 256;
+static inline ColReduce col_geom(int C, int E = 4) {
+    // at most 16 lanes (256 bytes) along a row: tensors of many channels and few rows (layer3 / layer4) then spread over gx column
+    // blocks x nblk row blocks instead of nblk workgroups of two row lanes with 8+ dependent load rounds each
+    int TC = C / E;
+    if (TC > 16) TC = 16;
+    while (256 % TC) --TC;
     return {TC, 256 / TC};
 }
 
@@ -30,81 +33,87 @@ static inline ColReduce col_geom(int C) {
 //         mask source: yact (the saved activation) or, when zmask_gamma is given (no residual fed the ReLU), the
 //         sign of (z - mean) * invstd * gamma + beta recomputed from z -- one tensor less to read
 //         or mask4: one byte per channel quad, bit k = "the ReLU output of channel 4q+k was positive" (written by the forward
-//         BatchNorm apply: 1/16 of the bytes of the activation it stands for)
+//         BatchNorm apply: 1/16 of the bytes of the activation it stands for; fp32 tensors only)
+// A lane owns E = 4 (float) or 8 (half) consecutive channels: one 16-byte access per tensor and row.
 template <int MODE, typename T = float>
-__global__ void col_reduce_kernel(const T* __restrict__ a, const T* __restrict__ yact, const T* __restrict__ z,
+__global__ __launch_bounds__(256) void col_reduce_kernel(const T* __restrict__ a, const T* __restrict__ yact, const T* __restrict__ z,
                                   const float* __restrict__ mean, const float* __restrict__ invstd,
                                   const float* __restrict__ zmask_gamma, const float* __restrict__ zmask_beta,
                                   double* __restrict__ partial, int64_t R, int C, int TC, int RL, int rows_per_block,
                                   const uint8_t* __restrict__ mask4 = nullptr) {
-    __shared__ double sh[2][256][4];
+    constexpr int E = Lane<T>::E;
+    using V = typename Lane<T>::vec;
+    __shared__ double sh[2][256][E];
     const int tid = threadIdx.x;
     const int tx = tid % TC, ty = tid / TC;
-    const int C4 = C / 4;
-    for (int cq = blockIdx.x * TC + tx; cq < C4 && ty < RL; cq += gridDim.x * TC) {
-        double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
-        f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {1.f, 1.f, 1.f, 1.f};
-        f32x4 mg = {0.f, 0.f, 0.f, 0.f}, mb = {0.f, 0.f, 0.f, 0.f};
-        if (MODE == 1 && z) { mu = ((const f32x4*)mean)[cq]; is = ((const f32x4*)invstd)[cq]; }
-        if (MODE == 1 && zmask_gamma) { mg = ((const f32x4*)zmask_gamma)[cq]; mb = ((const f32x4*)zmask_beta)[cq]; }
+    const int CE = C / E;
+    for (int cq = blockIdx.x * TC + tx; cq < CE && ty < RL; cq += gridDim.x * TC) {
+        double s0[E], s1[E];
+#pragma unroll
+        for (int k = 0; k < E; ++k) s0[k] = s1[k] = 0;
+        V mu = 0.f, is = 1.f, mg = 0.f, mb = 0.f;
+        if (MODE == 1 && z) { mu = ldpar<V>(mean, cq); is = ldpar<V>(invstd, cq); }
+        if (MODE == 1 && zmask_gamma) { mg = ldpar<V>(zmask_gamma, cq); mb = ldpar<V>(zmask_beta, cq); }
         const int64_t rb = (int64_t)blockIdx.y * rows_per_block;
         const int64_t re = rb + rows_per_block < R ? rb + rows_per_block : R;
-        // 4 rows per iteration: all loads of an iteration are issued before any is consumed (latency-bound otherwise).  Measured on the
-        // half instantiation (round 5, precision-16 step at batch 256: 19 launches, 1.0 ms, 2.5 TB/s): 8 rows per iteration -- the same
-        // bytes in flight per thread -- 4.8 ms (the row arrays leave the registers); the rows of an iteration summed in fp32 before
-        // they enter the double accumulators -- a quarter of the fp64 instructions -- 0.99 ms: unchanged.  It stays as it is.
-        constexpr int U = 4;
+        // U rows per iteration (64 bytes per tensor in flight per lane): all loads of an iteration are issued before any is consumed
+        // (latency-bound otherwise).  Measured on the first half instantiation (round 5, 8-byte accesses, precision-16 step at batch
+        // 256: 19 launches, 1.0 ms, 2.5 TB/s): 8 rows per iteration 4.8 ms (the row arrays leave the registers); the rows of an
+        // iteration summed in fp32 before they enter the double accumulators -- a quarter of the fp64 instructions -- 0.99 ms: unchanged.
+        constexpr int U = 16 / E;
         for (int64_t row = rb + ty; row < re; row += (int64_t)U * RL) {
-            f32x4 v[U], ya[U], zz[U];
+            V v[U], ya[U], zz[U];
             unsigned mk[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t rw = row + (int64_t)u * RL;
-                const int64_t o = (rw < re ? rw : rb + ty) * C4 + cq;       // clamp: tail rows re-read a valid row ...
-                v[u] = ld4(a + 4 * o);
-                if (MODE == 1 && yact) ya[u] = ld4(yact + 4 * o);
-                if (MODE == 1 && mask4) mk[u] = mask4[o];
-                if (MODE == 1 && z) zz[u] = ld4(z + 4 * o);
+                const int64_t o = (rw < re ? rw : rb + ty) * CE + cq;       // clamp: tail rows re-read a valid row ...
+                v[u] = ldv(a + E * o);
+                if (MODE == 1 && yact) ya[u] = ldv(yact + E * o);
+                if (MODE == 1 && E == 4 && mask4) mk[u] = mask4[o];
+                if (MODE == 1 && z) zz[u] = ldv(z + E * o);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (row + (int64_t)u * RL >= re) continue;                  // ... and are dropped here
                 if (MODE == 0) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) { s0[k] += (double)v[u][k]; s1[k] += (double)v[u][k] * (double)v[u][k]; }
+                    for (int k = 0; k < E; ++k) { s0[k] += (double)v[u][k]; s1[k] += (double)v[u][k] * (double)v[u][k]; }
                 } else {
                     if (yact) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) v[u][k] = ya[u][k] > 0.f ? v[u][k] : 0.f;
-                    } else if (mask4) {
+                        for (int k = 0; k < E; ++k) v[u][k] = ya[u][k] > 0.f ? v[u][k] : 0.f;
+                    } else if (E == 4 && mask4) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) v[u][k] = (mk[u] >> k) & 1u ? v[u][k] : 0.f;
+                        for (int k = 0; k < E; ++k) v[u][k] = (mk[u] >> k) & 1u ? v[u][k] : 0.f;
                     } else if (zmask_gamma) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) v[u][k] = (zz[u][k] - mu[k]) * is[k] * mg[k] + mb[k] > 0.f ? v[u][k] : 0.f;
+                        for (int k = 0; k < E; ++k) v[u][k] = (zz[u][k] - mu[k]) * is[k] * mg[k] + mb[k] > 0.f ? v[u][k] : 0.f;
                     }
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) s0[k] += (double)v[u][k];
+                    for (int k = 0; k < E; ++k) s0[k] += (double)v[u][k];
                     if (z) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) s1[k] += (double)v[u][k] * (double)((zz[u][k] - mu[k]) * is[k]);
+                        for (int k = 0; k < E; ++k) s1[k] += (double)v[u][k] * (double)((zz[u][k] - mu[k]) * is[k]);
                     }
                 }
             }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { sh[0][tid][k] = s0[k]; sh[1][tid][k] = s1[k]; }
+        for (int k = 0; k < E; ++k) { sh[0][tid][k] = s0[k]; sh[1][tid][k] = s1[k]; }
     }
     __syncthreads();
     if (ty == 0) {
-        for (int cq = blockIdx.x * TC + tx; cq < C4; cq += gridDim.x * TC) {
-            double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+        for (int cq = blockIdx.x * TC + tx; cq < CE; cq += gridDim.x * TC) {
+            double s0[E], s1[E];
+#pragma unroll
+            for (int k = 0; k < E; ++k) s0[k] = s1[k] = 0;
             for (int l = 0; l < RL; ++l)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { s0[k] += sh[0][l * TC + tx][k]; s1[k] += sh[1][l * TC + tx][k]; }
+                for (int k = 0; k < E; ++k) { s0[k] += sh[0][l * TC + tx][k]; s1[k] += sh[1][l * TC + tx][k]; }
             double* pp = partial + (int64_t)blockIdx.y * 2 * C;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { pp[cq * 4 + k] = s0[k]; pp[C + cq * 4 + k] = s1[k]; }
+            for (int k = 0; k < E; ++k) { pp[cq * E + k] = s0[k]; pp[C + cq * E + k] = s1[k]; }
         }
     }
 }
@@ -116,7 +125,18 @@ __global__ void col_reduce_kernel(const T* __restrict__ a, const T* __restrict__
 __device__ __forceinline__ bool channel_totals(const double* __restrict__ partial, int nblk, int C, int c, double& s0, double& s1) {
     __shared__ double wsum[4][2];
     double a = 0, b = 0;
-    for (int k = threadIdx.x; k < nblk; k += 256) {
+    int k = threadIdx.x;
+    for (; k + 7 * 256 < nblk; k += 8 * 256) {         // eight rows in flight per thread, added in the same order as one by one
+        double pa[8], pb[8];                            // (the halo-tile convs leave up to M / 128 = 8 192 partial rows at batch 256)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            pa[u] = partial[(int64_t)(k + u * 256) * 2 * C + c];
+            pb[u] = partial[(int64_t)(k + u * 256) * 2 * C + C + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a += pa[u]; b += pb[u]; }
+    }
+    for (; k < nblk; k += 256) {
         a += partial[(int64_t)k * 2 * C + c];
         b += partial[(int64_t)k * 2 * C + C + c];
     }
@@ -160,75 +180,80 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
     if (dgamma) dgamma[c] = (float)s1;
 }
 
-// y = (z - mean) * invstd * gamma + beta (+ res) (relu)
+// y = (z - mean) * invstd * gamma + beta (+ res) (relu).  A lane owns E = 4 (float) / 8 (half) consecutive channels; totalE, CE in
+// units of E.  mask4 (one byte per channel quad): fp32 tensors only.
 template <typename T>
-__global__ void bn_apply_fwd_kernel(const T* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ invstd,
+__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const T* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                    const T* __restrict__ res, T* __restrict__ y, int64_t total4, int C4, int relu,
+                                    const T* __restrict__ res, T* __restrict__ y, int64_t totalE, int CE, int relu,
                                     uint8_t* __restrict__ mask4 = nullptr) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
-        const int cq = (int)(i % C4);
-        const f32x4 mu = ((const f32x4*)mean)[cq], is = ((const f32x4*)invstd)[cq];
-        const f32x4 g = ((const f32x4*)gamma)[cq], b = ((const f32x4*)beta)[cq];
-        f32x4 v = ld4(z + 4 * i);
+    constexpr int E = Lane<T>::E;
+    using V = typename Lane<T>::vec;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < totalE; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cq = (int)(i % CE);
+        const V mu = ldpar<V>(mean, cq), is = ldpar<V>(invstd, cq);
+        const V g = ldpar<V>(gamma, cq), b = ldpar<V>(beta, cq);
+        V v = ldv(z + E * i);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = (v[k] - mu[k]) * is[k] * g[k] + b[k];
+        for (int k = 0; k < E; ++k) v[k] = (v[k] - mu[k]) * is[k] * g[k] + b[k];
         if (res) {
-            const f32x4 rr = ld4(res + 4 * i);
+            const V rr = ldv(res + E * i);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] += rr[k];
+            for (int k = 0; k < E; ++k) v[k] += rr[k];
         }
-        if (mask4) mask4[i] = (uint8_t)((v[0] > 0.f) | ((v[1] > 0.f) << 1) | ((v[2] > 0.f) << 2) | ((v[3] > 0.f) << 3));
+        if (E == 4 && mask4) mask4[i] = (uint8_t)((v[0] > 0.f) | ((v[1] > 0.f) << 1) | ((v[2] > 0.f) << 2) | ((v[3] > 0.f) << 3));
         if (relu) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+            for (int k = 0; k < E; ++k) v[k] = fmaxf(v[k], 0.f);
         }
-        st4(y + 4 * i, v);
+        stv(y + E * i, v);
     }
 }
 
 // g = dy * (yact > 0); dz = gamma*invstd*(g - dbeta/R - xhat*dgamma/R)  [train]   or  g*gamma*invstd  [eval];
 // optionally dres = g (gradient of the identity branch of a residual block)
 template <typename T>
-__global__ void bn_apply_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ yact, const T* __restrict__ z,
+__global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ yact, const T* __restrict__ z,
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ gamma, const float* __restrict__ dbeta,
                                     const float* __restrict__ dgamma, T* __restrict__ dz, T* __restrict__ dres,
-                                    int64_t total4, int C4, float invR, int eval_mode, const float* __restrict__ zmask_beta,
+                                    int64_t totalE, int CE, float invR, int eval_mode, const float* __restrict__ zmask_beta,
                                     const uint8_t* __restrict__ mask4 = nullptr) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
-        const int cq = (int)(i % C4);
-        const f32x4 mu = ((const f32x4*)mean)[cq], is = ((const f32x4*)invstd)[cq], ga = ((const f32x4*)gamma)[cq];
-        f32x4 g = ld4(dy + 4 * i);
+    constexpr int E = Lane<T>::E;
+    using V = typename Lane<T>::vec;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < totalE; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cq = (int)(i % CE);
+        const V mu = ldpar<V>(mean, cq), is = ldpar<V>(invstd, cq), ga = ldpar<V>(gamma, cq);
+        V g = ldv(dy + E * i);
         if (yact) {
-            const f32x4 ya = ld4(yact + 4 * i);
+            const V ya = ldv(yact + E * i);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) g[k] = ya[k] > 0.f ? g[k] : 0.f;
-        } else if (mask4) {
+            for (int k = 0; k < E; ++k) g[k] = ya[k] > 0.f ? g[k] : 0.f;
+        } else if (E == 4 && mask4) {
             const unsigned mk = mask4[i];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) g[k] = (mk >> k) & 1u ? g[k] : 0.f;
+            for (int k = 0; k < E; ++k) g[k] = (mk >> k) & 1u ? g[k] : 0.f;
         } else if (zmask_beta) {                 // ReLU mask recomputed from z (layer without residual)
-            const f32x4 zb = ((const f32x4*)zmask_beta)[cq];
-            const f32x4 zm = ld4(z + 4 * i);
+            const V zb = ldpar<V>(zmask_beta, cq);
+            const V zm = ldv(z + E * i);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) g[k] = (zm[k] - mu[k]) * is[k] * ga[k] + zb[k] > 0.f ? g[k] : 0.f;
+            for (int k = 0; k < E; ++k) g[k] = (zm[k] - mu[k]) * is[k] * ga[k] + zb[k] > 0.f ? g[k] : 0.f;
         }
-        if (dres) st4(dres + 4 * i, g);
-        f32x4 o;
+        if (dres) stv(dres + E * i, g);
+        V o;
         if (eval_mode) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = g[k] * ga[k] * is[k];
+            for (int k = 0; k < E; ++k) o[k] = g[k] * ga[k] * is[k];
         } else {
-            const f32x4 db = ((const f32x4*)dbeta)[cq], dg = ((const f32x4*)dgamma)[cq];
-            const f32x4 zz = ld4(z + 4 * i);
+            const V db = ldpar<V>(dbeta, cq), dg = ldpar<V>(dgamma, cq);
+            const V zz = ldv(z + E * i);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < E; ++k) {
                 const float xh = (zz[k] - mu[k]) * is[k];
                 o[k] = ga[k] * is[k] * (g[k] - db[k] * invR - xh * dg[k] * invR);
             }
         }
-        st4(dz + 4 * i, o);
+        stv(dz + E * i, o);
     }
 }
 
@@ -658,7 +683,7 @@ static inline int64_t col_blocks(int64_t R, const ColReduce& g) {
 }
 
 extern "C" int64_t ssad_colreduce_workspace(int64_t R, int C) {
-    ColReduce g = col_geom(C);
+    ColReduce g = col_geom(C);                        // the four-channel (float) geometry: never fewer row blocks than the half one
     return col_blocks(R, g) * 2 * C;
 }
 
@@ -666,11 +691,12 @@ template <typename T>
 static int launch_col_reduce(int mode, const T* a, const T* yact, const T* z, const float* mean,
                              const float* invstd, double* ws, int64_t R, int C, int* nblk_out, hipStream_t st,
                              const float* zg = nullptr, const float* zb = nullptr, const uint8_t* mask4 = nullptr) {
-    ColReduce g = col_geom(C);
+    constexpr int E = Lane<T>::E;
+    ColReduce g = col_geom(C, E);
     int64_t nblk = col_blocks(R, g);
     int rows_per_block = (int)cdiv64(R, nblk);
     nblk = cdiv64(R, rows_per_block);                 // no empty trailing blocks (their partial rows would be read uninitialised)
-    int gx = (C / 4 + g.TC - 1) / g.TC;
+    int gx = (C / E + g.TC - 1) / g.TC;
     dim3 grid(gx, (unsigned)nblk);
     if (mode == 0)
         hipLaunchKernelGGL((col_reduce_kernel<0, T>), grid, dim3(256), 0, st, a, yact, z, mean, invstd, zg, zb, ws, R, C, g.TC, g.RL, rows_per_block,
@@ -693,7 +719,7 @@ int ssad_bn_finalize_partials(const double* partial, int nblk, int64_t R, int C,
 template <typename T>
 static int bn_stats_impl(const T* z, int64_t R, int C, float eps, float momentum, float* mean, float* invstd,
                          float* running_mean, float* running_var, double* workspace, void* stream) {
-    SSAD_CHECK_ARG(z && mean && invstd && workspace && R > 0 && C > 0 && C % 4 == 0, "bad argument");
+    SSAD_CHECK_ARG(z && mean && invstd && workspace && R > 0 && C > 0 && C % Lane<T>::E == 0, "bad argument");
     int nblk;
     launch_col_reduce<T>(0, z, nullptr, nullptr, nullptr, nullptr, workspace, R, C, &nblk, (hipStream_t)stream);
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, workspace, nblk, R, C,
@@ -717,10 +743,11 @@ extern "C" int ssad_bn_stats_h(const void* z, int64_t R, int C, float eps, float
 template <typename T>
 static int bn_apply_fwd_impl(const T* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
                              const T* residual, T* y, int64_t R, int C, int relu, void* stream) {
-    SSAD_CHECK_ARG(z && mean && invstd && gamma && beta && y && R > 0 && C > 0 && C % 4 == 0, "bad argument");
-    const int64_t total4 = R * (C / 4);
-    hipLaunchKernelGGL(bn_apply_fwd_kernel<T>, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, z, mean, invstd, gamma,
-                       beta, residual, y, total4, C / 4, relu, (uint8_t*)nullptr);
+    constexpr int E = Lane<T>::E;
+    SSAD_CHECK_ARG(z && mean && invstd && gamma && beta && y && R > 0 && C > 0 && C % E == 0, "bad argument");
+    const int64_t totalE = R * (C / E);
+    hipLaunchKernelGGL(bn_apply_fwd_kernel<T>, dim3(ew_grid(totalE)), dim3(256), 0, (hipStream_t)stream, z, mean, invstd, gamma,
+                       beta, residual, y, totalE, C / E, relu, (uint8_t*)nullptr);
     SSAD_CHECK_LAUNCH();
     return 0;
 }
@@ -780,7 +807,8 @@ template <typename T>
 static int bn_bwd_reduce_impl(const T* dy, const T* yact, const T* z, const float* mean, const float* invstd,
                               float* dbeta, float* dgamma, int64_t R, int C, double* workspace, void* stream,
                               const float* zg, const float* zb, const uint8_t* mask4 = nullptr) {
-    SSAD_CHECK_ARG(dy && workspace && R > 0 && C > 0 && C % 4 == 0, "bad argument");
+    SSAD_CHECK_ARG(dy && workspace && R > 0 && C > 0 && C % Lane<T>::E == 0, "bad argument");
+    SSAD_CHECK_ARG(!mask4 || Lane<T>::E == 4, "nibble masks: fp32 tensors only");
     SSAD_CHECK_ARG(!z || (mean && invstd), "z needs mean/invstd");
     SSAD_CHECK_ARG(!zg || (z && zb && !yact), "mask-from-z needs z, gamma, beta and no yact");
     if constexpr (std::is_same<T, float>::value) {
@@ -830,11 +858,13 @@ static int bn_apply_bwd_impl(const T* dy, const T* yact, const T* z, const float
                                  const float* gamma, const float* dbeta, const float* dgamma, T* dz, T* dres,
                                  int64_t R, int C, int eval_mode, void* stream, const float* zmask_beta,
                                  const uint8_t* mask4 = nullptr) {
-    SSAD_CHECK_ARG(dy && mean && invstd && gamma && dz && R > 0 && C > 0 && C % 4 == 0, "bad argument");
+    constexpr int E = Lane<T>::E;
+    SSAD_CHECK_ARG(dy && mean && invstd && gamma && dz && R > 0 && C > 0 && C % E == 0, "bad argument");
+    SSAD_CHECK_ARG(!mask4 || E == 4, "nibble masks: fp32 tensors only");
     SSAD_CHECK_ARG(eval_mode || (z && dbeta && dgamma), "train-mode backward needs z, dbeta, dgamma");
-    const int64_t total4 = R * (C / 4);
-    hipLaunchKernelGGL(bn_apply_bwd_kernel<T>, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, dy, yact, z, mean, invstd,
-                       gamma, dbeta, dgamma, dz, dres, total4, C / 4, 1.f / (float)R, eval_mode, zmask_beta, mask4);
+    const int64_t totalE = R * (C / E);
+    hipLaunchKernelGGL(bn_apply_bwd_kernel<T>, dim3(ew_grid(totalE)), dim3(256), 0, (hipStream_t)stream, dy, yact, z, mean, invstd,
+                       gamma, dbeta, dgamma, dz, dres, totalE, C / E, 1.f / (float)R, eval_mode, zmask_beta, mask4);
     SSAD_CHECK_LAUNCH();
     return 0;
 }
