@@ -507,6 +507,19 @@ int64_t ssad_conv3x3_h_stats_rows(int64_t N, int H, int W, int Cout);
 int ssad_conv3x3_h(const void* in, const void* w_ohwi, void* out, const void* residual, const float* tr_mean, const float* tr_invstd,
                    const float* tr_gamma, const float* tr_beta, void* emit, int64_t N, int H, int W, int Cin, int Cout, double* stats_ws,
                    float eps, float momentum, float* mean, float* invstd, float* running_mean, float* running_var, void* stream);
+/* The same convolution with the filter fed to the matrix cores from registers (csrc/conv16w.hip), for launches that fill the chip
+ * (ssad_conv3x3_hw_ok: maps of 16 x 16 blocks or 8 x 8 maps, >= ~200 (tile, channel slab) pairs): a wave owns 128 pixels x 64 channels,
+ * the filter is packed once per step in fragment order [Cout/32][tap][Cin/16][2][32][8] halves (ssad_conv3x3_hw_pack_batch, from the
+ * fp32 master weights: desc[5 k ..] = source offset in floats, destination offset in halves, Cout, Cin of the conv that runs on it,
+ * flip = 1 when the source is the OHWI filter [Cin][3][3][Cout] of the forward conv whose input gradient this is), the halo is staged
+ * by two extra waves of the workgroup.  Arguments of ssad_conv3x3_hw as ssad_conv3x3_h, w_packed in place of w_ohwi. */
+int ssad_conv3x3_hw_ok(int64_t N, int H, int W, int Cin, int Cout);
+int64_t ssad_conv3x3_hw_packed_size(int Cin, int Cout);
+int64_t ssad_conv3x3_hw_stats_rows(int64_t N, int H, int W, int Cout);
+int ssad_conv3x3_hw_pack_batch(const float* src, void* dst, const int64_t* desc, int n, void* stream);
+int ssad_conv3x3_hw(const void* in, const void* w_packed, void* out, const void* residual, const float* tr_mean, const float* tr_invstd,
+                    const float* tr_gamma, const float* tr_beta, void* emit, int64_t N, int H, int W, int Cin, int Cout, double* stats_ws,
+                    float eps, float momentum, float* mean, float* invstd, float* running_mean, float* running_var, void* stream);
 /* Weight gradient of the 3 x 3 / pad 1 convolutions, stride 1 AND 2, over half tensors (csrc/wgrad16.hip): tiles go to LDS as they lie
  * in memory and the [pixel][channel] -> [channel][pixel] transpose the matrix instruction needs happens in the fragment reads (eight
  * 2-byte LDS reads per operand), so no staging waves, no conversion; same slab contract as ssad_conv_wgrad3x3_halo16:

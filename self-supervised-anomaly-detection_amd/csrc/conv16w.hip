@@ -1,0 +1,564 @@
+// 3x3 / stride 1 / pad 1 convolution over HALF tensors, second form: weights fed to the matrix cores from REGISTERS, wave-specialised
+// staging.  Same contract as csrc/conv16.hip (forward of the torchvision BasicBlock conv3x3 layers under pl.Trainer(precision=16),
+// models.py:224 / tools.py:263 of the reference, and -- with the flipped filter -- their input gradients), for the launches that
+// fill the chip: maps that tile into 16 x 16 blocks (or 8 x 8 maps, four per tile) and >= ~200 (tile, channel slab) pairs.
+//
+// Why a second form (measured on conv16.hip, profiles/r05_conv16_ablate.txt, 256 x 32 x 32 x 128 -> 128: 97 us against a 31 us matrix
+// floor): with 64 x 64 wave tiles every v_mfma_f32_32x32x16_f16 needs 1 KB of fragments from LDS -- 128 B/clk/CU at the matrix
+// rate, all the LDS has -- so the weight slices that go global -> registers -> LDS -> registers (38 us of the 97), the halo writes
+// and the per-tap barriers ADD to the matrix stream instead of hiding under it.  Here:
+//   * a wave owns 128 pixels x 64 output channels (8 accumulator tiles, 128 registers): 4 activation fragments from LDS and 2 weight
+//     fragments per 8 MFMAs -- the LDS serves 64 B/clk;
+//   * the weight fragments never touch LDS: the filters are packed once per step (ssad_conv3x3_hw_pack_batch, from the fp32 master
+//     weights) in fragment order, [Cout/32][tap][Cin/16][k half][32 channels][8 halves], so a wave's fragment is one coalesced 1 KB
+//     read of the L2, requested DB steps (6 x 8 MFMAs) ahead into a register ring; no barrier per tap;
+//   * the halo is staged by TWO EXTRA WAVES of the workgroup (one (tile, chunk) ahead, double-buffered in LDS): vmcnt counts in
+//     order per wave, so an HBM-latency halo load in the matrix waves' queue would hold back every weight fragment behind it --
+//     the stagers keep their own queue, apply the producer's BatchNorm + ReLU on load (fp32, rounded once) and emit the
+//     normalised activation for the weight gradient; the matrix waves only issue L2-latency loads;
+//   * one barrier per (tile, 64-channel chunk) = per 36 steps.
+// Workgroups are persistent over tiles of ONE channel slab (blockIdx.y), so the BatchNorm statistics of the stored halves stay in
+// registers (per tile in fp32, across tiles in double) and leave as one partial row per workgroup.
+#include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+#ifndef CONV16W_ABL      // timing ablations (tools/micro): 1 = no weight loads, 2 = no halo loads, 4 = no epilogue, 8 = no MFMAs,
+                         // 16 = no activation fragment reads, 32 = no per-fill barriers (matrix waves)
+#define CONV16W_ABL 0
+#endif
+
+namespace {
+
+constexpr int DB = 6;                  // weight fragments are requested DB steps ahead
+
+struct HWParams {
+    const hf* in;            // [N][H][W][Cin]
+    const hf* wp;            // packed filters (ssad_conv3x3_hw_pack_batch)
+    hf* out;                 // [N][H][W][Cout]
+    const hf* residual;      // optional [N][H][W][Cout], added before the rounding
+    const float* tr_mean;    // optional input transform x <- relu((x - mean) * invstd * gamma + beta), per input channel
+    const float* tr_invstd;
+    const float* tr_gamma;
+    const float* tr_beta;
+    hf* emit;                // optional (with a transform): the transformed input, written once (by channel slab 0)
+    double* stats;           // optional [gridDim.x][2][Cout]
+    int N, H, W, Cin, Cout;
+    int tiles_y, tiles_x, nchunks;
+    int64_t ntiles;          // TW16: N * tiles_y * tiles_x;  TW8: ceil(N / 4)
+};
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// WN: 64-channel wave columns per workgroup (output channels per workgroup = 64 WN); four matrix waves (WM x WN, WM = 4 / WN) of
+// 128 pixels x 64 channels each, two stager waves.  Tile: WN = 2: a 16 x 16 block (18 x 18 halo), or -- TW8, 8 x 8 maps -- four
+// consecutive images, each with its 10 x 10 halo; WN = 1 (the 64-channel layer): 16 rows x 32 columns (18 x 34 halo).
+// CK: input channels per chunk (64; 32 where two halo stages of 64 channels would not fit the LDS).
+template <int WN, bool TW8, int CK>
+__global__ __launch_bounds__(384) void conv3x3_hw_kernel(HWParams p) {
+    constexpr int WM = 4 / WN;
+    constexpr int TWX = WN == 1 ? 32 : 16;             // tile width in pixels (not TW8)
+    constexpr int LDP = CK + 8;                        // halves per LDS halo row (16-byte reads of 16 consecutive pixels: no conflicts)
+    constexpr int PPR = CK / 8;                        // 16-byte pieces per halo pixel
+    constexpr int KS = CK / 16;                        // k-steps (one MFMA deep) per tap
+    constexpr int SPC = 9 * KS;                        // steps per chunk
+    constexpr int HW_ = TW8 ? 10 : TWX + 2;
+    constexpr int NHP = TW8 ? 400 : 18 * HW_;
+    constexpr int NMW = 4;
+    constexpr int SL = 128;                            // stager lanes
+    constexpr int NSP = TW8 ? 256 : NHP;               // staged pixels: an 8 x 8 map's halo ring is all padding, zeroed once
+    constexpr int NR = (NSP * PPR + SL - 1) / SL;      // pieces per stager lane per chunk
+    constexpr int HALO_H = NHP * LDP;
+    constexpr int NT = 384;
+    static_assert(SPC % DB == 0 && SPC % 2 == 0, "ring / double-buffer periods must divide a chunk");
+    static_assert(!(TW8 && WN == 1), "8 x 8 maps: 128 output channels per workgroup");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    hf* halo = (hf*)lds;                               // [2][NHP][LDP]
+    float* trp = (float*)(halo + 2 * HALO_H);          // [4][Cin]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t my_tiles = p.ntiles > (int64_t)blockIdx.x ? (p.ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const int64_t nfill = my_tiles * p.nchunks;
+    const int tpi = p.tiles_y * p.tiles_x;
+
+    if (TW8) {                                         // padding rings of both halo stages
+        for (int i = tid; i < 2 * HALO_H / 8; i += NT) ((u32x4*)halo)[i] = u32x4{0u, 0u, 0u, 0u};
+    }
+    if (p.tr_mean) {
+        for (int c = tid; c < p.Cin; c += NT) {
+            trp[c] = p.tr_mean[c]; trp[p.Cin + c] = p.tr_invstd[c]; trp[2 * p.Cin + c] = p.tr_gamma[c]; trp[3 * p.Cin + c] = p.tr_beta[c];
+        }
+    }
+    __syncthreads();
+
+    if (wave >= NMW) {
+        // =====================================================================================================================
+        // stager waves: fill f -> halo[f & 1], one fill ahead of the matrix waves; the loads of fill f + 2 are requested BEFORE the
+        // barrier that ends fill f (they have a whole fill of matrix work to arrive: HBM latency is never on the barrier's path)
+        // =====================================================================================================================
+        // The stagers share two SIMDs with matrix waves: every instruction here delays a matrix wave, and the slowest wave sets the
+        // pace at the barrier (first form: ~1 500 instructions of index arithmetic per fill = 1.3 us per fill on every layer).
+        // Everything that depends only on (lane, piece) is computed ONCE: byte offset from the halo's first pixel, LDS byte offset,
+        // halo coordinates, interior flag; per fill there remain the in-image tests and the uniform base address.
+        const int sl = (wave - NMW) * 64 + lane;
+        const int piece = sl % PPR;                         // SL is a multiple of PPR: a lane stages the same piece of every pixel
+        u32x4 reg[NR];
+        unsigned goff[NR];                                  // bytes from the halo's pixel (-1, -1) (TW8: from image 4 tile, pixel (0, 0))
+        unsigned loff[NR];                                  // bytes from the start of a halo stage
+        unsigned hyx[NR];                                   // hy << 8 | hx (TW8: image within the tile)
+        unsigned inner = 0, valid = 0, inm = 0;
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            const int hp = (q * SL + sl) / PPR;             // TW8: hp = 64 image + 8 y + x (interior pixels only)
+            if (hp < NSP) valid |= 1u << q;
+            if (TW8) {
+                goff[q] = (unsigned)((hp * p.Cin + piece * 8) * 2);
+                loff[q] = (unsigned)((((hp >> 6) * 100 + (((hp >> 3) & 7) + 1) * 10 + (hp & 7) + 1) * LDP + piece * 8) * 2);
+                hyx[q] = (unsigned)(hp >> 6);
+                inner |= 1u << q;
+            } else {
+                const int hy = hp / HW_, hx = hp - HW_ * hy;
+                goff[q] = (unsigned)(((hy * p.W + hx) * p.Cin + piece * 8) * 2);
+                loff[q] = (unsigned)((hp * LDP + piece * 8) * 2);
+                hyx[q] = (unsigned)(hy << 8 | hx);
+                if (hy >= 1 && hy <= 16 && hx >= 1 && hx <= TWX) inner |= 1u << q;
+            }
+        }
+        // uniform per fill: element index of the halo's pixel (-1, -1) at channel chunk * CK (may lie before the tensor: only
+        // in-image pixels are dereferenced), and the tile's position
+        auto origin = [&](int64_t f, int64_t& base, int& chunk, int& y0, int& x0, int& nimg) {
+            const int64_t ti = f / p.nchunks;
+            chunk = (int)(f - ti * p.nchunks);
+            const int64_t tile = (int64_t)blockIdx.x + ti * gridDim.x;
+            if (TW8) {
+                y0 = x0 = 0;
+                nimg = p.N - (int)(4 * tile);               // images of this tile that exist
+                base = (int64_t)(4 * tile) * 64 * p.Cin + chunk * CK;
+            } else {
+                const int n0 = (int)(tile / tpi);
+                const int rem = (int)(tile - (int64_t)n0 * tpi);
+                y0 = (rem / p.tiles_x) * 16;
+                x0 = (rem % p.tiles_x) * TWX;
+                nimg = 1;
+                base = (((int64_t)n0 * p.H + y0 - 1) * p.W + x0 - 1) * p.Cin + chunk * CK;
+            }
+        };
+        auto load_fill = [&](int64_t f) {
+            int64_t base; int chunk, y0, x0, nimg;
+            origin(f, base, chunk, y0, x0, nimg);
+            const char* src = (const char*)(p.in + base);
+            inm = 0;
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                bool ok = (valid >> q) & 1u;
+                if (TW8) ok = ok && (int)hyx[q] < nimg;
+                else ok = ok && (unsigned)(y0 - 1 + (int)(hyx[q] >> 8)) < (unsigned)p.H && (unsigned)(x0 - 1 + (int)(hyx[q] & 255u)) < (unsigned)p.W;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (ok && !(CONV16W_ABL & 2)) v = *(const u32x4*)(src + goff[q]);
+                reg[q] = v;
+                inm |= (ok ? 1u : 0u) << q;
+            }
+        };
+        auto write_fill = [&](int64_t f) {
+            int64_t base; int chunk, y0, x0, nimg;
+            origin(f, base, chunk, y0, x0, nimg);
+            char* dst = (char*)(halo + (int)(f & 1) * HALO_H);
+            if (p.tr_mean) {
+                // producer's train-mode BatchNorm + ReLU on load: bn_apply_fwd's expression in fp32, rounded once.  Zero padding pads
+                // the TRANSFORMED activation: out-of-image pieces stay zero.  The eight channels of this lane's piece: once per fill.
+                const int c = chunk * CK + piece * 8;
+                float mu[8], sc[8], ga[8], be[8];
+#pragma unroll
+                for (int k = 0; k < 8; k += 4) {
+                    const f32x4 a = *(const f32x4*)(trp + c + k), b = *(const f32x4*)(trp + p.Cin + c + k);
+                    const f32x4 g = *(const f32x4*)(trp + 2 * p.Cin + c + k), e = *(const f32x4*)(trp + 3 * p.Cin + c + k);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { mu[k + u] = a[u]; sc[k + u] = b[u]; ga[k + u] = g[u]; be[k + u] = e[u]; }
+                }
+                char* em = (p.emit && blockIdx.y == 0) ? (char*)(p.emit + base) : nullptr;
+#pragma unroll
+                for (int q = 0; q < NR; ++q) {
+                    if (!((inm >> q) & 1u)) continue;
+                    f16x8 v = __builtin_bit_cast(f16x8, reg[q]);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = (hf)fmaxf(((float)v[k] - mu[k]) * sc[k] * ga[k] + be[k], 0.f);
+                    reg[q] = __builtin_bit_cast(u32x4, v);
+                    // interior pixels of the halo: the activation this layer's weight gradient reads
+                    if (em && ((inner >> q) & 1u)) *(u32x4*)(em + goff[q]) = reg[q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NR; ++q)
+                if ((valid >> q) & 1u) *(u32x4*)(dst + loff[q]) = reg[q];
+        };
+        if (nfill > 0) { load_fill(0); write_fill(0); }
+        if (nfill > 1) load_fill(1);
+        __syncthreads();
+        for (int64_t f = 0; f < nfill; ++f) {
+            if (f + 1 < nfill) write_fill(f + 1);
+            if (f + 2 < nfill) load_fill(f + 2);
+            __syncthreads();
+        }
+        if (p.stats) __syncthreads();
+        return;
+    }
+
+    // =========================================================================================================================
+    // matrix waves
+    // =========================================================================================================================
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int co0 = blockIdx.y * (64 * WN) + wn * 64;          // first output channel of this wave
+    // rows / columns of the tile this wave's 128 pixels start at (TW8: the wave's first image)
+    const int wrow = TW8 ? 0 : (WN == 1 ? 8 * (wm >> 1) : 8 * wm), wcol = (!TW8 && WN == 1) ? 16 * (wm & 1) : 0;
+
+    int abase[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        if (TW8) abase[m] = ((2 * wm + (m >> 1)) * 100 + (4 * (m & 1) + (r >> 3)) * 10 + (r & 7)) * LDP + 8 * h;
+        else abase[m] = ((wrow + 2 * m + (r >> 4)) * HW_ + wcol + (r & 15)) * LDP + 8 * h;
+    }
+    const int KB = p.Cin / 16;
+    const hf* bptr[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bptr[j] = p.wp + (int64_t)(co0 / 32 + j) * 9 * KB * 512 + lane * 8;
+
+    // Every workgroup walks the nine taps in its own rotation (conv16.hip: persistent workgroups run in lockstep, with one common order
+    // all of them ask the L2 for the same lines at the same moment).  fp32 accumulation order differs between workgroups by the
+    // rotation only: deterministic for a given launch geometry.
+    const int rot = (int)((blockIdx.x + blockIdx.y) % 9);
+    int toffA[9], tapB[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        int te = t + rot;
+        te = te >= 9 ? te - 9 : te;
+        const int ty3 = te >= 6 ? 2 : te >= 3 ? 1 : 0;
+        toffA[t] = (ty3 * HW_ + (te - 3 * ty3)) * LDP;
+        tapB[t] = te * KB * 512;
+    }
+
+    f32x16 acc[4][2];
+    double st0[2] = {0.0, 0.0}, st1[2] = {0.0, 0.0};
+
+    f16x8 breg[DB][2];
+    auto load_b = [&](int chunk, int s, int set) {        // s: step within a chunk (compile-time after unrolling)
+        if (CONV16W_ABL & 1) return;
+        const int off = tapB[s / KS] + (chunk * KS + (s % KS)) * 512;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) breg[set][j] = *(const f16x8*)(bptr[j] + off);
+    };
+    if (CONV16W_ABL & 1) {
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) breg[d][j][k] = (hf)0.f;
+    }
+    if (nfill > 0) {
+#pragma unroll
+        for (int d = 0; d < DB; ++d) load_b(0, d, d);
+    }
+    // this lane's share of an output address, in bytes: pixel column 4 h of the wave's first row, channel r of the wave's first 32
+    const unsigned lane_off = (unsigned)(((wrow * p.W + wcol + 4 * h) * p.Cout + wn * 64 + r) * 2);
+    typedef hf h2 __attribute__((ext_vector_type(2)));
+    __syncthreads();                                       // fill 0 is staged
+
+    int chunk = 0;
+    int64_t tile_i = 0;
+    for (int64_t f = 0; f < nfill; ++f) {
+        const hf* hb = halo + (int)(f & 1) * HALO_H;
+        const int cnext = chunk + 1 == p.nchunks ? 0 : chunk + 1;
+        const bool more = f + 1 < nfill;
+        f16x8 areg[2][4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) areg[0][m] = *(const f16x8*)(hb + abase[m] + toffA[0]);
+        if (CONV16W_ABL & 16) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) areg[1][m] = areg[0][m];
+        }
+#pragma unroll
+        for (int s = 0; s < SPC; ++s) {
+            if (s + 1 < SPC && !(CONV16W_ABL & 16)) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) areg[(s + 1) & 1][m] = *(const f16x8*)(hb + abase[m] + toffA[(s + 1) / KS] + ((s + 1) % KS) * 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);             // the next step's activation fragments are requested BEFORE this step's MFMAs
+            if (s == 0 && chunk == 0) {                    // first step of a tile: accumulate onto zero (no register clearing)
+                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(areg[0][m], breg[0][j], zero, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        if (!(CONV16W_ABL & 8)) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(areg[s & 1][m], breg[s % DB][j], acc[m][j], 0, 0, 0);
+            }
+            // the register set just consumed takes the fragments of the step DB ahead (this chunk, the next chunk, or the first
+            // chunk of the next tile: the same filters)
+            if (s + DB < SPC) load_b(chunk, s + DB, s % DB);
+            else if (more) load_b(cnext, s + DB - SPC, s % DB);
+            // the machine scheduler may not move anything across a step: left alone it sinks every fragment load to its use (fewer
+            // live registers) and the matrix stream then waits for the L2 each step -- the software pipeline IS the kernel
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();                                   // everyone is done with halo[f & 1]; fill f + 1 is staged
+        chunk = cnext;
+        if (chunk != 0) continue;
+
+        // ---- epilogue of a finished tile: straight from the accumulators, every lane its own halves (a wave store covers whole
+        // 64-byte runs: 32 consecutive channels of one pixel per lane half).  Addresses are a uniform base per (tile, register) plus
+        // this lane's constant byte offset; two registers (neighbouring pixels of one channel) are rounded as a pair, the BatchNorm
+        // statistics of the stored halves are two v_dot2_f32_f16 per pair (products of halves are exact in fp32) ----
+        const int64_t tile = (int64_t)blockIdx.x + tile_i * gridDim.x;
+        ++tile_i;
+        if (CONV16W_ABL & 4) {
+            float sum = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) sum += acc[m][j][e];
+            if (sum == 123.456f) p.out[0] = (hf)sum;
+            continue;
+        }
+        int64_t torg;                                      // first element of the tile (TW8: of image 4 tile), this workgroup's slab
+        if (TW8) {
+            torg = (int64_t)(4 * tile) * 64 * p.Cout;
+        } else {
+            const int n0 = (int)(tile / tpi);
+            const int rem = (int)(tile - (int64_t)n0 * tpi);
+            torg = (((int64_t)n0 * p.H + (rem / p.tiles_x) * 16) * p.W + (rem % p.tiles_x) * TWX) * p.Cout;
+        }
+        torg += blockIdx.y * (64 * WN);
+        const int rowst = p.W * p.Cout;
+        float fs[2] = {0.f, 0.f}, fq[2] = {0.f, 0.f};
+        const h2 ones = {(hf)1.f, (hf)1.f};
+        // laundered per tile: the 128 per-register offsets below are loop invariants, and hoisted out of the tile loop they are kept
+        // alive (in scratch: 119 spilled registers) through the matrix loop
+        unsigned lo = lane_off;
+        asm volatile("" : "+v"(lo));
+        // (two straight-line copies, with and without the residual: a per-register branch on it made the compiler park the rounded
+        // pairs in scratch between the store and the statistics blocks; the statistics are always taken -- two instructions per pair)
+        auto epilogue = [&](auto with_res) {
+            constexpr bool RES = decltype(with_res)::value;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                // pixel of register e (lane half h): TW16: row wrow + 2 m + (e >> 3), column wcol + (e & 3) + 4 h + 8 ((e >> 2) & 1);
+                //                                    TW8: image 2 wm + (m >> 1), row 4 (m & 1) + (e >> 2), column (e & 3) + 4 h
+                int64_t moff;
+                bool ok = true;
+                if (TW8) {
+                    ok = (int)(4 * tile) + 2 * wm + (m >> 1) < p.N;
+                    moff = torg + ((int64_t)(2 * wm + (m >> 1)) * 64 + 4 * (m & 1) * 8) * p.Cout;
+                } else {
+                    moff = torg + (int64_t)(2 * m) * rowst;
+                }
+                if (!ok) continue;
+                char* const ob = (char*)(p.out + moff);
+                const char* const rb = RES ? (const char*)(p.residual + moff) : nullptr;
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const int eo = TW8 ? (e >> 2) * rowst + (e & 3) * p.Cout : (e >> 3) * rowst + ((e & 3) + 8 * ((e >> 2) & 1)) * p.Cout;
+                    const unsigned o0 = lo + 2u * (unsigned)eo, o1 = o0 + 2u * (unsigned)p.Cout;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        float v0 = acc[m][j][e], v1 = acc[m][j][e + 1];
+                        if (RES) {
+                            v0 += (float)*(const hf*)(rb + o0 + 64 * j);
+                            v1 += (float)*(const hf*)(rb + o1 + 64 * j);
+                        }
+                        const h2 pk = {(hf)v0, (hf)v1};
+                        *(hf*)(ob + o0 + 64 * j) = pk[0];
+                        *(hf*)(ob + o1 + 64 * j) = pk[1];
+                        fs[j] = __builtin_amdgcn_fdot2(pk, ones, fs[j], false);        // statistics of what is stored
+                        fq[j] = __builtin_amdgcn_fdot2(pk, pk, fq[j], false);
+                    }
+                    // four registers' worth of residual loads / stores at a time (the scheduler would hoist every load of the tile)
+                    if (RES && (e & 2) != 0) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        if (p.residual) epilogue(std::true_type{});
+        else epilogue(std::false_type{});
+        if (p.stats) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { st0[j] += (double)fs[j]; st1[j] += (double)fq[j]; }
+        }
+    }
+
+    if (p.stats) {
+        // lane halves, then the row-waves in a fixed order through LDS (both halo stages are dead: the loop ended on a barrier)
+        double* S = (double*)lds;                  // [WM][2][64 WN]
+        constexpr int BN = 64 * WN;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            st0[j] += __shfl_xor(st0[j], 32);
+            st1[j] += __shfl_xor(st1[j], 32);
+            if (h == 0) {
+                S[(wm * 2 + 0) * BN + wn * 64 + j * 32 + r] = st0[j];
+                S[(wm * 2 + 1) * BN + wn * 64 + j * 32 + r] = st1[j];
+            }
+        }
+        __syncthreads();
+        for (int u = tid; u < 2 * BN; u += NMW * 64) {
+            const int which = u / BN, cc = u % BN;
+            double t = S[(0 * 2 + which) * BN + cc];
+#pragma unroll
+            for (int w = 1; w < WM; ++w) t += S[(w * 2 + which) * BN + cc];
+            p.stats[((int64_t)blockIdx.x * 2 + which) * p.Cout + blockIdx.y * BN + cc] = t;
+        }
+    }
+}
+
+// ---- filters in fragment order: dst[Cout/32][9][Cin/16][2][32][8] <- fp32 OHWI master weights (or their flipped transposes) ----
+struct PackTable {
+    int n;
+    int64_t e[32][6];       // src offset (floats), dst offset (halves), O, I (of the PACKED conv), flip, first block
+};
+
+__global__ __launch_bounds__(256) void pack_hw_kernel(const float* __restrict__ src, hf* __restrict__ dst, PackTable t) {
+    int k = 0;
+    while (k + 1 < t.n && (int64_t)blockIdx.x >= t.e[k + 1][5]) ++k;
+    const int O = (int)t.e[k][2], I = (int)t.e[k][3], flip = (int)t.e[k][4];
+    const int KB = I / 16;
+    const int64_t piece = ((int64_t)blockIdx.x - t.e[k][5]) * 256 + threadIdx.x;       // 16-byte piece of the destination
+    if (piece >= (int64_t)O * 9 * I / 8) return;
+    const int n = (int)(piece & 31), kh = (int)((piece >> 5) & 1);
+    int64_t rest = piece >> 6;
+    const int kb = (int)(rest % KB); rest /= KB;
+    const int tap = (int)(rest % 9);
+    const int ct = (int)(rest / 9);
+    const int o = ct * 32 + n, i0 = kb * 16 + kh * 8;
+    const float* w = src + t.e[k][0];
+    f16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        // plain: this conv's OHWI filter [O][9][I].  flip: this conv is the input gradient of a conv whose filter is [I][9][O]:
+        // its weight (o, tap, i) is that filter's (i, 8 - tap, o)
+        const float x = flip ? w[((int64_t)(i0 + j) * 9 + (8 - tap)) * O + o] : w[((int64_t)o * 9 + tap) * I + i0 + j];
+        v[j] = (hf)x;
+    }
+    *(f16x8*)(dst + t.e[k][1] + piece * 8) = v;
+}
+
+struct GeoW {
+    bool tw8, ck32;
+    int tiles_y, tiles_x, wn, gx, gy;
+    int64_t ntiles;
+};
+
+static GeoW geometry_w(int64_t N, int H, int W, int Cout) {
+    GeoW g;
+    g.tw8 = H == 8 && W == 8;
+    g.wn = Cout % 128 == 0 ? 2 : 1;
+    g.ck32 = g.wn == 1;                   // 16 x 32 tiles: two 18 x 34 halo stages of 64 channels would not fit the LDS
+    g.tiles_y = g.tw8 ? 1 : H / 16;
+    g.tiles_x = g.tw8 ? 1 : W / (g.wn == 1 ? 32 : 16);
+    g.ntiles = g.tw8 ? (N + 3) / 4 : N * g.tiles_y * g.tiles_x;
+    g.gy = Cout / (64 * g.wn);
+    static const int slots = getenv("SSAD_CONV16W_WGS") ? atoi(getenv("SSAD_CONV16W_WGS")) : 256;      // one workgroup per CU
+    int64_t gx = slots / g.gy;
+    if (gx < 1) gx = 1;
+    if (gx > g.ntiles) gx = g.ntiles;
+    g.gx = (int)gx;
+    return g;
+}
+
+template <int WN, bool TW8, int CK>
+static constexpr int lds_bytes_w() { return 2 * (TW8 ? 400 : 18 * (WN == 1 ? 34 : 18)) * (CK + 8) * 2 + 16 * 1024; }
+
+}  // namespace
+
+// 1 when ssad_conv3x3_hw takes the launch: channel counts multiples of 64, maps of 16 x 16 blocks (or 8 x 8 maps), and enough
+// (tile, channel slab) pairs to give every CU a workgroup (smaller launches stay on csrc/conv16.hip's 128-pixel tiles).
+extern "C" int ssad_conv3x3_hw_ok(int64_t N, int H, int W, int Cin, int Cout) {
+    static const int on = getenv("SSAD_CONV16W") ? atoi(getenv("SSAD_CONV16W")) : 1;
+    if (!on || Cin % 64 || Cout % 64 || Cin > 1024 || N <= 0) return 0;
+    const bool wn1 = Cout % 128 != 0;                     // 64 output channels per workgroup: 16 x 32 tiles
+    if (!((H == 8 && W == 8 && !wn1) || (H > 0 && W > 0 && H % 16 == 0 && W % (wn1 ? 32 : 16) == 0))) return 0;
+    const GeoW g = geometry_w(N, H, W, Cout);
+    static const int min_items = getenv("SSAD_CONV16W_MIN") ? atoi(getenv("SSAD_CONV16W_MIN")) : 200;
+    return g.ntiles * g.gy >= min_items;
+}
+
+// halves of one packed filter of Cout x 3 x 3 x Cin
+extern "C" int64_t ssad_conv3x3_hw_packed_size(int Cin, int Cout) { return (int64_t)Cout * 9 * Cin; }
+
+// rows of the statistics workspace (x 2 x Cout doubles)
+extern "C" int64_t ssad_conv3x3_hw_stats_rows(int64_t N, int H, int W, int Cout) { return geometry_w(N, H, W, Cout).gx; }
+
+// Packs n filters in one launch.  desc[5 k ..]: source offset (floats from src), destination offset (halves from dst), Cout, Cin of
+// the conv that will RUN on the packed filter, flip (0: src holds that conv's OHWI filter [Cout][3][3][Cin]; 1: src holds the OHWI
+// filter [Cin][3][3][Cout] of the forward conv whose input gradient this is).  Values are rounded to halves as ssad_cvt_f32_f16 does.
+extern "C" int ssad_conv3x3_hw_pack_batch(const float* src, void* dst, const int64_t* desc, int n, void* stream) {
+    SSAD_CHECK_ARG(src && dst && desc && n > 0, "bad argument");
+    for (int k = 0; k < n; ++k)
+        SSAD_CHECK_ARG(desc[5 * k + 2] > 0 && desc[5 * k + 3] > 0 && desc[5 * k + 2] % 64 == 0 && desc[5 * k + 3] % 64 == 0 &&
+                       desc[5 * k + 1] % 8 == 0, "bad filter shape (channel counts multiples of 64)");
+    for (int base = 0; base < n; base += 32) {
+        PackTable t;
+        t.n = n - base < 32 ? n - base : 32;
+        int64_t acc = 0;
+        for (int k = 0; k < t.n; ++k) {
+            for (int j = 0; j < 5; ++j) t.e[k][j] = desc[5 * (base + k) + j];
+            t.e[k][5] = acc;
+            acc += cdiv64(t.e[k][2] * 9 * t.e[k][3] / 8, 256);
+        }
+        SSAD_CHECK_ARG(acc < (int64_t)2147483647, "too many blocks");
+        hipLaunchKernelGGL(pack_hw_kernel, dim3((unsigned)acc), dim3(256), 0, (hipStream_t)stream, src, (hf*)dst, t);
+        SSAD_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+// ssad_conv3x3_h (csrc/conv16.hip) with the filter in packed form: out = conv3x3(pad 1, stride 1)(T(in)) (+ residual), half tensors
+// NHWC; T = identity or relu((x - tr_mean) * tr_invstd * tr_gamma + tr_beta) per input channel; emit receives T(in); stats_ws != NULL:
+// train-mode BatchNorm statistics of the stored output (ssad_conv3x3_hw_stats_rows(...) * 2 * Cout doubles), finalised as
+// ssad_conv_igemm_fwd_stats does.  The launch must satisfy ssad_conv3x3_hw_ok.
+extern "C" int ssad_conv3x3_hw(const void* in, const void* w_packed, void* out, const void* residual, const float* tr_mean,
+                               const float* tr_invstd, const float* tr_gamma, const float* tr_beta, void* emit, int64_t N, int H, int W,
+                               int Cin, int Cout, double* stats_ws, float eps, float momentum, float* mean, float* invstd,
+                               float* running_mean, float* running_var, void* stream) {
+    SSAD_CHECK_ARG(in && w_packed && out && N > 0 && H > 0 && W > 0, "bad argument");
+    SSAD_CHECK_ARG(Cin % 64 == 0 && Cout % 64 == 0 && Cin <= 1024, "channel counts must be multiples of 64 (Cin <= 1024)");
+    SSAD_CHECK_ARG((H == 8 && W == 8 && Cout % 128 == 0) || (H % 16 == 0 && W % (Cout % 128 == 0 ? 16 : 32) == 0),
+                   "maps of 16 x 16 blocks (16 x 32 when Cout is not a multiple of 128), or 8 x 8 maps with Cout a multiple of 128");
+    SSAD_CHECK_ARG(!tr_mean || (tr_invstd && tr_gamma && tr_beta), "input transform needs mean, invstd, gamma, beta");
+    SSAD_CHECK_ARG(!stats_ws || (mean && invstd), "statistics need mean / invstd outputs");
+    SSAD_CHECK_ARG(!emit || tr_mean, "emit without an input transform");
+    SSAD_CHECK_ARG(N * (int64_t)H * W < (int64_t)1 << 31, "too many pixels for one launch");
+    const GeoW g = geometry_w(N, H, W, Cout);
+    HWParams p;
+    p.in = (const hf*)in; p.wp = (const hf*)w_packed; p.out = (hf*)out; p.residual = (const hf*)residual;
+    p.tr_mean = tr_mean; p.tr_invstd = tr_invstd; p.tr_gamma = tr_gamma; p.tr_beta = tr_beta; p.emit = (hf*)emit;
+    p.stats = stats_ws;
+    p.N = (int)N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    p.tiles_y = g.tiles_y; p.tiles_x = g.tiles_x; p.nchunks = Cin / (g.ck32 ? 32 : 64); p.ntiles = g.ntiles;
+    const dim3 grid((unsigned)g.gx, (unsigned)g.gy);
+    hipStream_t st = (hipStream_t)stream;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SSAD_SET_DYN_LDS((conv3x3_hw_kernel<2, true, 64>), (lds_bytes_w<2, true, 64>()));
+        SSAD_SET_DYN_LDS((conv3x3_hw_kernel<2, false, 64>), (lds_bytes_w<2, false, 64>()));
+        SSAD_SET_DYN_LDS((conv3x3_hw_kernel<1, false, 32>), (lds_bytes_w<1, false, 32>()));
+        attr_set = true;
+    }
+    const int trb = tr_mean ? 16 * Cin : 0;
+    const int lds_ck = g.ck32 ? 32 : 64;
+    const int lds_dyn = 2 * (g.tw8 ? 400 : 18 * (g.wn == 1 ? 34 : 18)) * (lds_ck + 8) * 2 + trb;
+    if (g.wn == 2) {
+        if (g.tw8) hipLaunchKernelGGL((conv3x3_hw_kernel<2, true, 64>), grid, dim3(384), lds_dyn, st, p);
+        else hipLaunchKernelGGL((conv3x3_hw_kernel<2, false, 64>), grid, dim3(384), lds_dyn, st, p);
+    } else {
+        hipLaunchKernelGGL((conv3x3_hw_kernel<1, false, 32>), grid, dim3(384), lds_dyn, st, p);
+    }
+    SSAD_CHECK_LAUNCH();
+    if (stats_ws)
+        return ssad_bn_finalize_partials(stats_ws, g.gx, N * H * W, Cout, eps, momentum, mean, invstd, running_mean, running_var, stream);
+    return 0;
+}

@@ -152,6 +152,12 @@ SIGNATURES = {
     "ssad_conv3x3_h_stats_rows": [_c_l, _c_i, _c_i, _c_i],
     "ssad_conv3x3_h": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_f, _c_f,
                        _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
+    "ssad_conv3x3_hw_ok": [_c_l, _c_i, _c_i, _c_i, _c_i],
+    "ssad_conv3x3_hw_packed_size": [_c_i, _c_i],
+    "ssad_conv3x3_hw_stats_rows": [_c_l, _c_i, _c_i, _c_i],
+    "ssad_conv3x3_hw_pack_batch": [_c_fp, _c_fp, _c_fp, _c_i, _c_fp],
+    "ssad_conv3x3_hw": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_f, _c_f,
+                        _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
     "ssad_bn_stats_h": [_c_fp, _c_l, _c_i, _c_f, _c_f, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
     "ssad_bn_apply_fwd_h": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp],
     "ssad_gap_fwd_h": [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_fp],
@@ -169,7 +175,7 @@ SIGNATURES = {
     "ssad_conv_wgrad_f16_h": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_l, _c_fp],
     "ssad_stem_wgrad_h": [_c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_l, _c_i, _c_i, _c_fp, _c_fp],
 }
-RESTYPES = {"ssad_conv3x3_c64_stats_rows": _c_l, "ssad_conv3x3_h_stats_rows": _c_l, "ssad_colreduce_workspace": _c_l, "ssad_conv_stats_workspace": _c_l, "ssad_stem_wgrad_workspace": _c_l, "ssad_auroc_workspace": _c_l, "ssad_obj_mask_workspace": _c_l, "ssad_pro_curve_workspace": _c_l,
+RESTYPES = {"ssad_conv3x3_c64_stats_rows": _c_l, "ssad_conv3x3_h_stats_rows": _c_l, "ssad_conv3x3_hw_stats_rows": _c_l, "ssad_conv3x3_hw_packed_size": _c_l, "ssad_colreduce_workspace": _c_l, "ssad_conv_stats_workspace": _c_l, "ssad_stem_wgrad_workspace": _c_l, "ssad_auroc_workspace": _c_l, "ssad_obj_mask_workspace": _c_l, "ssad_pro_curve_workspace": _c_l,
             "ssad_best_f1_workspace": _c_l}
 
 _lib = None

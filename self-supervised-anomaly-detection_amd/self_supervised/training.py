@@ -269,18 +269,25 @@ class _Affine:
         mom = 0.1 if bn.momentum is None else bn.momentum
         st = (bn.eps, mom, bn.running_mean, bn.running_var)
         self.x_shape = tuple(x.shape)
-        w = a.w16(self.lin.weight)
+        n, h, wd, cin = x.shape
+        cout = self.lin.out_channels
+        if self.eng.sw_conv16w and ops.conv3x3_hw_ok(n, h, wd, cin, cout):      # launches that fill the chip: register-fed filters
+            wp = self.eng.packed_hw(self.lin, False)
+            conv = lambda **kw: ops.conv3x3_hw(x, wp, cout, **kw)
+        else:
+            w = a.w16(self.lin.weight)
+            conv = lambda **kw: ops.conv3x3_h(x, w, **kw)
         if producer is None:
-            z, self.mean, self.invstd = ops.conv3x3_h(x, w, stats=st)
+            z, self.mean, self.invstd = conv(stats=st)
             self.x = x
         else:
             pb = producer.bn
             tr = (producer.mean, producer.invstd, a.w(pb.weight), a.w(pb.bias))
             need_x = self.lin.weight.requires_grad and self.eng.param_grads and torch.is_grad_enabled()
             if need_x:
-                z, self.x, self.mean, self.invstd = ops.conv3x3_h(x, w, transform=tr, emit=True, stats=st)
+                z, self.x, self.mean, self.invstd = conv(transform=tr, emit=True, stats=st)
             else:
-                z, self.mean, self.invstd = ops.conv3x3_h(x, w, transform=tr, stats=st)
+                z, self.mean, self.invstd = conv(transform=tr, stats=st)
                 self.x = None
         with torch.no_grad():
             self.eng.count_batch(bn)
@@ -450,7 +457,11 @@ class _Affine:
                 wt[:cout] = w
             half = dz.dtype == torch.float16
             if half and dz.dim() == 4 and self.conv16_ok():
-                dx = ops.conv3x3_h(dzz, self.eng.flipped(self.lin, wt, half=True), residual=dx_residual)
+                n_, h_, w_, _ = dzz.shape
+                if self.eng.sw_conv16w and ops.conv3x3_hw_ok(n_, h_, w_, cout, self.lin.in_channels):
+                    dx = ops.conv3x3_hw(dzz, self.eng.packed_hw(self.lin, True), self.lin.in_channels, residual=dx_residual)
+                else:
+                    dx = ops.conv3x3_h(dzz, self.eng.flipped(self.lin, wt, half=True), residual=dx_residual)
             elif self.c64_ok() and dz.dim() == 4:
                 dx = ops.conv3x3_c64(dzz, self.eng.flipped(self.lin, wt), residual=dx_residual, res_mask=dx_res_mask, bf16=bf)
             elif half:
@@ -518,12 +529,15 @@ class TrainEngine:
         # (SSAD_ACT16=0: fp32 tensors with operands rounded while staged -- rounds 2-4)
         self.sw_act16 = os.environ.get("SSAD_ACT16", "1") != "0"
         self.sw_conv16 = os.environ.get("SSAD_CONV16", "1") != "0"
+        self.sw_conv16w = os.environ.get("SSAD_CONV16W", "1") != "0"     # register-fed form of the same conv (csrc/conv16w.hip)
+        self._packed = {False: None, True: None}      # packed 3x3 filters: forward / input-gradient (flipped) tables
+        self._packed_ready = {False: False, True: False}
         self.h16 = False              # decided per forward (trunk BatchNorms in training mode, whole images of >= 64 x 64)
         self._flip16_view, self._flip16_ready = {}, False
 
     def switches(self):
         """Everything besides shapes that decides which launches a step consists of (hipGraph plan key)."""
-        return (self.bf16, self.param_grads, self.sw_c64, self.sw_relu_mask, self.sw_wgrad_halo, self.sw_stem16, self.sw_c64_16, self.sw_act16, self.sw_conv16, self._side_on,
+        return (self.bf16, self.param_grads, self.sw_c64, self.sw_relu_mask, self.sw_wgrad_halo, self.sw_stem16, self.sw_c64_16, self.sw_act16, self.sw_conv16, self.sw_conv16w, self._side_on,
                 os.environ.get("SSAD_WGRAD_HALO", "1") != "0", torch.is_grad_enabled())
 
     # ---- second stream for the weight gradients ----
@@ -574,6 +588,29 @@ class TrainEngine:
                                                           self._flip16_n, _hip.stream()))
         self._flip16_ready = True
         return self._flip16_view[key]
+
+    def packed_hw(self, lin, flip):
+        """The 3x3 filter of a block conv in the fragment order ssad_conv3x3_hw reads (flip: as the input gradient's filter).  All
+        block convs are packed by ONE launch per table and step, from the fp32 master weights (the first request after a forward)."""
+        tab = self._packed[flip]
+        if tab is None:
+            entries, keys = [], []
+            for layer in [d[k] for d in self.blocks for k in ("c1", "c2")]:
+                p = layer.lin.weight
+                o, c, kh, kw = p.shape
+                if (kh, kw) != (3, 3) or layer.stride != 1 or o % 64 or c % 64:
+                    continue
+                entries.append((self.arena.offset[id(p)][0], c, o, True) if flip else (self.arena.offset[id(p)][0], o, c, False))
+                keys.append(id(p))
+            sizes = [e[1] * 9 * e[2] for e in entries]
+            buf = torch.empty(sum(sizes), device=self.arena.p.device, dtype=torch.float16)
+            offs = [sum(sizes[:i]) for i in range(len(sizes))]
+            tab = self._packed[flip] = {"buf": buf, "entries": entries,
+                                        "view": {k: buf[o:o + n] for k, o, n in zip(keys, offs, sizes)}}
+        if not self._packed_ready[flip]:
+            ops.conv3x3_hw_pack(self.arena.p, tab["entries"], out=tab["buf"])
+            self._packed_ready[flip] = True
+        return tab["view"][id(lin.weight)]
 
     def flipped(self, lin, w, half=False):
         """dgrad operand of a conv layer (ssad_flip_transpose_weight of its OHWI weight).  All block convs are flipped by one
@@ -626,6 +663,7 @@ class TrainEngine:
         b, _, h, w = x.shape
         self.trunk_grad = any(p.requires_grad for p in m.feature_extractor.parameters())
         self._nbt, self._flip_ready, self._flip16_ready = [], False, False
+        self._packed_ready = {False: False, True: False}
         self.h16 = bool(self.bf16 == 2 and self.sw_act16 and self.sw_stem16 and h >= 64 and w >= 64 and self.param_grads and
                         all(mod.training for mod in m.feature_extractor.modules() if isinstance(mod, BN_TYPES)))
         if self.h16:

@@ -150,6 +150,52 @@ def test_conv3x3_h_halo_kernel(dev, shape):
     assert torch.equal(z2, z3)
 
 
+@pytest.mark.parametrize("shape", [(26, 64, 64, 64, 64), (52, 32, 32, 128, 128), (104, 16, 16, 256, 256), (202, 8, 8, 512, 512),
+                                   (52, 32, 32, 64, 128), (26, 64, 64, 128, 64), (801, 8, 8, 64, 128)])
+def test_conv3x3_hw_register_fed_kernel(dev, shape):
+    """csrc/conv16w.hip (filters packed in fragment order and fed from registers, halo staged by two extra waves) against fp32 math on
+    the same half operands and against csrc/conv16.hip: 16 x 16 tiles and four 8 x 8 maps per tile (ragged last tile), one / two / four
+    channel slabs, 64- and 32-channel chunks, statistics, residual, producer BatchNorm + ReLU on load with the emitted activation; the
+    flipped pack == the pack of the flipped filter."""
+    from self_supervised import ops
+    n, h, w, cin, cout = shape
+    assert ops.conv3x3_hw_ok(n, h, w, cin, cout)
+    g = torch.Generator().manual_seed(n * 3 + h + cin)
+    x = torch.randn(n, h, w, cin, generator=g).half().to(dev)
+    w32 = (torch.randn(cout, 3, 3, cin, generator=g) / (9 * cin) ** 0.5).to(dev)
+    wt = w32.half()
+    res = torch.randn(n, h, w, cout, generator=g).half().to(dev)
+    wp, _ = ops.conv3x3_hw_pack(w32.reshape(-1), [(0, cout, cin, False)])
+    rm1, rv1 = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)
+    rm2, rv2 = rm1.clone(), rv1.clone()
+    zo, mo, io = ops.conv3x3_h(x, wt, stats=(1e-5, 0.1, rm1, rv1))
+    z, m, i = ops.conv3x3_hw(x, wp, cout, stats=(1e-5, 0.1, rm2, rv2))
+    tol = lambda ref: 2e-3 * max(1.0, ref.float().abs().max().item())               # one half ulp of the largest value, twice
+    want = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), wt.float().cpu().permute(0, 3, 1, 2), None, 1, 1).permute(0, 2, 3, 1)
+    assert z.dtype == torch.float16 and (z.float().cpu() - want).abs().max().item() <= tol(want)
+    assert (z.float() - zo.float()).abs().max().item() <= tol(want)
+    zc = z.double().reshape(-1, cout)
+    assert (m.double() - zc.mean(0)).abs().max().item() < 1e-5 * max(1.0, zc.abs().max().item())
+    assert ((i.double() - (zc.var(0, unbiased=False) + 1e-5).rsqrt()).abs() / i.double()).max().item() < 1e-5
+    assert (rm2 - rm1).abs().max().item() < 2e-3 and (rv2 - rv1).abs().max().item() < 2e-3
+    zr = ops.conv3x3_hw(x, wp, cout, residual=res)
+    assert (zr.float().cpu() - (want + res.float().cpu())).abs().max().item() <= tol(want + res.float().cpu())
+    tr = _bn_params(cin, g, dev)
+    act = ops.bn_apply_fwd(x, tr[0], tr[1], tr[2], tr[3], None, True)
+    z2, em, m2, i2 = ops.conv3x3_hw(x, wp, cout, transform=tr, emit=True, stats=(1e-5, 0.1, rm2, rv2))
+    assert torch.equal(em, act)                                                     # the same expression, rounded once
+    assert torch.equal(z2, ops.conv3x3_hw(act, wp, cout))
+    # input gradient: the flipped pack of the forward filter [cout][3][3][cin] runs a conv cout -> cin
+    if ops.conv3x3_hw_ok(n, h, w, cout, cin):
+        wpf, _ = ops.conv3x3_hw_pack(w32.reshape(-1), [(0, cin, cout, True)])
+        wflip = w32.flip(1, 2).permute(3, 1, 2, 0).contiguous()                     # [cin][3][3][cout]
+        wpf2, _ = ops.conv3x3_hw_pack(wflip.reshape(-1), [(0, cin, cout, False)])
+        assert torch.equal(wpf, wpf2)
+        dx = ops.conv3x3_hw(res, wpf, cin)
+        wantdx = F.conv_transpose2d(res.float().cpu().permute(0, 3, 1, 2), wt.float().cpu().permute(0, 3, 1, 2), None, 1, 1).permute(0, 2, 3, 1)
+        assert (dx.float().cpu() - wantdx).abs().max().item() <= tol(wantdx)
+
+
 @pytest.mark.parametrize("shape", [(3, 16, 16, 64, 64, 1), (2, 13, 21, 64, 128, 1), (5, 8, 8, 128, 64, 1), (3, 5, 7, 64, 64, 1),
                                    (40, 32, 32, 128, 128, 1), (9, 64, 64, 64, 64, 1), (3, 32, 32, 64, 128, 2), (2, 13, 21, 64, 64, 2),
                                    (5, 16, 16, 128, 256, 2), (40, 16, 16, 256, 512, 2), (3, 9, 9, 64, 64, 2)])

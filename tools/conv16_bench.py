@@ -37,8 +37,15 @@ for (hw, c) in [(64, 64), (32, 128), (16, 256), (8, 512)]:
     t["h stats"] = timeit(lambda: ops.conv3x3_h(x, w, stats=st))
     t["h tr+emit+stats"] = timeit(lambda: ops.conv3x3_h(x, w, transform=tr, emit=True, stats=st))
     t["h residual"] = timeit(lambda: ops.conv3x3_h(x, w, residual=res))
-    t["igemm stats"] = timeit(lambda: ops.conv_fwd_stats(x, w, 1e-5, 0.1, rm, rv, 1, 1, bf16=2))
-    if c == 64:
+    if ops.conv3x3_hw_ok(B, hw, hw, c, c):
+        wp, _ = ops.conv3x3_hw_pack(w.float().reshape(-1), [(0, c, c, False)])
+        t["hw plain"] = timeit(lambda: ops.conv3x3_hw(x, wp, c))
+        t["hw stats"] = timeit(lambda: ops.conv3x3_hw(x, wp, c, stats=st))
+        t["hw tr+emit+stats"] = timeit(lambda: ops.conv3x3_hw(x, wp, c, transform=tr, emit=True, stats=st))
+        t["hw residual"] = timeit(lambda: ops.conv3x3_hw(x, wp, c, residual=res))
+    if not os.environ.get("NO_IGEMM"):
+        t["igemm stats"] = timeit(lambda: ops.conv_fwd_stats(x, w, 1e-5, 0.1, rm, rv, 1, 1, bf16=2))
+    if c == 64 and not os.environ.get("NO_IGEMM"):
         wf = w.float()
         t["c64_h stats"] = timeit(lambda: ops.conv3x3_c64(x, wf, stats=st, bf16=2))
-    print(f"{hw}x{hw}x{c}: {gf:.1f} GFLOP, {mb:.0f} MB in+out | " + " | ".join(f"{k} {v:.1f} us ({mb / v:.2f} TB/s of in + out)" for k, v in t.items()))
+    print(f"{hw}x{hw}x{c}: {gf:.1f} GFLOP, {mb:.0f} MB in+out | " + " | ".join(f"{k} {v:.1f} us" for k, v in t.items()), flush=True)
