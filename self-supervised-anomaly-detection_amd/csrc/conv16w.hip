@@ -24,7 +24,7 @@
 #include <type_traits>
 
 #ifndef CONV16W_ABL      // timing ablations (tools/micro): 1 = no weight loads, 2 = no halo loads, 4 = no epilogue, 8 = no MFMAs,
-                         // 16 = no activation fragment reads, 32 = no per-fill barriers (matrix waves)
+                         // 16 = no activation fragment reads, 64 = the epilogue without its stores
 #define CONV16W_ABL 0
 #endif
 
@@ -51,11 +51,11 @@ struct HWParams {
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // WN: 64-channel wave columns per workgroup (output channels per workgroup = 64 WN); four matrix waves (WM x WN, WM = 4 / WN) of
-// 128 pixels x 64 channels each, two stager waves.  Tile: WN = 2: a 16 x 16 block (18 x 18 halo), or -- TW8, 8 x 8 maps -- four
+// 128 pixels x 64 channels each, four stager waves.  Tile: WN = 2: a 16 x 16 block (18 x 18 halo), or -- TW8, 8 x 8 maps -- four
 // consecutive images, each with its 10 x 10 halo; WN = 1 (the 64-channel layer): 16 rows x 32 columns (18 x 34 halo).
 // CK: input channels per chunk (64; 32 where two halo stages of 64 channels would not fit the LDS).
 template <int WN, bool TW8, int CK>
-__global__ __launch_bounds__(384) void conv3x3_hw_kernel(HWParams p) {
+__global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams p) {
     constexpr int WM = 4 / WN;
     constexpr int TWX = WN == 1 ? 32 : 16;             // tile width in pixels (not TW8)
     constexpr int LDP = CK + 8;                        // halves per LDS halo row (16-byte reads of 16 consecutive pixels: no conflicts)
@@ -65,11 +65,12 @@ __global__ __launch_bounds__(384) void conv3x3_hw_kernel(HWParams p) {
     constexpr int HW_ = TW8 ? 10 : TWX + 2;
     constexpr int NHP = TW8 ? 400 : 18 * HW_;
     constexpr int NMW = 4;
-    constexpr int SL = 128;                            // stager lanes
+    constexpr int SL = 256;                            // stager lanes: one stager wave beside each matrix wave (their instructions
+                                                       // delay that wave, and the slowest wave sets the pace at the barrier)
     constexpr int NSP = TW8 ? 256 : NHP;               // staged pixels: an 8 x 8 map's halo ring is all padding, zeroed once
     constexpr int NR = (NSP * PPR + SL - 1) / SL;      // pieces per stager lane per chunk
     constexpr int HALO_H = NHP * LDP;
-    constexpr int NT = 384;
+    constexpr int NT = 512;
     static_assert(SPC % DB == 0 && SPC % 2 == 0, "ring / double-buffer periods must divide a chunk");
     static_assert(!(TW8 && WN == 1), "8 x 8 maps: 128 output channels per workgroup");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -78,7 +79,12 @@ __global__ __launch_bounds__(384) void conv3x3_hw_kernel(HWParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t my_tiles = p.ntiles > (int64_t)blockIdx.x ? (p.ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-    const int64_t nfill = my_tiles * p.nchunks;
+    // fills of a tile: its nchunks input chunks, then -- with a residual -- the RF chunks of the residual's channel slab: the residual is
+    // ADDED BY THE MATRIX CORES (a centre-tap step against a one-hot fragment: fp16 x 1.0 into the fp32 accumulator, exact), so it rides
+    // the staging pipeline and its HBM latency is hidden like the input's (first form: 2-byte loads in the epilogue, +20 .. +150 us)
+    constexpr int RF = 64 * WN / CK;
+    const int fpt = p.nchunks + (p.residual ? RF : 0);
+    const int64_t nfill = my_tiles * fpt;
     const int tpi = p.tiles_y * p.tiles_x;
 
     if (TW8) {                                         // padding rings of both halo stages
@@ -102,23 +108,26 @@ __global__ __launch_bounds__(384) void conv3x3_hw_kernel(HWParams p) {
         // halo coordinates, interior flag; per fill there remain the in-image tests and the uniform base address.
         const int sl = (wave - NMW) * 64 + lane;
         const int piece = sl % PPR;                         // SL is a multiple of PPR: a lane stages the same piece of every pixel
-        u32x4 reg[NR];
+        u32x4 reg[2][NR];                                   // two sets: a fill's loads are requested TWO fills before they are written
         unsigned goff[NR];                                  // bytes from the halo's pixel (-1, -1) (TW8: from image 4 tile, pixel (0, 0))
         unsigned loff[NR];                                  // bytes from the start of a halo stage
+        unsigned goffr[NR];                                 // the same in the residual tensor (Cout channels per pixel)
         unsigned hyx[NR];                                   // hy << 8 | hx (TW8: image within the tile)
-        unsigned inner = 0, valid = 0, inm = 0;
+        unsigned inner = 0, valid = 0, inm[2] = {0u, 0u};
 #pragma unroll
         for (int q = 0; q < NR; ++q) {
             const int hp = (q * SL + sl) / PPR;             // TW8: hp = 64 image + 8 y + x (interior pixels only)
             if (hp < NSP) valid |= 1u << q;
             if (TW8) {
                 goff[q] = (unsigned)((hp * p.Cin + piece * 8) * 2);
+                goffr[q] = (unsigned)((hp * p.Cout + piece * 8) * 2);
                 loff[q] = (unsigned)((((hp >> 6) * 100 + (((hp >> 3) & 7) + 1) * 10 + (hp & 7) + 1) * LDP + piece * 8) * 2);
                 hyx[q] = (unsigned)(hp >> 6);
                 inner |= 1u << q;
             } else {
                 const int hy = hp / HW_, hx = hp - HW_ * hy;
                 goff[q] = (unsigned)(((hy * p.W + hx) * p.Cin + piece * 8) * 2);
+                goffr[q] = (unsigned)(((hy * p.W + hx) * p.Cout + piece * 8) * 2);
                 loff[q] = (unsigned)((hp * LDP + piece * 8) * 2);
                 hyx[q] = (unsigned)(hy << 8 | hx);
                 if (hy >= 1 && hy <= 16 && hx >= 1 && hx <= TWX) inner |= 1u << q;
@@ -126,77 +135,104 @@ __global__ __launch_bounds__(384) void conv3x3_hw_kernel(HWParams p) {
         }
         // uniform per fill: element index of the halo's pixel (-1, -1) at channel chunk * CK (may lie before the tensor: only
         // in-image pixels are dereferenced), and the tile's position
+        // chunk >= nchunks: a residual fill (chunk - nchunks of the workgroup's channel slab), base then indexes the residual tensor
         auto origin = [&](int64_t f, int64_t& base, int& chunk, int& y0, int& x0, int& nimg) {
-            const int64_t ti = f / p.nchunks;
-            chunk = (int)(f - ti * p.nchunks);
+            const int64_t ti = f / fpt;
+            chunk = (int)(f - ti * fpt);
             const int64_t tile = (int64_t)blockIdx.x + ti * gridDim.x;
+            const bool res = chunk >= p.nchunks;
+            const int C = res ? p.Cout : p.Cin;
+            const int c0 = res ? (int)blockIdx.y * (64 * WN) + (chunk - p.nchunks) * CK : chunk * CK;
             if (TW8) {
                 y0 = x0 = 0;
                 nimg = p.N - (int)(4 * tile);               // images of this tile that exist
-                base = (int64_t)(4 * tile) * 64 * p.Cin + chunk * CK;
+                base = (int64_t)(4 * tile) * 64 * C + c0;
             } else {
                 const int n0 = (int)(tile / tpi);
                 const int rem = (int)(tile - (int64_t)n0 * tpi);
                 y0 = (rem / p.tiles_x) * 16;
                 x0 = (rem % p.tiles_x) * TWX;
                 nimg = 1;
-                base = (((int64_t)n0 * p.H + y0 - 1) * p.W + x0 - 1) * p.Cin + chunk * CK;
+                base = (((int64_t)n0 * p.H + y0 - 1) * p.W + x0 - 1) * C + c0;
             }
         };
-        auto load_fill = [&](int64_t f) {
+        auto load_fill = [&](int64_t f, auto set_tag) {
+            constexpr int SET = decltype(set_tag)::value;
             int64_t base; int chunk, y0, x0, nimg;
             origin(f, base, chunk, y0, x0, nimg);
-            const char* src = (const char*)(p.in + base);
-            inm = 0;
+            const bool res = chunk >= p.nchunks;
+            const char* src = (const char*)((res ? p.residual : p.in) + base);
+            unsigned im = 0;
 #pragma unroll
             for (int q = 0; q < NR; ++q) {
                 bool ok = (valid >> q) & 1u;
+                if (res) ok = ok && ((inner >> q) & 1u);   // only the centre tap reads a residual fill
                 if (TW8) ok = ok && (int)hyx[q] < nimg;
                 else ok = ok && (unsigned)(y0 - 1 + (int)(hyx[q] >> 8)) < (unsigned)p.H && (unsigned)(x0 - 1 + (int)(hyx[q] & 255u)) < (unsigned)p.W;
                 u32x4 v = {0u, 0u, 0u, 0u};
-                if (ok && !(CONV16W_ABL & 2)) v = *(const u32x4*)(src + goff[q]);
-                reg[q] = v;
-                inm |= (ok ? 1u : 0u) << q;
+                if (ok && !(CONV16W_ABL & 2)) v = *(const u32x4*)(src + (res ? goffr[q] : goff[q]));
+                reg[SET][q] = v;
+                im |= (ok ? 1u : 0u) << q;
             }
+            inm[SET] = im;
         };
-        auto write_fill = [&](int64_t f) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        auto write_fill = [&](int64_t f, auto set_tag) {
+            constexpr int SET = decltype(set_tag)::value;
             int64_t base; int chunk, y0, x0, nimg;
             origin(f, base, chunk, y0, x0, nimg);
             char* dst = (char*)(halo + (int)(f & 1) * HALO_H);
-            if (p.tr_mean) {
-                // producer's train-mode BatchNorm + ReLU on load: bn_apply_fwd's expression in fp32, rounded once.  Zero padding pads
-                // the TRANSFORMED activation: out-of-image pieces stay zero.  The eight channels of this lane's piece: once per fill.
+            if (p.tr_mean && chunk < p.nchunks) {
+                // producer's train-mode BatchNorm + ReLU on load: bn_apply_fwd's expression in fp32 (two channels per packed
+                // instruction), rounded once, the ReLU on the rounded pair.  Zero padding pads the TRANSFORMED activation: out-of-image
+                // pieces stay zero.  The eight channels of this lane's piece: read once per fill.
                 const int c = chunk * CK + piece * 8;
-                float mu[8], sc[8], ga[8], be[8];
+                f32x2 mu[4], sc[4], ga[4], be[4];
 #pragma unroll
-                for (int k = 0; k < 8; k += 4) {
-                    const f32x4 a = *(const f32x4*)(trp + c + k), b = *(const f32x4*)(trp + p.Cin + c + k);
-                    const f32x4 g = *(const f32x4*)(trp + 2 * p.Cin + c + k), e = *(const f32x4*)(trp + 3 * p.Cin + c + k);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { mu[k + u] = a[u]; sc[k + u] = b[u]; ga[k + u] = g[u]; be[k + u] = e[u]; }
+                for (int k = 0; k < 4; ++k) {
+                    mu[k] = *(const f32x2*)(trp + c + 2 * k); sc[k] = *(const f32x2*)(trp + p.Cin + c + 2 * k);
+                    ga[k] = *(const f32x2*)(trp + 2 * p.Cin + c + 2 * k); be[k] = *(const f32x2*)(trp + 3 * p.Cin + c + 2 * k);
                 }
                 char* em = (p.emit && blockIdx.y == 0) ? (char*)(p.emit + base) : nullptr;
 #pragma unroll
                 for (int q = 0; q < NR; ++q) {
-                    if (!((inm >> q) & 1u)) continue;
-                    f16x8 v = __builtin_bit_cast(f16x8, reg[q]);
+                    if (!((inm[SET] >> q) & 1u)) continue;
+                    // (written over an f16x8: with the piece held as four dwords and the pairs bit-cast out of / into its elements,
+                    // hipcc fed pair 0's RESULT to pairs 1-3 -- found by the emitted activation, tests/test_hip_half.py)
+                    const f16x8 v = __builtin_bit_cast(f16x8, reg[SET][q]);
+                    f16x8 o;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = (hf)fmaxf(((float)v[k] - mu[k]) * sc[k] * ga[k] + be[k], 0.f);
-                    reg[q] = __builtin_bit_cast(u32x4, v);
+                    for (int k = 0; k < 4; ++k) {
+                        const f32x2 xf = {(float)v[2 * k], (float)v[2 * k + 1]};
+                        const f32x2 y = (xf - mu[k]) * sc[k] * ga[k] + be[k];
+                        o[2 * k] = (hf)fmaxf(y[0], 0.f);
+                        o[2 * k + 1] = (hf)fmaxf(y[1], 0.f);
+                    }
+                    const u32x4 w = __builtin_bit_cast(u32x4, o);
+                    reg[SET][q] = w;
                     // interior pixels of the halo: the activation this layer's weight gradient reads
-                    if (em && ((inner >> q) & 1u)) *(u32x4*)(em + goff[q]) = reg[q];
+                    if (em && ((inner >> q) & 1u)) *(u32x4*)(em + goff[q]) = w;
                 }
             }
 #pragma unroll
             for (int q = 0; q < NR; ++q)
-                if ((valid >> q) & 1u) *(u32x4*)(dst + loff[q]) = reg[q];
+                if ((valid >> q) & 1u) *(u32x4*)(dst + loff[q]) = reg[SET][q];
         };
-        if (nfill > 0) { load_fill(0); write_fill(0); }
-        if (nfill > 1) load_fill(1);
+        // fill g is loaded into set g & 1 while fill g - 2 (same set, already written) is being consumed: HBM has two fills of matrix
+        // work to answer (one was not enough on the 64-channel layer: 18 steps per fill)
+        const std::integral_constant<int, 0> S0;
+        const std::integral_constant<int, 1> S1;
+        if (nfill > 0) { load_fill(0, S0); write_fill(0, S0); }
+        if (nfill > 1) load_fill(1, S1);
+        if (nfill > 2) load_fill(2, S0);
         __syncthreads();
-        for (int64_t f = 0; f < nfill; ++f) {
-            if (f + 1 < nfill) write_fill(f + 1);
-            if (f + 2 < nfill) load_fill(f + 2);
+        for (int64_t f = 0; f < nfill; f += 2) {
+            if (f + 1 < nfill) write_fill(f + 1, S1);
+            if (f + 3 < nfill) load_fill(f + 3, S1);
+            __syncthreads();
+            if (f + 1 >= nfill) break;
+            if (f + 2 < nfill) write_fill(f + 2, S0);
+            if (f + 4 < nfill) load_fill(f + 4, S0);
             __syncthreads();
         }
         if (p.stats) __syncthreads();
@@ -266,10 +302,12 @@ __global__ __launch_bounds__(384) void conv3x3_hw_kernel(HWParams p) {
 
     int chunk = 0;
     int64_t tile_i = 0;
-    for (int64_t f = 0; f < nfill; ++f) {
+    int64_t f = 0;                                         // fills consumed so far (halo stage = f & 1)
+    const int64_t nin = my_tiles * p.nchunks;              // input fills
+    for (int64_t fi = 0; fi < nin; ++fi) {
         const hf* hb = halo + (int)(f & 1) * HALO_H;
         const int cnext = chunk + 1 == p.nchunks ? 0 : chunk + 1;
-        const bool more = f + 1 < nfill;
+        const bool more = cnext != 0 || tile_i + 1 < my_tiles;          // another input fill follows (this tile's or the next tile's)
         f16x8 areg[2][4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) areg[0][m] = *(const f16x8*)(hb + abase[m] + toffA[0]);
@@ -306,8 +344,39 @@ __global__ __launch_bounds__(384) void conv3x3_hw_kernel(HWParams p) {
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();                                   // everyone is done with halo[f & 1]; fill f + 1 is staged
+        ++f;
         chunk = cnext;
         if (chunk != 0) continue;
+
+        if (p.residual) {
+            // ---- the residual fills of this tile: acc += residual x one-hot.  Step kk of fill rc covers the slab's channels
+            // rc CK + 16 kk .. + 15; a wave takes the steps inside its own 64 channels: fragment element j of lane (r, h) of accumulator
+            // tile jt is 1 where jt 32 + r = cb + 8 h + j (the tile a step does not belong to adds zeros) ----
+#pragma unroll
+            for (int rc = 0; rc < RF; ++rc) {
+                const hf* hr = halo + (int)(f & 1) * HALO_H;
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) {
+                    const int cb = rc * CK + kk * 16 - wn * 64;       // first channel of the step, counted from the wave's first
+                    if (cb >= 0 && cb < 64) {
+                        f16x8 ar[4];
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) ar[m] = *(const f16x8*)(hr + abase[m] + (HW_ + 1) * LDP + kk * 16);
+#pragma unroll
+                        for (int jt = 0; jt < 2; ++jt) {
+                            const int hot = jt * 32 + r - cb - 8 * h;
+                            f16x8 one;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) one[j] = hot == j ? (hf)1.f : (hf)0.f;
+#pragma unroll
+                            for (int m = 0; m < 4; ++m) acc[m][jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[m], one, acc[m][jt], 0, 0, 0);
+                        }
+                    }
+                }
+                __syncthreads();
+                ++f;
+            }
+        }
 
         // ---- epilogue of a finished tile: straight from the accumulators, every lane its own halves (a wave store covers whole
         // 64-byte runs: 32 consecutive channels of one pixel per lane half).  Addresses are a uniform base per (tile, register) plus
@@ -342,53 +411,41 @@ __global__ __launch_bounds__(384) void conv3x3_hw_kernel(HWParams p) {
         // alive (in scratch: 119 spilled registers) through the matrix loop
         unsigned lo = lane_off;
         asm volatile("" : "+v"(lo));
-        // (two straight-line copies, with and without the residual: a per-register branch on it made the compiler park the rounded
-        // pairs in scratch between the store and the statistics blocks; the statistics are always taken -- two instructions per pair)
-        auto epilogue = [&](auto with_res) {
-            constexpr bool RES = decltype(with_res)::value;
+        // (the statistics are always taken -- two instructions per pair; a per-register branch on p.stats made the compiler park the
+        // rounded pairs in scratch between the store and the statistics blocks)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                // pixel of register e (lane half h): TW16: row wrow + 2 m + (e >> 3), column wcol + (e & 3) + 4 h + 8 ((e >> 2) & 1);
-                //                                    TW8: image 2 wm + (m >> 1), row 4 (m & 1) + (e >> 2), column (e & 3) + 4 h
-                int64_t moff;
-                bool ok = true;
-                if (TW8) {
-                    ok = (int)(4 * tile) + 2 * wm + (m >> 1) < p.N;
-                    moff = torg + ((int64_t)(2 * wm + (m >> 1)) * 64 + 4 * (m & 1) * 8) * p.Cout;
-                } else {
-                    moff = torg + (int64_t)(2 * m) * rowst;
-                }
-                if (!ok) continue;
-                char* const ob = (char*)(p.out + moff);
-                const char* const rb = RES ? (const char*)(p.residual + moff) : nullptr;
+        for (int m = 0; m < 4; ++m) {
+            // pixel of register e (lane half h): TW16: row wrow + 2 m + (e >> 3), column wcol + (e & 3) + 4 h + 8 ((e >> 2) & 1);
+            //                                    TW8: image 2 wm + (m >> 1), row 4 (m & 1) + (e >> 2), column (e & 3) + 4 h
+            int64_t moff;
+            bool ok = true;
+            if (TW8) {
+                ok = (int)(4 * tile) + 2 * wm + (m >> 1) < p.N;
+                moff = torg + ((int64_t)(2 * wm + (m >> 1)) * 64 + 4 * (m & 1) * 8) * p.Cout;
+            } else {
+                moff = torg + (int64_t)(2 * m) * rowst;
+            }
+            if (!ok) continue;
+            char* const ob = (char*)(p.out + moff);
 #pragma unroll
-                for (int e = 0; e < 16; e += 2) {
-                    const int eo = TW8 ? (e >> 2) * rowst + (e & 3) * p.Cout : (e >> 3) * rowst + ((e & 3) + 8 * ((e >> 2) & 1)) * p.Cout;
-                    const unsigned o0 = lo + 2u * (unsigned)eo, o1 = o0 + 2u * (unsigned)p.Cout;
+            for (int e = 0; e < 16; e += 2) {
+                const int eo = TW8 ? (e >> 2) * rowst + (e & 3) * p.Cout : (e >> 3) * rowst + ((e & 3) + 8 * ((e >> 2) & 1)) * p.Cout;
+                const unsigned o0 = lo + 2u * (unsigned)eo, o1 = o0 + 2u * (unsigned)p.Cout;
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        float v0 = acc[m][j][e], v1 = acc[m][j][e + 1];
-                        if (RES) {
-                            v0 += (float)*(const hf*)(rb + o0 + 64 * j);
-                            v1 += (float)*(const hf*)(rb + o1 + 64 * j);
-                        }
-                        const h2 pk = {(hf)v0, (hf)v1};
+                for (int j = 0; j < 2; ++j) {
+                    const h2 pk = {(hf)acc[m][j][e], (hf)acc[m][j][e + 1]};
+                    if (!(CONV16W_ABL & 64) || fs[j] == 123.456f) {       // ablation 64: the epilogue's arithmetic without its stores
                         *(hf*)(ob + o0 + 64 * j) = pk[0];
                         *(hf*)(ob + o1 + 64 * j) = pk[1];
-                        fs[j] = __builtin_amdgcn_fdot2(pk, ones, fs[j], false);        // statistics of what is stored
-                        fq[j] = __builtin_amdgcn_fdot2(pk, pk, fq[j], false);
                     }
-                    // four registers' worth of residual loads / stores at a time (the scheduler would hoist every load of the tile)
-                    if (RES && (e & 2) != 0) __builtin_amdgcn_sched_barrier(0);
+                    fs[j] = __builtin_amdgcn_fdot2(pk, ones, fs[j], false);        // statistics of what is stored
+                    fq[j] = __builtin_amdgcn_fdot2(pk, pk, fq[j], false);
                 }
             }
-        };
-        if (p.residual) epilogue(std::true_type{});
-        else epilogue(std::false_type{});
-        if (p.stats) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) { st0[j] += (double)fs[j]; st1[j] += (double)fq[j]; }
         }
+        // (unconditional: under `if (p.stats)` the compiler sinks the dot products into the conditional block and keeps every pair alive)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { st0[j] += (double)fs[j]; st1[j] += (double)fq[j]; }
     }
 
     if (p.stats) {
@@ -552,10 +609,10 @@ extern "C" int ssad_conv3x3_hw(const void* in, const void* w_packed, void* out, 
     const int lds_ck = g.ck32 ? 32 : 64;
     const int lds_dyn = 2 * (g.tw8 ? 400 : 18 * (g.wn == 1 ? 34 : 18)) * (lds_ck + 8) * 2 + trb;
     if (g.wn == 2) {
-        if (g.tw8) hipLaunchKernelGGL((conv3x3_hw_kernel<2, true, 64>), grid, dim3(384), lds_dyn, st, p);
-        else hipLaunchKernelGGL((conv3x3_hw_kernel<2, false, 64>), grid, dim3(384), lds_dyn, st, p);
+        if (g.tw8) hipLaunchKernelGGL((conv3x3_hw_kernel<2, true, 64>), grid, dim3(512), lds_dyn, st, p);
+        else hipLaunchKernelGGL((conv3x3_hw_kernel<2, false, 64>), grid, dim3(512), lds_dyn, st, p);
     } else {
-        hipLaunchKernelGGL((conv3x3_hw_kernel<1, false, 32>), grid, dim3(384), lds_dyn, st, p);
+        hipLaunchKernelGGL((conv3x3_hw_kernel<1, false, 32>), grid, dim3(512), lds_dyn, st, p);
     }
     SSAD_CHECK_LAUNCH();
     if (stats_ws)
