@@ -337,16 +337,19 @@ __global__ void pack_stem_weight_kernel(const float* __restrict__ w, float* __re
 // between conv1/bn1/relu and the pool never exists in HBM.
 struct PoolBN { const float* mean; const float* invstd; const float* gamma; const float* beta; };
 
+// A lane owns E = 4 (float) / 8 (half) consecutive channels: 16-byte accesses either way (totalE, CE in units of E).
 template <typename T>
-__global__ void maxpool3x3s2_kernel(const T* __restrict__ in, T* __restrict__ out, uint8_t* __restrict__ idx,
-                                    int64_t total4, int H, int W, int C4, int Ho, int Wo, int64_t N, int hwnc, PoolBN bn) {
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__ in, T* __restrict__ out, uint8_t* __restrict__ idx,
+                                    int64_t totalE, int H, int W, int CE, int Ho, int Wo, int64_t N, int hwnc, PoolBN bn) {
+    constexpr int E = Lane<T>::E;
+    using V = typename Lane<T>::vec;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total4) return;
-    int c4 = (int)(i % C4);
-    int64_t pix = i / C4;
+    if (i >= totalE) return;
+    int cq = (int)(i % CE);
+    int64_t pix = i / CE;
     int ox, oy;
     int64_t n;
-    if (hwnc) {                       // i enumerates [Ho][Wo][N][C4]
+    if (hwnc) {                       // i enumerates [Ho][Wo][N][CE]
         n = pix % N;
         int64_t t = pix / N;
         ox = (int)(t % Wo);
@@ -357,12 +360,14 @@ __global__ void maxpool3x3s2_kernel(const T* __restrict__ in, T* __restrict__ ou
         oy = (int)(t % Ho);
         n = t / Ho;
     }
-    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    int am[4] = {0, 0, 0, 0};                 // window slot (dy*3+dx) of the FIRST maximum, PyTorch's tie rule
-    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = mu, ga = mu, be = mu;
+    V m = -INFINITY;
+    int am[E];                                // window slot (dy*3+dx) of the FIRST maximum, PyTorch's tie rule
+#pragma unroll
+    for (int k = 0; k < E; ++k) am[k] = 0;
+    V mu = 0.f, is = 0.f, ga = 0.f, be = 0.f;
     if (bn.mean) {
-        mu = ((const f32x4*)bn.mean)[c4]; is = ((const f32x4*)bn.invstd)[c4];
-        ga = ((const f32x4*)bn.gamma)[c4]; be = ((const f32x4*)bn.beta)[c4];
+        mu = ldpar<V>(bn.mean, cq); is = ldpar<V>(bn.invstd, cq);
+        ga = ldpar<V>(bn.gamma, cq); be = ldpar<V>(bn.beta, cq);
     }
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
@@ -373,20 +378,25 @@ __global__ void maxpool3x3s2_kernel(const T* __restrict__ in, T* __restrict__ ou
             int x = ox * 2 - 1 + dx;
             if ((unsigned)x >= (unsigned)W) continue;
             const int64_t ip = hwnc ? ((int64_t)y * W + x) * N + n : (n * H + y) * W + x;
-            f32x4 v = ld4(in + 4 * (ip * C4 + c4));
+            V v = ldv(in + E * (ip * CE + cq));
             if (bn.mean) {
                 // (half tensors: the BatchNorm output is itself a stored half under autocast, so candidates are compared -- and tie --
                 // as halves)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = stored<T>(fmaxf((v[k] - mu[k]) * is[k] * ga[k] + be[k], 0.f));
+                for (int k = 0; k < E; ++k) v[k] = stored<T>(fmaxf((v[k] - mu[k]) * is[k] * ga[k] + be[k], 0.f));
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < E; ++k)
                 if (v[k] > m[k]) { m[k] = v[k]; am[k] = dy * 3 + dx; }
         }
     }
-    st4(out + 4 * i, m);
-    if (idx) ((uint32_t*)idx)[i] = (uint32_t)am[0] | ((uint32_t)am[1] << 8) | ((uint32_t)am[2] << 16) | ((uint32_t)am[3] << 24);
+    stv(out + E * i, m);
+    if (idx) {
+#pragma unroll
+        for (int q = 0; q < E / 4; ++q)
+            ((uint32_t*)idx)[i * (E / 4) + q] = (uint32_t)am[4 * q] | ((uint32_t)am[4 * q + 1] << 8) | ((uint32_t)am[4 * q + 2] << 16) |
+                                                ((uint32_t)am[4 * q + 3] << 24);
+    }
 }
 
 }  // namespace
@@ -493,10 +503,12 @@ static int maxpool_fwd_impl(const T* in, T* out, uint8_t* idx, int64_t N, int H,
     SSAD_CHECK_ARG(in && out, "null pointer");
     SSAD_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "bad shape (C % 4)");
     int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    int64_t total4 = N * Ho * Wo * (C / 4);
-    SSAD_CHECK_ARG(cdiv64(total4, 256) < (int64_t)2147483647, "too large");
-    hipLaunchKernelGGL(maxpool3x3s2_kernel<T>, dim3((unsigned)cdiv64(total4, 256)), dim3(256), 0, (hipStream_t)stream, in, out, idx,
-                       total4, H, W, C / 4, Ho, Wo, N, hwnc, bn);
+    constexpr int E = Lane<T>::E;
+    SSAD_CHECK_ARG(C % E == 0, "channel count must be a multiple of the 16-byte lane width");
+    int64_t totalE = N * Ho * Wo * (C / E);
+    SSAD_CHECK_ARG(cdiv64(totalE, 256) < (int64_t)2147483647, "too large");
+    hipLaunchKernelGGL(maxpool3x3s2_kernel<T>, dim3((unsigned)cdiv64(totalE, 256)), dim3(256), 0, (hipStream_t)stream, in, out, idx,
+                       totalE, H, W, C / E, Ho, Wo, N, hwnc, bn);
     SSAD_CHECK_LAUNCH();
     return 0;
 }

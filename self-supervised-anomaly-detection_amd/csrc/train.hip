@@ -361,6 +361,7 @@ __device__ __forceinline__ f32x4 pool_grad(const uint8_t* __restrict__ idx, cons
 // look-ups, not the streaming of z, set the pace of the one-pixel form (1.19 ms per step at 3.2 TB/s -> see DESIGN.md).
 // Block (a, b) = pixels (2a .. 2a+1, 2b .. 2b+1); cell (oy, ox) covers pixels 2oy-1 .. 2oy+1, so the block's pixels are covered by
 // cells oy in {a, a+1}, ox in {b, b+1} only; slot of pixel (y, x) in cell (oy, ox) = (y - 2oy + 1) * 3 + (x - 2ox + 1).
+// A lane owns E = 4 (float) / 8 (half) consecutive channels (16-byte accesses; E / 4 index words per cell).
 template <int APPLY, typename T = float>
 __global__ __launch_bounds__(256) void pool_bn_bwd_kernel(const uint8_t* __restrict__ idx, const T* __restrict__ dpool,
                                                           const T* __restrict__ z, const float* __restrict__ mean,
@@ -369,15 +370,19 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_kernel(const uint8_t* __restr
                                                           const float* __restrict__ dgamma, T* __restrict__ dz,
                                                           double* __restrict__ partial, int64_t R, int H, int W, int C,
                                                           int Ho, int Wo, int64_t rows_per_block) {
-    __shared__ double sh[2][256][4];
-    const int C4 = C / 4, RL = 256 / C4;
-    const int tid = threadIdx.x, c4 = tid % C4, ty = tid / C4;
-    const f32x4 mu = ((const f32x4*)mean)[c4], is = ((const f32x4*)invstd)[c4];
-    const f32x4 ga = ((const f32x4*)gamma)[c4], be = ((const f32x4*)beta)[c4];
-    f32x4 db = {0.f, 0.f, 0.f, 0.f}, dg = db;
-    if (APPLY) { db = ((const f32x4*)dbeta)[c4]; dg = ((const f32x4*)dgamma)[c4]; }
+    constexpr int E = Lane<T>::E;
+    using V = typename Lane<T>::vec;
+    __shared__ double sh[2][256][E];
+    const int CE = C / E, RL = 256 / CE;
+    const int tid = threadIdx.x, cq = tid % CE, ty = tid / CE;
+    const V mu = ldpar<V>(mean, cq), is = ldpar<V>(invstd, cq);
+    const V ga = ldpar<V>(gamma, cq), be = ldpar<V>(beta, cq);
+    V db = 0.f, dg = 0.f;
+    if (APPLY) { db = ldpar<V>(dbeta, cq); dg = ldpar<V>(dgamma, cq); }
     const float invR = 1.f / (float)R;
-    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    double s0[E], s1[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) s0[k] = s1[k] = 0;
     // "rows" here are 2 x 2 pixel blocks: Hb x Wb per image (H, W even or odd: the last block row / column may be half empty)
     const int Hb = (H + 1) / 2, Wb = (W + 1) / 2;
     const int64_t NB = (R / ((int64_t)H * W)) * Hb * Wb;
@@ -389,17 +394,18 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_kernel(const uint8_t* __restr
         const int a = (int)(t % Hb);
         const int64_t n = t / Hb;
         // the four candidate cells
-        uint32_t pk[2][2];
-        f32x4 gq[2][2];
+        uint32_t pk[2][2][E / 4];
+        V gq[2][2];
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx) {
                 const int oy = a + dy, ox = b + dx;
                 const bool ok = oy < Ho && ox < Wo;
-                const int64_t o = ((n * Ho + (ok ? oy : 0)) * Wo + (ok ? ox : 0)) * C4 + c4;
-                pk[dy][dx] = ok ? ((const uint32_t*)idx)[o] : 0xffffffffu;        // slot 255 never matches
-                gq[dy][dx] = ld4(dpool + 4 * o);
+                const int64_t o = ((n * Ho + (ok ? oy : 0)) * Wo + (ok ? ox : 0)) * CE + cq;
+#pragma unroll
+                for (int q = 0; q < E / 4; ++q) pk[dy][dx][q] = ok ? ((const uint32_t*)idx)[o * (E / 4) + q] : 0xffffffffu;   // slot 255 never matches
+                gq[dy][dx] = ldv(dpool + E * o);
             }
 #pragma unroll
         for (int py = 0; py < 2; ++py)
@@ -407,7 +413,7 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_kernel(const uint8_t* __restr
             for (int px = 0; px < 2; ++px) {
                 const int y = 2 * a + py, x = 2 * b + px;
                 if (y >= H || x >= W) continue;
-                f32x4 g = {0.f, 0.f, 0.f, 0.f};
+                V g = 0.f;
                 // same cell order as the one-pixel form (oy ascending, then ox): cells oy in {y/2, (y+1)/2}, ox likewise
 #pragma unroll
                 for (int dy = 0; dy < 2; ++dy)
@@ -417,39 +423,41 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_kernel(const uint8_t* __restr
                         if (dy > py || dx > px) continue;       // pixel (py, px) of the block lies in cells a .. a + py, b .. b + px
                         const uint32_t slot = (uint32_t)((y - (2 * oy - 1)) * 3 + (x - (2 * ox - 1)));
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) g[k] += ((pk[dy][dx] >> (8 * k)) & 0xffu) == slot ? gq[dy][dx][k] : 0.f;
+                        for (int k = 0; k < E; ++k) g[k] += ((pk[dy][dx][k >> 2] >> (8 * (k & 3))) & 0xffu) == slot ? gq[dy][dx][k] : 0.f;
                     }
                 const int64_t row = (n * H + y) * W + x;
-                const f32x4 zz = ld4(z + 4 * (row * C4 + c4));
-                f32x4 xh;
+                const V zz = ldv(z + E * (row * CE + cq));
+                V xh;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < E; ++k) {
                     xh[k] = (zz[k] - mu[k]) * is[k];
                     g[k] = (zz[k] - mu[k]) * is[k] * ga[k] + be[k] > 0.f ? g[k] : 0.f;      // the forward's expression
                 }
                 if (APPLY) {
-                    f32x4 o;
+                    V o;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] = ga[k] * is[k] * (g[k] - db[k] * invR - xh[k] * dg[k] * invR);
-                    st4(dz + 4 * (row * C4 + c4), o);
+                    for (int k = 0; k < E; ++k) o[k] = ga[k] * is[k] * (g[k] - db[k] * invR - xh[k] * dg[k] * invR);
+                    stv(dz + E * (row * CE + cq), o);
                 } else {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) { s0[k] += (double)g[k]; s1[k] += (double)g[k] * (double)xh[k]; }
+                    for (int k = 0; k < E; ++k) { s0[k] += (double)g[k]; s1[k] += (double)g[k] * (double)xh[k]; }
                 }
             }
     }
     if (APPLY) return;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { sh[0][tid][k] = s0[k]; sh[1][tid][k] = s1[k]; }
+    for (int k = 0; k < E; ++k) { sh[0][tid][k] = s0[k]; sh[1][tid][k] = s1[k]; }
     __syncthreads();
     if (ty == 0) {
-        double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+        double a0[E], a1[E];
+#pragma unroll
+        for (int k = 0; k < E; ++k) a0[k] = a1[k] = 0;
         for (int l = 0; l < RL; ++l)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { a0[k] += sh[0][l * C4 + c4][k]; a1[k] += sh[1][l * C4 + c4][k]; }
+            for (int k = 0; k < E; ++k) { a0[k] += sh[0][l * CE + cq][k]; a1[k] += sh[1][l * CE + cq][k]; }
         double* pp = partial + (int64_t)blockIdx.x * 2 * C;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { pp[c4 * 4 + k] = a0[k]; pp[C + c4 * 4 + k] = a1[k]; }
+        for (int k = 0; k < E; ++k) { pp[cq * E + k] = a0[k]; pp[C + cq * E + k] = a1[k]; }
     }
 }
 
@@ -1066,11 +1074,12 @@ static int pool_bn_relu_bwd_impl(const uint8_t* idx, const T* dpool, const T* z,
                                  const float* invstd, const float* gamma, const float* beta, float* dbeta, float* dgamma,
                                  T* dz, int64_t N, int H, int W, int C, int64_t dpool_elems, double* workspace, void* stream) {
     SSAD_CHECK_ARG(idx && dpool && z && mean && invstd && gamma && beta && dbeta && dgamma && dz && workspace, "null pointer");
-    SSAD_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0, "bad shape");
+    constexpr int E = Lane<T>::E;
+    SSAD_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % E == 0 && C <= 1024 && 256 % (C / E) == 0, "bad shape");
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     SSAD_CHECK_ARG(dpool_elems == N * Ho * Wo * C, "dpool / idx do not hold N x Ho x Wo x C elements for this z");
     const int64_t R = N * H * W;
-    const int RL = 256 / (C / 4);
+    const int RL = 256 / (C / E);
     const int64_t NB = N * ((H + 1) / 2) * ((W + 1) / 2);          // 2 x 2 pixel blocks: the unit a thread works on
     int64_t nblk = cdiv64(R, (int64_t)RL * 32);                      // = the rows ssad_colreduce_workspace(R, C) provides
     if (nblk > 2048) nblk = 2048;
