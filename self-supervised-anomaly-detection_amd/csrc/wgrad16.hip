@@ -18,9 +18,21 @@
 #include "common.h"
 #include <stdlib.h>
 
+#ifndef WG16_ABL         // timing ablations (tools/micro/wgrad16_ablate.hip): 1 = no global loads, 2 = no MFMAs, 4 = no LDS tile writes
+#define WG16_ABL 0
+#endif
+
 namespace {
 
-constexpr int LD = 64 + 8;          // halves per LDS pixel row (144 B)
+constexpr int LD = 96;              // halves per LDS pixel row (192 B = 48 banks: the four rows of a transposed read and the
+                                    // two 16-channel halves of a 32-lane group land on eight disjoint 8-bank runs)
+
+// ds_read_b64_tr_b16 (gfx950): per group of 16 lanes a 4-row x 16-column block of halves is read and delivered column-major --
+// lane 4 q + p supplies the address of row q, columns 4 p .. 4 p + 3; lane i receives column i, rows 0 .. 3 in its four halves.
+typedef __fp16 fp16x4v __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__device__ __forceinline__ f16x4 tr_read(const hf* p) {
+    return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)p));
+}
 
 struct Wg16Params {
     const hf* dz;       // [N][Ho][Wo][Cout]
@@ -44,15 +56,25 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_g16_kernel(Wg16Params p) {
     constexpr int NX = (NHP + 31) / 32;             // X pieces per thread
     static_assert(P % 32 == 0 && (TW == 16 || TW == 8), "tile shape");
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    hf* dzs = (hf*)lds;                             // [P][LD]
-    hf* xs = dzs + P * LD;                          // [NHP][LD]
+    // two stages of ([P][LD] dZ, [NHP][LD] X): tile t + 1 is written while tile t is contracted -- one barrier per tile
+    constexpr int STAGE = (P + NHP) * LD;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int cb = wave & 1, ib = wave >> 1;        // 32-wide co / ci block of this wave inside the 64 x 64 block
     const int piece = tid & 7, prow = tid >> 3;
+    // transposed-read roles: group g of 16 lanes = (pixel half g >> 1, channel half g & 1); lane 4 q + p of it addresses pixel q, channels 4 p ..
+    const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+    const int abase = (8 * (tg >> 1) + tq) * LD + cb * 32 + 16 * (tg & 1) + 4 * tp;
+    const int bbase = (TW == 16 ? S * (8 * (tg >> 1) + tq) : S * (tg >> 1) * (S * (TW - 1) + 3) + S * tq) * LD + ib * 32 + 16 * (tg & 1) + 4 * tp;
 
-    const int pair = blockIdx.x % p.npairs, split = blockIdx.x / p.npairs;
+    // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8), each XCD with its own L2.  The npairs workgroups of one split read
+    // the SAME pixel tiles (each its own 64 x 64 channel block) at the same pace: all of them are placed on one XCD (split % 8), so the
+    // tiles come from HBM once per split and from that XCD's L2 for the other pairs (the launches move ~5.4 x the tensors otherwise:
+    // 63 us of the 73 without a single MFMA, tools/micro/wgrad16_ablate.hip)
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int pair = jx % p.npairs, split = (jx / p.npairs) * 8 + xcd;
+    if (split >= p.splits) return;
     const int co0 = (pair / p.ci_tiles) * 64, ci0 = (pair % p.ci_tiles) * 64;
     const int64_t t_begin = (int64_t)split * p.chunk;
     const int64_t t_end = t_begin + p.chunk < p.ntiles ? t_begin + p.chunk : p.ntiles;
@@ -68,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_g16_kernel(Wg16Params p) {
             const int px = prow + 32 * i;
             const int y = y0 + px / TW, x = x0 + px % TW;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (y < p.Ho && x < p.Wo) v = *(const u32x4*)(p.dz + (((int64_t)n * p.Ho + y) * p.Wo + x) * p.Cout + co0 + piece * 8);
+            if (y < p.Ho && x < p.Wo && !(WG16_ABL & 1)) v = *(const u32x4*)(p.dz + (((int64_t)n * p.Ho + y) * p.Wo + x) * p.Cout + co0 + piece * 8);
             dreg[i] = v;
         }
 #pragma unroll
@@ -77,12 +99,15 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_g16_kernel(Wg16Params p) {
             const int hy = hp / HW, hx = hp - hy * HW;
             const int y = S * y0 - 1 + hy, x = S * x0 - 1 + hx;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (hp < NHP && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
+            if (hp < NHP && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W && !(WG16_ABL & 1))
                 v = *(const u32x4*)(p.x + (((int64_t)n * p.H + y) * p.W + x) * p.Cin + ci0 + piece * 8);
             xreg[i] = v;
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int stage) {
+        if (WG16_ABL & 4) return;
+        hf* dzs = (hf*)lds + stage * STAGE;
+        hf* xs = dzs + P * LD;
 #pragma unroll
         for (int i = 0; i < NDZ; ++i) *(u32x4*)(dzs + (prow + 32 * i) * LD + piece * 8) = dreg[i];
 #pragma unroll
@@ -98,35 +123,40 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_g16_kernel(Wg16Params p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
-    if (t_begin < t_end) load_tile(t_begin);
-    for (int64_t t = t_begin; t < t_end; ++t) {
-        __syncthreads();                            // the previous tile's readers are done
-        store_tile();
-        __syncthreads();
-        if (t + 1 < t_end) load_tile(t + 1);
+    if (t_begin < t_end) {
+        load_tile(t_begin);
+        store_tile(0);
+        if (t_begin + 1 < t_end) load_tile(t_begin + 1);
+    }
+    int stage = 0;
+    for (int64_t t = t_begin; t < t_end; ++t, stage ^= 1) {
+        __syncthreads();                            // stage `stage` is written; the other stage's readers (tile t - 1) are done
+        if (t + 1 < t_end) {
+            store_tile(stage ^ 1);                  // tile t + 1 (in registers since the previous iteration) -> the free stage
+            if (t + 2 < t_end) load_tile(t + 2);
+        }
+        const hf* dzs = (const hf*)lds + stage * STAGE;
+        const hf* xs = dzs + P * LD;
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
-            // this lane's 8 pixels of the K-step: TW = 16: tile row k, columns 8 h .. 8 h + 7; TW = 8: tile row 2 k + h, columns 0 .. 7
-            const int py = TW == 16 ? k : 2 * k + h, px0 = TW == 16 ? 8 * h : 0;
-            const hf* ap = dzs + (py * TW + px0) * LD + cb * 32 + r;
+            // K-step k = tile pixels 16 k .. 16 k + 15 (TW = 16: tile row k; TW = 8: rows 2 k, 2 k + 1); lane (r, h) needs pixels
+            // 16 k + 8 h .. + 7 of channel r: two transposed reads of 4 pixels each (u = 0, 1)
             f16x8 a;
+            {
+                const f16x4 lo = tr_read(dzs + abase + (k * 16) * LD), hi = tr_read(dzs + abase + (k * 16 + 4) * LD);
+                a = f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) a[j] = ap[j * LD];
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const hf* bp = xs + ((S * py + ky) * HW + S * px0) * LD + ib * 32 + r;
-                constexpr int NV = S * 7 + 3;       // input columns the three kx fragments of a filter row are cut from: 10 / 17
-                hf v[NV];
-#pragma unroll
-                for (int j = 0; j < NV; ++j) v[j] = bp[j * LD];
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    f16x8 b;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) b[j] = v[S * j + kx];
-                    acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[ky * 3 + kx], 0, 0, 0);
+                    // the input pixel under tap (ky, kx) of output pixel (py, px) is halo pixel (S py + ky, S px + kx)
+                    const int o0 = TW == 16 ? ((S * k + ky) * HW + kx) * LD : ((S * 2 * k + ky) * HW + kx) * LD;
+                    const f16x4 lo = tr_read(xs + bbase + o0), hi = tr_read(xs + bbase + o0 + S * 4 * LD);
+                    const f16x8 b = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    if (!(WG16_ABL & 2)) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[ky * 3 + kx], 0, 0, 0);
+                    else acc[ky * 3 + kx][0] += (float)b[0] + (float)a[0];
                 }
-            }
         }
     }
 
@@ -167,7 +197,12 @@ static G16Geo g16_geometry(int64_t N, int Ho, int Wo, int Cin, int Cout, int S) 
 template <int S, int TH, int TW>
 static int g16_launch(const Wg16Params& p, unsigned grid, hipStream_t st) {
     constexpr int HH = S * (TH - 1) + 3, HW = S * (TW - 1) + 3;
-    constexpr int bytes = (TH * TW + HH * HW) * LD * 2;
+    constexpr int bytes = 2 * (TH * TW + HH * HW) * LD * 2;        // two stages
+    static bool attr_set = false;
+    if (!attr_set) {
+        SSAD_SET_DYN_LDS((wgrad3x3_g16_kernel<S, TH, TW>), bytes);
+        attr_set = true;
+    }
     hipLaunchKernelGGL((wgrad3x3_g16_kernel<S, TH, TW>), dim3(grid), dim3(256), bytes, st, p);
     return 0;
 }
@@ -203,7 +238,7 @@ extern "C" int ssad_conv_wgrad3x3_g16_h(const void* dz, const void* x, float* sl
     p.N = (int)N; p.Ho = Ho; p.Wo = Wo; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
     p.tiles_y = g.tiles_y; p.tiles_x = g.tiles_x; p.ci_tiles = Cin / 64; p.npairs = g.npairs; p.splits = g.splits;
     p.ntiles = g.ntiles; p.chunk = g.chunk;
-    const unsigned grid = (unsigned)(g.npairs * g.splits);
+    const unsigned grid = (unsigned)(g.npairs * ((g.splits + 7) / 8) * 8);         // 8 XCDs x pairs x splits of that XCD (see the kernel)
     hipStream_t st = (hipStream_t)stream;
     if (stride == 1) {
         if (g.TW == 16) g16_launch<1, 4, 16>(p, grid, st);
