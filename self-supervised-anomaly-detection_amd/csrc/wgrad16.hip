@@ -80,6 +80,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_g16_kernel(Wg16Params p) {
     const int64_t t_end = t_begin + p.chunk < p.ntiles ? t_begin + p.chunk : p.ntiles;
     const int tpi = p.tiles_y * p.tiles_x;
 
+    // (two register sets -- a tile's loads requested two tiles before its LDS write -- were measured: 256 VGPRs, 9.32 -> 9.47 ms per
+    // step on one box; one set it stays)
     u32x4 dreg[NDZ], xreg[NX];
     auto load_tile = [&](int64_t t) {
         const int n = (int)(t / tpi);
