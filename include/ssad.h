@@ -520,6 +520,17 @@ int ssad_conv3x3_hw_pack_batch(const float* src, void* dst, const int64_t* desc,
 int ssad_conv3x3_hw(const void* in, const void* w_packed, void* out, const void* residual, const float* tr_mean, const float* tr_invstd,
                     const float* tr_gamma, const float* tr_beta, void* emit, int64_t N, int H, int W, int Cin, int Cout, double* stats_ws,
                     float eps, float momentum, float* mean, float* invstd, float* running_mean, float* running_var, void* stream);
+/* The exact-fp32 instantiation of the same kernel (csrc/conv16w.hip, T = float: v_mfma_f32_32x32x2_f32, statistics in double per value):
+ * the 3 x 3 / stride 1 convs of the fp32 training step (models.py:224) forward and -- with the flipped pack -- their input gradients,
+ * whenever the launch fills the chip (ssad_conv3x3_fw_ok; other launches stay on ssad_conv3x3_c64 / ssad_conv_igemm_*).  The filter pack
+ * holds floats in fragment order [Cout/32][tap][Cin/8][2][32][4]; res_mask: the residual is the identity-branch gradient (dy, nibble mask)
+ * of ssad_bn_apply_fwd_mask, applied while the residual is staged. */
+int ssad_conv3x3_fw_ok(int64_t N, int H, int W, int Cin, int Cout);
+int ssad_conv3x3_fw_pack_batch(const float* src, float* dst, const int64_t* desc, int n, void* stream);
+int ssad_conv3x3_fw(const float* in, const float* w_packed, float* out, const float* residual, const uint8_t* res_mask,
+                    const float* tr_mean, const float* tr_invstd, const float* tr_gamma, const float* tr_beta, float* emit, int64_t N,
+                    int H, int W, int Cin, int Cout, double* stats_ws, float eps, float momentum, float* mean, float* invstd,
+                    float* running_mean, float* running_var, void* stream);
 /* Weight gradient of the 3 x 3 / pad 1 convolutions, stride 1 AND 2, over half tensors (csrc/wgrad16.hip): tiles go to LDS as they lie
  * in memory and the [pixel][channel] -> [channel][pixel] transpose the matrix instruction needs happens in the fragment reads (eight
  * 2-byte LDS reads per operand), so no staging waves, no conversion; same slab contract as ssad_conv_wgrad3x3_halo16:

@@ -30,18 +30,21 @@
 
 namespace {
 
-constexpr int DB = 6;                  // weight fragments are requested DB steps ahead
-
+// T = hf: the precision-16 step's half tensors (v_mfma_f32_32x32x16_f16).  T = float: the exact-fp32 step (v_mfma_f32_32x32x2_f32, four
+// per 16-byte fragment: lane half h contracts channels 4 h + q of a group of eight at sub-step q).  Everything is laid out in BYTES --
+// 16-byte pieces, 128-byte (or 64-byte) chunk rows, 1 KB fragments -- so both types share the staging, the LDS image and the filter pack.
+template <typename T>
 struct HWParams {
-    const hf* in;            // [N][H][W][Cin]
-    const hf* wp;            // packed filters (ssad_conv3x3_hw_pack_batch)
-    hf* out;                 // [N][H][W][Cout]
-    const hf* residual;      // optional [N][H][W][Cout], added before the rounding
+    const T* in;             // [N][H][W][Cin]
+    const T* wp;             // packed filters (ssad_conv3x3_hw_pack_batch / ssad_conv3x3_fw_pack_batch)
+    T* out;                  // [N][H][W][Cout]
+    const T* residual;       // optional [N][H][W][Cout], added before the rounding
+    const uint8_t* res_mask; // optional (float): one byte per channel quad of the residual, bit k = "pass channel 4 q + k"
     const float* tr_mean;    // optional input transform x <- relu((x - mean) * invstd * gamma + beta), per input channel
     const float* tr_invstd;
     const float* tr_gamma;
     const float* tr_beta;
-    hf* emit;                // optional (with a transform): the transformed input, written once (by channel slab 0)
+    T* emit;                 // optional (with a transform): the transformed input, written once (by channel slab 0)
     double* stats;           // optional [gridDim.x][2][Cout]
     int N, H, W, Cin, Cout;
     int tiles_y, tiles_x, nchunks;
@@ -50,17 +53,30 @@ struct HWParams {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// one fragment deep: a 16-channel MFMA over halves, or four 2-channel MFMAs over floats (element q of both fragments = sub-step q)
+__device__ __forceinline__ f32x16 mma_frag(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mma_frag(f32x4 a, f32x4 b, f32x16 c) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q], c, 0, 0, 0);
+    return c;
+}
+
 // WN: 64-channel wave columns per workgroup (output channels per workgroup = 64 WN); four matrix waves (WM x WN, WM = 4 / WN) of
 // 128 pixels x 64 channels each, four stager waves.  Tile: WN = 2: a 16 x 16 block (18 x 18 halo), or -- TW8, 8 x 8 maps -- four
 // consecutive images, each with its 10 x 10 halo; WN = 1 (the 64-channel layer): 16 rows x 32 columns (18 x 34 halo).
 // CK: input channels per chunk (64; 32 where two halo stages of 64 channels would not fit the LDS).
-template <int WN, bool TW8, int CK>
-__global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams p) {
+template <typename T, int WN, bool TW8, int CK>
+__global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
+    constexpr bool F32 = std::is_same<T, float>::value;
+    constexpr int E = 16 / (int)sizeof(T);             // elements per 16-byte piece (8 halves / 4 floats)
+    constexpr int KST = 2 * E;                         // input channels per step (one fragment deep)
+    constexpr int DB = F32 ? 3 : 6;                    // filter fragments are requested DB steps ahead (an fp32 step is 32 MFMAs of 64 cycles)
+    using frag_t = typename std::conditional<F32, f32x4, f16x8>::type;
     constexpr int WM = 4 / WN;
     constexpr int TWX = WN == 1 ? 32 : 16;             // tile width in pixels (not TW8)
-    constexpr int LDP = CK + 8;                        // halves per LDS halo row (16-byte reads of 16 consecutive pixels: no conflicts)
-    constexpr int PPR = CK / 8;                        // 16-byte pieces per halo pixel
-    constexpr int KS = CK / 16;                        // k-steps (one MFMA deep) per tap
+    constexpr int LDP = CK + E;                        // elements per LDS halo row (16-byte reads of 16 consecutive pixels: no conflicts)
+    constexpr int PPR = CK / E;                        // 16-byte pieces per halo pixel
+    constexpr int KS = CK / KST;                       // steps (one fragment deep) per tap
     constexpr int SPC = 9 * KS;                        // steps per chunk
     constexpr int HW_ = TW8 ? 10 : TWX + 2;
     constexpr int NHP = TW8 ? 400 : 18 * HW_;
@@ -74,7 +90,7 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams p) {
     static_assert(SPC % DB == 0 && SPC % 2 == 0, "ring / double-buffer periods must divide a chunk");
     static_assert(!(TW8 && WN == 1), "8 x 8 maps: 128 output channels per workgroup");
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    hf* halo = (hf*)lds;                               // [2][NHP][LDP]
+    T* halo = (T*)lds;                                 // [2][NHP][LDP]
     float* trp = (float*)(halo + 2 * HALO_H);          // [4][Cin]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -88,7 +104,7 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams p) {
     const int tpi = p.tiles_y * p.tiles_x;
 
     if (TW8) {                                         // padding rings of both halo stages
-        for (int i = tid; i < 2 * HALO_H / 8; i += NT) ((u32x4*)halo)[i] = u32x4{0u, 0u, 0u, 0u};
+        for (int i = tid; i < 2 * HALO_H / E; i += NT) ((u32x4*)halo)[i] = u32x4{0u, 0u, 0u, 0u};
     }
     if (p.tr_mean) {
         for (int c = tid; c < p.Cin; c += NT) {
@@ -114,21 +130,22 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams p) {
         unsigned goffr[NR];                                 // the same in the residual tensor (Cout channels per pixel)
         unsigned hyx[NR];                                   // hy << 8 | hx (TW8: image within the tile)
         unsigned inner = 0, valid = 0, inm[2] = {0u, 0u};
+        unsigned rmask[2][F32 ? NR : 1];                    // (float) the residual's pass bits of each piece, 4 bits
 #pragma unroll
         for (int q = 0; q < NR; ++q) {
             const int hp = (q * SL + sl) / PPR;             // TW8: hp = 64 image + 8 y + x (interior pixels only)
             if (hp < NSP) valid |= 1u << q;
             if (TW8) {
-                goff[q] = (unsigned)((hp * p.Cin + piece * 8) * 2);
-                goffr[q] = (unsigned)((hp * p.Cout + piece * 8) * 2);
-                loff[q] = (unsigned)((((hp >> 6) * 100 + (((hp >> 3) & 7) + 1) * 10 + (hp & 7) + 1) * LDP + piece * 8) * 2);
+                goff[q] = (unsigned)((hp * p.Cin + piece * E) * sizeof(T));
+                goffr[q] = (unsigned)((hp * p.Cout + piece * E) * sizeof(T));
+                loff[q] = (unsigned)((((hp >> 6) * 100 + (((hp >> 3) & 7) + 1) * 10 + (hp & 7) + 1) * LDP + piece * E) * sizeof(T));
                 hyx[q] = (unsigned)(hp >> 6);
                 inner |= 1u << q;
             } else {
                 const int hy = hp / HW_, hx = hp - HW_ * hy;
-                goff[q] = (unsigned)(((hy * p.W + hx) * p.Cin + piece * 8) * 2);
-                goffr[q] = (unsigned)(((hy * p.W + hx) * p.Cout + piece * 8) * 2);
-                loff[q] = (unsigned)((hp * LDP + piece * 8) * 2);
+                goff[q] = (unsigned)(((hy * p.W + hx) * p.Cin + piece * E) * sizeof(T));
+                goffr[q] = (unsigned)(((hy * p.W + hx) * p.Cout + piece * E) * sizeof(T));
+                loff[q] = (unsigned)((hp * LDP + piece * E) * sizeof(T));
                 hyx[q] = (unsigned)(hy << 8 | hx);
                 if (hy >= 1 && hy <= 16 && hx >= 1 && hx <= TWX) inner |= 1u << q;
             }
@@ -172,6 +189,13 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams p) {
                 u32x4 v = {0u, 0u, 0u, 0u};
                 if (ok && !(CONV16W_ABL & 2)) v = *(const u32x4*)(src + (res ? goffr[q] : goff[q]));
                 reg[SET][q] = v;
+                if (F32) {
+                    // the identity-branch gradient is (dy, nibble mask), never materialised: one mask byte per 16-byte piece, at the
+                    // piece's element index / 4
+                    unsigned mk = 0xfu;
+                    if (res && p.res_mask && ok) mk = p.res_mask[(base * (int64_t)sizeof(T) + goffr[q]) >> 4];
+                    rmask[SET][F32 ? q : 0] = mk;
+                }
                 im |= (ok ? 1u : 0u) << q;
             }
             inm[SET] = im;
@@ -184,12 +208,12 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams p) {
             char* dst = (char*)(halo + (int)(f & 1) * HALO_H);
             if (p.tr_mean && chunk < p.nchunks) {
                 // producer's train-mode BatchNorm + ReLU on load: bn_apply_fwd's expression in fp32 (two channels per packed
-                // instruction), rounded once, the ReLU on the rounded pair.  Zero padding pads the TRANSFORMED activation: out-of-image
-                // pieces stay zero.  The eight channels of this lane's piece: read once per fill.
-                const int c = chunk * CK + piece * 8;
-                f32x2 mu[4], sc[4], ga[4], be[4];
+                // instruction); halves: rounded once.  Zero padding pads the TRANSFORMED activation: out-of-image pieces stay zero.
+                // The E channels of this lane's piece: read once per fill.
+                const int c = chunk * CK + piece * E;
+                f32x2 mu[E / 2], sc[E / 2], ga[E / 2], be[E / 2];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < E / 2; ++k) {
                     mu[k] = *(const f32x2*)(trp + c + 2 * k); sc[k] = *(const f32x2*)(trp + p.Cin + c + 2 * k);
                     ga[k] = *(const f32x2*)(trp + 2 * p.Cin + c + 2 * k); be[k] = *(const f32x2*)(trp + 3 * p.Cin + c + 2 * k);
                 }
@@ -197,21 +221,30 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams p) {
 #pragma unroll
                 for (int q = 0; q < NR; ++q) {
                     if (!((inm[SET] >> q) & 1u)) continue;
-                    // (written over an f16x8: with the piece held as four dwords and the pairs bit-cast out of / into its elements,
-                    // hipcc fed pair 0's RESULT to pairs 1-3 -- found by the emitted activation, tests/test_hip_half.py)
-                    const f16x8 v = __builtin_bit_cast(f16x8, reg[SET][q]);
-                    f16x8 o;
+                    // (written over an element vector: with the piece held as four dwords and the pairs bit-cast out of / into its
+                    // elements, hipcc fed pair 0's RESULT to pairs 1-3 -- found by the emitted activation, tests/test_hip_half.py)
+                    const frag_t v = __builtin_bit_cast(frag_t, reg[SET][q]);
+                    frag_t o;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
+                    for (int k = 0; k < E / 2; ++k) {
                         const f32x2 xf = {(float)v[2 * k], (float)v[2 * k + 1]};
                         const f32x2 y = (xf - mu[k]) * sc[k] * ga[k] + be[k];
-                        o[2 * k] = (hf)fmaxf(y[0], 0.f);
-                        o[2 * k + 1] = (hf)fmaxf(y[1], 0.f);
+                        o[2 * k] = (T)fmaxf(y[0], 0.f);
+                        o[2 * k + 1] = (T)fmaxf(y[1], 0.f);
                     }
                     const u32x4 w = __builtin_bit_cast(u32x4, o);
                     reg[SET][q] = w;
                     // interior pixels of the halo: the activation this layer's weight gradient reads
                     if (em && ((inner >> q) & 1u)) *(u32x4*)(em + goff[q]) = w;
+                }
+            }
+            if (F32 && p.res_mask && chunk >= p.nchunks) {
+#pragma unroll
+                for (int q = 0; q < NR; ++q) {
+                    u32x4 w = reg[SET][q];
+                    const unsigned mk = rmask[SET][F32 ? q : 0];
+                    w[0] = (mk & 1u) ? w[0] : 0u; w[1] = (mk & 2u) ? w[1] : 0u; w[2] = (mk & 4u) ? w[2] : 0u; w[3] = (mk & 8u) ? w[3] : 0u;
+                    reg[SET][q] = w;
                 }
             }
 #pragma unroll
@@ -251,18 +284,20 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams p) {
     int abase[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-        if (TW8) abase[m] = ((2 * wm + (m >> 1)) * 100 + (4 * (m & 1) + (r >> 3)) * 10 + (r & 7)) * LDP + 8 * h;
-        else abase[m] = ((wrow + 2 * m + (r >> 4)) * HW_ + wcol + (r & 15)) * LDP + 8 * h;
+        if (TW8) abase[m] = ((2 * wm + (m >> 1)) * 100 + (4 * (m & 1) + (r >> 3)) * 10 + (r & 7)) * LDP + E * h;
+        else abase[m] = ((wrow + 2 * m + (r >> 4)) * HW_ + wcol + (r & 15)) * LDP + E * h;
     }
-    const int KB = p.Cin / 16;
-    const hf* bptr[2];
+    const int KB = p.Cin / KST;                                // fragments (64 lanes x 16 bytes = 64 E elements) per (channel tile, tap)
+    const T* bptr[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) bptr[j] = p.wp + (int64_t)(co0 / 32 + j) * 9 * KB * 512 + lane * 8;
+    for (int j = 0; j < 2; ++j) bptr[j] = p.wp + (int64_t)(co0 / 32 + j) * 9 * KB * (64 * E) + lane * E;
 
     // Every workgroup walks the nine taps in its own rotation (conv16.hip: persistent workgroups run in lockstep, with one common order
     // all of them ask the L2 for the same lines at the same moment).  fp32 accumulation order differs between workgroups by the
     // rotation only: deterministic for a given launch geometry.
-    const int rot = (int)((blockIdx.x + blockIdx.y) % 9);
+    // (fp32: no rotation -- a fragment is requested every 2 048 cycles, and one common tap order keeps every output value's summation
+    // order independent of the launch geometry)
+    const int rot = F32 ? 0 : (int)((blockIdx.x + blockIdx.y) % 9);
     int toffA[9], tapB[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -270,18 +305,18 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams p) {
         te = te >= 9 ? te - 9 : te;
         const int ty3 = te >= 6 ? 2 : te >= 3 ? 1 : 0;
         toffA[t] = (ty3 * HW_ + (te - 3 * ty3)) * LDP;
-        tapB[t] = te * KB * 512;
+        tapB[t] = te * KB * (64 * E);
     }
 
     f32x16 acc[4][2];
     double st0[2] = {0.0, 0.0}, st1[2] = {0.0, 0.0};
 
-    f16x8 breg[DB][2];
+    frag_t breg[DB][2];
     auto load_b = [&](int chunk, int s, int set) {        // s: step within a chunk (compile-time after unrolling)
         if (CONV16W_ABL & 1) return;
-        const int off = tapB[s / KS] + (chunk * KS + (s % KS)) * 512;
+        const int off = tapB[s / KS] + (chunk * KS + (s % KS)) * (64 * E);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) breg[set][j] = *(const f16x8*)(bptr[j] + off);
+        for (int j = 0; j < 2; ++j) breg[set][j] = *(const frag_t*)(bptr[j] + off);
     };
     if (CONV16W_ABL & 1) {
 #pragma unroll
@@ -289,14 +324,14 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int k = 0; k < 8; ++k) breg[d][j][k] = (hf)0.f;
+                for (int k = 0; k < E; ++k) breg[d][j][k] = (T)0.f;
     }
     if (nfill > 0) {
 #pragma unroll
         for (int d = 0; d < DB; ++d) load_b(0, d, d);
     }
     // this lane's share of an output address, in bytes: pixel column 4 h of the wave's first row, channel r of the wave's first 32
-    const unsigned lane_off = (unsigned)(((wrow * p.W + wcol + 4 * h) * p.Cout + wn * 64 + r) * 2);
+    const unsigned lane_off = (unsigned)(((wrow * p.W + wcol + 4 * h) * p.Cout + wn * 64 + r) * sizeof(T));
     typedef hf h2 __attribute__((ext_vector_type(2)));
     __syncthreads();                                       // fill 0 is staged
 
@@ -305,12 +340,12 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams p) {
     int64_t f = 0;                                         // fills consumed so far (halo stage = f & 1)
     const int64_t nin = my_tiles * p.nchunks;              // input fills
     for (int64_t fi = 0; fi < nin; ++fi) {
-        const hf* hb = halo + (int)(f & 1) * HALO_H;
+        const T* hb = halo + (int)(f & 1) * HALO_H;
         const int cnext = chunk + 1 == p.nchunks ? 0 : chunk + 1;
         const bool more = cnext != 0 || tile_i + 1 < my_tiles;          // another input fill follows (this tile's or the next tile's)
-        f16x8 areg[2][4];
+        frag_t areg[2][4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) areg[0][m] = *(const f16x8*)(hb + abase[m] + toffA[0]);
+        for (int m = 0; m < 4; ++m) areg[0][m] = *(const frag_t*)(hb + abase[m] + toffA[0]);
         if (CONV16W_ABL & 16) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) areg[1][m] = areg[0][m];
@@ -319,7 +354,7 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams p) {
         for (int s = 0; s < SPC; ++s) {
             if (s + 1 < SPC && !(CONV16W_ABL & 16)) {
 #pragma unroll
-                for (int m = 0; m < 4; ++m) areg[(s + 1) & 1][m] = *(const f16x8*)(hb + abase[m] + toffA[(s + 1) / KS] + ((s + 1) % KS) * 16);
+                for (int m = 0; m < 4; ++m) areg[(s + 1) & 1][m] = *(const frag_t*)(hb + abase[m] + toffA[(s + 1) / KS] + ((s + 1) % KS) * KST);
             }
             __builtin_amdgcn_sched_barrier(0);             // the next step's activation fragments are requested BEFORE this step's MFMAs
             if (s == 0 && chunk == 0) {                    // first step of a tile: accumulate onto zero (no register clearing)
@@ -327,13 +362,13 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams p) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(areg[0][m], breg[0][j], zero, 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) acc[m][j] = mma_frag(areg[0][m], breg[0][j], zero);
             } else {
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        if (!(CONV16W_ABL & 8)) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(areg[s & 1][m], breg[s % DB][j], acc[m][j], 0, 0, 0);
+                        if (!(CONV16W_ABL & 8)) acc[m][j] = mma_frag(areg[s & 1][m], breg[s % DB][j], acc[m][j]);
             }
             // the register set just consumed takes the fragments of the step DB ahead (this chunk, the next chunk, or the first
             // chunk of the next tile: the same filters)
@@ -350,26 +385,27 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams p) {
 
         if (p.residual) {
             // ---- the residual fills of this tile: acc += residual x one-hot.  Step kk of fill rc covers the slab's channels
-            // rc CK + 16 kk .. + 15; a wave takes the steps inside its own 64 channels: fragment element j of lane (r, h) of accumulator
-            // tile jt is 1 where jt 32 + r = cb + 8 h + j (the tile a step does not belong to adds zeros) ----
+            // rc CK + KST kk .. + KST - 1; a wave takes the steps inside its own 64 channels: fragment element j of lane (r, h) of
+            // accumulator tile jt is 1 where jt 32 + r = cb + E h + j (the tile a step does not belong to adds zeros) ----
 #pragma unroll
             for (int rc = 0; rc < RF; ++rc) {
-                const hf* hr = halo + (int)(f & 1) * HALO_H;
+                const T* hr = halo + (int)(f & 1) * HALO_H;
 #pragma unroll
                 for (int kk = 0; kk < KS; ++kk) {
-                    const int cb = rc * CK + kk * 16 - wn * 64;       // first channel of the step, counted from the wave's first
+                    const int cb = rc * CK + kk * KST - wn * 64;      // first channel of the step, counted from the wave's first
                     if (cb >= 0 && cb < 64) {
-                        f16x8 ar[4];
+                        frag_t ar[4];
 #pragma unroll
-                        for (int m = 0; m < 4; ++m) ar[m] = *(const f16x8*)(hr + abase[m] + (HW_ + 1) * LDP + kk * 16);
+                        for (int m = 0; m < 4; ++m) ar[m] = *(const frag_t*)(hr + abase[m] + (HW_ + 1) * LDP + kk * KST);
 #pragma unroll
                         for (int jt = 0; jt < 2; ++jt) {
-                            const int hot = jt * 32 + r - cb - 8 * h;
-                            f16x8 one;
+                            if (F32 && jt != (cb >> 5)) continue;     // (float: a step lies inside one accumulator tile; 4 MFMAs saved per skip)
+                            const int hot = jt * 32 + r - cb - E * h;
+                            frag_t one;
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) one[j] = hot == j ? (hf)1.f : (hf)0.f;
+                            for (int j = 0; j < E; ++j) one[j] = hot == j ? (T)1.f : (T)0.f;
 #pragma unroll
-                            for (int m = 0; m < 4; ++m) acc[m][jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[m], one, acc[m][jt], 0, 0, 0);
+                            for (int m = 0; m < 4; ++m) acc[m][jt] = mma_frag(ar[m], one, acc[m][jt]);
                         }
                     }
                 }
@@ -392,7 +428,7 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams p) {
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) sum += acc[m][j][e];
-            if (sum == 123.456f) p.out[0] = (hf)sum;
+            if (sum == 123.456f) p.out[0] = (T)sum;
             continue;
         }
         int64_t torg;                                      // first element of the tile (TW8: of image 4 tile), this workgroup's slab
@@ -427,6 +463,22 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams p) {
             }
             if (!ok) continue;
             char* const ob = (char*)(p.out + moff);
+            if constexpr (F32) {
+                // exact-fp32 step: values stored as they are, statistics in double per value (as the other fp32 kernels take them;
+                // an fp32 tile is ~300 k cycles of matrix work, its 128 conversions do not show)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int eo = TW8 ? (e >> 2) * rowst + (e & 3) * p.Cout : (e >> 3) * rowst + ((e & 3) + 8 * ((e >> 2) & 1)) * p.Cout;
+                    const unsigned o0 = lo + 4u * (unsigned)eo;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const float v = acc[m][j][e];
+                        *(float*)(ob + o0 + 128 * j) = v;
+                        st0[j] += (double)v;
+                        st1[j] += (double)v * (double)v;
+                    }
+                }
+            } else {
 #pragma unroll
             for (int e = 0; e < 16; e += 2) {
                 const int eo = TW8 ? (e >> 2) * rowst + (e & 3) * p.Cout : (e >> 3) * rowst + ((e & 3) + 8 * ((e >> 2) & 1)) * p.Cout;
@@ -441,6 +493,7 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams p) {
                     fs[j] = __builtin_amdgcn_fdot2(pk, ones, fs[j], false);        // statistics of what is stored
                     fq[j] = __builtin_amdgcn_fdot2(pk, pk, fq[j], false);
                 }
+            }
             }
         }
         // (unconditional: under `if (p.stats)` the compiler sinks the dot products into the conditional block and keeps every pair alive)
@@ -478,29 +531,32 @@ struct PackTable {
     int64_t e[32][6];       // src offset (floats), dst offset (halves), O, I (of the PACKED conv), flip, first block
 };
 
-__global__ __launch_bounds__(256) void pack_hw_kernel(const float* __restrict__ src, hf* __restrict__ dst, PackTable t) {
+template <typename T>
+__global__ __launch_bounds__(256) void pack_hw_kernel(const float* __restrict__ src, T* __restrict__ dst, PackTable t) {
+    constexpr int E = 16 / (int)sizeof(T), KST = 2 * E;
+    using frag_t = typename std::conditional<std::is_same<T, float>::value, f32x4, f16x8>::type;
     int k = 0;
     while (k + 1 < t.n && (int64_t)blockIdx.x >= t.e[k + 1][5]) ++k;
     const int O = (int)t.e[k][2], I = (int)t.e[k][3], flip = (int)t.e[k][4];
-    const int KB = I / 16;
+    const int KB = I / KST;
     const int64_t piece = ((int64_t)blockIdx.x - t.e[k][5]) * 256 + threadIdx.x;       // 16-byte piece of the destination
-    if (piece >= (int64_t)O * 9 * I / 8) return;
+    if (piece >= (int64_t)O * 9 * I / E) return;
     const int n = (int)(piece & 31), kh = (int)((piece >> 5) & 1);
     int64_t rest = piece >> 6;
     const int kb = (int)(rest % KB); rest /= KB;
     const int tap = (int)(rest % 9);
     const int ct = (int)(rest / 9);
-    const int o = ct * 32 + n, i0 = kb * 16 + kh * 8;
+    const int o = ct * 32 + n, i0 = kb * KST + kh * E;
     const float* w = src + t.e[k][0];
-    f16x8 v;
+    frag_t v;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < E; ++j) {
         // plain: this conv's OHWI filter [O][9][I].  flip: this conv is the input gradient of a conv whose filter is [I][9][O]:
         // its weight (o, tap, i) is that filter's (i, 8 - tap, o)
         const float x = flip ? w[((int64_t)(i0 + j) * 9 + (8 - tap)) * O + o] : w[((int64_t)o * 9 + tap) * I + i0 + j];
-        v[j] = (hf)x;
+        v[j] = (T)x;
     }
-    *(f16x8*)(dst + t.e[k][1] + piece * 8) = v;
+    *(frag_t*)(dst + t.e[k][1] + piece * E) = v;
 }
 
 struct GeoW {
@@ -526,16 +582,11 @@ static GeoW geometry_w(int64_t N, int H, int W, int Cout) {
     return g;
 }
 
-template <int WN, bool TW8, int CK>
-static constexpr int lds_bytes_w() { return 2 * (TW8 ? 400 : 18 * (WN == 1 ? 34 : 18)) * (CK + 8) * 2 + 16 * 1024; }
+// bytes of the two halo stages (+ 16 KB: the largest transform table); CKB = bytes of a chunk row (128, or 64 for 16 x 32 tiles)
+static constexpr int lds_bytes_w(bool wn1, bool tw8) { return 2 * (tw8 ? 400 : 18 * (wn1 ? 34 : 18)) * ((wn1 ? 64 : 128) + 16) + 16 * 1024; }
 
-}  // namespace
-
-// 1 when ssad_conv3x3_hw takes the launch: channel counts multiples of 64, maps of 16 x 16 blocks (or 8 x 8 maps), and enough
-// (tile, channel slab) pairs to give every CU a workgroup (smaller launches stay on csrc/conv16.hip's 128-pixel tiles).
-extern "C" int ssad_conv3x3_hw_ok(int64_t N, int H, int W, int Cin, int Cout) {
-    static const int on = getenv("SSAD_CONV16W") ? atoi(getenv("SSAD_CONV16W")) : 1;
-    if (!on || Cin % 64 || Cout % 64 || Cin > 1024 || N <= 0) return 0;
+static int shape_ok(int64_t N, int H, int W, int Cin, int Cout) {
+    if (Cin % 64 || Cout % 64 || Cin > 1024 || N <= 0) return 0;
     const bool wn1 = Cout % 128 != 0;                     // 64 output channels per workgroup: 16 x 32 tiles
     if (!((H == 8 && W == 8 && !wn1) || (H > 0 && W > 0 && H % 16 == 0 && W % (wn1 ? 32 : 16) == 0))) return 0;
     const GeoW g = geometry_w(N, H, W, Cout);
@@ -543,20 +594,13 @@ extern "C" int ssad_conv3x3_hw_ok(int64_t N, int H, int W, int Cin, int Cout) {
     return g.ntiles * g.gy >= min_items;
 }
 
-// halves of one packed filter of Cout x 3 x 3 x Cin
-extern "C" int64_t ssad_conv3x3_hw_packed_size(int Cin, int Cout) { return (int64_t)Cout * 9 * Cin; }
-
-// rows of the statistics workspace (x 2 x Cout doubles)
-extern "C" int64_t ssad_conv3x3_hw_stats_rows(int64_t N, int H, int W, int Cout) { return geometry_w(N, H, W, Cout).gx; }
-
-// Packs n filters in one launch.  desc[5 k ..]: source offset (floats from src), destination offset (halves from dst), Cout, Cin of
-// the conv that will RUN on the packed filter, flip (0: src holds that conv's OHWI filter [Cout][3][3][Cin]; 1: src holds the OHWI
-// filter [Cin][3][3][Cout] of the forward conv whose input gradient this is).  Values are rounded to halves as ssad_cvt_f32_f16 does.
-extern "C" int ssad_conv3x3_hw_pack_batch(const float* src, void* dst, const int64_t* desc, int n, void* stream) {
+template <typename T>
+static int pack_batch_impl(const float* src, T* dst, const int64_t* desc, int n, void* stream) {
+    constexpr int E = 16 / (int)sizeof(T);
     SSAD_CHECK_ARG(src && dst && desc && n > 0, "bad argument");
     for (int k = 0; k < n; ++k)
         SSAD_CHECK_ARG(desc[5 * k + 2] > 0 && desc[5 * k + 3] > 0 && desc[5 * k + 2] % 64 == 0 && desc[5 * k + 3] % 64 == 0 &&
-                       desc[5 * k + 1] % 8 == 0, "bad filter shape (channel counts multiples of 64)");
+                       desc[5 * k + 1] % E == 0, "bad filter shape (channel counts multiples of 64)");
     for (int base = 0; base < n; base += 32) {
         PackTable t;
         t.n = n - base < 32 ? n - base : 32;
@@ -564,13 +608,92 @@ extern "C" int ssad_conv3x3_hw_pack_batch(const float* src, void* dst, const int
         for (int k = 0; k < t.n; ++k) {
             for (int j = 0; j < 5; ++j) t.e[k][j] = desc[5 * (base + k) + j];
             t.e[k][5] = acc;
-            acc += cdiv64(t.e[k][2] * 9 * t.e[k][3] / 8, 256);
+            acc += cdiv64(t.e[k][2] * 9 * t.e[k][3] / E, 256);
         }
         SSAD_CHECK_ARG(acc < (int64_t)2147483647, "too many blocks");
-        hipLaunchKernelGGL(pack_hw_kernel, dim3((unsigned)acc), dim3(256), 0, (hipStream_t)stream, src, (hf*)dst, t);
+        hipLaunchKernelGGL(pack_hw_kernel<T>, dim3((unsigned)acc), dim3(256), 0, (hipStream_t)stream, src, dst, t);
         SSAD_CHECK_LAUNCH();
     }
     return 0;
+}
+
+template <typename T>
+static int conv_impl(const T* in, const T* w_packed, T* out, const T* residual, const uint8_t* res_mask, const float* tr_mean,
+                     const float* tr_invstd, const float* tr_gamma, const float* tr_beta, T* emit, int64_t N, int H, int W, int Cin,
+                     int Cout, double* stats_ws, float eps, float momentum, float* mean, float* invstd, float* running_mean,
+                     float* running_var, void* stream) {
+    constexpr int CKW = 128 / (int)sizeof(T), CKN = 64 / (int)sizeof(T);     // channels per chunk: 128-byte rows; 64-byte rows for 16 x 32 tiles
+    SSAD_CHECK_ARG(in && w_packed && out && N > 0 && H > 0 && W > 0, "bad argument");
+    SSAD_CHECK_ARG(Cin % 64 == 0 && Cout % 64 == 0 && Cin <= 1024, "channel counts must be multiples of 64 (Cin <= 1024)");
+    SSAD_CHECK_ARG((H == 8 && W == 8 && Cout % 128 == 0) || (H % 16 == 0 && W % (Cout % 128 == 0 ? 16 : 32) == 0),
+                   "maps of 16 x 16 blocks (16 x 32 when Cout is not a multiple of 128), or 8 x 8 maps with Cout a multiple of 128");
+    SSAD_CHECK_ARG(!tr_mean || (tr_invstd && tr_gamma && tr_beta), "input transform needs mean, invstd, gamma, beta");
+    SSAD_CHECK_ARG(!stats_ws || (mean && invstd), "statistics need mean / invstd outputs");
+    SSAD_CHECK_ARG(!emit || tr_mean, "emit without an input transform");
+    SSAD_CHECK_ARG(!res_mask || residual, "a residual mask without a residual");
+    SSAD_CHECK_ARG(N * (int64_t)H * W < (int64_t)1 << 31, "too many pixels for one launch");
+    const GeoW g = geometry_w(N, H, W, Cout);
+    HWParams<T> p;
+    p.in = in; p.wp = w_packed; p.out = out; p.residual = residual; p.res_mask = res_mask;
+    p.tr_mean = tr_mean; p.tr_invstd = tr_invstd; p.tr_gamma = tr_gamma; p.tr_beta = tr_beta; p.emit = emit;
+    p.stats = stats_ws;
+    p.N = (int)N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    p.tiles_y = g.tiles_y; p.tiles_x = g.tiles_x; p.nchunks = Cin / (g.ck32 ? CKN : CKW); p.ntiles = g.ntiles;
+    const dim3 grid((unsigned)g.gx, (unsigned)g.gy);
+    hipStream_t st = (hipStream_t)stream;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SSAD_SET_DYN_LDS((conv3x3_hw_kernel<T, 2, true, CKW>), lds_bytes_w(false, true));
+        SSAD_SET_DYN_LDS((conv3x3_hw_kernel<T, 2, false, CKW>), lds_bytes_w(false, false));
+        SSAD_SET_DYN_LDS((conv3x3_hw_kernel<T, 1, false, CKN>), lds_bytes_w(true, false));
+        attr_set = true;
+    }
+    const int lds_dyn = lds_bytes_w(g.wn == 1, g.tw8) - 16 * 1024 + (tr_mean ? 16 * Cin : 0);
+    if (g.wn == 2) {
+        if (g.tw8) hipLaunchKernelGGL((conv3x3_hw_kernel<T, 2, true, CKW>), grid, dim3(512), lds_dyn, st, p);
+        else hipLaunchKernelGGL((conv3x3_hw_kernel<T, 2, false, CKW>), grid, dim3(512), lds_dyn, st, p);
+    } else {
+        hipLaunchKernelGGL((conv3x3_hw_kernel<T, 1, false, CKN>), grid, dim3(512), lds_dyn, st, p);
+    }
+    SSAD_CHECK_LAUNCH();
+    if (stats_ws)
+        return ssad_bn_finalize_partials(stats_ws, g.gx, N * H * W, Cout, eps, momentum, mean, invstd, running_mean, running_var, stream);
+    return 0;
+}
+
+}  // namespace
+
+// 1 when ssad_conv3x3_hw takes the launch: channel counts multiples of 64, maps of 16 x 16 blocks (16 x 32 for 64 output channels; or
+// 8 x 8 maps), and enough (tile, channel slab) pairs to give every CU a workgroup (smaller launches stay on csrc/conv16.hip).
+extern "C" int ssad_conv3x3_hw_ok(int64_t N, int H, int W, int Cin, int Cout) {
+    static const int on = getenv("SSAD_CONV16W") ? atoi(getenv("SSAD_CONV16W")) : 1;
+    return on && shape_ok(N, H, W, Cin, Cout);
+}
+// the same for the exact-fp32 form (ssad_conv3x3_fw); smaller launches stay on csrc/conv_c64.hip / csrc/conv_igemm.hip
+// (and at least two tiles per workgroup, or tiles of >= 8 chunks: a workgroup's first halo and its last epilogue are not overlapped,
+// measured on the 64-channel layer at batch 32 -- one 70 us tile per workgroup -- the batch-32 step lost 0.08 ms against the c64 kernel)
+extern "C" int ssad_conv3x3_fw_ok(int64_t N, int H, int W, int Cin, int Cout) {
+    static const int on = getenv("SSAD_CONV32W") ? atoi(getenv("SSAD_CONV32W")) : 1;
+    if (!on || !shape_ok(N, H, W, Cin, Cout)) return 0;
+    const GeoW g = geometry_w(N, H, W, Cout);
+    return g.ntiles * g.gy >= 512 || Cin >= 256;
+}
+
+// elements of one packed filter of Cout x 3 x 3 x Cin (halves / floats)
+extern "C" int64_t ssad_conv3x3_hw_packed_size(int Cin, int Cout) { return (int64_t)Cout * 9 * Cin; }
+
+// rows of the statistics workspace (x 2 x Cout doubles), both forms
+extern "C" int64_t ssad_conv3x3_hw_stats_rows(int64_t N, int H, int W, int Cout) { return geometry_w(N, H, W, Cout).gx; }
+
+// Packs n filters in one launch.  desc[5 k ..]: source offset (floats from src), destination offset (elements from dst), Cout, Cin of
+// the conv that will RUN on the packed filter, flip (0: src holds that conv's OHWI filter [Cout][3][3][Cin]; 1: src holds the OHWI
+// filter [Cin][3][3][Cout] of the forward conv whose input gradient this is).  _hw: values rounded to halves as ssad_cvt_f32_f16 does;
+// _fw: floats, fragment order [Cout/32][tap][Cin/8][2][32][4].
+extern "C" int ssad_conv3x3_hw_pack_batch(const float* src, void* dst, const int64_t* desc, int n, void* stream) {
+    return pack_batch_impl<hf>(src, (hf*)dst, desc, n, stream);
+}
+extern "C" int ssad_conv3x3_fw_pack_batch(const float* src, float* dst, const int64_t* desc, int n, void* stream) {
+    return pack_batch_impl<float>(src, dst, desc, n, stream);
 }
 
 // ssad_conv3x3_h (csrc/conv16.hip) with the filter in packed form: out = conv3x3(pad 1, stride 1)(T(in)) (+ residual), half tensors
@@ -581,41 +704,17 @@ extern "C" int ssad_conv3x3_hw(const void* in, const void* w_packed, void* out, 
                                const float* tr_invstd, const float* tr_gamma, const float* tr_beta, void* emit, int64_t N, int H, int W,
                                int Cin, int Cout, double* stats_ws, float eps, float momentum, float* mean, float* invstd,
                                float* running_mean, float* running_var, void* stream) {
-    SSAD_CHECK_ARG(in && w_packed && out && N > 0 && H > 0 && W > 0, "bad argument");
-    SSAD_CHECK_ARG(Cin % 64 == 0 && Cout % 64 == 0 && Cin <= 1024, "channel counts must be multiples of 64 (Cin <= 1024)");
-    SSAD_CHECK_ARG((H == 8 && W == 8 && Cout % 128 == 0) || (H % 16 == 0 && W % (Cout % 128 == 0 ? 16 : 32) == 0),
-                   "maps of 16 x 16 blocks (16 x 32 when Cout is not a multiple of 128), or 8 x 8 maps with Cout a multiple of 128");
-    SSAD_CHECK_ARG(!tr_mean || (tr_invstd && tr_gamma && tr_beta), "input transform needs mean, invstd, gamma, beta");
-    SSAD_CHECK_ARG(!stats_ws || (mean && invstd), "statistics need mean / invstd outputs");
-    SSAD_CHECK_ARG(!emit || tr_mean, "emit without an input transform");
-    SSAD_CHECK_ARG(N * (int64_t)H * W < (int64_t)1 << 31, "too many pixels for one launch");
-    const GeoW g = geometry_w(N, H, W, Cout);
-    HWParams p;
-    p.in = (const hf*)in; p.wp = (const hf*)w_packed; p.out = (hf*)out; p.residual = (const hf*)residual;
-    p.tr_mean = tr_mean; p.tr_invstd = tr_invstd; p.tr_gamma = tr_gamma; p.tr_beta = tr_beta; p.emit = (hf*)emit;
-    p.stats = stats_ws;
-    p.N = (int)N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
-    p.tiles_y = g.tiles_y; p.tiles_x = g.tiles_x; p.nchunks = Cin / (g.ck32 ? 32 : 64); p.ntiles = g.ntiles;
-    const dim3 grid((unsigned)g.gx, (unsigned)g.gy);
-    hipStream_t st = (hipStream_t)stream;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SSAD_SET_DYN_LDS((conv3x3_hw_kernel<2, true, 64>), (lds_bytes_w<2, true, 64>()));
-        SSAD_SET_DYN_LDS((conv3x3_hw_kernel<2, false, 64>), (lds_bytes_w<2, false, 64>()));
-        SSAD_SET_DYN_LDS((conv3x3_hw_kernel<1, false, 32>), (lds_bytes_w<1, false, 32>()));
-        attr_set = true;
-    }
-    const int trb = tr_mean ? 16 * Cin : 0;
-    const int lds_ck = g.ck32 ? 32 : 64;
-    const int lds_dyn = 2 * (g.tw8 ? 400 : 18 * (g.wn == 1 ? 34 : 18)) * (lds_ck + 8) * 2 + trb;
-    if (g.wn == 2) {
-        if (g.tw8) hipLaunchKernelGGL((conv3x3_hw_kernel<2, true, 64>), grid, dim3(512), lds_dyn, st, p);
-        else hipLaunchKernelGGL((conv3x3_hw_kernel<2, false, 64>), grid, dim3(512), lds_dyn, st, p);
-    } else {
-        hipLaunchKernelGGL((conv3x3_hw_kernel<1, false, 32>), grid, dim3(512), lds_dyn, st, p);
-    }
-    SSAD_CHECK_LAUNCH();
-    if (stats_ws)
-        return ssad_bn_finalize_partials(stats_ws, g.gx, N * H * W, Cout, eps, momentum, mean, invstd, running_mean, running_var, stream);
-    return 0;
+    return conv_impl<hf>((const hf*)in, (const hf*)w_packed, (hf*)out, (const hf*)residual, nullptr, tr_mean, tr_invstd, tr_gamma, tr_beta,
+                         (hf*)emit, N, H, W, Cin, Cout, stats_ws, eps, momentum, mean, invstd, running_mean, running_var, stream);
+}
+
+// The exact-fp32 form of the same kernel (fp32 tensors, v_mfma_f32_32x32x2_f32, statistics in double per value): the 3 x 3 / stride 1
+// convs of the fp32 training step forward and -- with the flipped pack -- their input gradients.  res_mask (optional): the residual is the
+// identity-branch gradient (dy, nibble mask) of a residual block, one byte per channel quad as ssad_bn_apply_fwd_mask writes them.
+extern "C" int ssad_conv3x3_fw(const float* in, const float* w_packed, float* out, const float* residual, const uint8_t* res_mask,
+                               const float* tr_mean, const float* tr_invstd, const float* tr_gamma, const float* tr_beta, float* emit,
+                               int64_t N, int H, int W, int Cin, int Cout, double* stats_ws, float eps, float momentum, float* mean,
+                               float* invstd, float* running_mean, float* running_var, void* stream) {
+    return conv_impl<float>(in, w_packed, out, residual, res_mask, tr_mean, tr_invstd, tr_gamma, tr_beta, emit, N, H, W, Cin, Cout, stats_ws,
+                            eps, momentum, mean, invstd, running_mean, running_var, stream);
 }

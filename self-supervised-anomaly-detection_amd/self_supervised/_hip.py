@@ -158,6 +158,10 @@ SIGNATURES = {
     "ssad_conv3x3_hw_pack_batch": [_c_fp, _c_fp, _c_fp, _c_i, _c_fp],
     "ssad_conv3x3_hw": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_f, _c_f,
                         _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
+    "ssad_conv3x3_fw_ok": [_c_l, _c_i, _c_i, _c_i, _c_i],
+    "ssad_conv3x3_fw_pack_batch": [_c_fp, _c_fp, _c_fp, _c_i, _c_fp],
+    "ssad_conv3x3_fw": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_f,
+                        _c_f, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
     "ssad_bn_stats_h": [_c_fp, _c_l, _c_i, _c_f, _c_f, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
     "ssad_bn_apply_fwd_h": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp],
     "ssad_gap_fwd_h": [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_fp],

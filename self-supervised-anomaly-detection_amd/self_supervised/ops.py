@@ -360,38 +360,47 @@ def conv3x3_h(x, w_ohwi, residual=None, transform=None, emit=False, stats=None):
     return res[0] if len(res) == 1 else tuple(res)
 
 
-def conv3x3_hw_ok(n, h, w, cin, cout):
-    """Whether ssad_conv3x3_hw (csrc/conv16w.hip: register-fed filters, 128 x 64 wave tiles) takes a launch of this shape."""
-    return bool(_hip.lib().ssad_conv3x3_hw_ok(n, h, w, cin, cout))
+def conv3x3_hw_ok(n, h, w, cin, cout, f32=False):
+    """Whether ssad_conv3x3_hw / _fw (csrc/conv16w.hip: register-fed filters, 128 x 64 wave tiles) takes a launch of this shape."""
+    lib = _hip.lib()
+    return bool((lib.ssad_conv3x3_fw_ok if f32 else lib.ssad_conv3x3_hw_ok)(n, h, w, cin, cout))
 
 
-def conv3x3_hw_pack(src_f32, entries, out=None):
+def conv3x3_hw_pack(src_f32, entries, out=None, f32=False):
     """Packs 3x3 filters for conv3x3_hw in ONE launch.  src_f32: a flat fp32 tensor holding OHWI filters; entries: iterable of
     (source offset in floats, Cout, Cin of the conv that will run on the packed filter, flip) -- flip: the source is the OHWI filter
-    [Cin][3][3][Cout] of the forward conv whose input gradient this is.  Returns (flat half tensor, [offset of each packed filter])."""
+    [Cin][3][3][Cout] of the forward conv whose input gradient this is.  f32: the pack of the exact-fp32 form (floats).
+    Returns (flat tensor, [offset of each packed filter])."""
     import ctypes
     desc, offs, off = [], [], 0
     for (so, o, i, flip) in entries:
         desc += [int(so), off, int(o), int(i), int(bool(flip))]
         offs.append(off)
         off += o * 9 * i
+    dt = torch.float32 if f32 else torch.float16
     if out is None:
-        out = torch.empty(off, device=src_f32.device, dtype=torch.float16)
-    assert out.numel() >= off and src_f32.dtype == torch.float32 and src_f32.is_contiguous()
+        out = torch.empty(off, device=src_f32.device, dtype=dt)
+    assert out.numel() >= off and out.dtype == dt and src_f32.dtype == torch.float32 and src_f32.is_contiguous()
     arr = (ctypes.c_int64 * len(desc))(*desc)
-    _hip.check(_hip.lib().ssad_conv3x3_hw_pack_batch(_hip.ptr(src_f32), out.data_ptr(), arr, len(offs), _hip.stream()))
+    lib = _hip.lib()
+    _hip.check((lib.ssad_conv3x3_fw_pack_batch if f32 else lib.ssad_conv3x3_hw_pack_batch)(_hip.ptr(src_f32), out.data_ptr(), arr, len(offs),
+                                                                                            _hip.stream()))
     return out, offs
 
 
-def conv3x3_hw(x, w_packed, cout, residual=None, transform=None, emit=False, stats=None):
-    """conv3x3_h with the filter packed by conv3x3_hw_pack (a flat half tensor of cout * 9 * cin values); the launch must satisfy
+def conv3x3_hw(x, w_packed, cout, residual=None, transform=None, emit=False, stats=None, res_mask=None):
+    """conv3x3_h with the filter packed by conv3x3_hw_pack (a flat tensor of cout * 9 * cin values); half tensors, or -- x fp32 -- the
+    exact-fp32 instantiation (res_mask: the residual is gated by the nibble mask of bn_apply_fwd_mask).  The launch must satisfy
     conv3x3_hw_ok.  Returns out[, emitted][, mean, invstd]."""
     n, h, w, cin = x.shape
-    assert _is_h(x) and _is_h(w_packed) and w_packed.numel() == cout * 9 * cin and w_packed.is_contiguous()
-    assert conv3x3_hw_ok(n, h, w, cin, cout), "shape outside ssad_conv3x3_hw_ok"
-    assert residual is None or (_is_h(residual) and tuple(residual.shape) == (n, h, w, cout)), "residual must have the output's shape"
+    f32 = x.dtype == torch.float32
+    assert (f32 or _is_h(x)) and w_packed.dtype == x.dtype and w_packed.numel() == cout * 9 * cin and w_packed.is_contiguous()
+    assert x.is_contiguous() and conv3x3_hw_ok(n, h, w, cin, cout, f32), "shape outside ssad_conv3x3_hw_ok"
+    assert residual is None or (residual.dtype == x.dtype and tuple(residual.shape) == (n, h, w, cout) and residual.is_contiguous()), \
+        "residual must have the output's shape"
+    assert res_mask is None or (f32 and residual is not None and res_mask.numel() == n * h * w * cout // 4 and res_mask.dtype == torch.uint8)
     lib = _hip.lib()
-    out = _newh((n, h, w, cout), x)
+    out = torch.empty((n, h, w, cout), device=x.device, dtype=x.dtype)
     em = torch.empty_like(x) if emit else None
     tr = transform if transform is not None else (None, None, None, None)
     mean = invstd = ws = None
@@ -401,12 +410,20 @@ def conv3x3_hw(x, w_packed, cout, residual=None, transform=None, emit=False, sta
         eps, mom, rm, rv = stats
         mean, invstd = _new((cout,), x), _new((cout,), x)
         ws = torch.empty(lib.ssad_conv3x3_hw_stats_rows(n, h, w, cout) * 2 * cout, device=x.device, dtype=torch.float64)
-    nb = 2.0 * (x.numel() + out.numel() * (2 if residual is not None else 1) + (x.numel() if emit else 0) + w_packed.numel())
-    _run("conv3x3_hw16", 2.0 * out.numel() * 9 * cin, nb,
-         lambda: lib.ssad_conv3x3_hw(x.data_ptr(), w_packed.data_ptr(), out.data_ptr(), _p(residual, True), _hip.ptr(tr[0], True),
-                                     _hip.ptr(tr[1], True), _hip.ptr(tr[2], True), _hip.ptr(tr[3], True), _p(em, True), n, h, w, cin, cout,
-                                     ws.data_ptr() if ws is not None else None, eps, mom, _hip.ptr(mean, True), _hip.ptr(invstd, True),
-                                     _hip.ptr(rm, True), _hip.ptr(rv, True), _hip.stream()))
+    nb = x.element_size() * (x.numel() + out.numel() * (2 if residual is not None else 1) + (x.numel() if emit else 0) + w_packed.numel())
+    wsp = ws.data_ptr() if ws is not None else None
+    if f32:
+        _run("conv3x3_fw32", 2.0 * out.numel() * 9 * cin, float(nb),
+             lambda: lib.ssad_conv3x3_fw(x.data_ptr(), w_packed.data_ptr(), out.data_ptr(), _p(residual, True),
+                                         res_mask.data_ptr() if res_mask is not None else None, _hip.ptr(tr[0], True), _hip.ptr(tr[1], True),
+                                         _hip.ptr(tr[2], True), _hip.ptr(tr[3], True), _p(em, True), n, h, w, cin, cout, wsp, eps, mom,
+                                         _hip.ptr(mean, True), _hip.ptr(invstd, True), _hip.ptr(rm, True), _hip.ptr(rv, True), _hip.stream()))
+    else:
+        _run("conv3x3_hw16", 2.0 * out.numel() * 9 * cin, float(nb),
+             lambda: lib.ssad_conv3x3_hw(x.data_ptr(), w_packed.data_ptr(), out.data_ptr(), _p(residual, True), _hip.ptr(tr[0], True),
+                                         _hip.ptr(tr[1], True), _hip.ptr(tr[2], True), _hip.ptr(tr[3], True), _p(em, True), n, h, w, cin, cout,
+                                         wsp, eps, mom, _hip.ptr(mean, True), _hip.ptr(invstd, True), _hip.ptr(rm, True), _hip.ptr(rv, True),
+                                         _hip.stream()))
     res = [out]
     if emit:
         res.append(em)

@@ -236,18 +236,23 @@ class _Affine:
         mom = 0.1 if bn.momentum is None else bn.momentum
         st = (bn.eps, mom, bn.running_mean, bn.running_var)
         self.x_shape = tuple(x.shape)
+        n_, h_, w_, ci_ = x.shape
+        if x.dtype == torch.float32 and self.eng.conv32w_ok(self, n_, h_, w_, ci_, self.lin.out_channels):
+            wp = self.eng.packed_hw(self.lin, False, f32=True)         # launches that fill the chip: the register-fed form
+            conv = lambda **kw: ops.conv3x3_hw(x, wp, self.lin.out_channels, **kw)
+        else:
+            conv = lambda **kw: ops.conv3x3_c64(x, a.w(self.lin.weight), bf16=self.eng.bf16, **kw)
         if producer is None:
-            z, self.mean, self.invstd = ops.conv3x3_c64(x, a.w(self.lin.weight), stats=st, bf16=self.eng.bf16)
+            z, self.mean, self.invstd = conv(stats=st)
             self.x = x
         else:
             pb = producer.bn
             tr = (producer.mean, producer.invstd, a.w(pb.weight), a.w(pb.bias))
             need_x = self.lin.weight.requires_grad and self.eng.param_grads and torch.is_grad_enabled()
             if need_x:
-                z, self.x, self.mean, self.invstd = ops.conv3x3_c64(x, a.w(self.lin.weight), transform=tr, emit=True, stats=st,
-                                                                    bf16=self.eng.bf16)
+                z, self.x, self.mean, self.invstd = conv(transform=tr, emit=True, stats=st)
             else:
-                z, self.mean, self.invstd = ops.conv3x3_c64(x, a.w(self.lin.weight), transform=tr, stats=st, bf16=self.eng.bf16)
+                z, self.mean, self.invstd = conv(transform=tr, stats=st)
                 self.x = None
         with torch.no_grad():
             self.eng.count_batch(bn)
@@ -341,8 +346,12 @@ class _Affine:
                 return y
             if bias is None and c % 4 == 0:
                 # batch statistics taken in the conv epilogue (no second pass over z)
-                z, self.mean, self.invstd = ops.conv_fwd_stats(x, w, bn.eps, mom, bn.running_mean, bn.running_var,
-                                                               self.stride, self.pad, bf)
+                if x.dtype == torch.float32 and x.dim() == 4 and self.eng.conv32w_ok(self, x.shape[0], x.shape[1], x.shape[2], x.shape[3], c):
+                    z, self.mean, self.invstd = ops.conv3x3_hw(x, self.eng.packed_hw(self.lin, False, f32=True), c,
+                                                               stats=(bn.eps, mom, bn.running_mean, bn.running_var))
+                else:
+                    z, self.mean, self.invstd = ops.conv_fwd_stats(x, w, bn.eps, mom, bn.running_mean, bn.running_var,
+                                                                   self.stride, self.pad, bf)
             else:
                 z = ops.conv_fwd(x, w, None, a.w(bias) if bias is not None else None, None, False, self.stride, self.pad, bf)
                 self.mean, self.invstd = ops.bn_stats(z, c, bn.eps, mom, bn.running_mean, bn.running_var)
@@ -462,6 +471,10 @@ class _Affine:
                     dx = ops.conv3x3_hw(dzz, self.eng.packed_hw(self.lin, True), self.lin.in_channels, residual=dx_residual)
                 else:
                     dx = ops.conv3x3_h(dzz, self.eng.flipped(self.lin, wt, half=True), residual=dx_residual)
+            elif (dz.dtype == torch.float32 and dz.dim() == 4 and wt is w and self.is_conv
+                  and self.eng.conv32w_ok(self, dz.shape[0], dz.shape[1], dz.shape[2], cout, self.lin.in_channels)):
+                dx = ops.conv3x3_hw(dzz.contiguous(), self.eng.packed_hw(self.lin, True, f32=True), self.lin.in_channels,
+                                    residual=dx_residual, res_mask=dx_res_mask)
             elif self.c64_ok() and dz.dim() == 4:
                 dx = ops.conv3x3_c64(dzz, self.eng.flipped(self.lin, wt), residual=dx_residual, res_mask=dx_res_mask, bf16=bf)
             elif half:
@@ -530,14 +543,15 @@ class TrainEngine:
         self.sw_act16 = os.environ.get("SSAD_ACT16", "1") != "0"
         self.sw_conv16 = os.environ.get("SSAD_CONV16", "1") != "0"
         self.sw_conv16w = os.environ.get("SSAD_CONV16W", "1") != "0"     # register-fed form of the same conv (csrc/conv16w.hip)
-        self._packed = {False: None, True: None}      # packed 3x3 filters: forward / input-gradient (flipped) tables
-        self._packed_ready = {False: False, True: False}
+        self.sw_conv32w = os.environ.get("SSAD_CONV32W", "1") != "0"     # ... and its exact-fp32 instantiation (the fp32 step)
+        self._packed = {}             # packed 3x3 filters, key (flip, f32): forward / input-gradient (flipped) tables, halves / floats
+        self._packed_ready = {}
         self.h16 = False              # decided per forward (trunk BatchNorms in training mode, whole images of >= 64 x 64)
         self._flip16_view, self._flip16_ready = {}, False
 
     def switches(self):
         """Everything besides shapes that decides which launches a step consists of (hipGraph plan key)."""
-        return (self.bf16, self.param_grads, self.sw_c64, self.sw_relu_mask, self.sw_wgrad_halo, self.sw_stem16, self.sw_c64_16, self.sw_act16, self.sw_conv16, self.sw_conv16w, self._side_on,
+        return (self.bf16, self.param_grads, self.sw_c64, self.sw_relu_mask, self.sw_wgrad_halo, self.sw_stem16, self.sw_c64_16, self.sw_act16, self.sw_conv16, self.sw_conv16w, self.sw_conv32w, self._side_on,
                 os.environ.get("SSAD_WGRAD_HALO", "1") != "0", torch.is_grad_enabled())
 
     # ---- second stream for the weight gradients ----
@@ -589,10 +603,12 @@ class TrainEngine:
         self._flip16_ready = True
         return self._flip16_view[key]
 
-    def packed_hw(self, lin, flip):
-        """The 3x3 filter of a block conv in the fragment order ssad_conv3x3_hw reads (flip: as the input gradient's filter).  All
-        block convs are packed by ONE launch per table and step, from the fp32 master weights (the first request after a forward)."""
-        tab = self._packed[flip]
+    def packed_hw(self, lin, flip, f32=False):
+        """The 3x3 filter of a block conv in the fragment order ssad_conv3x3_hw / _fw reads (flip: as the input gradient's filter; f32: the
+        pack of the exact-fp32 form).  All block convs are packed by ONE launch per table and step, from the fp32 master weights (the
+        first request after a forward)."""
+        key = (bool(flip), bool(f32))
+        tab = self._packed.get(key)
         if tab is None:
             entries, keys = [], []
             for layer in [d[k] for d in self.blocks for k in ("c1", "c2")]:
@@ -603,14 +619,21 @@ class TrainEngine:
                 entries.append((self.arena.offset[id(p)][0], c, o, True) if flip else (self.arena.offset[id(p)][0], o, c, False))
                 keys.append(id(p))
             sizes = [e[1] * 9 * e[2] for e in entries]
-            buf = torch.empty(sum(sizes), device=self.arena.p.device, dtype=torch.float16)
+            buf = torch.empty(sum(sizes), device=self.arena.p.device, dtype=torch.float32 if f32 else torch.float16)
             offs = [sum(sizes[:i]) for i in range(len(sizes))]
-            tab = self._packed[flip] = {"buf": buf, "entries": entries,
-                                        "view": {k: buf[o:o + n] for k, o, n in zip(keys, offs, sizes)}}
-        if not self._packed_ready[flip]:
-            ops.conv3x3_hw_pack(self.arena.p, tab["entries"], out=tab["buf"])
-            self._packed_ready[flip] = True
+            tab = self._packed[key] = {"buf": buf, "entries": entries,
+                                       "view": {k: buf[o:o + n] for k, o, n in zip(keys, offs, sizes)}}
+        if not self._packed_ready.get(key, False):
+            ops.conv3x3_hw_pack(self.arena.p, tab["entries"], out=tab["buf"], f32=f32)
+            self._packed_ready[key] = True
         return tab["view"][id(lin.weight)]
+
+    def conv32w_ok(self, layer, n, h, w, cin, cout):
+        """Whether the exact-fp32 step runs this 3x3 / stride 1 conv (forward: cin -> cout; input gradient: the roles swapped) on the
+        register-fed form (csrc/conv16w.hip, T = float)."""
+        l = layer.lin
+        return (self.sw_conv32w and not self.bf16 and layer.is_conv and not layer.stem and l.kernel_size == (3, 3) and layer.stride == 1
+                and layer.pad == 1 and l.bias is None and ops.conv3x3_hw_ok(n, h, w, cin, cout, f32=True))
 
     def flipped(self, lin, w, half=False):
         """dgrad operand of a conv layer (ssad_flip_transpose_weight of its OHWI weight).  All block convs are flipped by one
@@ -663,7 +686,7 @@ class TrainEngine:
         b, _, h, w = x.shape
         self.trunk_grad = any(p.requires_grad for p in m.feature_extractor.parameters())
         self._nbt, self._flip_ready, self._flip16_ready = [], False, False
-        self._packed_ready = {False: False, True: False}
+        self._packed_ready = {}
         self.h16 = bool(self.bf16 == 2 and self.sw_act16 and self.sw_stem16 and h >= 64 and w >= 64 and self.param_grads and
                         all(mod.training for mod in m.feature_extractor.modules() if isinstance(mod, BN_TYPES)))
         if self.h16:

@@ -196,6 +196,48 @@ def test_conv3x3_hw_register_fed_kernel(dev, shape):
         assert (dx.float().cpu() - wantdx).abs().max().item() <= tol(wantdx)
 
 
+@pytest.mark.parametrize("shape", [(64, 64, 64, 64, 64), (128, 32, 32, 128, 128), (104, 16, 16, 256, 256), (202, 8, 8, 512, 512),
+                                   (128, 32, 32, 64, 128), (64, 64, 64, 128, 64)])
+def test_conv3x3_fw_exact_fp32_form(dev, shape):
+    """The float instantiation of csrc/conv16w.hip (v_mfma_f32_32x32x2_f32, statistics in double per value) against F.conv2d in fp32 and
+    against the implicit GEMM of the exact-fp32 step: plain + statistics, residual, residual gated by a nibble mask (the identity-branch
+    gradient of a residual block), producer BatchNorm + ReLU on load with the emitted activation, the flipped pack as input gradient."""
+    from self_supervised import ops
+    n, h, w, cin, cout = shape
+    assert ops.conv3x3_hw_ok(n, h, w, cin, cout, f32=True)
+    g = torch.Generator().manual_seed(n * 7 + h + cin)
+    x = torch.randn(n, h, w, cin, generator=g).to(dev)
+    w32 = (torch.randn(cout, 3, 3, cin, generator=g) / (9 * cin) ** 0.5).to(dev)
+    res = torch.randn(n, h, w, cout, generator=g).to(dev)
+    wp, _ = ops.conv3x3_hw_pack(w32.reshape(-1), [(0, cout, cin, False)], f32=True)
+    rm1, rv1 = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)
+    rm2, rv2 = rm1.clone(), rv1.clone()
+    zi, mi, ii = ops.conv_fwd_stats(x, w32, 1e-5, 0.1, rm1, rv1, 1, 1)
+    z, m, i = ops.conv3x3_hw(x, wp, cout, stats=(1e-5, 0.1, rm2, rv2))
+    want = F.conv2d(x.cpu().permute(0, 3, 1, 2), w32.cpu().permute(0, 3, 1, 2), None, 1, 1).permute(0, 2, 3, 1)
+    tol = 2e-5 * max(1.0, want.abs().max().item())
+    assert z.dtype == torch.float32 and (z.cpu() - want).abs().max().item() <= tol
+    assert (z - zi).abs().max().item() <= tol
+    assert (m - mi).abs().max().item() < 1e-6 and ((i - ii).abs() / ii).max().item() < 1e-6
+    assert (rm2 - rm1).abs().max().item() < 1e-6 and (rv2 - rv1).abs().max().item() < 1e-6
+    zr = ops.conv3x3_hw(x, wp, cout, residual=res)
+    assert (zr.cpu() - (want + res.cpu())).abs().max().item() <= tol
+    mask = torch.randint(0, 16, (n, h, w, cout // 4), generator=g, dtype=torch.uint8).to(dev)
+    bits = torch.stack([(mask >> k) & 1 for k in range(4)], -1).reshape(n, h, w, cout).float()
+    zm = ops.conv3x3_hw(x, wp, cout, residual=res, res_mask=mask)
+    assert (zm.cpu() - (want + (res * bits).cpu())).abs().max().item() <= tol
+    tr = _bn_params(cin, g, dev)
+    act = ops.bn_apply_fwd(x, tr[0], tr[1], tr[2], tr[3], None, True)
+    z2, em, m2, i2 = ops.conv3x3_hw(x, wp, cout, transform=tr, emit=True, stats=(1e-5, 0.1, rm2, rv2))
+    assert torch.equal(em, act)                                                     # the same expression
+    assert torch.equal(z2, ops.conv3x3_hw(act, wp, cout))
+    if ops.conv3x3_hw_ok(n, h, w, cout, cin, f32=True):
+        wpf, _ = ops.conv3x3_hw_pack(w32.reshape(-1), [(0, cin, cout, True)], f32=True)
+        dx = ops.conv3x3_hw(res, wpf, cin)
+        wantdx = F.conv_transpose2d(res.cpu().permute(0, 3, 1, 2), w32.cpu().permute(0, 3, 1, 2), None, 1, 1).permute(0, 2, 3, 1)
+        assert (dx.cpu() - wantdx).abs().max().item() <= 2e-5 * max(1.0, wantdx.abs().max().item())
+
+
 @pytest.mark.parametrize("shape", [(3, 16, 16, 64, 64, 1), (2, 13, 21, 64, 128, 1), (5, 8, 8, 128, 64, 1), (3, 5, 7, 64, 64, 1),
                                    (40, 32, 32, 128, 128, 1), (9, 64, 64, 64, 64, 1), (3, 32, 32, 64, 128, 2), (2, 13, 21, 64, 64, 2),
                                    (5, 16, 16, 128, 256, 2), (40, 16, 16, 256, 512, 2), (3, 9, 9, 64, 64, 2)])
