@@ -155,7 +155,13 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
         // chunk >= nchunks: a residual fill (chunk - nchunks of the workgroup's channel slab), base then indexes the residual tensor
         auto origin = [&](int64_t f, int64_t& base, int& chunk, int& y0, int& x0, int& nimg) {
             const int64_t ti = f / fpt;
-            chunk = (int)(f - ti * fpt);
+            const int k = (int)(f - ti * fpt);
+            // order of a tile's fills: input chunk 0, residual chunk 0, input 1, residual 1, ... -- a residual fill is four steps of matrix
+            // work, and behind a long input fill its loads (requested two fills ahead) have time to arrive; whatever one kind has more of
+            // follows (first form: all residual fills after the last input chunk, +59 us on the fp32 layer2 shape)
+            const int mpair = p.residual ? (p.nchunks < RF ? p.nchunks : RF) : 0;
+            if (k < 2 * mpair) chunk = (k & 1) ? p.nchunks + (k >> 1) : (k >> 1);
+            else chunk = (p.nchunks > mpair ? 0 : p.nchunks) + (k - mpair);
             const int64_t tile = (int64_t)blockIdx.x + ti * gridDim.x;
             const bool res = chunk >= p.nchunks;
             const int C = res ? p.Cout : p.Cin;
@@ -380,38 +386,40 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
         }
         __syncthreads();                                   // everyone is done with halo[f & 1]; fill f + 1 is staged
         ++f;
-        chunk = cnext;
-        if (chunk != 0) continue;
-
-        if (p.residual) {
-            // ---- the residual fills of this tile: acc += residual x one-hot.  Step kk of fill rc covers the slab's channels
-            // rc CK + KST kk .. + KST - 1; a wave takes the steps inside its own 64 channels: fragment element j of lane (r, h) of
-            // accumulator tile jt is 1 where jt 32 + r = cb + E h + j (the tile a step does not belong to adds zeros) ----
+        // ---- a residual fill: acc += residual x one-hot.  Step kk of fill rc covers the slab's channels rc CK + KST kk .. + KST - 1; a wave
+        // takes the steps inside its own 64 channels: fragment element j of lane (r, h) of accumulator tile jt is 1 where
+        // jt 32 + r = cb + E h + j (halves: the tile a step does not belong to adds zeros).  Residual fill rc follows input chunk rc
+        // (see the stagers); those beyond the number of input chunks follow the last one ----
+        auto residual_fill = [&](int rc) {
+            const T* hr = halo + (int)(f & 1) * HALO_H;
 #pragma unroll
-            for (int rc = 0; rc < RF; ++rc) {
-                const T* hr = halo + (int)(f & 1) * HALO_H;
+            for (int kk = 0; kk < KS; ++kk) {
+                const int cb = rc * CK + kk * KST - wn * 64;          // first channel of the step, counted from the wave's first
+                if (cb >= 0 && cb < 64) {
+                    frag_t ar[4];
 #pragma unroll
-                for (int kk = 0; kk < KS; ++kk) {
-                    const int cb = rc * CK + kk * KST - wn * 64;      // first channel of the step, counted from the wave's first
-                    if (cb >= 0 && cb < 64) {
-                        frag_t ar[4];
+                    for (int m = 0; m < 4; ++m) ar[m] = *(const frag_t*)(hr + abase[m] + (HW_ + 1) * LDP + kk * KST);
 #pragma unroll
-                        for (int m = 0; m < 4; ++m) ar[m] = *(const frag_t*)(hr + abase[m] + (HW_ + 1) * LDP + kk * KST);
+                    for (int jt = 0; jt < 2; ++jt) {
+                        if (F32 && jt != (cb >> 5)) continue;         // (float: a step lies inside one accumulator tile; 4 MFMAs saved per skip)
+                        const int hot = jt * 32 + r - cb - E * h;
+                        frag_t one;
 #pragma unroll
-                        for (int jt = 0; jt < 2; ++jt) {
-                            if (F32 && jt != (cb >> 5)) continue;     // (float: a step lies inside one accumulator tile; 4 MFMAs saved per skip)
-                            const int hot = jt * 32 + r - cb - E * h;
-                            frag_t one;
+                        for (int j = 0; j < E; ++j) one[j] = hot == j ? (T)1.f : (T)0.f;
 #pragma unroll
-                            for (int j = 0; j < E; ++j) one[j] = hot == j ? (T)1.f : (T)0.f;
-#pragma unroll
-                            for (int m = 0; m < 4; ++m) acc[m][jt] = mma_frag(ar[m], one, acc[m][jt]);
-                        }
+                        for (int m = 0; m < 4; ++m) acc[m][jt] = mma_frag(ar[m], one, acc[m][jt]);
                     }
                 }
-                __syncthreads();
-                ++f;
             }
+            __syncthreads();
+            ++f;
+        };
+        if (p.residual && chunk < RF) residual_fill(chunk);
+        const int done = chunk;
+        chunk = cnext;
+        if (chunk != 0) continue;
+        if (p.residual) {
+            for (int rc = done + 1; rc < RF; ++rc) residual_fill(rc);
         }
 
         // ---- epilogue of a finished tile: straight from the accumulators, every lane its own halves (a wave store covers whole

@@ -44,4 +44,4 @@ for (hw, c) in [(64, 64), (32, 128), (16, 256), (8, 512)]:
     if c == 64:
         t["c64 stats"] = timeit(lambda: ops.conv3x3_c64(x, w, stats=st))
         t["c64 tr+emit+stats"] = timeit(lambda: ops.conv3x3_c64(x, w, transform=tr, emit=True, stats=st))
-    print(f"{hw}x{hw}x{c}: {gf:.1f} GFLOP | " + " | ".join(f"{k} {v:.0f} us ({gf / v * 1e-3:.0f} TFLOP/s)" for k, v in t.items()), flush=True)
+    print(f"{hw}x{hw}x{c}: {gf:.1f} GFLOP | " + " | ".join(f"{k} {v:.0f} us ({gf / v * 1e3:.0f} TFLOP/s)" for k, v in t.items()), flush=True)
