@@ -743,7 +743,8 @@ def main():
               "traffic_unit": "fabric-side bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, rocprofv3 PMC passes of this command; "
                               "Infinity-Cache hits included)" if tprof else None,
               "traffic_profile": tprof,
-              "kernel": "conv_igemm_f32_kernel" + " + ".join(f"{k} x {v['launches']}" for k, v in inst.items()),
+              "kernel": ("conv3x3_hw_kernel<float> (csrc/conv16w.hip) x %d" % len(recs)) if tag == "conv3x3_fw32" else
+                        "conv_igemm_f32_kernel" + " + ".join(f"{k} x {v['launches']}" for k, v in inst.items()),
               "instantiations": inst, "phase": phase, "launches": len(recs),
               "avg_launch_ms": round(1e3 * t / len(recs), 4),
               "alg_gflop_per_launch": round(fl / len(recs) / 1e9, 3),
@@ -752,7 +753,13 @@ def main():
               "alg_GBps": round(sum(r["bytes"] for r in recs) / t / 1e9, 1),
               "share_of_gpu_time": round(t / allk, 4)}
         return rf
-    rf_score, rf_train = roofline_of("score", "conv_igemm_pos_f32"), roofline_of("train", "conv_igemm_f32")
+    # the training pass's dominant matrix kernel: the register-fed 3x3 conv (csrc/conv16w.hip, T = float) where it runs, else the implicit GEMM
+    tms = {}
+    for r in prof.get("train", []):
+        if r["kernel"] in ("conv3x3_fw32", "conv_igemm_f32"):
+            tms[r["kernel"]] = tms.get(r["kernel"], 0.0) + r["ms"]
+    train_tag = max(tms, key=tms.get) if tms else "conv_igemm_f32"
+    rf_score, rf_train = roofline_of("score", "conv_igemm_pos_f32"), roofline_of("train", train_tag)
     if rf_score or rf_train:
         out["roofline"] = dict(rf_score or rf_train)
         out["roofline"]["note"] = ("achieved / frac = MFMA FLOPs issued per second of kernel time (HIP events on the launch stream) "
