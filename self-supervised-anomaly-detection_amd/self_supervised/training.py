@@ -544,6 +544,7 @@ class TrainEngine:
         self.sw_conv16 = os.environ.get("SSAD_CONV16", "1") != "0"
         self.sw_conv16w = os.environ.get("SSAD_CONV16W", "1") != "0"     # register-fed form of the same conv (csrc/conv16w.hip)
         self.sw_conv32w = os.environ.get("SSAD_CONV32W", "1") != "0"     # ... and its exact-fp32 instantiation (the fp32 step)
+        self.sw_raw32 = os.environ.get("SSAD_RAW32", "1") != "0"         # fp32: bn1 + ReLU inside conv2's staging on every block it runs
         self._packed = {}             # packed 3x3 filters, key (flip, f32): forward / input-gradient (flipped) tables, halves / floats
         self._packed_ready = {}
         self.h16 = False              # decided per forward (trunk BatchNorms in training mode, whole images of >= 64 x 64)
@@ -551,7 +552,7 @@ class TrainEngine:
 
     def switches(self):
         """Everything besides shapes that decides which launches a step consists of (hipGraph plan key)."""
-        return (self.bf16, self.param_grads, self.sw_c64, self.sw_relu_mask, self.sw_wgrad_halo, self.sw_stem16, self.sw_c64_16, self.sw_act16, self.sw_conv16, self.sw_conv16w, self.sw_conv32w, self._side_on,
+        return (self.bf16, self.param_grads, self.sw_c64, self.sw_relu_mask, self.sw_wgrad_halo, self.sw_stem16, self.sw_c64_16, self.sw_act16, self.sw_conv16, self.sw_conv16w, self.sw_conv32w, self.sw_raw32, self._side_on,
                 os.environ.get("SSAD_WGRAD_HALO", "1") != "0", torch.is_grad_enabled())
 
     # ---- second stream for the weight gradients ----
@@ -709,6 +710,15 @@ class TrainEngine:
                 a = d["c2"].apply_bn(residual=idt)
             elif d["ds"] is None and d["c1"].c64_ok() and d["c2"].c64_ok():
                 z1 = d["c1"].fwd_raw_c64(a)                       # bn1 + ReLU happen inside conv2's input staging
+                d["c2"].fwd_raw_c64(z1, producer=d["c1"])
+                a = d["c2"].apply_bn(residual=idt)
+            elif (self.sw_raw32 and not self.bf16 and a.dtype == torch.float32 and d["c1"].bn.training and d["c2"].bn.training and
+                  self.conv32w_ok(d["c2"], a.shape[0], (a.shape[1] - 1) // d["c1"].stride + 1, (a.shape[2] - 1) // d["c1"].stride + 1,
+                                  d["c2"].lin.in_channels, d["c2"].lin.out_channels)):
+                # exact fp32, launches that fill the chip: the same hand-over on every block -- conv1 leaves its raw output and its batch
+                # statistics, conv2 (register-fed form) applies bn1 + ReLU while it stages its input and emits the activation its weight
+                # gradient reads: one pass over the activation less per block than a separate BatchNorm apply
+                z1 = d["c1"].fwd(a, raw=True)
                 d["c2"].fwd_raw_c64(z1, producer=d["c1"])
                 a = d["c2"].apply_bn(residual=idt)
             else:
