@@ -323,6 +323,20 @@ int ssad_maxpool3x3s2_fwd_idx(const float* in, float* out, uint8_t* idx, int64_t
  * workspace: ssad_colreduce_workspace(N*H*W, C) doubles. */
 int ssad_bn_relu_maxpool_fwd(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
                              float* out, uint8_t* idx, int64_t N, int H, int W, int C, void* stream);
+/* Round 5: the stem's BatchNorm backward reduction over the POOLED tensors.  ..._fwd_win also writes zwin[N][Ho][Wo][C], the raw z of each
+ * window's winner; sum over pixels of g and g * xhat = sum over windows of dpool * mask(zwin) and dpool * mask * xhat(zwin) (a window
+ * routes its gradient to exactly one pixel), i.e. ssad_bn_bwd_reduce_zmask(dpool, zwin, ...) over N * Ho * Wo rows; ..._bwd_apply is the
+ * apply pass alone with dbeta / dgamma as inputs.  Half forms: ssad_bn_relu_maxpool_fwd_win_h, ssad_pool_bn_relu_bwd_apply_h. */
+int ssad_bn_relu_maxpool_fwd_win(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta, float* out,
+                                 uint8_t* idx, float* zwin, int64_t N, int H, int W, int C, void* stream);
+int ssad_bn_relu_maxpool_fwd_win_h(const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta, void* out,
+                                   uint8_t* idx, void* zwin, int64_t N, int H, int W, int C, void* stream);
+int ssad_pool_bn_relu_bwd_apply(const uint8_t* idx, const float* dpool, const float* z, const float* mean, const float* invstd,
+                                const float* gamma, const float* beta, const float* dbeta, const float* dgamma, float* dz, int64_t N, int H,
+                                int W, int C, int64_t dpool_elems, void* stream);
+int ssad_pool_bn_relu_bwd_apply_h(const uint8_t* idx, const void* dpool, const void* z, const float* mean, const float* invstd,
+                                  const float* gamma, const float* beta, const float* dbeta, const float* dgamma, void* dz, int64_t N, int H,
+                                  int W, int C, int64_t dpool_elems, void* stream);
 int ssad_pool_bn_relu_bwd(const uint8_t* idx, const float* dpool, const float* z, const float* mean, const float* invstd,
                           const float* gamma, const float* beta, float* dbeta, float* dgamma, float* dz, int64_t N, int H,
                           int W, int C, int64_t dpool_elems, double* workspace, void* stream);

@@ -340,7 +340,8 @@ struct PoolBN { const float* mean; const float* invstd; const float* gamma; cons
 // A lane owns E = 4 (float) / 8 (half) consecutive channels: 16-byte accesses either way (totalE, CE in units of E).
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__ in, T* __restrict__ out, uint8_t* __restrict__ idx,
-                                    int64_t totalE, int H, int W, int CE, int Ho, int Wo, int64_t N, int hwnc, PoolBN bn) {
+                                    int64_t totalE, int H, int W, int CE, int Ho, int Wo, int64_t N, int hwnc, PoolBN bn,
+                                    T* __restrict__ zwin = nullptr) {
     constexpr int E = Lane<T>::E;
     using V = typename Lane<T>::vec;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__
         oy = (int)(t % Ho);
         n = t / Ho;
     }
-    V m = -INFINITY;
+    V m = -INFINITY, zw = 0.f;                // zw: the RAW input value of the winner (zwin: what the BatchNorm backward reduction needs of z)
     int am[E];                                // window slot (dy*3+dx) of the FIRST maximum, PyTorch's tie rule
 #pragma unroll
     for (int k = 0; k < E; ++k) am[k] = 0;
@@ -379,6 +380,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__
             if ((unsigned)x >= (unsigned)W) continue;
             const int64_t ip = hwnc ? ((int64_t)y * W + x) * N + n : (n * H + y) * W + x;
             V v = ldv(in + E * (ip * CE + cq));
+            const V raw = v;
             if (bn.mean) {
                 // (half tensors: the BatchNorm output is itself a stored half under autocast, so candidates are compared -- and tie --
                 // as halves)
@@ -387,10 +389,11 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__
             }
 #pragma unroll
             for (int k = 0; k < E; ++k)
-                if (v[k] > m[k]) { m[k] = v[k]; am[k] = dy * 3 + dx; }
+                if (v[k] > m[k]) { m[k] = v[k]; am[k] = dy * 3 + dx; zw[k] = raw[k]; }
         }
     }
     stv(out + E * i, m);
+    if (zwin) stv(zwin + E * i, zw);
     if (idx) {
 #pragma unroll
         for (int q = 0; q < E / 4; ++q)
@@ -499,7 +502,7 @@ extern "C" int ssad_stem_patch_pool_fwd(const float* img, int B, int H, int W, i
 
 template <typename T>
 static int maxpool_fwd_impl(const T* in, T* out, uint8_t* idx, int64_t N, int H, int W, int C, int hwnc, void* stream,
-                            PoolBN bn = PoolBN{nullptr, nullptr, nullptr, nullptr}) {
+                            PoolBN bn = PoolBN{nullptr, nullptr, nullptr, nullptr}, T* zwin = nullptr) {
     SSAD_CHECK_ARG(in && out, "null pointer");
     SSAD_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "bad shape (C % 4)");
     int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
@@ -508,7 +511,7 @@ static int maxpool_fwd_impl(const T* in, T* out, uint8_t* idx, int64_t N, int H,
     int64_t totalE = N * Ho * Wo * (C / E);
     SSAD_CHECK_ARG(cdiv64(totalE, 256) < (int64_t)2147483647, "too large");
     hipLaunchKernelGGL(maxpool3x3s2_kernel<T>, dim3((unsigned)cdiv64(totalE, 256)), dim3(256), 0, (hipStream_t)stream, in, out, idx,
-                       totalE, H, W, C / E, Ho, Wo, N, hwnc, bn);
+                       totalE, H, W, C / E, Ho, Wo, N, hwnc, bn, zwin);
     SSAD_CHECK_LAUNCH();
     return 0;
 }
@@ -528,6 +531,23 @@ extern "C" int ssad_bn_relu_maxpool_fwd_h(const void* z, const float* mean, cons
                                           void* stream) {
     SSAD_CHECK_ARG(mean && invstd && gamma && beta && idx, "null pointer");
     return maxpool_fwd_impl<hf>((const hf*)z, (hf*)out, idx, N, H, W, C, 0, stream, PoolBN{mean, invstd, gamma, beta});
+}
+
+// ... also writing zwin[N][Ho][Wo][C]: the RAW z of each window's winner.  The BatchNorm backward reduction of the stem then runs over the
+// POOLED tensors (sum over pixels of g and g * xhat = sum over windows of dpool * mask(zwin) and dpool * mask * xhat(zwin): every window
+// routes its gradient to exactly one pixel) -- 1/4 of the rows and no pass over the 128 x 128 z (ssad_bn_bwd_reduce_zmask on (dpool, zwin),
+// then ssad_pool_bn_relu_bwd_apply).
+extern "C" int ssad_bn_relu_maxpool_fwd_win(const float* z, const float* mean, const float* invstd, const float* gamma,
+                                            const float* beta, float* out, uint8_t* idx, float* zwin, int64_t N, int H, int W, int C,
+                                            void* stream) {
+    SSAD_CHECK_ARG(mean && invstd && gamma && beta && idx && zwin, "null pointer");
+    return maxpool_fwd_impl<float>(z, out, idx, N, H, W, C, 0, stream, PoolBN{mean, invstd, gamma, beta}, zwin);
+}
+extern "C" int ssad_bn_relu_maxpool_fwd_win_h(const void* z, const float* mean, const float* invstd, const float* gamma,
+                                              const float* beta, void* out, uint8_t* idx, void* zwin, int64_t N, int H, int W, int C,
+                                              void* stream) {
+    SSAD_CHECK_ARG(mean && invstd && gamma && beta && idx && zwin, "null pointer");
+    return maxpool_fwd_impl<hf>((const hf*)z, (hf*)out, idx, N, H, W, C, 0, stream, PoolBN{mean, invstd, gamma, beta}, (hf*)zwin);
 }
 
 extern "C" int ssad_maxpool3x3s2_fwd(const float* in, float* out, int64_t N, int H, int W, int C, int hwnc, void* stream) {

@@ -1094,6 +1094,39 @@ static int pool_bn_relu_bwd_impl(const uint8_t* idx, const T* dpool, const T* z,
     return 0;
 }
 
+// The apply pass alone: dbeta / dgamma are INPUTS (taken over the pooled tensors: ssad_bn_relu_maxpool_fwd_win, ssad_bn_bwd_reduce_zmask).
+template <typename T>
+static int pool_bn_relu_bwd_apply_impl(const uint8_t* idx, const T* dpool, const T* z, const float* mean, const float* invstd,
+                                       const float* gamma, const float* beta, const float* dbeta, const float* dgamma, T* dz, int64_t N,
+                                       int H, int W, int C, int64_t dpool_elems, void* stream) {
+    constexpr int E = Lane<T>::E;
+    SSAD_CHECK_ARG(idx && dpool && z && mean && invstd && gamma && beta && dbeta && dgamma && dz, "null pointer");
+    SSAD_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % E == 0 && C <= 1024 && 256 % (C / E) == 0, "bad shape");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    SSAD_CHECK_ARG(dpool_elems == N * Ho * Wo * C, "dpool / idx do not hold N x Ho x Wo x C elements for this z");
+    const int64_t R = N * H * W;
+    const int RL = 256 / (C / E);
+    const int64_t NB = N * ((H + 1) / 2) * ((W + 1) / 2);
+    int64_t nblk = cdiv64(R, (int64_t)RL * 32);
+    if (nblk > 2048) nblk = 2048;
+    const int64_t rows_per_block = cdiv64(NB, nblk);
+    hipLaunchKernelGGL((pool_bn_bwd_kernel<1, T>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, idx, dpool, z, mean, invstd, gamma,
+                       beta, dbeta, dgamma, dz, (double*)nullptr, R, H, W, C, Ho, Wo, rows_per_block);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int ssad_pool_bn_relu_bwd_apply(const uint8_t* idx, const float* dpool, const float* z, const float* mean, const float* invstd,
+                                           const float* gamma, const float* beta, const float* dbeta, const float* dgamma, float* dz,
+                                           int64_t N, int H, int W, int C, int64_t dpool_elems, void* stream) {
+    return pool_bn_relu_bwd_apply_impl<float>(idx, dpool, z, mean, invstd, gamma, beta, dbeta, dgamma, dz, N, H, W, C, dpool_elems, stream);
+}
+extern "C" int ssad_pool_bn_relu_bwd_apply_h(const uint8_t* idx, const void* dpool, const void* z, const float* mean, const float* invstd,
+                                             const float* gamma, const float* beta, const float* dbeta, const float* dgamma, void* dz,
+                                             int64_t N, int H, int W, int C, int64_t dpool_elems, void* stream) {
+    return pool_bn_relu_bwd_apply_impl<hf>(idx, (const hf*)dpool, (const hf*)z, mean, invstd, gamma, beta, dbeta, dgamma, (hf*)dz, N, H, W,
+                                           C, dpool_elems, stream);
+}
+
 extern "C" int ssad_pool_bn_relu_bwd(const uint8_t* idx, const float* dpool, const float* z, const float* mean,
                                      const float* invstd, const float* gamma, const float* beta, float* dbeta, float* dgamma,
                                      float* dz, int64_t N, int H, int W, int C, int64_t dpool_elems, double* workspace, void* stream) {

@@ -873,42 +873,59 @@ def bn_bwd_zmask(dy, z, mean, invstd, gamma, beta, dbeta, dgamma):
     return dz
 
 
-def bn_relu_maxpool_fwd(z, mean, invstd, gamma, beta):
-    """Training stem tail: pooled = maxpool3x3s2(relu(bn(z))) + argmax slots, without storing the activation."""
+def bn_relu_maxpool_fwd(z, mean, invstd, gamma, beta, winners=False):
+    """Training stem tail: pooled = maxpool3x3s2(relu(bn(z))) + argmax slots, without storing the activation.  winners: also the raw z of
+    each window's winner ([N][Ho][Wo][C]): pool_bn_relu_bwd then takes the BatchNorm reduction over the pooled tensors."""
     n, h, w, c = z.shape
     ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
     idx = torch.empty((n, ho, wo, c), device=z.device, dtype=torch.uint8)
-    if _is_h(z):
-        out = _newh((n, ho, wo, c), z)
-        _run("maxpool3x3s2_h16", 0.0, 2.0 * (z.numel() + out.numel()) + idx.numel(),
-             lambda: _hip.lib().ssad_bn_relu_maxpool_fwd_h(z.data_ptr(), _hip.ptr(mean), _hip.ptr(invstd), _hip.ptr(gamma),
-                                                           _hip.ptr(beta), out.data_ptr(), idx.data_ptr(), n, h, w, c, _hip.stream()))
-        return out, idx
-    out = _new((n, ho, wo, c), z)
-    _run("maxpool3x3s2", 0.0, 4.0 * (z.numel() + out.numel()) + idx.numel(),
-         lambda: _hip.lib().ssad_bn_relu_maxpool_fwd(_hip.ptr(z), _hip.ptr(mean), _hip.ptr(invstd), _hip.ptr(gamma),
-                                                     _hip.ptr(beta), _hip.ptr(out), idx.data_ptr(), n, h, w, c, _hip.stream()))
+    half = _is_h(z)
+    out = _newh((n, ho, wo, c), z) if half else _new((n, ho, wo, c), z)
+    zw = torch.empty_like(out) if winners else None
+    lib = _hip.lib()
+    eb = z.element_size()
+    if winners:
+        fn = lib.ssad_bn_relu_maxpool_fwd_win_h if half else lib.ssad_bn_relu_maxpool_fwd_win
+        _run("maxpool3x3s2_h16" if half else "maxpool3x3s2", 0.0, eb * (z.numel() + 2.0 * out.numel()) + idx.numel(),
+             lambda: fn(z.data_ptr(), _hip.ptr(mean), _hip.ptr(invstd), _hip.ptr(gamma), _hip.ptr(beta), out.data_ptr(), idx.data_ptr(),
+                        zw.data_ptr(), n, h, w, c, _hip.stream()))
+        return out, idx, zw
+    fn = lib.ssad_bn_relu_maxpool_fwd_h if half else lib.ssad_bn_relu_maxpool_fwd
+    _run("maxpool3x3s2_h16" if half else "maxpool3x3s2", 0.0, eb * (z.numel() + out.numel()) + idx.numel(),
+         lambda: fn(z.data_ptr(), _hip.ptr(mean), _hip.ptr(invstd), _hip.ptr(gamma), _hip.ptr(beta), out.data_ptr(), idx.data_ptr(), n, h, w, c,
+                    _hip.stream()))
     return out, idx
 
 
-def pool_bn_relu_bwd(idx, dpool, z, mean, invstd, gamma, beta, dbeta, dgamma):
-    """Training stem head of the backward pass: (idx, dpool, z) -> dz, filling dbeta / dgamma."""
+def pool_bn_relu_bwd(idx, dpool, z, mean, invstd, gamma, beta, dbeta, dgamma, zwin=None):
+    """Training stem head of the backward pass: (idx, dpool, z) -> dz, filling dbeta / dgamma.  zwin (bn_relu_maxpool_fwd(winners=True)):
+    the BatchNorm reduction runs over (dpool, zwin) -- a quarter of the rows, no pass over z -- and only the apply pass reads z."""
     n, h, w, c = z.shape
     ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
     assert tuple(dpool.shape) == (n, ho, wo, c) and tuple(idx.shape) == (n, ho, wo, c) and dpool.dtype == z.dtype, \
         f"pooled gradient {tuple(dpool.shape)} / slots {tuple(idx.shape)} do not belong to z {tuple(z.shape)}"
     dz = torch.empty_like(z)
-    ws = _colreduce_ws(n * h * w, c, z)
-    if _is_h(z):
-        _run("pool_bn_bwd_h16", 0.0, 2.0 * (3 * z.numel() + 2 * dpool.numel()),
-             lambda: _hip.lib().ssad_pool_bn_relu_bwd_h(idx.data_ptr(), dpool.data_ptr(), z.data_ptr(), _hip.ptr(mean), _hip.ptr(invstd),
-                                                        _hip.ptr(gamma), _hip.ptr(beta), _hip.ptr(dbeta), _hip.ptr(dgamma),
-                                                        dz.data_ptr(), n, h, w, c, dpool.numel(), ws.data_ptr(), _hip.stream()))
+    half = _is_h(z)
+    lib = _hip.lib()
+    eb = z.element_size()
+    if zwin is not None:
+        assert tuple(zwin.shape) == (n, ho, wo, c) and zwin.dtype == z.dtype and dpool.is_contiguous() and zwin.is_contiguous()
+        r = n * ho * wo
+        ws = _colreduce_ws(r, c, z)
+        red = lib.ssad_bn_bwd_reduce_zmask_h if half else lib.ssad_bn_bwd_reduce_zmask
+        _run("bn_bwd_reduce_h16" if half else "bn_bwd_reduce", 0.0, eb * 2.0 * dpool.numel(),
+             lambda: red(dpool.data_ptr(), zwin.data_ptr(), _hip.ptr(mean), _hip.ptr(invstd), _hip.ptr(gamma), _hip.ptr(beta), _hip.ptr(dbeta),
+                         _hip.ptr(dgamma), r, c, ws.data_ptr(), _hip.stream()))
+        app = lib.ssad_pool_bn_relu_bwd_apply_h if half else lib.ssad_pool_bn_relu_bwd_apply
+        _run("pool_bn_bwd_h16" if half else "pool_bn_bwd", 0.0, eb * (2.0 * z.numel() + dpool.numel()),
+             lambda: app(idx.data_ptr(), dpool.data_ptr(), z.data_ptr(), _hip.ptr(mean), _hip.ptr(invstd), _hip.ptr(gamma), _hip.ptr(beta),
+                         _hip.ptr(dbeta), _hip.ptr(dgamma), dz.data_ptr(), n, h, w, c, dpool.numel(), _hip.stream()))
         return dz
-    _run("pool_bn_bwd", 0.0, 4.0 * (3 * z.numel() + 2 * dpool.numel()),
-         lambda: _hip.lib().ssad_pool_bn_relu_bwd(idx.data_ptr(), _hip.ptr(dpool), _hip.ptr(z), _hip.ptr(mean), _hip.ptr(invstd),
-                                                  _hip.ptr(gamma), _hip.ptr(beta), _hip.ptr(dbeta), _hip.ptr(dgamma),
-                                                  _hip.ptr(dz), n, h, w, c, dpool.numel(), ws.data_ptr(), _hip.stream()))
+    ws = _colreduce_ws(n * h * w, c, z)
+    fn = lib.ssad_pool_bn_relu_bwd_h if half else lib.ssad_pool_bn_relu_bwd
+    _run("pool_bn_bwd_h16" if half else "pool_bn_bwd", 0.0, eb * (3.0 * z.numel() + 2.0 * dpool.numel()),
+         lambda: fn(idx.data_ptr(), dpool.data_ptr(), z.data_ptr(), _hip.ptr(mean), _hip.ptr(invstd), _hip.ptr(gamma), _hip.ptr(beta),
+                    _hip.ptr(dbeta), _hip.ptr(dgamma), dz.data_ptr(), n, h, w, c, dpool.numel(), ws.data_ptr(), _hip.stream()))
     return dz
 
 

@@ -203,6 +203,11 @@ class _Affine:
             self.eng.count_batch(bn)
         a = self.eng.arena
         self.z, self.y = z, None
+        self.zwin = None
+        if self.eng.sw_poolwin and torch.is_grad_enabled() and self.eng.param_grads and self.eng.trunk_grad:
+            # also the raw z of every window's winner: the backward pass takes the BatchNorm reduction over the pooled tensors
+            pooled, idx, self.zwin = ops.bn_relu_maxpool_fwd(z, self.mean, self.invstd, a.w(bn.weight), a.w(bn.bias), winners=True)
+            return pooled, idx
         return ops.bn_relu_maxpool_fwd(z, self.mean, self.invstd, a.w(bn.weight), a.w(bn.bias))
 
     def bwd_pool(self, idx, dpool, a0_shape):
@@ -214,7 +219,9 @@ class _Affine:
         pg = self.eng.param_grads
         dbeta = a.grad(bn.bias) if (bn.bias.requires_grad and pg) else torch.empty(64, device=dpool.device)
         dgamma = a.grad(bn.weight) if (bn.weight.requires_grad and pg) else torch.empty(64, device=dpool.device)
-        dz = ops.pool_bn_relu_bwd(idx, dpool, self.z, self.mean, self.invstd, a.w(bn.weight), a.w(bn.bias), dbeta, dgamma)
+        dz = ops.pool_bn_relu_bwd(idx, dpool.contiguous(), self.z, self.mean, self.invstd, a.w(bn.weight), a.w(bn.bias), dbeta, dgamma,
+                                  zwin=getattr(self, "zwin", None))
+        self.zwin = None
         if self.lin.weight.requires_grad and pg:
             with self.eng.wgrad_stream(dz, self.x):
                 ops.stem_wgrad(self.x, dz, a.grad(self.lin.weight))
@@ -545,6 +552,7 @@ class TrainEngine:
         self.sw_conv16w = os.environ.get("SSAD_CONV16W", "1") != "0"     # register-fed form of the same conv (csrc/conv16w.hip)
         self.sw_conv32w = os.environ.get("SSAD_CONV32W", "1") != "0"     # ... and its exact-fp32 instantiation (the fp32 step)
         self.sw_raw32 = os.environ.get("SSAD_RAW32", "1") != "0"         # fp32: bn1 + ReLU inside conv2's staging on every block it runs
+        self.sw_poolwin = os.environ.get("SSAD_POOLWIN", "1") != "0"     # stem: BatchNorm backward reduction over the pooled tensors
         self._packed = {}             # packed 3x3 filters, key (flip, f32): forward / input-gradient (flipped) tables, halves / floats
         self._packed_ready = {}
         self.h16 = False              # decided per forward (trunk BatchNorms in training mode, whole images of >= 64 x 64)
@@ -552,7 +560,7 @@ class TrainEngine:
 
     def switches(self):
         """Everything besides shapes that decides which launches a step consists of (hipGraph plan key)."""
-        return (self.bf16, self.param_grads, self.sw_c64, self.sw_relu_mask, self.sw_wgrad_halo, self.sw_stem16, self.sw_c64_16, self.sw_act16, self.sw_conv16, self.sw_conv16w, self.sw_conv32w, self.sw_raw32, self._side_on,
+        return (self.bf16, self.param_grads, self.sw_c64, self.sw_relu_mask, self.sw_wgrad_halo, self.sw_stem16, self.sw_c64_16, self.sw_act16, self.sw_conv16, self.sw_conv16w, self.sw_conv32w, self.sw_raw32, self.sw_poolwin, self._side_on,
                 os.environ.get("SSAD_WGRAD_HALO", "1") != "0", torch.is_grad_enabled())
 
     # ---- second stream for the weight gradients ----

@@ -169,6 +169,42 @@ def test_bn_pool_kernels(dev):
     assert torch.equal(ops.maxpool3x3s2_bwd_idx(idx, nh(dp), nh(a).shape).cpu(), nh(a.grad).cpu())
 
 
+@pytest.mark.parametrize("half", [False, True])
+def test_stem_reduction_over_pooled_tensors(dev, half):
+    """BatchNorm + ReLU + max-pool of the stem, backward: the reduction over (dpool, z of each window's winner) -- a quarter of the rows,
+    no pass over z -- gives the parameter gradients and the dz of the two-pass form over z (same sums in another order), and both are
+    autograd's; odd map sizes, ties on ReLU zeros, fp32 and half tensors."""
+    from self_supervised import ops
+    g = torch.Generator().manual_seed(5)
+    z = (torch.randn(5, 64, 21, 18, generator=g) * 2 - 0.3).requires_grad_()
+    bn = torch.nn.BatchNorm2d(64)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(64, generator=g) + 0.5); bn.bias.copy_(torch.randn(64, generator=g) * 0.3)
+    p = F.max_pool2d(F.relu(bn(z)), 3, 2, 1)
+    dp = torch.randn(p.shape, generator=g)
+    p.backward(dp)
+    nh = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().to(dev)
+    zz, dpp = nh(z), nh(dp)
+    if half:
+        zz, dpp = zz.half(), dpp.half()
+    rm, rv = torch.zeros(64, device=dev), torch.ones(64, device=dev)
+    mean, invstd = ops.bn_stats(zz, 64, bn.eps, 0.1, rm, rv)
+    ga, be = bn.weight.detach().to(dev), bn.bias.detach().to(dev)
+    pooled, idx = ops.bn_relu_maxpool_fwd(zz, mean, invstd, ga, be)
+    pooled2, idx2, zwin = ops.bn_relu_maxpool_fwd(zz, mean, invstd, ga, be, winners=True)
+    assert torch.equal(pooled, pooled2) and torch.equal(idx, idx2)
+    # the winner's raw value: relu(bn(zwin)) is the pooled value (up to the kernel's fused multiply-add / the half rounding)
+    act = torch.relu((zwin.float() - mean) * invstd * ga + be)
+    assert (act - pooled.float()).abs().max().item() <= (2e-3 if half else 2e-6) * max(1.0, pooled.float().abs().max().item())
+    db1, dg1, db2, dg2 = (torch.empty(64, device=dev) for _ in range(4))
+    dz1 = ops.pool_bn_relu_bwd(idx, dpp, zz, mean, invstd, ga, be, db1, dg1)
+    dz2 = ops.pool_bn_relu_bwd(idx, dpp, zz, mean, invstd, ga, be, db2, dg2, zwin=zwin)
+    assert rel_err(db2, db1) < 1e-6 and rel_err(dg2, dg1) < 1e-6
+    assert rel_err(dz2, dz1) < (2e-3 if half else 1e-6)
+    if not half:
+        assert rel_err(db2, bn.bias.grad) < 1e-5 and rel_err(dg2, bn.weight.grad) < 1e-5 and rel_err(dz2, nh(z.grad)) < 2e-5
+
+
 def test_stem_wgrad_kernel(dev):
     """conv1 weight gradient straight from the NCHW image vs torch autograd (incl. ragged tiles and the <64 px resize)."""
     from self_supervised import ops
