@@ -164,6 +164,9 @@ int ssad_bn_small_bwd(const float* dy, const float* z, const float* mean, const 
  * SSAD_LINEAR_SMALL=0 in the environment switches the range off (max_rows 0). */
 int ssad_linear_small_max_rows(void);
 int ssad_linear_wgrad_small(const float* dy, const float* x, float* dw, int64_t M, int Cin, int Cout, int accumulate, void* stream);
+/* the same with its operands rounded to bf16 (round = 1) / fp16 (round = 2) while loaded: the precision-16 step's linear layers */
+int ssad_linear_wgrad_small_r(const float* dy, const float* x, float* dw, int64_t M, int Cin, int Cout, int accumulate, int round,
+                              void* stream);
 /* Replaces autograd's conv2d/linear weight-gradient.  Two launches: partial tiles per pixel split into
  * slab[splits][Cout][KH*KW*Cin], then a fixed-order sum written as OIHW (to_oihw=1, checkpoint layout) or OHWI.
  * Guard convention (round 5): wherever an entry point reads a SECOND tensor over extents it derives from the first one's (dy from

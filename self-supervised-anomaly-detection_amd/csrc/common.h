@@ -50,7 +50,8 @@ int ssad_bn_finalize_partials(const double* partial, int nblk, int64_t R, int C,
 // 1 x 1 layers on 1 x 1 maps there when ssad_linear_small_ok says so
 bool ssad_linear_small_ok(const void* a, const void* b, int64_t M, int K);
 int ssad_linear_small_launch(const float* a, const float* b, float* y, const float* scale, const float* shift,
-                             const float* residual, int relu, int M, int K, int N, double* stats, int* stat_rows, void* stream);
+                             const float* residual, int relu, int M, int K, int N, double* stats, int* stat_rows, void* stream,
+                             int round = 0);      // round: operands rounded to bf16 (1) / fp16 (2) as they are loaded
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

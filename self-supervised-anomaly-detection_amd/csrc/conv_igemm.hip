@@ -1103,9 +1103,10 @@ int conv_fwd_impl(const float* in, const float* w_ohwi, float* out, const float*
     SSAD_CHECK_ARG(in && w_ohwi && out, "null pointer");
     SSAD_CHECK_ARG(!io16 || (bf16 == 2 && !hwnc && Cout % 4 == 0), "half tensors: fp16 operands, NHWC, Cout % 4 == 0");
     SSAD_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "empty shape");
-    if (!bf16 && !hwnc && KH == 1 && KW == 1 && H == 1 && W == 1 && stride == 1 && pad == 0 &&
-        ssad_linear_small_ok(in, w_ohwi, N, Cin))          // a linear layer over a training batch's few rows
-        return ssad_linear_small_launch(in, w_ohwi, out, scale, shift, residual, relu, (int)N, Cin, Cout, stats, stat_rows, stream);
+    if ((bf16 == 0 || bf16 == 1 || bf16 == 2) && !io16 && !hwnc && KH == 1 && KW == 1 && H == 1 && W == 1 && stride == 1 && pad == 0 &&
+        ssad_linear_small_ok(in, w_ohwi, N, Cin))          // a linear layer over a training batch's few rows (16-bit modes: operands
+                                                           // rounded while loaded, the same arithmetic as the 16-bit MFMA)
+        return ssad_linear_small_launch(in, w_ohwi, out, scale, shift, residual, relu, (int)N, Cin, Cout, stats, stat_rows, stream, bf16);
     SSAD_CHECK_ARG(Cin % KALIGN == 0, "Cin must be a multiple of 32");
     SSAD_CHECK_ARG(KH > 0 && KW > 0 && stride > 0 && pad >= 0 && KH * KW <= 32, "bad filter geometry (<= 32 taps)");
     ConvParams p;
@@ -1239,9 +1240,9 @@ static int dgrad_impl(const float* dy, const float* w_flipT, float* dx, const fl
     SSAD_CHECK_ARG(dy && w_flipT && dx, "null pointer");
     SSAD_CHECK_ARG(!io16 || (bf16 == 2 && !res_mask && Cin % 4 == 0), "half tensors: fp16 operands, no residual mask, Cin % 4 == 0");
     SSAD_CHECK_ARG(N > 0 && Hy > 0 && Wy > 0 && Hx > 0 && Wx > 0 && Cin > 0 && Cout > 0, "empty shape");
-    if (!bf16 && !res_mask && KH == 1 && KW == 1 && Hy == 1 && Wy == 1 && Hx == 1 && Wx == 1 && stride == 1 && pad == 0 &&
-        ssad_linear_small_ok(dy, w_flipT, N, Cout))        // dx[M][Cin] = dy[M][Cout] . w_flipT[Cin][Cout]^T
-        return ssad_linear_small_launch(dy, w_flipT, dx, nullptr, nullptr, residual, 0, (int)N, Cout, Cin, nullptr, nullptr, stream);
+    if ((bf16 == 0 || bf16 == 1 || bf16 == 2) && !io16 && !res_mask && KH == 1 && KW == 1 && Hy == 1 && Wy == 1 && Hx == 1 && Wx == 1 &&
+        stride == 1 && pad == 0 && ssad_linear_small_ok(dy, w_flipT, N, Cout))        // dx[M][Cin] = dy[M][Cout] . w_flipT[Cin][Cout]^T
+        return ssad_linear_small_launch(dy, w_flipT, dx, nullptr, nullptr, residual, 0, (int)N, Cout, Cin, nullptr, nullptr, stream, bf16);
     SSAD_CHECK_ARG(Cout % KALIGN == 0, "Cout (the contraction) must be a multiple of 32");
     SSAD_CHECK_ARG(KH > 0 && KW > 0 && pad >= 0 && pad < KH && pad < KW, "bad filter geometry");
     SSAD_CHECK_ARG(stride == 1 || stride == 2, "stride 1 or 2");

@@ -40,6 +40,14 @@ __device__ __forceinline__ void spill_tile(float* red, const f32x16& acc, int la
 
 constexpr int GW = 8;         // waves of a forward / input-gradient workgroup: K = 512 is one batch of eight chunks per wave
 
+// RND: operands rounded to bf16 (1) / fp16 (2) as they are loaded -- the precision-16 step's linear layers (autocast runs them on 16-bit
+// operands with fp32 accumulation; products of two 16-bit values are exact in fp32, so the fp32 MFMA over rounded operands is that
+// arithmetic in another summation order).  Round 5: these layers ran on the 16-bit implicit GEMM before, 21-28 us per launch against 7.5.
+template <int RND> __device__ __forceinline__ float rnd16(float x) { return x; }
+template <> __device__ __forceinline__ float rnd16<1>(float x) { return (float)(__bf16)x; }
+template <> __device__ __forceinline__ float rnd16<2>(float x) { return (float)(hf)x; }
+
+template <int RND>
 __global__ __launch_bounds__(64 * GW) void small_gemm_kernel(SmallGemm p) {
     __shared__ float red[GW][32 * RP];
     __shared__ float cs[2][2 * GW][32];
@@ -67,7 +75,7 @@ __global__ __launch_bounds__(64 * GW) void small_gemm_kernel(SmallGemm p) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc = mfma32(av[u][e], bv[u][e], acc);
+            for (int e = 0; e < 4; ++e) acc = mfma32(rnd16<RND>(av[u][e]), rnd16<RND>(bv[u][e]), acc);
     }
     spill_tile(red[w], acc, lane);
     __syncthreads();
@@ -108,6 +116,7 @@ __global__ __launch_bounds__(64 * GW) void small_gemm_kernel(SmallGemm p) {
 
 // dw[O][K] (+)= sum_m dz[m][o] * x[m][k]: lane (r, h) of a pair step supplies dz[2q + h][o0 + r] and x[2q + h][k0 + r] -- two
 // 128-byte rows per operand per MFMA; wave w takes the row pairs q = w, w + 4, ...
+template <int RND>
 __global__ __launch_bounds__(256) void small_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x,
                                                            float* __restrict__ dw, int M, int O, int K, int accumulate) {
     __shared__ float red[4][32 * RP];
@@ -130,7 +139,7 @@ __global__ __launch_bounds__(256) void small_wgrad_kernel(const float* __restric
             bv[u] = ok && bok ? x[(size_t)m * K + k0 + r] : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) acc = mfma32(av[u], bv[u], acc);
+        for (int u = 0; u < U; ++u) acc = mfma32(rnd16<RND>(av[u]), rnd16<RND>(bv[u]), acc);
     }
     spill_tile(red[w], acc, lane);
     __syncthreads();
@@ -162,22 +171,34 @@ bool ssad_linear_small_ok(const void* a, const void* b, int64_t M, int K) {
 }
 
 int ssad_linear_small_launch(const float* a, const float* b, float* y, const float* scale, const float* shift,
-                             const float* residual, int relu, int M, int K, int N, double* stats, int* stat_rows, void* stream) {
+                             const float* residual, int relu, int M, int K, int N, double* stats, int* stat_rows, void* stream, int round) {
     SmallGemm p{a, b, y, scale, shift, residual, stats, M, K, N, relu};
     dim3 grid((N + 31) / 32, (M + 31) / 32);
-    hipLaunchKernelGGL(small_gemm_kernel, grid, dim3(64 * GW), 0, (hipStream_t)stream, p);
+    if (round == 2) hipLaunchKernelGGL(small_gemm_kernel<2>, grid, dim3(64 * GW), 0, (hipStream_t)stream, p);
+    else if (round == 1) hipLaunchKernelGGL(small_gemm_kernel<1>, grid, dim3(64 * GW), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(small_gemm_kernel<0>, grid, dim3(64 * GW), 0, (hipStream_t)stream, p);
     if (stat_rows) *stat_rows = (int)grid.y;
     SSAD_CHECK_LAUNCH();
     return 0;
 }
 
 // Weight gradient of a linear layer over M <= ssad_linear_small_max_rows() rows: dw[Cout][Cin] (+)= dy[M][Cout]^T x[M][Cin].
-extern "C" int ssad_linear_wgrad_small(const float* dy, const float* x, float* dw, int64_t M, int Cin, int Cout, int accumulate,
-                                       void* stream) {
+// round: 0 exact fp32; 1 / 2: operands rounded to bf16 / fp16 while loaded (the precision-16 step's linear layers).
+extern "C" int ssad_linear_wgrad_small_r(const float* dy, const float* x, float* dw, int64_t M, int Cin, int Cout, int accumulate,
+                                         int round, void* stream) {
     SSAD_CHECK_ARG(dy && x && dw, "null pointer");
     SSAD_CHECK_ARG(M > 0 && M <= max_rows() && Cin > 0 && Cout > 0, "row count outside the small-batch range");
+    SSAD_CHECK_ARG(round >= 0 && round <= 2, "round: 0 (fp32), 1 (bf16 operands) or 2 (fp16 operands)");
     dim3 grid((Cin + 31) / 32, (Cout + 31) / 32);
-    hipLaunchKernelGGL(small_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, x, dw, (int)M, Cout, Cin, accumulate);
+    hipStream_t st = (hipStream_t)stream;
+    if (round == 2) hipLaunchKernelGGL(small_wgrad_kernel<2>, grid, dim3(256), 0, st, dy, x, dw, (int)M, Cout, Cin, accumulate);
+    else if (round == 1) hipLaunchKernelGGL(small_wgrad_kernel<1>, grid, dim3(256), 0, st, dy, x, dw, (int)M, Cout, Cin, accumulate);
+    else hipLaunchKernelGGL(small_wgrad_kernel<0>, grid, dim3(256), 0, st, dy, x, dw, (int)M, Cout, Cin, accumulate);
     SSAD_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int ssad_linear_wgrad_small(const float* dy, const float* x, float* dw, int64_t M, int Cin, int Cout, int accumulate,
+                                       void* stream) {
+    return ssad_linear_wgrad_small_r(dy, x, dw, M, Cin, Cout, accumulate, 0, stream);
 }

@@ -47,6 +47,7 @@ SIGNATURES = {
     "ssad_bn_small_bwd": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_fp],
     "ssad_linear_small_max_rows": [],
     "ssad_linear_wgrad_small": [_c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_linear_wgrad_small_r": [_c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_fp],
     "ssad_wgrad_splits": [_c_l, _c_i, _c_i, _c_i, _c_i],
     "ssad_wgrad_splits_bf16": [_c_l, _c_i, _c_i, _c_i, _c_i],
     "ssad_conv_wgrad": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_l, _c_fp],

@@ -680,11 +680,13 @@ def conv_wgrad(dy, x, dw_out, kh, kw, stride, pad, kreal=None, to_oihw=False, ac
              lambda: lib.ssad_wgrad_reduce(_hip.ptr(slab), _hip.ptr(dw_out), splits, cout, kh * kw * cin, kh, kw, cin, int(to_oihw),
                                            int(accumulate), _hip.stream()))
         return dw_out
-    if (not bf16 and kreal is None and kh == 1 and kw == 1 and h == 1 and w == 1 and m <= lib.ssad_linear_small_max_rows()):
-        # linear layer over a training batch's rows: one launch straight into the gradient (OIHW == OHWI for 1 x 1)
-        _run("wgrad_f32", 2.0 * m * cout * cin, 4.0 * (dy.numel() + x.numel() + cout * cin),
-             lambda: lib.ssad_linear_wgrad_small(_hip.ptr(dy), _hip.ptr(x), _hip.ptr(dw_out), m, cin, cout, int(accumulate),
-                                                 _hip.stream()))
+    if (int(bf16) in (0, 1, 2) and not _is_h(dy) and kreal is None and kh == 1 and kw == 1 and h == 1 and w == 1
+            and m <= lib.ssad_linear_small_max_rows()):
+        # linear layer over a training batch's rows: one launch straight into the gradient (OIHW == OHWI for 1 x 1); the 16-bit modes
+        # round the operands while they are loaded
+        _run("wgrad_f32" if not bf16 else "wgrad_small16", 2.0 * m * cout * cin, 4.0 * (dy.numel() + x.numel() + cout * cin),
+             lambda: lib.ssad_linear_wgrad_small_r(_hip.ptr(dy), _hip.ptr(x), _hip.ptr(dw_out), m, cin, cout, int(accumulate), int(bf16),
+                                                   _hip.stream()))
         return dw_out
     halo = (lib.ssad_wgrad3x3_halo_ok(cin, cout, kh, kw, stride, pad)
             if not bf16 and kreal is None and os.environ.get("SSAD_WGRAD_HALO", "1") != "0" else 0)

@@ -462,7 +462,7 @@ class _Affine:
         if need_dx:
             w = self.weight()
             dzz, wt = dz, w
-            small = (not bf and not self.is_conv and cout % 4 == 0 and w.data_ptr() % 16 == 0 and
+            small = (int(bf) in (0, 1, 2) and not self.is_conv and cout % 4 == 0 and w.data_ptr() % 16 == 0 and
                      dz.numel() // cout <= _hip.lib().ssad_linear_small_max_rows())
             if cout % 32 and not small:         # classifier: pad the contraction to a multiple of 32 with zeros (the small-batch
                                                 # linear kernel takes any multiple of 4)
