@@ -548,6 +548,14 @@ int ssad_conv3x3_fw(const float* in, const float* w_packed, float* out, const fl
                     const float* tr_mean, const float* tr_invstd, const float* tr_gamma, const float* tr_beta, float* emit, int64_t N,
                     int H, int W, int Cin, int Cout, double* stats_ws, float eps, float momentum, float* mean, float* invstd,
                     float* running_mean, float* running_var, void* stream);
+/* Inference form of ssad_conv3x3_fw (the layer1 convs of the patch-scoring pass, models.py:224 in eval mode, replacing ssad_conv3x3_c64_eval
+ * on launches that fill the chip): out = act(conv(in) + shift (+ residual)); the folded BatchNorm's SCALE goes into the packed filter
+ * (ssad_conv3x3_fw_pack_scaled: w[o][..] * scale[o], fragment order), its shift is added in the epilogue, the residual (NHWC) by the matrix
+ * cores.  16 x 16 maps of 64 channels run two maps per tile.  out_hwnc: output written position-major [H][W][N][C]. */
+int ssad_conv3x3_fw_eval_ok(int64_t N, int H, int W, int Cin, int Cout);
+int ssad_conv3x3_fw_pack_scaled(const float* w_ohwi, const float* scale, float* dst, int Cout, int Cin, void* stream);
+int ssad_conv3x3_fw_eval(const float* in, const float* w_packed, float* out, const float* shift, const float* residual, int relu, int64_t N,
+                         int H, int W, int Cin, int Cout, int out_hwnc, void* stream);
 /* Weight gradient of the 3 x 3 / pad 1 convolutions, stride 1 AND 2, over half tensors (csrc/wgrad16.hip): tiles go to LDS as they lie
  * in memory and the [pixel][channel] -> [channel][pixel] transpose the matrix instruction needs happens in the fragment reads (eight
  * 2-byte LDS reads per operand), so no staging waves, no conversion; same slab contract as ssad_conv_wgrad3x3_halo16:

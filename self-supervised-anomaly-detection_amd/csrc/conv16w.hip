@@ -44,6 +44,11 @@ struct HWParams {
     const float* tr_invstd;
     const float* tr_gamma;
     const float* tr_beta;
+    const float* shift;      // optional (float): INFERENCE epilogue out = act(acc + shift[c]) -- the folded BatchNorm's shift, its scale
+                             // folded into the packed filter (ssad_conv3x3_fw_pack_scaled); no statistics
+    int relu;                // ... with act = ReLU
+    int64_t os_n;            // (float) element strides of the output / residual tensors: image, row, pixel (NHWC: H W C, W C, C;
+    int os_y, os_x;          //  position-major [H][W][N][C]: C, W N C, N C)
     T* emit;                 // optional (with a transform): the transformed input, written once (by channel slab 0)
     double* stats;           // optional [gridDim.x][2][Cout]
     int N, H, W, Cin, Cout;
@@ -65,7 +70,8 @@ __device__ __forceinline__ f32x16 mma_frag(f32x4 a, f32x4 b, f32x16 c) {
 // 128 pixels x 64 channels each, four stager waves.  Tile: WN = 2: a 16 x 16 block (18 x 18 halo), or -- TW8, 8 x 8 maps -- four
 // consecutive images, each with its 10 x 10 halo; WN = 1 (the 64-channel layer): 16 rows x 32 columns (18 x 34 halo).
 // CK: input channels per chunk (64; 32 where two halo stages of 64 channels would not fit the LDS).
-template <typename T, int WN, bool TW8, int CK>
+// TWP (WN = 1): a tile is TWO consecutive 16 x 16 maps, each with its 18 x 18 halo (the 16 x 16 x 64 maps of the patch-scoring pass).
+template <typename T, int WN, bool TW8, int CK, bool TWP = false>
 __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
     constexpr bool F32 = std::is_same<T, float>::value;
     constexpr int E = 16 / (int)sizeof(T);             // elements per 16-byte piece (8 halves / 4 floats)
@@ -73,13 +79,13 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
     constexpr int DB = F32 ? 3 : 6;                    // filter fragments are requested DB steps ahead (an fp32 step is 32 MFMAs of 64 cycles)
     using frag_t = typename std::conditional<F32, f32x4, f16x8>::type;
     constexpr int WM = 4 / WN;
-    constexpr int TWX = WN == 1 ? 32 : 16;             // tile width in pixels (not TW8)
+    constexpr int TWX = (WN == 1 && !TWP) ? 32 : 16;   // tile width in pixels (not TW8)
     constexpr int LDP = CK + E;                        // elements per LDS halo row (16-byte reads of 16 consecutive pixels: no conflicts)
     constexpr int PPR = CK / E;                        // 16-byte pieces per halo pixel
     constexpr int KS = CK / KST;                       // steps (one fragment deep) per tap
     constexpr int SPC = 9 * KS;                        // steps per chunk
     constexpr int HW_ = TW8 ? 10 : TWX + 2;
-    constexpr int NHP = TW8 ? 400 : 18 * HW_;
+    constexpr int NHP = TW8 ? 400 : (TWP ? 2 : 1) * 18 * HW_;
     constexpr int NMW = 4;
     constexpr int SL = 256;                            // stager lanes: one stager wave beside each matrix wave (their instructions
                                                        // delay that wave, and the slowest wave sets the pace at the barrier)
@@ -89,6 +95,7 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
     constexpr int NT = 512;
     static_assert(SPC % DB == 0 && SPC % 2 == 0, "ring / double-buffer periods must divide a chunk");
     static_assert(!(TW8 && WN == 1), "8 x 8 maps: 128 output channels per workgroup");
+    static_assert(!TWP || (WN == 1 && !TW8), "two-map tiles: the 64-channel form");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     T* halo = (T*)lds;                                 // [2][NHP][LDP]
     float* trp = (float*)(halo + 2 * HALO_H);          // [4][Cin]
@@ -142,11 +149,12 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
                 hyx[q] = (unsigned)(hp >> 6);
                 inner |= 1u << q;
             } else {
-                const int hy = hp / HW_, hx = hp - HW_ * hy;
-                goff[q] = (unsigned)(((hy * p.W + hx) * p.Cin + piece * E) * sizeof(T));
-                goffr[q] = (unsigned)(((hy * p.W + hx) * p.Cout + piece * E) * sizeof(T));
+                const int img = TWP ? hp / (18 * HW_) : 0, hq = hp - img * 18 * HW_;
+                const int hy = hq / HW_, hx = hq - HW_ * hy;
+                goff[q] = (unsigned)((((img * p.H + hy) * p.W + hx) * p.Cin + piece * E) * sizeof(T));
+                goffr[q] = (unsigned)((((img * p.H + hy) * p.W + hx) * p.Cout + piece * E) * sizeof(T));
                 loff[q] = (unsigned)((hp * LDP + piece * E) * sizeof(T));
-                hyx[q] = (unsigned)(hy << 8 | hx);
+                hyx[q] = (unsigned)(img << 16 | hy << 8 | hx);
                 if (hy >= 1 && hy <= 16 && hx >= 1 && hx <= TWX) inner |= 1u << q;
             }
         }
@@ -170,6 +178,10 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
                 y0 = x0 = 0;
                 nimg = p.N - (int)(4 * tile);               // images of this tile that exist
                 base = (int64_t)(4 * tile) * 64 * C + c0;
+            } else if (TWP) {
+                y0 = x0 = 0;
+                nimg = p.N - (int)(2 * tile);
+                base = (((int64_t)(2 * tile) * p.H - 1) * p.W - 1) * C + c0;
             } else {
                 const int n0 = (int)(tile / tpi);
                 const int rem = (int)(tile - (int64_t)n0 * tpi);
@@ -191,7 +203,8 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
                 bool ok = (valid >> q) & 1u;
                 if (res) ok = ok && ((inner >> q) & 1u);   // only the centre tap reads a residual fill
                 if (TW8) ok = ok && (int)hyx[q] < nimg;
-                else ok = ok && (unsigned)(y0 - 1 + (int)(hyx[q] >> 8)) < (unsigned)p.H && (unsigned)(x0 - 1 + (int)(hyx[q] & 255u)) < (unsigned)p.W;
+                else ok = ok && (unsigned)(y0 - 1 + (int)((hyx[q] >> 8) & 255u)) < (unsigned)p.H && (unsigned)(x0 - 1 + (int)(hyx[q] & 255u)) < (unsigned)p.W
+                          && (int)(hyx[q] >> 16) < nimg;
                 u32x4 v = {0u, 0u, 0u, 0u};
                 if (ok && !(CONV16W_ABL & 2)) v = *(const u32x4*)(src + (res ? goffr[q] : goff[q]));
                 reg[SET][q] = v;
@@ -285,13 +298,14 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
     const int wm = wave / WN, wn = wave % WN;
     const int co0 = blockIdx.y * (64 * WN) + wn * 64;          // first output channel of this wave
     // rows / columns of the tile this wave's 128 pixels start at (TW8: the wave's first image)
-    const int wrow = TW8 ? 0 : (WN == 1 ? 8 * (wm >> 1) : 8 * wm), wcol = (!TW8 && WN == 1) ? 16 * (wm & 1) : 0;
+    const int wrow = TW8 ? 0 : (WN == 1 ? 8 * (wm >> 1) : 8 * wm), wcol = (!TW8 && WN == 1 && !TWP) ? 16 * (wm & 1) : 0;
+    const int wimg = TWP ? (wm & 1) : 0;                       // TWP: the wave's map of the tile's two
 
     int abase[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         if (TW8) abase[m] = ((2 * wm + (m >> 1)) * 100 + (4 * (m & 1) + (r >> 3)) * 10 + (r & 7)) * LDP + E * h;
-        else abase[m] = ((wrow + 2 * m + (r >> 4)) * HW_ + wcol + (r & 15)) * LDP + E * h;
+        else abase[m] = (wimg * 18 * HW_ + (wrow + 2 * m + (r >> 4)) * HW_ + wcol + (r & 15)) * LDP + E * h;
     }
     const int KB = p.Cin / KST;                                // fragments (64 lanes x 16 bytes = 64 E elements) per (channel tile, tap)
     const T* bptr[2];
@@ -337,7 +351,8 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
         for (int d = 0; d < DB; ++d) load_b(0, d, d);
     }
     // this lane's share of an output address, in bytes: pixel column 4 h of the wave's first row, channel r of the wave's first 32
-    const unsigned lane_off = (unsigned)(((wrow * p.W + wcol + 4 * h) * p.Cout + wn * 64 + r) * sizeof(T));
+    const unsigned lane_off = F32 ? (unsigned)((wrow * p.os_y + (wcol + 4 * h) * p.os_x + wn * 64 + r) * sizeof(T))
+                                  : (unsigned)(((wrow * p.W + wcol + 4 * h) * p.Cout + wn * 64 + r) * sizeof(T));
     typedef hf h2 __attribute__((ext_vector_type(2)));
     __syncthreads();                                       // fill 0 is staged
 
@@ -440,15 +455,21 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
             continue;
         }
         int64_t torg;                                      // first element of the tile (TW8: of image 4 tile), this workgroup's slab
+        const int rowst = F32 ? p.os_y : p.W * p.Cout;     // (float: output strides are parameters -- NHWC or position-major)
+        const int pixst = F32 ? p.os_x : p.Cout;
+        const int64_t imgst = F32 ? p.os_n : (int64_t)p.H * p.W * p.Cout;
+        bool wave_ok = true;
         if (TW8) {
-            torg = (int64_t)(4 * tile) * 64 * p.Cout;
+            torg = (int64_t)(4 * tile) * imgst;
+        } else if (TWP) {
+            torg = (int64_t)(2 * tile + wimg) * imgst;
+            wave_ok = (int)(2 * tile) + wimg < p.N;
         } else {
             const int n0 = (int)(tile / tpi);
             const int rem = (int)(tile - (int64_t)n0 * tpi);
-            torg = (((int64_t)n0 * p.H + (rem / p.tiles_x) * 16) * p.W + (rem % p.tiles_x) * TWX) * p.Cout;
+            torg = (int64_t)n0 * imgst + (int64_t)((rem / p.tiles_x) * 16) * rowst + (int64_t)((rem % p.tiles_x) * TWX) * pixst;
         }
         torg += blockIdx.y * (64 * WN);
-        const int rowst = p.W * p.Cout;
         float fs[2] = {0.f, 0.f}, fq[2] = {0.f, 0.f};
         const h2 ones = {(hf)1.f, (hf)1.f};
         // laundered per tile: the 128 per-register offsets below are loop invariants, and hoisted out of the tile loop they are kept
@@ -465,25 +486,34 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
             bool ok = true;
             if (TW8) {
                 ok = (int)(4 * tile) + 2 * wm + (m >> 1) < p.N;
-                moff = torg + ((int64_t)(2 * wm + (m >> 1)) * 64 + 4 * (m & 1) * 8) * p.Cout;
+                moff = torg + (int64_t)(2 * wm + (m >> 1)) * imgst + (int64_t)(4 * (m & 1)) * rowst;
             } else {
+                ok = wave_ok;
                 moff = torg + (int64_t)(2 * m) * rowst;
             }
             if (!ok) continue;
             char* const ob = (char*)(p.out + moff);
             if constexpr (F32) {
                 // exact-fp32 step: values stored as they are, statistics in double per value (as the other fp32 kernels take them;
-                // an fp32 tile is ~300 k cycles of matrix work, its 128 conversions do not show)
+                // an fp32 tile is ~300 k cycles of matrix work, its 128 conversions do not show).  Inference (p.shift): the folded
+                // BatchNorm's shift and the ReLU instead, no statistics.
+                float sh[2] = {0.f, 0.f};
+                if (p.shift) { sh[0] = p.shift[co0 + r]; sh[1] = p.shift[co0 + 32 + r]; }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int eo = TW8 ? (e >> 2) * rowst + (e & 3) * p.Cout : (e >> 3) * rowst + ((e & 3) + 8 * ((e >> 2) & 1)) * p.Cout;
+                    const int eo = TW8 ? (e >> 2) * rowst + (e & 3) * pixst : (e >> 3) * rowst + ((e & 3) + 8 * ((e >> 2) & 1)) * pixst;
                     const unsigned o0 = lo + 4u * (unsigned)eo;
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        const float v = acc[m][j][e];
+                        float v = acc[m][j][e];
+                        if (p.shift) {
+                            v += sh[j];
+                            if (p.relu) v = fmaxf(v, 0.f);
+                        } else {
+                            st0[j] += (double)v;
+                            st1[j] += (double)v * (double)v;
+                        }
                         *(float*)(ob + o0 + 128 * j) = v;
-                        st0[j] += (double)v;
-                        st1[j] += (double)v * (double)v;
                     }
                 }
             } else {
@@ -540,7 +570,8 @@ struct PackTable {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void pack_hw_kernel(const float* __restrict__ src, T* __restrict__ dst, PackTable t) {
+__global__ __launch_bounds__(256) void pack_hw_kernel(const float* __restrict__ src, T* __restrict__ dst, PackTable t,
+                                                      const float* __restrict__ oscale = nullptr) {
     constexpr int E = 16 / (int)sizeof(T), KST = 2 * E;
     using frag_t = typename std::conditional<std::is_same<T, float>::value, f32x4, f16x8>::type;
     int k = 0;
@@ -562,13 +593,13 @@ __global__ __launch_bounds__(256) void pack_hw_kernel(const float* __restrict__ 
         // plain: this conv's OHWI filter [O][9][I].  flip: this conv is the input gradient of a conv whose filter is [I][9][O]:
         // its weight (o, tap, i) is that filter's (i, 8 - tap, o)
         const float x = flip ? w[((int64_t)(i0 + j) * 9 + (8 - tap)) * O + o] : w[((int64_t)o * 9 + tap) * I + i0 + j];
-        v[j] = (T)x;
+        v[j] = (T)(oscale ? x * oscale[o] : x);          // inference: the folded BatchNorm's scale of output channel o
     }
     *(frag_t*)(dst + t.e[k][1] + piece * E) = v;
 }
 
 struct GeoW {
-    bool tw8, ck32;
+    bool tw8, ck32, twp;
     int tiles_y, tiles_x, wn, gx, gy;
     int64_t ntiles;
 };
@@ -578,9 +609,10 @@ static GeoW geometry_w(int64_t N, int H, int W, int Cout) {
     g.tw8 = H == 8 && W == 8;
     g.wn = Cout % 128 == 0 ? 2 : 1;
     g.ck32 = g.wn == 1;                   // 16 x 32 tiles: two 18 x 34 halo stages of 64 channels would not fit the LDS
+    g.twp = g.wn == 1 && H == 16 && W == 16;               // 16 x 16 maps of 64 channels: two maps per tile
     g.tiles_y = g.tw8 ? 1 : H / 16;
     g.tiles_x = g.tw8 ? 1 : W / (g.wn == 1 ? 32 : 16);
-    g.ntiles = g.tw8 ? (N + 3) / 4 : N * g.tiles_y * g.tiles_x;
+    g.ntiles = g.tw8 ? (N + 3) / 4 : g.twp ? (N + 1) / 2 : N * g.tiles_y * g.tiles_x;
     g.gy = Cout / (64 * g.wn);
     static const int slots = getenv("SSAD_CONV16W_WGS") ? atoi(getenv("SSAD_CONV16W_WGS")) : 256;      // one workgroup per CU
     int64_t gx = slots / g.gy;
@@ -591,12 +623,14 @@ static GeoW geometry_w(int64_t N, int H, int W, int Cout) {
 }
 
 // bytes of the two halo stages (+ 16 KB: the largest transform table); CKB = bytes of a chunk row (128, or 64 for 16 x 32 tiles)
-static constexpr int lds_bytes_w(bool wn1, bool tw8) { return 2 * (tw8 ? 400 : 18 * (wn1 ? 34 : 18)) * ((wn1 ? 64 : 128) + 16) + 16 * 1024; }
+static constexpr int lds_bytes_w(bool wn1, bool tw8, bool twp = false) {
+    return 2 * (tw8 ? 400 : twp ? 648 : 18 * (wn1 ? 34 : 18)) * ((wn1 ? 64 : 128) + 16) + 16 * 1024;
+}
 
 static int shape_ok(int64_t N, int H, int W, int Cin, int Cout) {
     if (Cin % 64 || Cout % 64 || Cin > 1024 || N <= 0) return 0;
     const bool wn1 = Cout % 128 != 0;                     // 64 output channels per workgroup: 16 x 32 tiles
-    if (!((H == 8 && W == 8 && !wn1) || (H > 0 && W > 0 && H % 16 == 0 && W % (wn1 ? 32 : 16) == 0))) return 0;
+    if (!((H == 8 && W == 8 && !wn1) || (wn1 && H == 16 && W == 16) || (H > 0 && W > 0 && H % 16 == 0 && W % (wn1 ? 32 : 16) == 0))) return 0;
     const GeoW g = geometry_w(N, H, W, Cout);
     static const int min_items = getenv("SSAD_CONV16W_MIN") ? atoi(getenv("SSAD_CONV16W_MIN")) : 200;
     return g.ntiles * g.gy >= min_items;
@@ -629,12 +663,13 @@ template <typename T>
 static int conv_impl(const T* in, const T* w_packed, T* out, const T* residual, const uint8_t* res_mask, const float* tr_mean,
                      const float* tr_invstd, const float* tr_gamma, const float* tr_beta, T* emit, int64_t N, int H, int W, int Cin,
                      int Cout, double* stats_ws, float eps, float momentum, float* mean, float* invstd, float* running_mean,
-                     float* running_var, void* stream) {
+                     float* running_var, void* stream, const float* shift = nullptr, int relu = 0, int out_hwnc = 0) {
     constexpr int CKW = 128 / (int)sizeof(T), CKN = 64 / (int)sizeof(T);     // channels per chunk: 128-byte rows; 64-byte rows for 16 x 32 tiles
     SSAD_CHECK_ARG(in && w_packed && out && N > 0 && H > 0 && W > 0, "bad argument");
     SSAD_CHECK_ARG(Cin % 64 == 0 && Cout % 64 == 0 && Cin <= 1024, "channel counts must be multiples of 64 (Cin <= 1024)");
-    SSAD_CHECK_ARG((H == 8 && W == 8 && Cout % 128 == 0) || (H % 16 == 0 && W % (Cout % 128 == 0 ? 16 : 32) == 0),
-                   "maps of 16 x 16 blocks (16 x 32 when Cout is not a multiple of 128), or 8 x 8 maps with Cout a multiple of 128");
+    SSAD_CHECK_ARG((H == 8 && W == 8 && Cout % 128 == 0) || (H == 16 && W == 16) || (H % 16 == 0 && W % (Cout % 128 == 0 ? 16 : 32) == 0),
+                   "maps of 16 x 16 blocks (16 x 32 when Cout is not a multiple of 128, or 16 x 16 maps), or 8 x 8 maps with Cout a multiple of 128");
+    SSAD_CHECK_ARG(!(shift || out_hwnc) || (std::is_same<T, float>::value && !stats_ws), "inference epilogue / position-major output: float, no statistics");
     SSAD_CHECK_ARG(!tr_mean || (tr_invstd && tr_gamma && tr_beta), "input transform needs mean, invstd, gamma, beta");
     SSAD_CHECK_ARG(!stats_ws || (mean && invstd), "statistics need mean / invstd outputs");
     SSAD_CHECK_ARG(!emit || tr_mean, "emit without an input transform");
@@ -645,6 +680,9 @@ static int conv_impl(const T* in, const T* w_packed, T* out, const T* residual, 
     p.in = in; p.wp = w_packed; p.out = out; p.residual = residual; p.res_mask = res_mask;
     p.tr_mean = tr_mean; p.tr_invstd = tr_invstd; p.tr_gamma = tr_gamma; p.tr_beta = tr_beta; p.emit = emit;
     p.stats = stats_ws;
+    p.shift = shift; p.relu = relu;
+    p.os_n = out_hwnc ? Cout : (int64_t)H * W * Cout; p.os_y = out_hwnc ? (int)(W * N * Cout) : W * Cout; p.os_x = out_hwnc ? (int)(N * Cout) : Cout;
+    SSAD_CHECK_ARG(!out_hwnc || (int64_t)H * W * N * Cout < (int64_t)1 << 31, "position-major output too large for 32-bit strides");
     p.N = (int)N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
     p.tiles_y = g.tiles_y; p.tiles_x = g.tiles_x; p.nchunks = Cin / (g.ck32 ? CKN : CKW); p.ntiles = g.ntiles;
     const dim3 grid((unsigned)g.gx, (unsigned)g.gy);
@@ -654,12 +692,15 @@ static int conv_impl(const T* in, const T* w_packed, T* out, const T* residual, 
         SSAD_SET_DYN_LDS((conv3x3_hw_kernel<T, 2, true, CKW>), lds_bytes_w(false, true));
         SSAD_SET_DYN_LDS((conv3x3_hw_kernel<T, 2, false, CKW>), lds_bytes_w(false, false));
         SSAD_SET_DYN_LDS((conv3x3_hw_kernel<T, 1, false, CKN>), lds_bytes_w(true, false));
+        SSAD_SET_DYN_LDS((conv3x3_hw_kernel<T, 1, false, CKN, true>), lds_bytes_w(true, false, true));
         attr_set = true;
     }
-    const int lds_dyn = lds_bytes_w(g.wn == 1, g.tw8) - 16 * 1024 + (tr_mean ? 16 * Cin : 0);
+    const int lds_dyn = lds_bytes_w(g.wn == 1, g.tw8, g.twp) - 16 * 1024 + (tr_mean ? 16 * Cin : 0);
     if (g.wn == 2) {
         if (g.tw8) hipLaunchKernelGGL((conv3x3_hw_kernel<T, 2, true, CKW>), grid, dim3(512), lds_dyn, st, p);
         else hipLaunchKernelGGL((conv3x3_hw_kernel<T, 2, false, CKW>), grid, dim3(512), lds_dyn, st, p);
+    } else if (g.twp) {
+        hipLaunchKernelGGL((conv3x3_hw_kernel<T, 1, false, CKN, true>), grid, dim3(512), lds_dyn, st, p);
     } else {
         hipLaunchKernelGGL((conv3x3_hw_kernel<T, 1, false, CKN>), grid, dim3(512), lds_dyn, st, p);
     }
@@ -725,4 +766,29 @@ extern "C" int ssad_conv3x3_fw(const float* in, const float* w_packed, float* ou
                                float* invstd, float* running_mean, float* running_var, void* stream) {
     return conv_impl<float>(in, w_packed, out, residual, res_mask, tr_mean, tr_invstd, tr_gamma, tr_beta, emit, N, H, W, Cin, Cout, stats_ws,
                             eps, momentum, mean, invstd, running_mean, running_var, stream);
+}
+
+// Inference form (the layer1 convs of the patch-scoring pass, models.py:224 in eval mode): out = act(conv(in) + shift (+ residual)) with the
+// folded BatchNorm's SCALE folded into the packed filter (ssad_conv3x3_fw_pack_scaled) and its shift added here; 16 x 16 maps of 64
+// channels run two maps per tile.  out_hwnc: the output is written position-major [H][W][N][C] (in and residual are NHWC).
+extern "C" int ssad_conv3x3_fw_eval_ok(int64_t N, int H, int W, int Cin, int Cout) {
+    if (!shape_ok(N, H, W, Cin, Cout)) return 0;
+    const GeoW g = geometry_w(N, H, W, Cout);
+    return g.ntiles * g.gy >= 512 || Cin >= 256;
+}
+extern "C" int ssad_conv3x3_fw_pack_scaled(const float* w_ohwi, const float* scale, float* dst, int Cout, int Cin, void* stream) {
+    SSAD_CHECK_ARG(w_ohwi && dst && Cout > 0 && Cin > 0 && Cout % 64 == 0 && Cin % 64 == 0, "bad argument (channel counts multiples of 64)");
+    PackTable t;
+    t.n = 1;
+    t.e[0][0] = 0; t.e[0][1] = 0; t.e[0][2] = Cout; t.e[0][3] = Cin; t.e[0][4] = 0; t.e[0][5] = 0;
+    const int64_t blocks = cdiv64((int64_t)Cout * 9 * Cin / 4, 256);
+    hipLaunchKernelGGL(pack_hw_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w_ohwi, dst, t, scale);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int ssad_conv3x3_fw_eval(const float* in, const float* w_packed, float* out, const float* shift, const float* residual, int relu,
+                                    int64_t N, int H, int W, int Cin, int Cout, int out_hwnc, void* stream) {
+    SSAD_CHECK_ARG(shift, "null shift");
+    return conv_impl<float>(in, w_packed, out, residual, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, Cin, Cout, nullptr, 0.f,
+                            0.f, nullptr, nullptr, nullptr, nullptr, stream, shift, relu, out_hwnc);
 }

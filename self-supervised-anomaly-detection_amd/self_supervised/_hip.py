@@ -167,6 +167,9 @@ SIGNATURES = {
     "ssad_bn_relu_maxpool_fwd_win_h": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_fp],
     "ssad_pool_bn_relu_bwd_apply": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_l, _c_fp],
     "ssad_pool_bn_relu_bwd_apply_h": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_l, _c_fp],
+    "ssad_conv3x3_fw_eval_ok": [_c_l, _c_i, _c_i, _c_i, _c_i],
+    "ssad_conv3x3_fw_pack_scaled": [_c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_fp],
+    "ssad_conv3x3_fw_eval": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
     "ssad_bn_stats_h": [_c_fp, _c_l, _c_i, _c_f, _c_f, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
     "ssad_bn_apply_fwd_h": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp],
     "ssad_gap_fwd_h": [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_fp],

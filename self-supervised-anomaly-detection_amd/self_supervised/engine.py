@@ -122,6 +122,10 @@ def trunk_eval(plan, x, patch_dim, patch_stride, layer_outputs, pooled):
     else:
         conv = (lambda *a: ops.conv_fwd(*a, x3)) if x3 else ops.conv_fwd
     c64 = not x3 and _os.environ.get("SSAD_C64_EVAL", "1") != "0"      # exact-fp32 layer1 through csrc/conv_c64.hip
+    # ... or csrc/conv16w.hip's inference form (SSAD_CONV32W_EVAL=1).  OFF: measured on the scoring pass (8 launches of 107 648 maps of
+    # 16 x 16 x 64, round 5) 128.6 ms against 125.1 for the c64 kernel -- 64 input channels give tiles of four 16-channel chunks, and the
+    # residual costs fp32 MFMAs there
+    fw_eval = c64 and _os.environ.get("SSAD_CONV32W_EVAL", "0") == "1"
     win = (patch_dim, patch_dim) if patch_dim else (h, w)
     if win == (32, 32):
         # exact 2x nearest upsample: folded 4x4 conv + BN + ReLU + max-pool fused, the conv map never reaches HBM
@@ -144,8 +148,16 @@ def trunk_eval(plan, x, patch_dim, patch_stride, layer_outputs, pooled):
             # halo-tile kernel: one halo load per 8 x 16 pixel tile instead of one gather per filter tap
             # (measured at 15 979 patches of 16 x 16: 2.39 ms against 2.53 position-major implicit GEMM; NHWC tensors are
             # another 5 % faster than position-major ones, so layer1 stays NHWC and its last conv writes [H][W][N][C])
-            t = ops.conv3x3_c64_eval(a, d["w1"], d["s1"], d["t1"], None, True, False, False)
-            a = ops.conv3x3_c64_eval(t, d["w2"], d["s2"], d["t2"], idt, True, False, hwnc and i == 1, False)
+            if fw_eval and a.dim() == 4 and ops.conv3x3_fw_eval_ok(a.shape[0], a.shape[1], a.shape[2], 64, 64):
+                # launches that fill the chip: the register-fed conv (csrc/conv16w.hip, T = float), BatchNorm scale folded into its
+                # packed filter once per plan, two 16 x 16 maps per tile
+                if "p1" not in d:
+                    d["p1"], d["p2"] = ops.conv3x3_fw_pack_scaled(d["w1"], d["s1"]), ops.conv3x3_fw_pack_scaled(d["w2"], d["s2"])
+                t = ops.conv3x3_fw_eval(a, d["p1"], 64, d["t1"], None, True, False)
+                a = ops.conv3x3_fw_eval(t, d["p2"], 64, d["t2"], idt, True, hwnc and i == 1)
+            else:
+                t = ops.conv3x3_c64_eval(a, d["w1"], d["s1"], d["t1"], None, True, False, False)
+                a = ops.conv3x3_c64_eval(t, d["w2"], d["s2"], d["t2"], idt, True, False, hwnc and i == 1, False)
         else:
             t = conv(a, d["w1"], d["s1"], d["t1"], None, True, s, 1)
         if not (c64 and name == "layer1"):

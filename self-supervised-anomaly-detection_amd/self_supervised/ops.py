@@ -432,6 +432,33 @@ def conv3x3_hw(x, w_packed, cout, residual=None, transform=None, emit=False, sta
     return res[0] if len(res) == 1 else tuple(res)
 
 
+def conv3x3_fw_eval_ok(n, h, w, cin, cout):
+    return bool(_hip.lib().ssad_conv3x3_fw_eval_ok(n, h, w, cin, cout))
+
+
+def conv3x3_fw_pack_scaled(w_ohwi, scale):
+    """The filter of an inference conv in the register-fed kernel's fragment order, the folded BatchNorm's scale multiplied in."""
+    cout, kh, kw, cin = w_ohwi.shape
+    assert (kh, kw) == (3, 3) and w_ohwi.is_contiguous() and (scale is None or scale.numel() == cout)
+    out = torch.empty(cout * 9 * cin, device=w_ohwi.device, dtype=torch.float32)
+    _hip.check(_hip.lib().ssad_conv3x3_fw_pack_scaled(_hip.ptr(w_ohwi), _hip.ptr(scale, True), _hip.ptr(out), cout, cin, _hip.stream()))
+    return out
+
+
+def conv3x3_fw_eval(x, w_packed, cout, shift, residual=None, relu=False, out_hwnc=False):
+    """Inference 3x3 / stride 1 conv on the register-fed kernel (csrc/conv16w.hip, T = float): act(conv(x) + shift (+ residual)), x and
+    residual NHWC, the output NHWC or position-major [H][W][N][C]; the filter from conv3x3_fw_pack_scaled."""
+    n, h, w, cin = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous() and w_packed.numel() == cout * 9 * cin and shift.numel() == cout
+    assert residual is None or (tuple(residual.shape) == (n, h, w, cout) and residual.is_contiguous())
+    out = _new((h, w, n, cout) if out_hwnc else (n, h, w, cout), x)
+    nb = 4.0 * (x.numel() + out.numel() * (2 if residual is not None else 1) + w_packed.numel())
+    _run("conv3x3_fw32", 2.0 * out.numel() * 9 * cin, nb,
+         lambda: _hip.lib().ssad_conv3x3_fw_eval(_hip.ptr(x), _hip.ptr(w_packed), _hip.ptr(out), _hip.ptr(shift), _hip.ptr(residual, True),
+                                                 int(relu), n, h, w, cin, cout, int(out_hwnc), _hip.stream()))
+    return out
+
+
 def conv3x3_c64_eval(x, w_ohwi, scale=None, shift=None, residual=None, relu=False, in_hwnc=False, out_hwnc=False,
                      res_hwnc=None):
     """Halo-tile 3x3 / stride 1 / pad 1 convolution 64 -> 64 with the inference epilogue act(conv * scale + shift + residual).

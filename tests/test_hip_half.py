@@ -238,6 +238,29 @@ def test_conv3x3_fw_exact_fp32_form(dev, shape):
         assert (dx.cpu() - wantdx).abs().max().item() <= 2e-5 * max(1.0, wantdx.abs().max().item())
 
 
+@pytest.mark.parametrize("shape", [(1025, 16, 16, 64, 64), (64, 64, 64, 64, 64), (128, 32, 32, 128, 128)])
+def test_conv3x3_fw_inference_form(dev, shape):
+    """Inference epilogue of the register-fed conv (BatchNorm scale folded into the packed filter, shift + residual + ReLU, output NHWC or
+    position-major) against the halo c64 kernel / the implicit GEMM with the same folded BatchNorm; two 16 x 16 maps per tile with an odd
+    number of maps."""
+    from self_supervised import ops
+    n, h, w, cin, cout = shape
+    assert ops.conv3x3_fw_eval_ok(n, h, w, cin, cout)
+    g = torch.Generator().manual_seed(n + h)
+    x = torch.randn(n, h, w, cin, generator=g).to(dev)
+    wt = (torch.randn(cout, 3, 3, cin, generator=g) / (9 * cin) ** 0.5).to(dev)
+    sc, sh = (torch.rand(cout, generator=g) + 0.5).to(dev), torch.randn(cout, generator=g).to(dev)
+    res = torch.randn(n, h, w, cout, generator=g).to(dev)
+    wp = ops.conv3x3_fw_pack_scaled(wt, sc)
+    for r_, relu in ((None, True), (res, True), (res, False)):
+        want = ops.conv_fwd(x, wt, sc, sh, r_, relu, 1, 1)
+        got = ops.conv3x3_fw_eval(x, wp, cout, sh, r_, relu)
+        tol = 2e-5 * max(1.0, want.abs().max().item())
+        assert (got - want).abs().max().item() <= tol
+        got_pm = ops.conv3x3_fw_eval(x, wp, cout, sh, r_, relu, out_hwnc=True)
+        assert torch.equal(got_pm.permute(2, 0, 1, 3), got)
+
+
 @pytest.mark.parametrize("shape", [(3, 16, 16, 64, 64, 1), (2, 13, 21, 64, 128, 1), (5, 8, 8, 128, 64, 1), (3, 5, 7, 64, 64, 1),
                                    (40, 32, 32, 128, 128, 1), (9, 64, 64, 64, 64, 1), (3, 32, 32, 64, 128, 2), (2, 13, 21, 64, 64, 2),
                                    (5, 16, 16, 128, 256, 2), (40, 16, 16, 256, 512, 2), (3, 9, 9, 64, 64, 2)])
