@@ -151,7 +151,7 @@ def test_conv3x3_h_halo_kernel(dev, shape):
 
 
 @pytest.mark.parametrize("shape", [(26, 64, 64, 64, 64), (52, 32, 32, 128, 128), (104, 16, 16, 256, 256), (202, 8, 8, 512, 512),
-                                   (52, 32, 32, 64, 128), (26, 64, 64, 128, 64), (801, 8, 8, 64, 128)])
+                                   (52, 32, 32, 64, 128), (26, 64, 64, 128, 64), (801, 8, 8, 64, 128), (401, 16, 16, 64, 64)])
 def test_conv3x3_hw_register_fed_kernel(dev, shape):
     """csrc/conv16w.hip (filters packed in fragment order and fed from registers, halo staged by two extra waves) against fp32 math on
     the same half operands and against csrc/conv16.hip: 16 x 16 tiles and four 8 x 8 maps per tile (ragged last tile), one / two / four
@@ -197,7 +197,7 @@ def test_conv3x3_hw_register_fed_kernel(dev, shape):
 
 
 @pytest.mark.parametrize("shape", [(64, 64, 64, 64, 64), (128, 32, 32, 128, 128), (104, 16, 16, 256, 256), (202, 8, 8, 512, 512),
-                                   (128, 32, 32, 64, 128), (64, 64, 64, 128, 64)])
+                                   (128, 32, 32, 64, 128), (64, 64, 64, 128, 64), (1025, 16, 16, 64, 64)])
 def test_conv3x3_fw_exact_fp32_form(dev, shape):
     """The float instantiation of csrc/conv16w.hip (v_mfma_f32_32x32x2_f32, statistics in double per value) against F.conv2d in fp32 and
     against the implicit GEMM of the exact-fp32 step: plain + statistics, residual, residual gated by a nibble mask (the identity-branch
