@@ -529,7 +529,7 @@ int ssad_conv3x3_h(const void* in, const void* w_ohwi, void* out, const void* re
  * the filter is packed once per step in fragment order [Cout/32][tap][Cin/16][2][32][8] halves (ssad_conv3x3_hw_pack_batch, from the
  * fp32 master weights: desc[5 k ..] = source offset in floats, destination offset in halves, Cout, Cin of the conv that runs on it,
  * flip = 1 when the source is the OHWI filter [Cin][3][3][Cout] of the forward conv whose input gradient this is), the halo is staged
- * by two extra waves of the workgroup.  Arguments of ssad_conv3x3_hw as ssad_conv3x3_h, w_packed in place of w_ohwi. */
+ * by four extra waves of the workgroup.  Arguments of ssad_conv3x3_hw as ssad_conv3x3_h, w_packed in place of w_ohwi. */
 int ssad_conv3x3_hw_ok(int64_t N, int H, int W, int Cin, int Cout);
 int64_t ssad_conv3x3_hw_packed_size(int Cin, int Cout);
 int64_t ssad_conv3x3_hw_stats_rows(int64_t N, int H, int W, int Cout);

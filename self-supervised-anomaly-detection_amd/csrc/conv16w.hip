@@ -1,24 +1,29 @@
-// 3x3 / stride 1 / pad 1 convolution over HALF tensors, second form: weights fed to the matrix cores from REGISTERS, wave-specialised
-// staging.  Same contract as csrc/conv16.hip (forward of the torchvision BasicBlock conv3x3 layers under pl.Trainer(precision=16),
-// models.py:224 / tools.py:263 of the reference, and -- with the flipped filter -- their input gradients), for the launches that
-// fill the chip: maps that tile into 16 x 16 blocks (or 8 x 8 maps, four per tile) and >= ~200 (tile, channel slab) pairs.
+// 3x3 / stride 1 / pad 1 convolution, register-fed form: the filter goes to the matrix cores from REGISTERS, the halo is staged by extra
+// waves of the workgroup.  Two instantiations of one kernel laid out in bytes (16-byte pieces, 128-byte chunk rows, 1 KB fragments):
+//   T = hf    the precision-16 step's half tensors (v_mfma_f32_32x32x16_f16): same contract as csrc/conv16.hip -- forward of the
+//             torchvision BasicBlock conv3x3 layers under pl.Trainer(precision=16) (models.py:224 / tools.py:263 of the reference) and,
+//             with the flipped filter, their input gradients -- for the launches that fill the chip;
+//   T = float the exact-fp32 step (v_mfma_f32_32x32x2_f32, four per fragment), replacing csrc/conv_c64.hip / the implicit GEMM on those
+//             launches; an inference epilogue (folded BatchNorm) exists and is off (see ssad_conv3x3_fw_eval).
 //
-// Why a second form (measured on conv16.hip, profiles/r05_conv16_ablate.txt, 256 x 32 x 32 x 128 -> 128: 97 us against a 31 us matrix
-// floor): with 64 x 64 wave tiles every v_mfma_f32_32x32x16_f16 needs 1 KB of fragments from LDS -- 128 B/clk/CU at the matrix
-// rate, all the LDS has -- so the weight slices that go global -> registers -> LDS -> registers (38 us of the 97), the halo writes
-// and the per-tap barriers ADD to the matrix stream instead of hiding under it.  Here:
-//   * a wave owns 128 pixels x 64 output channels (8 accumulator tiles, 128 registers): 4 activation fragments from LDS and 2 weight
+// Why (measured on conv16.hip, profiles/r05_conv16_ablate.txt, 256 x 32 x 32 x 128 -> 128: 97 us against a 31 us matrix floor): with
+// 64 x 64 wave tiles every v_mfma_f32_32x32x16_f16 needs 1 KB of fragments from LDS -- 128 B/clk/CU at the matrix rate, all the LDS has --
+// so the weight slices that go global -> registers -> LDS -> registers (38 us of the 97), the halo writes and the per-tap barriers ADD to
+// the matrix stream instead of hiding under it.  Here:
+//   * a wave owns 128 pixels x 64 output channels (8 accumulator tiles, 128 registers): 4 activation fragments from LDS and 2 filter
 //     fragments per 8 MFMAs -- the LDS serves 64 B/clk;
-//   * the weight fragments never touch LDS: the filters are packed once per step (ssad_conv3x3_hw_pack_batch, from the fp32 master
+//   * the filter fragments never touch LDS: the filters are packed once per step (ssad_conv3x3_hw_pack_batch, from the fp32 master
 //     weights) in fragment order, [Cout/32][tap][Cin/16][k half][32 channels][8 halves], so a wave's fragment is one coalesced 1 KB
-//     read of the L2, requested DB steps (6 x 8 MFMAs) ahead into a register ring; no barrier per tap;
-//   * the halo is staged by TWO EXTRA WAVES of the workgroup (one (tile, chunk) ahead, double-buffered in LDS): vmcnt counts in
-//     order per wave, so an HBM-latency halo load in the matrix waves' queue would hold back every weight fragment behind it --
-//     the stagers keep their own queue, apply the producer's BatchNorm + ReLU on load (fp32, rounded once) and emit the
-//     normalised activation for the weight gradient; the matrix waves only issue L2-latency loads;
-//   * one barrier per (tile, 64-channel chunk) = per 36 steps.
-// Workgroups are persistent over tiles of ONE channel slab (blockIdx.y), so the BatchNorm statistics of the stored halves stay in
-// registers (per tile in fp32, across tiles in double) and leave as one partial row per workgroup.
+//     read of the L2, requested DB steps ahead into a register ring (sched_barrier per step: the compiler would sink the loads to
+//     their uses); no barrier per tap;
+//   * the halo is staged by FOUR EXTRA WAVES of the workgroup, one beside each matrix wave (one (tile, chunk) ahead in LDS, loads
+//     requested two fills ahead, double-buffered): vmcnt counts in order per wave, so an HBM-latency halo load in a matrix wave's queue
+//     would hold back every filter fragment behind it -- the stagers keep their own queue, apply the producer's BatchNorm + ReLU on load
+//     (fp32, rounded once) and emit the normalised activation for the weight gradient; all their per-lane index arithmetic is done once;
+//   * a residual is ADDED BY THE MATRIX CORES (centre-tap steps against a one-hot fragment: exact), its tiles riding the same staging;
+//   * one barrier per (tile, chunk) = per 36 steps.
+// Workgroups are persistent over tiles of ONE channel slab (blockIdx.y), so the BatchNorm statistics of the stored output stay in
+// registers (per tile in fp32, across tiles in double; the float form: double per value) and leave as one partial row per workgroup.
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
