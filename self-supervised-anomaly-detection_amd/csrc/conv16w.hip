@@ -702,6 +702,14 @@ static int conv_impl(const T* in, const T* w_packed, T* out, const T* residual, 
     }
     const int lds_dyn = lds_bytes_w(g.wn == 1, g.tw8, g.twp) - 16 * 1024 + (tr_mean ? 16 * Cin : 0);
     if (g.wn == 2) {
+#ifdef CONV16W_FORCE_CKN      // experiment (tools/micro): the 128-channel form with half-size fills -- twice the barriers, same MFMAs
+        if (!g.tw8) {
+            p.nchunks = Cin / CKN;
+            hipLaunchKernelGGL((conv3x3_hw_kernel<T, 2, false, CKN>), grid, dim3(512), lds_dyn, st, p);
+            SSAD_CHECK_LAUNCH();
+            return 0;
+        }
+#endif
         if (g.tw8) hipLaunchKernelGGL((conv3x3_hw_kernel<T, 2, true, CKW>), grid, dim3(512), lds_dyn, st, p);
         else hipLaunchKernelGGL((conv3x3_hw_kernel<T, 2, false, CKW>), grid, dim3(512), lds_dyn, st, p);
     } else if (g.twp) {
