@@ -125,6 +125,14 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
     }
     __syncthreads();
 
+    // The matrix waves issue ahead of the stagers they share a SIMD with: a stager instruction taken first delays the next MFMA by its
+    // issue slot, and a fill's worth of them (1-2 us of stager work per fill with everything else ablated) showed up in full in the
+    // matrix stream.  (The guard must be provably wave-uniform: s_setprio ignores EXEC.)  Measured: zero-operand launches 83 / 64 / 58 / 55 ->
+    // 79 / 61 / 56 / 53 us (halves), 611 -> 600 us (float, 64-channel layer); the steps themselves: unchanged within noise.
+#ifndef CONV16W_NO_PRIO
+    if (__builtin_amdgcn_readfirstlane(tid) < NMW * 64) __builtin_amdgcn_s_setprio(3);
+#endif
+
     if (wave >= NMW) {
         // =====================================================================================================================
         // stager waves: fill f -> halo[f & 1], one fill ahead of the matrix waves; the loads of fill f + 2 are requested BEFORE the
@@ -448,6 +456,7 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
         // statistics of the stored halves are two v_dot2_f32_f16 per pair (products of halves are exact in fp32) ----
         const int64_t tile = (int64_t)blockIdx.x + tile_i * gridDim.x;
         ++tile_i;
+        if (CONV16W_ABL & 128) continue;                   // ablation 128: a tile ends without a single instruction reading its accumulators
         if (CONV16W_ABL & 4) {
             float sum = 0.f;
 #pragma unroll
