@@ -46,6 +46,43 @@ U_TRAIN_GFLOP = 14.22            # SURVEY s.8d: one 256x256 image through fwd + 
 U_MAP_GFLOP = 252.06             # SURVEY s.8d: one 256x256 image -> anomaly map
 
 
+# Sources a committed PMC pass speaks for (profiles/r*_traffic.json carry the digest of these files as they were when the pass ran; bench.py
+# attaches a pass to its line only while the digest still matches the tree -- VERDICT r5 item 6)
+SCORE_TRAFFIC_SOURCES = ["self-supervised-anomaly-detection_amd/csrc/conv_igemm.hip", "self-supervised-anomaly-detection_amd/csrc/common.h"]
+P16_TRAFFIC_SOURCES = ["self-supervised-anomaly-detection_amd/csrc/*.hip", "self-supervised-anomaly-detection_amd/csrc/common.h",
+                       "self-supervised-anomaly-detection_amd/self_supervised/training.py"]
+
+
+def source_sha(patterns):
+    """sha256 over the named source files (repo-relative glob patterns, sorted paths, path + contents)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for pat in patterns:
+        for f in sorted(glob.glob(os.path.join(ROOT, pat))):
+            h.update(os.path.relpath(f, ROOT).encode() + b"\0")
+            h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def pinned_traffic(pattern, match, sources):
+    """The newest committed PMC pass matching `match` -> (profile dict or None, reason when dropped).  A pass whose recorded
+    source digest differs from the tree's (or that carries none) is NOT attached: the kernel it measured is not this one."""
+    import glob
+    now = source_sha(sources)
+    for tj in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+        tjd = json.load(open(tj))
+        if not match(tjd):
+            continue
+        rec = (tjd.get("source_sha") or {}).get("sha256")
+        name = "profiles/" + os.path.basename(tj)
+        if rec != now:
+            return None, (f"{name} was taken on other kernel sources (recorded digest {str(rec)[:12]}, tree {now[:12]}): not attached; "
+                          "re-run tools/profile_round.sh / tools/profile_p16.sh")
+        return dict(tjd, file=name), None
+    return None, "no committed PMC pass with this launch geometry"
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -387,6 +424,44 @@ def main():
     from self_supervised import ops, training
     from self_supervised.models import AnomalyDetector
 
+    def rccl_probe():
+        """First contact of a multi-GPU run, OUTSIDE every timed region: which (rank, device) pairs are in the job (an all-gather of
+        rank, local device index, device uuid), the collective library and its version, and the bus bandwidth of ONE all-reduce of the
+        step's gradient payload (12 691 524 fp32 = 50.8 MB; busbw = 2 (n - 1) / n x bytes / time, the ring figure of merit).  A run
+        that later stalls or scales badly then says what it ran on."""
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": local_rank, "device": dev.index, "uuid": str(getattr(props, "uuid", "")), "name": props.name}
+        seen = [None] * world
+        dist.all_gather_object(seen, mine)
+        n_el = 12691524
+        buf = torch.ones(n_el, device=dev, dtype=torch.float32)
+        for _ in range(2):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        dist.barrier()
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+        ver = None
+        if backend == "nccl":
+            try:
+                ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as e:          # noqa: BLE001
+                ver = f"unknown ({type(e).__name__})"
+        uu = [s["uuid"] for s in seen]
+        return {"backend": "rccl (torch.distributed 'nccl')" if backend == "nccl" else backend, "version": ver, "ranks_seen": seen,
+                "distinct_devices": len(set((s["uuid"] or s["device"]) for s in seen)) if all(uu) else len(set(s["device"] for s in seen)),
+                "allreduce_probe": {"bytes": 4 * n_el, "seconds": round(dt, 6), "algbw_GBps": round(4 * n_el / dt / 1e9, 2),
+                                    "busbw_GBps": round(2 * (world - 1) / world * 4 * n_el / dt / 1e9, 2),
+                                    "note": "one fp32 all-reduce of the gradient payload, mean of 5 after 2 warm-ups, max over ranks; "
+                                            "xGMI: 7 links x ~153 GB/s per GPU, a ring is bound by one link per direction"}}
+
     strong_headline = args.scaling == "strong"
     if strong_headline:
         if args.global_batch % world:
@@ -439,6 +514,8 @@ def main():
             return None
 
     res, prof = {}, {}
+    if world > 1:
+        res["rccl"] = optional("rccl_probe", rccl_probe)
     extras = [e for e in args.extras.split(",") if e]
     # bf16x6 (every fp32 product formed from three bf16 parts per operand, the six largest partial products, fp32 accumulate: the
     # accuracy of the fp32 MFMA at 6/16 of its matrix time) is measured by default on one GPU beside the exact-fp32 headline
@@ -526,14 +603,13 @@ def main():
             by = {}
             for r in pr:
                 e = by.setdefault(r["kernel"], [0.0, 0, 0.0, 0.0]); e[0] += r["ms"]; e[1] += 1; e[2] += r["flops"]; e[3] += r["bytes"]
-            tprof = None                   # PMC passes cannot run inside this process: the newest committed pass with this batch size
-            import glob
-            for tj in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_p16_traffic.json")), reverse=True):
-                tjd = json.load(open(tj))
-                if tjd.get("images_per_step") == per_rank:
-                    tprof = {"file": "profiles/" + os.path.basename(tj), "traffic_MB_per_step": tjd["traffic_MB_per_step"],
-                             "ratio_to_algorithmic": tjd.get("ratio_to_algorithmic"), "counters": tjd.get("correction")}
-                    break
+            # PMC passes cannot run inside this process: the newest committed pass with this batch size, IF it was taken on these sources
+            tjd, why16 = pinned_traffic("r*_p16_traffic.json", lambda d: d.get("images_per_step") == per_rank, P16_TRAFFIC_SOURCES)
+            tprof = None
+            if tjd:
+                tprof = {"file": tjd["file"], "traffic_MB_per_step": tjd["traffic_MB_per_step"],
+                         "ratio_to_algorithmic": tjd.get("ratio_to_algorithmic"), "counters": tjd.get("correction"),
+                         "source_sha256": tjd["source_sha"]["sha256"]}
             act_mb = per_rank * U_TRAIN_ACT_MB_F32 / 2
             alg_gb = (act_mb + OPTIMIZER_MB_PER_STEP) / 1e3
             kern_gb = sum(r["bytes"] for r in pr) / 2 / 1e9
@@ -547,7 +623,7 @@ def main():
                              "traffic": round(tprof["traffic_MB_per_step"] * 1e6) if tprof else None,
                              "traffic_unit": "fabric-side bytes per STEP, all kernels (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 PMC passes; "
                                              "Infinity-Cache hits included)" if tprof else None,
-                             "traffic_profile": tprof,
+                             "traffic_profile": tprof if tprof else {"dropped": why16},
                              "alg_GB_per_step": round(alg_gb, 3),
                              "definition": f"SURVEY 8d: {per_rank} images x 3 x 33.55 MB / 2 (half activations: forward, input gradients, "
                                            f"weight-gradient reads) + {OPTIMIZER_MB_PER_STEP} MB optimizer traffic, over the replayed step's wall time",
@@ -654,7 +730,10 @@ def main():
                    "images_per_gpu": per_rank, "global_batch": per_rank * world, "patches_per_image": 841, "bank_rows": 588,
                    "parallelism": f"dp{world} ({mode}: {per_rank} images per rank, global batch {per_rank * world}; bucketed gradient "
                                   f"all-reduce overlapped with backward)" if world > 1 else f"dp1 ({per_rank} images)",
-                   "train_step_launch": res.get("launch_mode", "hipGraph segments" if use_graph else "eager")},
+                   "train_step_launch": res.get("launch_mode", "hipGraph segments" if use_graph else "eager"),
+                   "input_binding": "in place: the timed steps read the batch from the recorded step's own input buffer (DataParallelStep.bind_inputs; "
+                                    "no device-to-device copy of the batch inside the clock, warm-up outside it).  Rounds 1-4 timed step(x, y) "
+                                    "with a 201 MB copy per 256-image step (~0.05 ms): their img/s are lower by that much and otherwise comparable"},
     }
     if args.train_precision != "32":
         out["dtype"] = {"16": "f16 operands / f32 accumulate", "bf16": "bf16 operands / f32 accumulate"}[args.train_precision]
@@ -666,6 +745,8 @@ def main():
         out["config"]["train_graph_segments"] = res["train_graph_segments"]
         if res.get("self_check"):
             out["self_check"] = res["self_check"]
+        if res.get("rccl"):
+            out["rccl"] = res["rccl"]
         if res.get("comm"):
             out["comm"] = dict(res["comm"], note="comm_exposed_ms: HIP events around the wait for the bucketed all-reduce, max over ranks, "
                                                  "mean over steps; allreduce_bytes: fp32 gradient bytes per rank per step")
@@ -710,13 +791,12 @@ def main():
     def latest_traffic(samples):
         """HBM-side bytes per launch of the position-major kernel need rocprofv3 PMC passes, which cannot run inside this
         process: the newest committed, counter-corrected pass of this command line with the same launch geometry."""
-        import glob
-        for tj in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
-            tjd = json.load(open(tj))
-            if tjd.get("patches_per_launch") == samples:
-                return {"file": "profiles/" + os.path.basename(tj), "traffic_MB_per_launch": tjd["traffic_MB_per_launch"],
-                        "ratio_to_algorithmic": tjd.get("ratio_to_algorithmic"), "counters": tjd.get("correction")}
-        return None
+        tjd, why = pinned_traffic("r[0-9][0-9]_traffic.json", lambda d: d.get("patches_per_launch") == samples, SCORE_TRAFFIC_SOURCES)
+        if tjd is None:
+            return {"dropped": why}
+        return {"file": tjd["file"], "traffic_MB_per_launch": tjd["traffic_MB_per_launch"],
+                "ratio_to_algorithmic": tjd.get("ratio_to_algorithmic"), "counters": tjd.get("correction"),
+                "source_sha256": tjd["source_sha"]["sha256"]}
 
     def roofline_of(phase, tag):
         recs = [r for r in prof.get(phase, []) if r["kernel"] == tag]
@@ -739,9 +819,9 @@ def main():
               "frac": round(xfl / t / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
               "alg_achieved": round(fl / t / 1e12, 2), "alg_frac": round(fl / t / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
               "skipped_tap_share": round(1.0 - xfl / fl, 4),
-              "traffic": round(tprof["traffic_MB_per_launch"] * 1e6) if tprof else None,
+              "traffic": round(tprof["traffic_MB_per_launch"] * 1e6) if tprof and "dropped" not in tprof else None,
               "traffic_unit": "fabric-side bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, rocprofv3 PMC passes of this command; "
-                              "Infinity-Cache hits included)" if tprof else None,
+                              "Infinity-Cache hits included)" if tprof and "dropped" not in tprof else None,
               "traffic_profile": tprof,
               "kernel": ("conv3x3_hw_kernel<float> (csrc/conv16w.hip) x %d" % len(recs)) if tag == "conv3x3_fw32" else
                         "conv_igemm_f32_kernel" + " + ".join(f"{k} x {v['launches']}" for k, v in inst.items()),

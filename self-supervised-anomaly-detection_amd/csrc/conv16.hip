@@ -527,6 +527,8 @@ extern "C" int ssad_conv3x3_h(const void* in, const void* w_ohwi, void* out, con
                               float* running_var, void* stream) {
     SSAD_CHECK_ARG(in && w_ohwi && out && N > 0 && H > 0 && W > 0, "bad argument");
     SSAD_CHECK_ARG(Cin % 64 == 0 && Cout % 64 == 0, "channel counts must be multiples of 64");
+    SSAD_CHECK_ARG((((uintptr_t)in | (uintptr_t)w_ohwi | (uintptr_t)out | (uintptr_t)residual | (uintptr_t)emit) & 15) == 0,
+                   "half tensors and filters must be 16-byte aligned (they are read in 16-byte pieces)");
     SSAD_CHECK_ARG(!tr_mean || (tr_invstd && tr_gamma && tr_beta), "input transform needs mean, invstd, gamma, beta");
     SSAD_CHECK_ARG(!stats_ws || (mean && invstd), "statistics need mean / invstd outputs");
     SSAD_CHECK_ARG(!emit || tr_mean, "emit without an input transform");

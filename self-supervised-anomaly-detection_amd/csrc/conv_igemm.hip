@@ -1327,6 +1327,7 @@ extern "C" int ssad_conv_igemm_fwd_stats_h(const void* in, const void* w_ohwi, v
                                            float* mean, float* invstd, float* running_mean, float* running_var,
                                            double* workspace, void* stream) {
     SSAD_CHECK_ARG(mean && invstd && workspace, "null pointer");
+    SSAD_CHECK_ARG((((uintptr_t)in | (uintptr_t)w_ohwi | (uintptr_t)out) & 15) == 0, "half tensors and filters must be 16-byte aligned");
     int rows = 0;
     int rc = conv_fwd_impl((const float*)in, (const float*)w_ohwi, (float*)out, nullptr, nullptr, nullptr, 0, N, H, W, Cin, Cout, KH, KW,
                            stride, pad, 0, stream, 2, workspace, &rows, 1);
@@ -1339,6 +1340,8 @@ extern "C" int ssad_conv_igemm_fwd_stats_h(const void* in, const void* w_ohwi, v
 extern "C" int ssad_conv_igemm_dgrad_h(const void* dy, const void* w_flipT, void* dx, const void* residual, int64_t N,
                                        int Hy, int Wy, int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride,
                                        int pad, void* stream) {
+    SSAD_CHECK_ARG((((uintptr_t)dy | (uintptr_t)w_flipT | (uintptr_t)dx | (uintptr_t)residual) & 15) == 0,
+                   "half tensors and filters must be 16-byte aligned");
     return dgrad_impl((const float*)dy, (const float*)w_flipT, (float*)dx, (const float*)residual, N, Hy, Wy, Cout, Hx, Wx, Cin, KH, KW,
                       stride, pad, stream, 2, nullptr, 1);
 }

@@ -35,6 +35,7 @@ class GradCam:
             raise RuntimeError("Grad-CAM belongs to the image-level branch: disable patch-level mode first")
         eng = training.get_engine(m)
         bf16, eng.bf16 = eng.bf16, False
+        pg, eng.param_grads = eng.param_grads, False              # input gradients only: the fused conv + BatchNorm + ReLU epilogues, no kept z
         try:
             logits, _ = eng.forward(x)                            # eval statistics everywhere; keeps the head tape
             if class_idx is None:
@@ -45,7 +46,7 @@ class GradCam:
             dlogits[torch.arange(b, device=logits.device), idx] = 1.0
             dpooled, act = eng.head_input_grad(dlogits)
         finally:
-            eng.bf16 = bf16
+            eng.bf16, eng.param_grads = bf16, pg
         _, u, v, k = act.shape
         off = eng.gap_off["layer4"]
         alpha = dpooled[:, off:off + k] / float(u * v)            # spatial mean of the (constant) layer4 gradient, :39-41

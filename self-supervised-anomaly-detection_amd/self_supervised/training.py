@@ -51,11 +51,17 @@ class ParamArena:
     def __init__(self, model):
         params, head_count = _backward_order(model)
         dev = params[0].device
-        total = sum(p.numel() for p in params)
-        self.p = torch.empty(total, device=dev, dtype=torch.float32)
+        # every parameter starts at a multiple of ALIGN elements: 32-byte aligned floats, 16-byte aligned halves in the rounded copy
+        # (`w16`: the half-tensor convs read their filters with 16-byte loads).  The pads stay zero in all three arenas (SGD maps
+        # p = g = m = 0 to itself) and belong to the range of the parameter in front of them, so contiguous trainable parameters
+        # still merge into one SGD launch / one all-reduce bucket.
+        ALIGN = 8
+        pad = lambda n: (n + ALIGN - 1) // ALIGN * ALIGN
+        total = sum(pad(p.numel()) for p in params)
+        self.p = torch.zeros(total, device=dev, dtype=torch.float32)
         self.g = torch.zeros(total, device=dev, dtype=torch.float32)
         self.m = torch.zeros(total, device=dev, dtype=torch.float32)
-        self.params, self.offset = params, {}
+        self.params, self.offset, self.span = params, {}, {}
         off = 0
         with torch.no_grad():
             for i, p in enumerate(params):
@@ -72,7 +78,8 @@ class ParamArena:
                     flat.copy_(p.detach())
                     p.data = flat
                     p.grad = self.g[off:off + n].view(p.shape)
-                off += n
+                self.span[id(p)] = (off, off + pad(n))
+                off += pad(n)
                 if i + 1 == head_count:
                     self.head_end = off
         self.total = total
@@ -123,11 +130,11 @@ class ParamArena:
         for p in self.params:
             if not p.requires_grad:
                 continue
-            off, n = self.offset[id(p)]
+            off, end = self.span[id(p)]          # the parameter and its alignment pad
             if ranges and ranges[-1][1] == off:
-                ranges[-1][1] = off + n
+                ranges[-1][1] = end
             else:
-                ranges.append([off, off + n])
+                ranges.append([off, end])
         return [tuple(r) for r in ranges]
 
 
@@ -140,6 +147,7 @@ class _Affine:
     def __init__(self, eng, lin, bn, stride=1, pad=0, relu=False, stem=False):
         self.eng, self.lin, self.bn, self.stride, self.pad, self.relu, self.stem = eng, lin, bn, stride, pad, relu, stem
         self.is_conv = isinstance(lin, nn.Conv2d)
+        self.eval_stats = False       # the last forward kept z under EVAL-mode statistics (trainable BatchNorm weight)
 
     def weight(self):
         a = self.eng.arena
@@ -152,6 +160,7 @@ class _Affine:
         """conv1 straight from the NCHW image (the unfused fp32-MFMA form; the training step takes fwd_pool); train or eval BatchNorm + ReLU."""
         bn = self.bn
         self.x, self.res_used = img, False
+        self.eval_stats = False
         if bn.training:
             z = ops.stem_fwd(img, w, None, None, relu=False)
             mom = 0.1 if bn.momentum is None else bn.momentum
@@ -188,6 +197,7 @@ class _Affine:
         """Stem + max-pool: (pooled NHWC, argmax slots).  With batch statistics the BatchNorm + ReLU run inside the
         pooling kernel and the 128x128 activation is never stored (its backward recomputes the mask from z)."""
         bn = self.bn
+        self.eval_stats = False       # a flag of the LAST forward only (set below where eval-mode statistics meet a trainable weight)
         if not bn.training:
             return ops.maxpool3x3s2_fwd_idx(self._stem_fwd(img, self.weight()))
         self.x, self.res_used = img, False
@@ -243,6 +253,7 @@ class _Affine:
         mom = 0.1 if bn.momentum is None else bn.momentum
         st = (bn.eps, mom, bn.running_mean, bn.running_var)
         self.x_shape = tuple(x.shape)
+        self.eval_stats = False
         n_, h_, w_, ci_ = x.shape
         if x.dtype == torch.float32 and self.eng.conv32w_ok(self, n_, h_, w_, ci_, self.lin.out_channels):
             wp = self.eng.packed_hw(self.lin, False, f32=True)         # launches that fill the chip: the register-fed form
@@ -281,6 +292,7 @@ class _Affine:
         mom = 0.1 if bn.momentum is None else bn.momentum
         st = (bn.eps, mom, bn.running_mean, bn.running_var)
         self.x_shape = tuple(x.shape)
+        self.eval_stats = False
         n, h, wd, cin = x.shape
         cout = self.lin.out_channels
         if self.eng.sw_conv16w and ops.conv3x3_hw_ok(n, h, wd, cin, cout):      # launches that fill the chip: register-fed filters
@@ -793,9 +805,7 @@ class TrainEngine:
                 if prev in self.gap_off:
                     ops.gap_bwd(dpooled, dy, self.gap_off[prev], accumulate=True)
             if i % 2 == 0:
-                notify(a.offset[id(blk["c1"].lin.weight)][0] + blk["c1"].lin.weight.numel()
-                       if blk["ds"] is None else
-                       a.offset[id(blk["ds"].lin.weight)][0] + blk["ds"].lin.weight.numel())
+                notify(a.span[id(blk["c1"].lin.weight if blk["ds"] is None else blk["ds"].lin.weight)][1])
         self.stem.bwd_pool(self.pool_idx, dy, self.a0_shape)
         notify(a.total)
         self.join_wgrad()
@@ -805,13 +815,13 @@ class TrainEngine:
         """d(sum(logits * dlogits)) / d(pooled features) [B][pooled_dim]: the head's backward without touching any
         parameter gradient (gradcam.py:36: score.backward() up to the layer4 hook).  Consumes the tape."""
         b = self.batch
-        self.param_grads = False
+        pg, self.param_grads = self.param_grads, False
         try:
             d, _ = self.cls.bwd(dlogits.view(b, 1, 1, -1), need_dx=True)
             for layer in reversed(self.head):
                 d, _ = layer.bwd(d, need_dx=True)
         finally:
-            self.param_grads = True
+            self.param_grads = pg
         act = self.last_act
         self._drop_tape()
         self.last_act = None
@@ -823,12 +833,15 @@ class TrainEngine:
             for k in ("c1", "c2", "ds"):
                 if d[k] is not None:
                     d[k].x = d[k].z = d[k].y = d[k].mask = None
+                    d[k].eval_stats = False
         self.stem.x = self.stem.z = self.stem.y = None
+        self.stem.eval_stats = False
 
     def _drop_tape(self):
         self._drop_trunk_tape()
         for l in self.head + [self.cls]:
             l.x = l.z = l.y = None
+            l.eval_stats = False
 
 
 def get_engine(model):
@@ -1057,6 +1070,93 @@ class LossScaler:
         return float(self.state[0])
 
 
+class StepWatchdog:
+    """Stall detector of a replayed multi-rank step.  `_replay` records a HIP event behind every plan op (graph segment, all-reduce,
+    wait); a daemon thread looks at the newest issued step once a second, and when its last event is still pending `bound_s` seconds
+    after the step was issued it reports the FIRST op whose event has not completed -- `[ssad watchdog] rank R: step S stalled
+    > B s at plan op i of n (kind)` on stderr -- and ends the process with a non-zero status (os._exit: a rank that hangs inside a
+    collective cannot be unwound; torchrun then takes the other ranks down, so every rank exits non-zero).  It never re-execs
+    anything; a launcher may start a fresh job with SSAD_GRAPH=0.  Why: hipGraph segments interleaved with RCCL all-reduces first
+    meet on the driver's 8-GPU run, and a silent hang there would say nothing about where it stopped.
+    Bound: SSAD_STEP_TIMEOUT_S (default 120 s; 0 switches the watchdog off).  `on_stall` replaces the exit (tests)."""
+
+    EXIT_CODE = 87
+
+    def __init__(self, rank=0, bound_s=None, on_stall=None, poll_s=1.0):
+        import threading
+        self.rank = rank
+        self.bound_s = float(os.environ.get("SSAD_STEP_TIMEOUT_S", "120")) if bound_s is None else float(bound_s)
+        self.on_stall, self.poll_s = on_stall, poll_s
+        self._lock = threading.Lock()
+        self._pending = []            # issued steps not yet seen complete, oldest first: (step index, issue time, [(kind, event)])
+        self._steps = 0
+        self._paused = False
+        self._thread = None
+
+    def enabled(self):
+        return self.bound_s > 0
+
+    def arm(self, ops_events):
+        """Called by the issuing thread once a step's launches are out: ops_events = [(kind, event with .query())]."""
+        import threading
+        import time
+        if not self.enabled():
+            return
+        with self._lock:
+            self._steps += 1
+            self._pending.append((self._steps, time.monotonic(), list(ops_events)))
+            if len(self._pending) > 256:          # (the issuing thread never runs this far ahead of the device; a bound all the same)
+                del self._pending[:-256]
+        if self._thread is None:
+            self._thread = threading.Thread(target=self._run, name="ssad-step-watchdog", daemon=True)
+            self._thread.start()
+
+    def pause(self, flag):
+        """No event queries while the issuing thread records a graph (stream capture)."""
+        with self._lock:
+            self._paused = bool(flag)
+
+    def check(self, now=None):
+        """One look at the OLDEST unfinished step (the issuing thread runs ahead of the device: a stall belongs to the first step whose
+        events stop completing) -> None, or (step, op index, n ops, kind) of its first pending op once it is overdue."""
+        import time
+        with self._lock:
+            if self._paused:
+                return None
+            while self._pending and (not self._pending[0][2] or self._pending[0][2][-1][1].query()):
+                self._pending.pop(0)              # finished steps leave the queue
+            cur = self._pending[0] if self._pending else None
+        if cur is None:
+            return None
+        step, t0, evs = cur
+        now = time.monotonic() if now is None else now
+        if now - t0 <= self.bound_s:
+            return None
+        for i, (kind, ev) in enumerate(evs):
+            if not ev.query():
+                return step, i, len(evs), kind
+        return None
+
+    def _run(self):
+        import sys
+        import time
+        while True:
+            time.sleep(self.poll_s)
+            hit = self.check()
+            if hit is None:
+                continue
+            step, i, n, kind = hit
+            msg = (f"[ssad watchdog] rank {self.rank}: step {step} stalled > {self.bound_s:g} s at plan op {i} of {n} ({kind}); "
+                   f"exiting with status {self.EXIT_CODE} (relaunch with SSAD_GRAPH=0 for eager launches)")
+            print(msg, file=sys.stderr, flush=True)
+            if self.on_stall is not None:
+                self.on_stall(hit)
+                with self._lock:
+                    self._pending = []
+                continue
+            os._exit(self.EXIT_CODE)
+
+
 class DataParallelStep:
     """forward + loss + backward + (bucketed RCCL all-reduce overlapped with backward) + SGD for one rank.
 
@@ -1095,6 +1195,10 @@ class DataParallelStep:
         self.launch_mode = "hipGraph segments" if self.use_graph else "eager"
         self.self_check_report = None
         self.comm_events = None       # bench.py: a list -> (event, event) pairs around every wait for the gradient all-reduce
+        # multi-rank replays are watched (StepWatchdog); SSAD_WATCHDOG=1 forces it on one rank (tests), =0 switches it off
+        wd = os.environ.get("SSAD_WATCHDOG", "")
+        rank = dist.get_rank(process_group) if (dist.is_available() and dist.is_initialized()) else 0
+        self.watchdog = StepWatchdog(rank) if ((self.world > 1 and wd != "0") or wd == "1") else None
 
     # ---- pieces ----
     def _sync_hyper(self):
@@ -1183,6 +1287,8 @@ class DataParallelStep:
         self.bucketer.reset(self.eng.arena.trainable_ranges())
         self.bucketer.recorder = _Recorder()
         stream.wait_stream(torch.cuda.current_stream())
+        if self.watchdog is not None:
+            self.watchdog.pause(True)
         try:
             with torch.cuda.stream(stream):
                 begin()
@@ -1197,6 +1303,8 @@ class DataParallelStep:
                 end()
         finally:
             self.bucketer.recorder = None
+            if self.watchdog is not None:
+                self.watchdog.pause(False)
         torch.cuda.current_stream().wait_stream(stream)
         self._plans[key] = plan
         return plan
@@ -1208,7 +1316,19 @@ class DataParallelStep:
             plan["y"].copy_(y, non_blocking=True)
         works = []
         g = self.eng.arena.g
-        for op in plan["ops"]:
+        wd = self.watchdog if (self.watchdog is not None and self.watchdog.enabled()) else None
+        evs = None
+        if wd is not None:
+            # one event per plan op, in a ring of four sets: a set is re-recorded only after the step that last used it has finished
+            # (the issuing thread stays at most four steps ahead of the device), so a pending event always belongs to the step the
+            # watchdog attributes it to
+            if "events" not in plan:
+                plan["events"], plan["ev_step"] = [[torch.cuda.Event() for _ in plan["ops"]] for _ in range(4)], 0
+            evs = plan["events"][plan["ev_step"] % 4]
+            if plan["ev_step"] >= 4:
+                evs[-1].synchronize()
+            plan["ev_step"] += 1
+        for i, op in enumerate(plan["ops"]):
             if op[0] == "graph":
                 op[1].replay()
             elif op[0] == "allreduce":
@@ -1216,6 +1336,15 @@ class DataParallelStep:
             else:
                 self._wait_works(works)
                 works = []
+            if wd is not None:
+                # (an all-reduce runs on RCCL's stream: its event marks the compute stream's position when it was issued; a stalled
+                # collective shows up at the "wait" op that follows it)
+                evs[i].record()
+        if wd is not None:
+            kinds = [f"graph segment {sum(1 for o in plan['ops'][:i + 1] if o[0] == 'graph')}" if op[0] == "graph" else
+                     (f"all-reduce of g[{op[1]}:{op[2]}]" if op[0] == "allreduce" else "wait for the all-reduces")
+                     for i, op in enumerate(plan["ops"])]
+            wd.arm(list(zip(kinds, evs)))
         return plan["out"]
 
     def _wait_works(self, works):

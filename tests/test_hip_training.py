@@ -433,6 +433,36 @@ def test_trainable_batchnorm_weights_under_eval_statistics(dev, seeded_sd):
             assert torch.allclose(b1, b2.cpu()), n1
 
 
+def test_eval_statistics_flag_does_not_leak_into_the_next_step(dev, seeded_sd):
+    """a forward under eval-mode statistics with trainable BatchNorm weights marks its layers (`eval_stats`); the
+    mark belongs to THAT forward only.  A forward without a backward (validation with gradients enabled), then model.train() and an
+    eager step: the stem, the raw-output convs of layer1 and every block's second conv must take the batch-statistics backward
+    again -- gradients equal to the oracle's."""
+    from self_supervised import training
+    from oracle import weights as ow
+    from oracle.peranet import train_step
+    ref, m = _pair(seeded_sd, dev)
+    m.unfreeze()
+    bns = [mod for mod in m.feature_extractor.modules() if isinstance(mod, torch.nn.BatchNorm2d)]
+    for mod in bns:
+        mod.eval()
+    x, y = ow.synthetic_images(8, 64, seed=65), ow.synthetic_labels(8, seed=66)
+    eng = training.get_engine(m)
+    eng.forward(x.to(dev))                               # leaves eval_stats set on every trunk layer, tape not consumed
+    assert eng.stem.eval_stats and eng.blocks[0]["c2"].eval_stats
+    for mod in bns:
+        mod.train()
+    loss_ref, _, _ = train_step(ref, x, y)
+    loss_ref.backward()
+    step = training.DataParallelStep(m, lr=0.01, world_size=1, graph=False)
+    la = step.step(x.to(dev), y.to(dev))
+    assert not eng.stem.eval_stats and not any(d[k].eval_stats for d in eng.blocks for k in ("c1", "c2"))
+    np.testing.assert_allclose(la[0].item(), loss_ref.item(), rtol=1e-5)
+    ref_params = dict(ref.named_parameters())
+    for name, p in m.named_parameters():
+        assert rel_err(p.grad, ref_params[name].grad, grad_floor(ref)) < 1e-3, name
+
+
 def test_bound_step_inputs(dev, seeded_sd):
     """DataParallelStep.bind_inputs: a producer fills the recorded step's own input buffers in place; replays from them equal replays
     that copy the batch in, bit for bit."""
@@ -660,6 +690,9 @@ def test_rccl_bucketed_allreduce_single_rank(dev, seeded_sd):
         torch.cuda.synchronize()
         plan = next(iter(s1._plans.values()))
         assert sum(1 for o in plan["ops"] if o[0] == "allreduce") >= 2 and sum(1 for o in plan["ops"] if o[0] == "graph") >= 3
+        # the replays were watched: an event behind every plan op, every step seen to finish (StepWatchdog)
+        assert s1.watchdog is not None and len(plan["events"][0]) == len(plan["ops"]) and plan["ev_step"] >= 2
+        assert s1.watchdog.check() is None and all(e.query() for e in plan["events"][(plan["ev_step"] - 1) % 4])
         assert torch.equal(s1.eng.arena.p, s2.eng.arena.p) and torch.equal(s1.eng.arena.m, s2.eng.arena.m)
     finally:
         dist.destroy_process_group()

@@ -21,11 +21,11 @@ static void run(int64_t N, int H, int W, int Cin, int Cout) {
     }
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) ssad_conv_wgrad3x3_halo(dz, x, slab, splits, N, H, W, Cin, Cout, nullptr);
+    for (int i = 0; i < 3; ++i) ssad_conv_wgrad3x3_halo(dz, x, slab, splits, N, H, W, Cin, Cout, (int64_t)N * H * W * Cout, nullptr);
     hipDeviceSynchronize();
     const int reps = 10;
     hipEventRecord(e0);
-    for (int i = 0; i < reps; ++i) ssad_conv_wgrad3x3_halo(dz, x, slab, splits, N, H, W, Cin, Cout, nullptr);
+    for (int i = 0; i < reps; ++i) ssad_conv_wgrad3x3_halo(dz, x, slab, splits, N, H, W, Cin, Cout, (int64_t)N * H * W * Cout, nullptr);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
@@ -38,7 +38,7 @@ static void run(int64_t N, int H, int W, int Cin, int Cout) {
         hipMalloc(&tr, (size_t)nwg * 72 * 8);
         hipMemset(tr, 0, (size_t)nwg * 72 * 8);
         hipMemcpyToSymbol(HIP_SYMBOL(g_wgh_trace), &tr, sizeof(tr));
-        ssad_conv_wgrad3x3_halo(dz, x, slab, splits, N, H, W, Cin, Cout, nullptr);
+        ssad_conv_wgrad3x3_halo(dz, x, slab, splits, N, H, W, Cin, Cout, (int64_t)N * H * W * Cout, nullptr);
         hipDeviceSynchronize();
         std::vector<unsigned long long> h((size_t)nwg * 72);
         hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost);

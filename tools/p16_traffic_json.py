@@ -43,5 +43,9 @@ out["ratio_to_algorithmic"] = round(out["traffic_MB_per_step"] / alg, 3)
 out["by_kernel_MB"] = {k: {"launches": pf[k][0], "fetch_x2": round(2 * pf[k][1] * 1024 / 1e6, 1), "write": round(pw.get(k, [0, 0.0])[1] * 1024 / 1e6, 1)}
                        for k in sorted(pf, key=lambda k: -pf[k][1])}
 out["note"] = "fabric-side counters: Infinity-Cache hits are included, so this is an upper bound on HBM bytes"
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench
+out["source_sha"] = {"files": bench.P16_TRAFFIC_SOURCES, "sha256": bench.source_sha(bench.P16_TRAFFIC_SOURCES)}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print({k: v for k, v in out.items() if k != "by_kernel_MB"})

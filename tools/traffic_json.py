@@ -26,5 +26,9 @@ out["patches_per_launch"] = int(sys.argv[4])
 out["algorithmic_MB_per_launch"] = 5764.4
 out["ratio_to_algorithmic"] = round(out["traffic_MB_per_launch"] / 5764.4, 3)
 out["note"] = "fabric-side counters: Infinity-Cache hits are included, so this is an upper bound on HBM bytes"
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench
+out["source_sha"] = {"files": bench.SCORE_TRAFFIC_SOURCES, "sha256": bench.source_sha(bench.SCORE_TRAFFIC_SOURCES)}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(out)
