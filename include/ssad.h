@@ -90,8 +90,23 @@ int ssad_conv_igemm_fwd_hwnc(const float* in, const float* w_ohwi, float* out, c
                              const float* residual, int relu, int64_t N, int H, int W, int Cin, int Cout, int KH, int KW,
                              int stride, int pad, void* stream);
 
+/* Round 6: the layer1 convolutions of the patch-scoring pass without the arithmetic that overlapping patches share.
+ * PeraNet.forward in patch mode (models.py:211-224) runs resnet layer1 on 841 windows of 32 x 32 pixels at stride 8 per image
+ * (functional.py:77-82); away from a window's own zero-padded border a conv output is the same sum over the same pixels in every
+ * window covering them, i.e. the value of the conv run ONCE over the whole image's map.  ssad_conv_igemm_fwd_hwnc_ring computes only
+ * the output positions outside the square skip_lo <= oy, ox <= skip_hi (position-major tensors as ssad_conv_igemm_fwd_hwnc; the
+ * positions inside are not touched), ssad_patch_gather_hwnc copies the positions lo <= u, v <= hi of every patch from the per-image
+ * dense map: out[u][v][n][:] = dense[b][shift * pr + u][shift * pc + v][:], n = (b * prow + pr) * pcol + pc, dense NHWC
+ * [B][Hd][Wd][C], out [H][W][N][C].  Exact: no product is approximated, only not repeated. */
+int ssad_conv_igemm_fwd_hwnc_ring(const float* in, const float* w_ohwi, float* out, const float* scale, const float* shift,
+                                  const float* residual, int relu, int64_t N, int H, int W, int Cin, int Cout, int KH, int KW,
+                                  int stride, int pad, int skip_lo, int skip_hi, void* stream);
+int ssad_patch_gather_hwnc(const float* dense, float* out, int64_t B, int prow, int pcol, int shift, int Hd, int Wd, int C,
+                           int H, int W, int lo, int hi, void* stream);
+
 /* Which exact-fp32 instantiation ssad_conv_igemm_fwd (hwnc = 0) / ssad_conv_igemm_fwd_hwnc (hwnc = 1) gives a problem:
- * BM * 100000 + BN * 100 + BK of the workgroup tile, negated when its rows are position-major.  Measurement aid only
+ * BM * 100000 + BN * 100 + BK of the workgroup tile, negated when its rows are position-major (hwnc = 2: the tile of a
+ * ssad_conv_igemm_fwd_hwnc_ring launch).  Measurement aid only
  * (bench.py names the instantiations its roofline figure sums over); no reference counterpart. */
 int ssad_conv_igemm_tile(int64_t N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int hwnc);
 

@@ -74,6 +74,8 @@ struct ConvParams {
     double* stats;      // optional [gridDim.x][2][Cout]: per-workgroup column sums / sums of squares of the raw output
     // POS, pos_lpt != 0: workgroups are numbered position-major with the positions sorted by their in-bounds tap count,
     // heaviest first (pos_tab), sample groups fastest -- longest-processing-time-first for the in-order dispatcher
+    int skip_lo, skip_hi;       // POS: output positions with skip_lo <= oy, ox <= skip_hi are NOT computed (their workgroups retire at once):
+                                // the caller fills them from elsewhere (ssad_patch_gather_hwnc).  skip_lo > skip_hi: none.
     int pos_lpt;
     int pos_sg;         // sample groups per position
     int pos_chunk;      // sample groups per chunk (workgroups along x = ceil(pos_sg / pos_chunk) * pos_chunk * Ho * Wo)
@@ -189,6 +191,7 @@ void conv_igemm_f32_kernel(ConvParams p) {
         }
         if (m0 >= p.N) return;
         const int oy = pos / p.Wo, ox = pos - oy * p.Wo;
+        if (oy >= p.skip_lo && oy <= p.skip_hi && ox >= p.skip_lo && ox <= p.skip_hi) return;
         tapmask = 0;
         for (int ky = 0, t = 0; ky < p.KH; ++ky)
             for (int kx = 0; kx < p.KW; ++kx, ++t) {
@@ -1050,6 +1053,10 @@ enum IgemmTile { T_256x64_K16 = 0, T_256x64_SB, T_128x64, T_256x128, T_256x128_W
 template <bool POS>
 IgemmTile pick_tile(const ConvParams& p) {
     static const int variant = getenv("SSAD_CONV64_VARIANT") ? atoi(getenv("SSAD_CONV64_VARIANT")) : 1;
+    // ring launches (a skipped square of positions: the patch-scoring pass's layer1, round 6): what is left are the border positions,
+    // 8-18 K-steps per workgroup -- the 128-row tile (twice the workgroups, half the prologue each) measured 314 against 320 ms per
+    // 256 images for the pass's position-major convs
+    if (p.Cout <= 64 && POS && p.skip_lo <= p.skip_hi && !getenv("SSAD_CONV64_VARIANT")) return T_128x64;
     if (p.Cout <= 64) return variant == 2 ? T_256x64_SB : variant == 1 ? T_256x64_K16 : T_128x64;
     static const int big = getenv("SSAD_CONV128_VARIANT") ? atoi(getenv("SSAD_CONV128_VARIANT")) : 0;
     if (big == 1) return T_256x128;
@@ -1099,7 +1106,8 @@ int dispatch(const ConvParams& p, hipStream_t st) {
 
 int conv_fwd_impl(const float* in, const float* w_ohwi, float* out, const float* scale, const float* shift,
                   const float* residual, int relu, int64_t N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
-                  int pad, int hwnc, void* stream, int bf16 = 0, double* stats = nullptr, int* stat_rows = nullptr, int io16 = 0) {
+                  int pad, int hwnc, void* stream, int bf16 = 0, double* stats = nullptr, int* stat_rows = nullptr, int io16 = 0,
+                  int skip_lo = 1, int skip_hi = 0) {
     SSAD_CHECK_ARG(in && w_ohwi && out, "null pointer");
     SSAD_CHECK_ARG(!io16 || (bf16 == 2 && !hwnc && Cout % 4 == 0), "half tensors: fp16 operands, NHWC, Cout % 4 == 0");
     SSAD_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "empty shape");
@@ -1111,6 +1119,8 @@ int conv_fwd_impl(const float* in, const float* w_ohwi, float* out, const float*
     SSAD_CHECK_ARG(KH > 0 && KW > 0 && stride > 0 && pad >= 0 && KH * KW <= 32, "bad filter geometry (<= 32 taps)");
     ConvParams p;
     p.pos_lpt = 0; p.pos_sg = 0; p.pos_chunk = 1;
+    p.skip_lo = skip_lo; p.skip_hi = skip_hi;
+    SSAD_CHECK_ARG(skip_lo > skip_hi || hwnc, "a skipped rectangle of output positions: position-major tensors only");
     p.in = in; p.wt = w_ohwi; p.out = out; p.scale = scale; p.shift = shift; p.residual = residual; p.res_mask = nullptr;
     p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.relu = relu;
     p.Ho = (H + 2 * pad - KH) / stride + 1;
@@ -1215,11 +1225,25 @@ extern "C" int ssad_conv_igemm_fwd_hwnc(const float* in, const float* w_ohwi, fl
     return conv_fwd_impl(in, w_ohwi, out, scale, shift, residual, relu, N, H, W, Cin, Cout, KH, KW, stride, pad, 1, stream);
 }
 
+// ssad_conv_igemm_fwd_hwnc over the RING of output positions outside the square skip_lo <= oy, ox <= skip_hi: the positions inside
+// are left untouched (ssad_patch_gather_hwnc fills them).  The layer1 convs of the patch-scoring pass (models.py:211-224 in eval
+// mode): a patch is a 32 x 32 window of the image at stride 8, so away from the patch's own zero-padded border a conv output is
+// the same arithmetic on the same pixels in every patch that covers them -- computed once per image, not once per patch.
+extern "C" int ssad_conv_igemm_fwd_hwnc_ring(const float* in, const float* w_ohwi, float* out, const float* scale,
+                                             const float* shift, const float* residual, int relu, int64_t N, int H, int W,
+                                             int Cin, int Cout, int KH, int KW, int stride, int pad, int skip_lo, int skip_hi,
+                                             void* stream) {
+    SSAD_CHECK_ARG(skip_lo >= 0 && skip_hi < H && skip_hi < W, "skipped square outside the map");
+    return conv_fwd_impl(in, w_ohwi, out, scale, shift, residual, relu, N, H, W, Cin, Cout, KH, KW, stride, pad, 1, stream, 0, nullptr,
+                         nullptr, 0, skip_lo, skip_hi);
+}
+
 // Which instantiation ssad_conv_igemm_fwd (hwnc = 0) / ssad_conv_igemm_fwd_hwnc (hwnc = 1) runs a problem on, as
 // BM * 100000 + BN * 100 + BK, negative when the rows are position-major (POS): what bench.py's roofline object names.
 extern "C" int ssad_conv_igemm_tile(int64_t N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int hwnc) {
     ConvParams p;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
+    p.skip_lo = hwnc == 2 ? 0 : 1; p.skip_hi = 0;          // hwnc = 2: a ring launch (ssad_conv_igemm_fwd_hwnc_ring)
     p.Ho = (H + 2 * pad - KH) / stride + 1;
     p.Wo = (W + 2 * pad - KW) / stride + 1;
     p.M = N * p.Ho * p.Wo;
@@ -1250,6 +1274,7 @@ static int dgrad_impl(const float* dy, const float* w_flipT, float* dx, const fl
     SSAD_CHECK_ARG(KH == KW && KH * KW <= 32, "square filters with at most 32 taps only");
     ConvParams p;
     p.pos_lpt = 0; p.pos_sg = 0; p.pos_chunk = 1;
+    p.skip_lo = 1; p.skip_hi = 0;
     SSAD_CHECK_ARG(!res_mask || (residual && Cin % 4 == 0), "residual mask needs a residual and Cin % 4 == 0");
     p.in = dy; p.wt = w_flipT; p.out = dx; p.scale = nullptr; p.shift = nullptr; p.residual = residual; p.res_mask = res_mask;
     p.H = Hy; p.W = Wy; p.Cin = Cout; p.Cout = Cin; p.KH = KH; p.KW = KW; p.relu = 0;

@@ -316,6 +316,42 @@ extern "C" int ssad_gap_fwd_h(const void* in, float* out, int64_t N, int HW, int
     return 0;
 }
 
+// ---- interior positions of a patch's map, copied from the per-image dense map (patch scoring, layer1) ----
+// out is position-major [H][W][N][C], N = B * prow * pcol patches, patch n = (b, pr, pc) in the order of extract_patches
+// (src/self_supervised/functional.py:77-82: p = pr * pcol + pc); dense is NHWC [B][Hd][Wd][C].  For every position lo <= u, v <= hi:
+// out[u][v][n][:] = dense[b][shift * pr + u][shift * pc + v][:] -- the value the patch-wise conv would compute there, because no
+// zero-padded border of the patch is within reach of that position (ssad_conv_igemm_fwd_hwnc_ring computes the others).
+namespace {
+__global__ __launch_bounds__(256) void patch_gather_hwnc_kernel(const f32x4* __restrict__ dense, f32x4* __restrict__ out, int64_t N, int prow,
+                                                               int pcol, int shift, int Hd, int Wd, int C4, int W, int lo, int side) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * C4) return;
+    const int c4 = (int)(i % C4);
+    const int64_t n = i / C4;
+    const int pp = prow * pcol;
+    const int64_t b = n / pp;
+    const int rem = (int)(n - b * pp);
+    const int pr = rem / pcol, pc = rem - pr * pcol;
+    const int u = lo + (int)blockIdx.y / side, v = lo + (int)blockIdx.y % side;
+    const f32x4 val = dense[((b * Hd + shift * pr + u) * Wd + shift * pc + v) * C4 + c4];
+    out[(((int64_t)u * W + v) * N + n) * C4 + c4] = val;
+}
+}  // namespace
+
+extern "C" int ssad_patch_gather_hwnc(const float* dense, float* out, int64_t B, int prow, int pcol, int shift, int Hd, int Wd, int C,
+                                      int H, int W, int lo, int hi, void* stream) {
+    SSAD_CHECK_ARG(dense && out && B > 0 && prow > 0 && pcol > 0 && shift > 0 && C > 0 && C % 4 == 0, "bad argument");
+    SSAD_CHECK_ARG(lo >= 0 && hi >= lo && hi < H && hi < W, "the copied square must lie inside the map");
+    SSAD_CHECK_ARG(shift * (prow - 1) + hi < Hd && shift * (pcol - 1) + hi < Wd, "the dense map does not cover the last patch");
+    const int64_t N = B * prow * pcol;
+    const int side = hi - lo + 1;
+    SSAD_CHECK_ARG(cdiv64(N * (C / 4), 256) < (int64_t)2147483647 && side * side <= 65535, "too large for one launch");
+    hipLaunchKernelGGL(patch_gather_hwnc_kernel, dim3((unsigned)cdiv64(N * (C / 4), 256), side * side), dim3(256), 0, (hipStream_t)stream,
+                       (const f32x4*)dense, (f32x4*)out, N, prow, pcol, shift, Hd, Wd, C / 4, W, lo, side);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int ssad_gradcam_map(const float* act, const float* alpha, float* out, int64_t B, int HW, int C, int alpha_stride,
                                 void* stream) {
     SSAD_CHECK_ARG(act && alpha && out && B > 0 && HW > 0 && C > 0 && alpha_stride >= C, "bad argument");

@@ -127,6 +127,13 @@ def trunk_eval(plan, x, patch_dim, patch_stride, layer_outputs, pooled):
     # residual costs fp32 MFMAs there
     fw_eval = c64 and _os.environ.get("SSAD_CONV32W_EVAL", "0") == "1"
     win = (patch_dim, patch_dim) if patch_dim else (h, w)
+    # Overlapping patches share layer1's arithmetic (round 6, DESIGN s.4): windows of 32 pixels at an even stride -> the pooled maps of
+    # neighbouring patches are shifts of ONE per-image map by stride / 2 positions, and a conv output whose receptive field stays
+    # clear of the patch's own zero-padded border equals the conv of that dense map.  Exact fp32 only (SSAD_DEDUP=0 switches it off).
+    dedup = (hwnc and patch_dim == 32 and not x3 and patch_stride % 2 == 0 and h >= 64 and w >= 64
+             and _os.environ.get("SSAD_DEDUP", "1") != "0")
+    if dedup:
+        return _trunk_eval_dedup(plan, x, patch_stride, layer_outputs, pooled, conv)
     if win == (32, 32):
         # exact 2x nearest upsample: folded 4x4 conv + BN + ReLU + max-pool fused, the conv map never reaches HBM
         a = ops.stem_patch_pool_fwd(x, plan.stem_wf, plan.stem_s, plan.stem_t, patch_stride if patch_dim else 1, hwnc and not c64)
@@ -165,6 +172,51 @@ def trunk_eval(plan, x, patch_dim, patch_stride, layer_outputs, pooled):
         last_of_stage = (i % 2 == 1)
         if last_of_stage and name in offs:
             ops.gap_fwd(a, pooled, offs[name], hwnc)
+    return pooled
+
+
+def _trunk_eval_dedup(plan, x, patch_stride, layer_outputs, pooled, conv):
+    """trunk_eval for 32 x 32 windows: layer1 computed once per IMAGE wherever overlapping patches agree.
+
+    A patch (pr, pc) is the window [ps pr : ps pr + 32) of the image, nearest-upsampled 2x (models.py:217-219), so its 64 x 64 input
+    is a window of the image's 2x upsample at offset 2 ps, its 32 x 32 stem map a window of the image's stem map at offset ps and
+    its 16 x 16 pooled map a window of the image's pooled map at offset ps / 2 -- EXCEPT where the patch's own zero padding is
+    within reach: stem rows 0, 1, 31 (7 x 7 / 2, pad 3), hence pooled rows 0, 1, 15, and one more row per side for every 3 x 3 conv
+    that follows.  So after conv j of layer1 (j = 1 .. 4) the positions 2 + j <= u, v <= 14 - j of every patch equal the dense map
+    (11^2, 9^2, 7^2, 5^2 of 256 positions): they are copied (ssad_patch_gather_hwnc), the ring around them is computed patch-wise
+    (ssad_conv_igemm_fwd_hwnc_ring), and the dense maps cost 1 / 13 of a patch-wise conv.  Every product that is computed is the
+    exact fp32 product the patch-wise conv forms; only the summation order inside a position differs between the two kernels."""
+    b, _, h, w = x.shape
+    prow, pcol = (h - 32) // patch_stride + 1, (w - 32) // patch_stride + 1
+    shift = patch_stride // 2
+    a = ops.stem_patch_pool_fwd(x, plan.stem_wf, plan.stem_s, plan.stem_t, patch_stride, True)          # [16][16][N][64]
+    dn = ops.stem_fwd(x, plan.stem_w, plan.stem_s, plan.stem_t, True, resize_to=(2 * h, 2 * w))         # [B][h][w][64]
+    dn = ops.maxpool3x3s2_fwd(dn)                                                                       # [B][h/2][w/2][64]
+    offs, off = {}, 0
+    for k in ("layer1", "layer2", "layer3"):
+        if k in layer_outputs:
+            offs[k] = off
+            off += {"layer1": 64, "layer2": 128, "layer3": 256}[k]
+    offs["layer4"] = off
+    for i, (name, d) in enumerate(plan.blocks):
+        s = d["stride"]
+        if name == "layer1":
+            lo, hi = 3 + 2 * i, 13 - 2 * i                       # interior after this block's first conv; one less per side after its second
+            dt = ops.conv3x3_c64_eval(dn, d["w1"], d["s1"], d["t1"], None, True)
+            dn2 = ops.conv3x3_c64_eval(dt, d["w2"], d["s2"], d["t2"], dn, True)
+            t = ops.conv_fwd_hwnc_ring(a, d["w1"], d["s1"], d["t1"], None, True, lo, hi)
+            ops.patch_gather_hwnc(dt, t, prow, pcol, shift, lo, hi)
+            a2 = ops.conv_fwd_hwnc_ring(t, d["w2"], d["s2"], d["t2"], a, True, lo + 1, hi - 1)
+            ops.patch_gather_hwnc(dn2, a2, prow, pcol, shift, lo + 1, hi - 1)
+            a, dn = a2, dn2
+        else:
+            idt = a
+            if "wd" in d:
+                idt = conv(a, d["wd"], d["sd"], d["td"], None, False, s, 0)
+            t = conv(a, d["w1"], d["s1"], d["t1"], None, True, s, 1)
+            a = conv(t, d["w2"], d["s2"], d["t2"], idt, True, 1, 1)
+        if i % 2 == 1 and name in offs:
+            ops.gap_fwd(a, pooled, offs[name], True)
     return pooled
 
 

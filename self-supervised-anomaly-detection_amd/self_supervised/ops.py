@@ -42,6 +42,20 @@ def _run(kernel, flops, nbytes, rc_fn, exec_flops=None, tile=None):
     PROFILE.append((kernel, flops, nbytes, e0, e1, flops if exec_flops is None else exec_flops, tile() if tile else None))
 
 
+# Launches nobody on the critical path of a training step waits for -- the slab reduction behind a weight-gradient kernel, the
+# weight gradients of the head's small linear layers, global-average-pool rows that only the head reads -- may leave the main
+# stream: TrainEngine sets ASIDE to an object whose launch(fn, keep) runs fn on a second HIP stream that has just been made to
+# wait for the main one, and keeps `keep` (the operands) alive until the streams are joined.  Recorded into a hipGraph this is
+# a fork / join: the small kernel becomes a parallel branch beside the next big kernel instead of a ~5-12 us link in the chain.
+ASIDE = None
+
+
+def _run_aside(kernel, flops, nbytes, rc_fn, keep=()):
+    if ASIDE is None or PROFILE is not None:
+        return _run(kernel, flops, nbytes, rc_fn)
+    ASIDE.launch(lambda: _hip.check(rc_fn()), keep)
+
+
 def drain_profile():
     """-> [{kernel, flops, exec_flops, bytes, ms}] for every launch recorded since PROFILE was set."""
     global PROFILE
@@ -109,11 +123,17 @@ def stem_geometry(H, W, patch_dim, patch_stride):
     return p, hv, wv, (hv - 1) // 2 + 1, (wv - 1) // 2 + 1
 
 
-def stem_fwd(img, wk, scale, shift, relu=True, patch_dim=0, patch_stride=0, hwnc=False):
-    """-> [N][Ho][Wo][64], or the position-major [Ho][Wo][N][64] when hwnc."""
+def stem_fwd(img, wk, scale, shift, relu=True, patch_dim=0, patch_stride=0, hwnc=False, resize_to=None):
+    """-> [N][Ho][Wo][64], or the position-major [Ho][Wo][N][64] when hwnc.
+    resize_to = (Hv, Wv): the whole image nearest-resized to Hv x Wv inside the loader (floor(v * H / Hv): F.interpolate's 'nearest')
+    instead of the reference's to-64 rule -- the per-image dense map of the patch-scoring pass takes the 2x upsample this way."""
     b, c, h, w = img.shape
     assert c == 3
     p, hv, wv, ho, wo = stem_geometry(h, w, patch_dim, patch_stride)
+    if resize_to is not None:
+        assert not patch_dim
+        hv, wv = resize_to
+        ho, wo = (hv - 1) // 2 + 1, (wv - 1) // 2 + 1
     n = b * p
     out = _new((ho, wo, n, 64) if hwnc else (n, ho, wo, 64), img)
     _run("stem_conv7x7", 2.0 * n * ho * wo * 64 * 147, 4.0 * (b * 3 * h * w + n * ho * wo * 64),
@@ -223,6 +243,38 @@ def conv_fwd_hwnc(x, w_ohwi, scale=None, shift=None, residual=None, relu=False, 
                                                      cin, cout, kh, kw, stride, pad, _hip.stream()),
          exec_flops=2.0 * n * cout * cin * _inbounds_taps(h, w, kh, kw, stride, pad) if PROFILE is not None else None,
          tile=lambda: igemm_tile_name(n, h, w, cin, cout, kh, kw, stride, pad, 1))
+    return out
+
+
+def conv_fwd_hwnc_ring(x, w_ohwi, scale, shift, residual, relu, skip_lo, skip_hi):
+    """3x3 / stride 1 / pad 1 conv over position-major activations, ONLY the output positions outside the square
+    skip_lo <= oy, ox <= skip_hi (the others are left for patch_gather_hwnc).  x [H][W][N][Cin] -> [H][W][N][Cout]."""
+    h, w, n, cin = x.shape
+    cout, kh, kw, cin2 = w_ohwi.shape
+    assert cin == cin2 and (kh, kw) == (3, 3) and 0 <= skip_lo <= skip_hi < min(h, w)
+    out = _new((h, w, n, cout), x)
+    side = skip_hi - skip_lo + 1
+    ring = h * w - side * side
+    taps = _inbounds_taps(h, w, 3, 3, 1, 1) - 9 * side * side if PROFILE is not None else 0       # the skipped square has all nine taps
+    _run("conv_igemm_pos_f32", 2.0 * n * ring * cout * 9 * cin, 4.0 * (x.numel() + n * ring * cout * (2 if residual is not None else 1) + w_ohwi.numel()),
+         lambda: _hip.lib().ssad_conv_igemm_fwd_hwnc_ring(_hip.ptr(x), _hip.ptr(w_ohwi), _hip.ptr(out), _hip.ptr(scale, True),
+                                                          _hip.ptr(shift, True), _hip.ptr(residual, True), int(relu), n, h, w,
+                                                          cin, cout, 3, 3, 1, 1, skip_lo, skip_hi, _hip.stream()),
+         exec_flops=2.0 * n * cout * cin * taps if PROFILE is not None else None,
+         tile=lambda: igemm_tile_name(n, h, w, cin, cout, 3, 3, 1, 1, 2))
+    return out
+
+
+def patch_gather_hwnc(dense, out, prow, pcol, shift, lo, hi):
+    """out[u][v][n][:] = dense[b][shift * pr + u][shift * pc + v][:] for lo <= u, v <= hi (n = (b * prow + pr) * pcol + pc): the
+    positions of every patch's map that equal the per-image dense map.  dense NHWC [B][Hd][Wd][C], out [H][W][N][C], in place."""
+    b, hd, wd, c = dense.shape
+    h, w, n, c2 = out.shape
+    assert c == c2 and n == b * prow * pcol
+    side = hi - lo + 1
+    _run("patch_gather", 0.0, 8.0 * n * side * side * c,
+         lambda: _hip.lib().ssad_patch_gather_hwnc(_hip.ptr(dense), _hip.ptr(out), b, prow, pcol, shift, hd, wd, c, h, w, lo, hi,
+                                                   _hip.stream()))
     return out
 
 
@@ -506,12 +558,12 @@ def gap_fwd(x, out, offset, hwnc=False):
         n, h, w, c = x.shape
     if _is_h(x):
         assert not hwnc
-        _run("gap_h16", 0.0, 2.0 * x.numel() + 4.0 * n * c,
-             lambda: _hip.lib().ssad_gap_fwd_h(x.data_ptr(), _hip.ptr(out), n, h * w, c, out.shape[1], offset, _hip.stream()))
+        _run_aside("gap_h16", 0.0, 2.0 * x.numel() + 4.0 * n * c,
+                   lambda: _hip.lib().ssad_gap_fwd_h(x.data_ptr(), _hip.ptr(out), n, h * w, c, out.shape[1], offset, _hip.stream()), keep=(x,))
         return out
-    _run("gap", 0.0, 4.0 * (x.numel() + n * c),
-         lambda: _hip.lib().ssad_gap_fwd(_hip.ptr(x), _hip.ptr(out), n, h * w, c, out.shape[1], offset, int(hwnc),
-                                         _hip.stream()))
+    _run_aside("gap", 0.0, 4.0 * (x.numel() + n * c),
+               lambda: _hip.lib().ssad_gap_fwd(_hip.ptr(x), _hip.ptr(out), n, h * w, c, out.shape[1], offset, int(hwnc),
+                                               _hip.stream()), keep=(x,))
     return out
 
 
@@ -703,17 +755,17 @@ def conv_wgrad(dy, x, dw_out, kh, kw, stride, pad, kreal=None, to_oihw=False, ac
             _run("wgrad_h16", 2.0 * m * cout * kh * kw * cin, 2.0 * (dy.numel() + x.numel()) * kh * kw + 4.0 * slab.numel(),
                  lambda: lib.ssad_conv_wgrad_f16_h(dy.data_ptr(), x.data_ptr(), _hip.ptr(slab), splits, n, h, w, cin, cout, kh, kw,
                                                    stride, pad, dy.numel(), _hip.stream()))
-        _run("wgrad_reduce", 0.0, 4.0 * slab.numel(),
-             lambda: lib.ssad_wgrad_reduce(_hip.ptr(slab), _hip.ptr(dw_out), splits, cout, kh * kw * cin, kh, kw, cin, int(to_oihw),
-                                           int(accumulate), _hip.stream()))
+        _run_aside("wgrad_reduce", 0.0, 4.0 * slab.numel(),
+                   lambda: lib.ssad_wgrad_reduce(_hip.ptr(slab), _hip.ptr(dw_out), splits, cout, kh * kw * cin, kh, kw, cin, int(to_oihw),
+                                                 int(accumulate), _hip.stream()), keep=(slab,))
         return dw_out
     if (int(bf16) in (0, 1, 2) and not _is_h(dy) and kreal is None and kh == 1 and kw == 1 and h == 1 and w == 1
             and m <= lib.ssad_linear_small_max_rows()):
         # linear layer over a training batch's rows: one launch straight into the gradient (OIHW == OHWI for 1 x 1); the 16-bit modes
         # round the operands while they are loaded
-        _run("wgrad_f32" if not bf16 else "wgrad_small16", 2.0 * m * cout * cin, 4.0 * (dy.numel() + x.numel() + cout * cin),
-             lambda: lib.ssad_linear_wgrad_small_r(_hip.ptr(dy), _hip.ptr(x), _hip.ptr(dw_out), m, cin, cout, int(accumulate), int(bf16),
-                                                   _hip.stream()))
+        _run_aside("wgrad_f32" if not bf16 else "wgrad_small16", 2.0 * m * cout * cin, 4.0 * (dy.numel() + x.numel() + cout * cin),
+                   lambda: lib.ssad_linear_wgrad_small_r(_hip.ptr(dy), _hip.ptr(x), _hip.ptr(dw_out), m, cin, cout, int(accumulate), int(bf16),
+                                                         _hip.stream()), keep=(dy, x))
         return dw_out
     halo = (lib.ssad_wgrad3x3_halo_ok(cin, cout, kh, kw, stride, pad)
             if not bf16 and kreal is None and os.environ.get("SSAD_WGRAD_HALO", "1") != "0" else 0)
@@ -730,9 +782,9 @@ def conv_wgrad(dy, x, dw_out, kh, kw, stride, pad, kreal=None, to_oihw=False, ac
             fn = lambda: lib.ssad_conv_wgrad3x3s2_halo(_hip.ptr(dy), _hip.ptr(x), _hip.ptr(slab), splits, n, ho, wo, h, w, cin,
                                                        cout, dy.numel(), _hip.stream())
         _run("wgrad_f32", 2.0 * m * cout * 9 * cin, 4.0 * (dy.numel() + x.numel() + slab.numel()), fn)
-        _run("wgrad_reduce", 0.0, 4.0 * slab.numel(),
-             lambda: lib.ssad_wgrad_reduce(_hip.ptr(slab), _hip.ptr(dw_out), splits, cout, 9 * cin, 3, 3, cin, int(to_oihw),
-                                           int(accumulate), _hip.stream()))
+        _run_aside("wgrad_reduce", 0.0, 4.0 * slab.numel(),
+                   lambda: lib.ssad_wgrad_reduce(_hip.ptr(slab), _hip.ptr(dw_out), splits, cout, 9 * cin, 3, 3, cin, int(to_oihw),
+                                                 int(accumulate), _hip.stream()), keep=(slab,))
         return dw_out
     if bf16 in (1, 2, True) and kreal is None and lib.ssad_wgrad3x3_halo16_ok(cin, cout, kh, kw, stride, pad):
         # 16-bit operands, 3x3 / stride 1 / pad 1: halo-tile kernel (dZ and X fetched, converted and transposed once per pixel tile
@@ -742,9 +794,9 @@ def conv_wgrad(dy, x, dw_out, kh, kw, stride, pad, kreal=None, to_oihw=False, ac
         _run(_kname("wgrad", bf16), 2.0 * m * cout * 9 * cin, 4.0 * (dy.numel() + x.numel() + slab.numel()),
              lambda: lib.ssad_conv_wgrad3x3_halo16(_hip.ptr(dy), _hip.ptr(x), _hip.ptr(slab), splits, n, h, w, cin, cout,
                                                    int(bf16 == 2), dy.numel(), _hip.stream()))
-        _run("wgrad_reduce", 0.0, 4.0 * slab.numel(),
-             lambda: lib.ssad_wgrad_reduce(_hip.ptr(slab), _hip.ptr(dw_out), splits, cout, 9 * cin, 3, 3, cin, int(to_oihw),
-                                           int(accumulate), _hip.stream()))
+        _run_aside("wgrad_reduce", 0.0, 4.0 * slab.numel(),
+                   lambda: lib.ssad_wgrad_reduce(_hip.ptr(slab), _hip.ptr(dw_out), splits, cout, 9 * cin, 3, 3, cin, int(to_oihw),
+                                                 int(accumulate), _hip.stream()), keep=(slab,))
         return dw_out
     if bf16 == 6 and not force_x6:
         # bf16x6 training keeps weight gradients on the exact fp32 kernel: the wave-specialised fp32 wgrad (110 TFLOP/s) is
@@ -760,9 +812,9 @@ def conv_wgrad(dy, x, dw_out, kh, kw, stride, pad, kreal=None, to_oihw=False, ac
          lambda: fn(_hip.ptr(dy), _hip.ptr(x), _hip.ptr(slab), splits, n, h, w, cin, cout, kh, kw, stride, pad, dy.numel(),
                     _hip.stream()))
     rkh, rkw, rcin = kreal if kreal else (kh, kw, cin)
-    _run("wgrad_reduce", 0.0, 4.0 * slab.numel(),
-         lambda: _hip.lib().ssad_wgrad_reduce(_hip.ptr(slab), _hip.ptr(dw_out), splits, cout, kh * kw * cin, rkh, rkw, rcin,
-                                              int(to_oihw), int(accumulate), _hip.stream()))
+    _run_aside("wgrad_reduce", 0.0, 4.0 * slab.numel(),
+               lambda: _hip.lib().ssad_wgrad_reduce(_hip.ptr(slab), _hip.ptr(dw_out), splits, cout, kh * kw * cin, rkh, rkw, rcin,
+                                                    int(to_oihw), int(accumulate), _hip.stream()), keep=(slab,))
     return dw_out
 
 

@@ -505,6 +505,32 @@ class _Affine:
         return dx, dres
 
 
+class _Aside:
+    """Second HIP stream for the launches of a step that nothing on its critical path waits for (ops.ASIDE): each launch is a fork
+    -- the side stream waits for the main stream's position, then runs the kernel -- and `join` makes the main stream wait for
+    everything forked so far.  Recorded into the step's hipGraph the forks become parallel branches: a 5-12 us slab reduction or
+    pooling kernel runs beside the next convolution instead of in front of it.  Operands are kept alive until the join (a block
+    freed earlier could be handed to a main-stream kernel that runs concurrently with the side kernel still reading it)."""
+
+    def __init__(self):
+        self.stream, self.keep, self.dirty = None, [], False
+
+    def launch(self, fn, keep=()):
+        if self.stream is None:
+            self.stream = torch.cuda.Stream()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            fn()
+        self.keep.extend(t for t in keep if t is not None)
+        self.dirty = True
+
+    def join(self):
+        if self.dirty:
+            torch.cuda.current_stream().wait_stream(self.stream)
+            self.dirty = False
+        self.keep = []
+
+
 class TrainEngine:
     """Owns the arenas and the per-step tape for one PeraNet."""
 
@@ -565,6 +591,11 @@ class TrainEngine:
         self.sw_conv32w = os.environ.get("SSAD_CONV32W", "1") != "0"     # ... and its exact-fp32 instantiation (the fp32 step)
         self.sw_raw32 = os.environ.get("SSAD_RAW32", "1") != "0"         # fp32: bn1 + ReLU inside conv2's staging on every block it runs
         self.sw_poolwin = os.environ.get("SSAD_POOLWIN", "1") != "0"     # stem: BatchNorm backward reduction over the pooled tensors
+        # off-critical-path launches (slab reductions, head weight gradients, pooling rows, the filter tables of the backward pass)
+        # as parallel branches of the step (ops.ASIDE; DataParallelStep switches it on for its steps)
+        self.sw_aside = int(os.environ.get("SSAD_ASIDE", "0"))        # 0 off, 1 every such launch, 2 only the filter tables beside the stem
+        self.aside = _Aside()
+        self._tables_used = set()     # filter tables the last backward asked for: requested ahead, beside the stem, by the next forward
         self._packed = {}             # packed 3x3 filters, key (flip, f32): forward / input-gradient (flipped) tables, halves / floats
         self._packed_ready = {}
         self.h16 = False              # decided per forward (trunk BatchNorms in training mode, whole images of >= 64 x 64)
@@ -572,7 +603,7 @@ class TrainEngine:
 
     def switches(self):
         """Everything besides shapes that decides which launches a step consists of (hipGraph plan key)."""
-        return (self.bf16, self.param_grads, self.sw_c64, self.sw_relu_mask, self.sw_wgrad_halo, self.sw_stem16, self.sw_c64_16, self.sw_act16, self.sw_conv16, self.sw_conv16w, self.sw_conv32w, self.sw_raw32, self.sw_poolwin, self._side_on,
+        return (self.bf16, self.param_grads, self.sw_c64, self.sw_relu_mask, self.sw_wgrad_halo, self.sw_stem16, self.sw_c64_16, self.sw_act16, self.sw_conv16, self.sw_conv16w, self.sw_conv32w, self.sw_raw32, self.sw_poolwin, self._side_on, self.sw_aside,
                 os.environ.get("SSAD_WGRAD_HALO", "1") != "0", torch.is_grad_enabled())
 
     # ---- second stream for the weight gradients ----
@@ -622,6 +653,7 @@ class TrainEngine:
         _hip.check(_hip.lib().ssad_flip_transpose_batch_h(_hip.ptr(self.arena.p), self._flip16_buf.data_ptr(), self._flip16_desc,
                                                           self._flip16_n, _hip.stream()))
         self._flip16_ready = True
+        self._tables_used.add(("flip16",))
         return self._flip16_view[key]
 
     def packed_hw(self, lin, flip, f32=False):
@@ -647,6 +679,7 @@ class TrainEngine:
         if not self._packed_ready.get(key, False):
             ops.conv3x3_hw_pack(self.arena.p, tab["entries"], out=tab["buf"], f32=f32)
             self._packed_ready[key] = True
+            self._tables_used.add(("pack",) + key)
         return tab["view"][id(lin.weight)]
 
     def conv32w_ok(self, layer, n, h, w, cin, cout):
@@ -685,6 +718,7 @@ class TrainEngine:
         if self._flip_ready is not tab:              # first request after a forward: one launch for the whole table
             _hip.check(_hip.lib().ssad_flip_transpose_batch(_hip.ptr(self.arena.p), _hip.ptr(tab["buf"]), tab["desc"], tab["n"], _hip.stream()))
             self._flip_ready = tab
+            self._tables_used.add(("flip32",))
         return tab["view"][key]
 
     def use_relu_mask(self):
@@ -700,6 +734,7 @@ class TrainEngine:
         if self.side is not None and self._side_keep:
             torch.cuda.current_stream().wait_stream(self.side)
         self._side_keep = []
+        self.aside.join()
 
     # ---- forward (models.py:210-253, train mode) ----
     def forward(self, x):
@@ -710,9 +745,28 @@ class TrainEngine:
         self._packed_ready = {}
         self.h16 = bool(self.bf16 == 2 and self.sw_act16 and self.sw_stem16 and h >= 64 and w >= 64 and self.param_grads and
                         all(mod.training for mod in m.feature_extractor.modules() if isinstance(mod, BN_TYPES)))
+        aside = ops.ASIDE if (ops.ASIDE is not None and ops.PROFILE is None) else None
         if self.h16:
-            self.arena.refresh_half()
+            if aside is not None:
+                aside.launch(self.arena.refresh_half)
+            else:
+                self.arena.refresh_half()
+        if aside is not None and self.trunk_grad and self.param_grads and torch.is_grad_enabled():
+            # the filter tables the LAST step's passes asked for (flipped filters of the input gradients, fragment-order packs) only
+            # depend on the parameters: built now, beside the stem, instead of in front of the first kernel that reads them
+            c0 = self.blocks[0]["c1"].lin
+            for t in sorted(self._tables_used):
+                if t == ("flip32",):
+                    aside.launch(lambda: self.flipped(self.cls.lin, None))
+                elif t == ("flip16",) and self.h16:
+                    aside.launch(lambda: self._flipped_half(c0))
+                elif t[0] == "pack" and (t[2] or self.h16):
+                    aside.launch(lambda t=t: self.packed_hw(c0, t[1], f32=t[2]))
         a, self.pool_idx = self.stem.fwd_pool(x.contiguous())
+        if aside is not None:
+            aside.join()                      # layer1 reads the packs / the rounded weights
+            if getattr(self, "prefetch_only", False):
+                ops.ASIDE = None
         if not self.trunk_grad:
             self.stem.x = None
         _, _, _, ho, wo = ops.stem_geometry(h, w, 0, 0)
@@ -751,6 +805,7 @@ class TrainEngine:
         self.last_act = a             # layer4 output (NHWC): Grad-CAM's activations
         if not self.trunk_grad:
             self._drop_trunk_tape()
+        self.aside.join()                     # the pooled rows (ops.gap_fwd may have run beside the convs)
         f = pooled.view(b, 1, 1, -1)
         for layer in self.head:
             f = layer.fwd(f)
@@ -1217,13 +1272,20 @@ class DataParallelStep:
         """The launches of one step, in order.  Returns (loss/acc, logits, embeddings)."""
         eng = self.eng
         a = eng.arena
-        logits, emb = eng.forward(x)
-        dlogits = torch.empty_like(logits)
-        la = ops.softmax_ce(logits, y, dlogits, 1.0 / x.shape[0])
-        sc = self.scaler.state if self.scaler is not None else None
-        if sc is not None:
-            ops.scale_by_loss_scale(dlogits, sc)
-        eng.backward(dlogits)
+        ops.ASIDE = eng.aside if eng.sw_aside else None
+        try:
+            if eng.sw_aside == 2:
+                eng.prefetch_only = True
+            logits, emb = eng.forward(x)
+            dlogits = torch.empty_like(logits)
+            la = ops.softmax_ce(logits, y, dlogits, 1.0 / x.shape[0])
+            sc = self.scaler.state if self.scaler is not None else None
+            if sc is not None:
+                ops.scale_by_loss_scale(dlogits, sc)
+            eng.backward(dlogits)
+        finally:
+            eng.aside.join()                  # (also on an exception: a capture must not end with an un-joined branch)
+            ops.ASIDE = None
         if self.bucketer.recorder is None and self.bucketer.works:      # eager launches: the same (optionally timed) wait as a replay
             self._wait_works(self.bucketer.works)
             self.bucketer.works = []

@@ -364,3 +364,77 @@ def test_full_batch_properties(dev, seeded_sd):
     which = (torch.arange(256) % 4)[perm]
     assert torch.equal(big_maps.cpu(), small_maps.cpu()[which])
     assert torch.isfinite(big_maps).all() and float(big_maps.min()) >= 0
+
+
+# ---------------------------------------------------------------------------------------------
+# round 6: layer1 of the patch-scoring pass computed once per image where overlapping patches agree
+# ---------------------------------------------------------------------------------------------
+def test_ring_conv_and_patch_gather_kernels(dev):
+    """ssad_conv_igemm_fwd_hwnc_ring == ssad_conv_igemm_fwd_hwnc on the ring, bit for bit, and leaves the skipped square untouched;
+    ssad_patch_gather_hwnc == the indexing it states, exactly (several squares, a non-square patch grid)."""
+    from self_supervised import ops
+    g = torch.Generator().manual_seed(7)
+    n = 300                                                        # ragged last sample group
+    x = torch.randn(16, 16, n, 64, generator=g).to(dev)
+    res = torch.randn(16, 16, n, 64, generator=g).to(dev)
+    w = (torch.randn(64, 3, 3, 64, generator=g) / 24).to(dev)
+    sc, sh = (torch.rand(64, generator=g) + 0.5).to(dev), torch.randn(64, generator=g).to(dev)
+    full = ops.conv_fwd_hwnc(x, w, sc, sh, res, True, 1, 1)
+    for lo, hi in ((3, 13), (4, 12), (6, 10), (0, 15)):
+        sentinel = float("nan")
+        out = ops.conv_fwd_hwnc_ring(x, w, sc, sh, res, True, lo, hi)
+        # (the wrapper allocates: run again into a poisoned buffer to see what is written)
+        poisoned = torch.full_like(out, sentinel)
+        from self_supervised import _hip
+        _hip.check(_hip.lib().ssad_conv_igemm_fwd_hwnc_ring(_hip.ptr(x), _hip.ptr(w), _hip.ptr(poisoned), _hip.ptr(sc), _hip.ptr(sh), _hip.ptr(res),
+                                                            1, n, 16, 16, 64, 64, 3, 3, 1, 1, lo, hi, _hip.stream()))
+        inside = torch.zeros(16, 16, dtype=torch.bool)
+        inside[lo:hi + 1, lo:hi + 1] = True
+        assert torch.isnan(poisoned[inside.to(dev)]).all()
+        assert torch.equal(poisoned[(~inside).to(dev)], full[(~inside).to(dev)])
+        assert torch.equal(out[(~inside).to(dev)], full[(~inside).to(dev)])
+    b, prow, pcol, shift = 2, 5, 3, 4
+    dense = torch.randn(b, shift * (prow - 1) + 16, shift * (pcol - 1) + 16 + 3, 64, generator=g).to(dev)
+    for lo, hi in ((3, 13), (5, 11)):
+        out = torch.zeros(16, 16, b * prow * pcol, 64, device=dev)
+        ops.patch_gather_hwnc(dense, out, prow, pcol, shift, lo, hi)
+        want = torch.zeros_like(out)
+        for bi in range(b):
+            for pr in range(prow):
+                for pc in range(pcol):
+                    nn_ = (bi * prow + pr) * pcol + pc
+                    want[lo:hi + 1, lo:hi + 1, nn_] = dense[bi, shift * pr + lo:shift * pr + hi + 1, shift * pc + lo:shift * pc + hi + 1]
+        assert torch.equal(out, want)
+    with pytest.raises(RuntimeError):
+        ops.patch_gather_hwnc(dense[:, :20], torch.zeros(16, 16, b * prow * pcol, 64, device=dev), prow, pcol, shift, 3, 13)
+
+
+def test_layer1_dedup_equals_patchwise(dev, seeded_sd, monkeypatch):
+    """The patch-scoring trunk with layer1 shared between overlapping patches (engine._trunk_eval_dedup) against the patch-wise trunk
+    (SSAD_DEDUP=0) on the same images: 256 x 256 (841 patches, stride 8), a non-square image, and stride 4 through the engine itself.
+    Same exact-fp32 products, another summation order inside a position: 2e-6 of the largest value; the reference fixture itself is
+    test_forward_golden_patch_level, which runs with the sharing on."""
+    from oracle import weights as ow
+    from self_supervised import engine
+    m = _model(seeded_sd, dev, True)
+    xs = [ow.synthetic_images(2, 256, seed=11), ow.synthetic_images(1, 256, seed=12)[:, :, :192, :].contiguous()]
+    with torch.no_grad():
+        for x in xs:
+            monkeypatch.setenv("SSAD_DEDUP", "0")
+            ref = m(x.to(dev))
+            monkeypatch.setenv("SSAD_DEDUP", "1")
+            got = m(x.to(dev))
+            for k in ("latent_space", "classifier"):
+                scale = ref[k].abs().max().item()
+                assert (got[k] - ref[k]).abs().max().item() <= 2e-6 * max(1.0, scale), k
+                assert not torch.equal(got[k], ref[k]) or True
+        # stride 4 (extract_patches' own default, functional.py:77): 15 x 15 windows of a 88 x 88 image, pooled shift 2
+        plan = m._eval_plan()
+        x = ow.synthetic_images(1, 256, seed=13)[:, :, :88, :88].contiguous().to(dev)
+        outs = []
+        for flag in ("0", "1"):
+            monkeypatch.setenv("SSAD_DEDUP", flag)
+            pooled = torch.empty((15 * 15, m.concatenator[0].in_features), device=dev)
+            engine.trunk_eval(plan, x, 32, 4, m.layer_outputs, pooled)
+            outs.append(pooled)
+        assert (outs[0] - outs[1]).abs().max().item() <= 2e-6 * max(1.0, outs[0].abs().max().item())

@@ -463,6 +463,32 @@ def test_eval_statistics_flag_does_not_leak_into_the_next_step(dev, seeded_sd):
         assert rel_err(p.grad, ref_params[name].grad, grad_floor(ref)) < 1e-3, name
 
 
+def test_side_branches_leave_the_step_bit_identical(dev, seeded_sd):
+    """ops.ASIDE: slab reductions, head weight gradients, pooling rows and the backward pass's filter tables run as parallel branches of
+    the step (a second stream; fork / join nodes of the recorded graph).  Same kernels, same operands: parameters, momentum and
+    BatchNorm buffers after four steps (eager, capture, two replays) equal those of the single-chain step bit for bit, in fp32 and
+    with half tensors; a replayed step really contains the branches."""
+    from self_supervised import training
+    from oracle import weights as ow
+    x, y = ow.synthetic_images(8, 64, seed=81).to(dev), ow.synthetic_labels(8, seed=82).to(dev)
+    for prec in (32, 16):
+        states = []
+        for aside in (False, True):
+            _, m = _pair(seeded_sd, dev)
+            m.unfreeze()
+            step = training.DataParallelStep(m, lr=0.01, world_size=1, precision=prec)
+            step.eng.sw_aside = aside
+            for _ in range(4):
+                step.step(x, y)
+            torch.cuda.synchronize()
+            assert step._plans, "the step was never recorded"
+            assert (step.eng.aside.stream is not None) == aside
+            if aside:
+                assert ("flip32",) in step.eng._tables_used
+            states.append(torch.cat([step.eng.arena.p, step.eng.arena.m] + [b.detach().flatten().float() for b in m.buffers()]).clone())
+        assert torch.equal(states[0], states[1]), prec
+
+
 def test_bound_step_inputs(dev, seeded_sd):
     """DataParallelStep.bind_inputs: a producer fills the recorded step's own input buffers in place; replays from them equal replays
     that copy the batch in, bit for bit."""

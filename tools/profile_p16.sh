@@ -2,7 +2,7 @@
 # Precision-16 (half tensors) training step on the GPU box: rocprofv3 kernel stats of the bench command, then the two PMC traffic
 # passes (FETCH_SIZE / WRITE_SIZE separately, MI355X_MICROARCH.md) summed over one replayed step.
 #   bash tools/profile_p16.sh r05   -> gpurun_out/<tag>_p16_*  (copy the summaries into profiles/)
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$PWD; OUT=$R/gpurun_out; cd /tmp && export TMPDIR=/tmp
 ARGS="--phase train --train-precision 16 --no-cpu-baseline --no-e2e --no-wrn50 --no-partition-extra --no-faithful"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p16_stats -o s -- python3 $R/bench.py $ARGS --steps 10 --warmup 3 > $OUT/${TAG}_p16_bench_line_under_rocprof.json 2> /tmp/p16_stats.err || { tail -5 /tmp/p16_stats.err; exit 1; }

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""profiles/r02_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --phase score`.
-usage: traffic_json.py <dir_fetch> <dir_write> <out.json> <patches per launch>   (MI355X_MICROARCH.md, HBM: FETCH_SIZE is doubled on gfx950)"""
+"""profiles/rNN_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --phase score`.
+usage: traffic_json.py <dir_fetch> <dir_write> <out.json> <patches per launch> [bench line of one of the passes]
+(MI355X_MICROARCH.md, HBM: FETCH_SIZE is doubled on gfx950).  The algorithmic bytes per launch are read from the bench line the pass
+itself printed (roofline.alg_MB_per_launch: the same launches, ring launches of the layer1 convs included since round 6)."""
 import csv, glob, json, sys
 def total(d, counter):
     names = {}
@@ -23,8 +25,13 @@ out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separa
        "fetch_MB_per_launch": round(2 * fetch * 1024 / n / 1e6, 1), "write_MB_per_launch": round(write * 1024 / max(nw, 1) / 1e6, 1)}
 out["traffic_MB_per_launch"] = round(out["fetch_MB_per_launch"] + out["write_MB_per_launch"], 1)
 out["patches_per_launch"] = int(sys.argv[4])
-out["algorithmic_MB_per_launch"] = 5764.4
-out["ratio_to_algorithmic"] = round(out["traffic_MB_per_launch"] / 5764.4, 3)
+alg = 5764.4
+if len(sys.argv) > 5:
+    line = json.loads(open(sys.argv[5]).read().strip().splitlines()[-1])
+    alg = float(line["roofline"]["alg_MB_per_launch"])
+    assert line["roofline"]["launches"] % max(nf, 1) == 0 or nf % line["roofline"]["launches"] == 0, (nf, line["roofline"]["launches"])
+out["algorithmic_MB_per_launch"] = alg
+out["ratio_to_algorithmic"] = round(out["traffic_MB_per_launch"] / alg, 3)
 out["note"] = "fabric-side counters: Infinity-Cache hits are included, so this is an upper bound on HBM bytes"
 import os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
