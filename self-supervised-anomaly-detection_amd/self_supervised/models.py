@@ -179,7 +179,12 @@ class PeraNet(_Base):
     def load_from_checkpoint(cls, checkpoint_path, map_location='cpu', **overrides):
         """LightningModule.load_from_checkpoint: rebuild from ``hyper_parameters`` (+ overrides, tools.py:277-281),
         load ``state_dict``, restore the memory bank.  Callable on the class or on an instance (quirk Q8)."""
-        ck = torch.load(checkpoint_path, map_location=map_location, weights_only=False)
+        try:
+            # memory-mapped: the tensors are read from the page cache when they move to the device, not copied into fresh host storage
+            # first (the optimizer state of a full checkpoint is never touched at all)
+            ck = torch.load(checkpoint_path, map_location=map_location, weights_only=False, mmap=True)
+        except (RuntimeError, ValueError, TypeError):            # legacy (non-zipfile) checkpoints cannot be mapped
+            ck = torch.load(checkpoint_path, map_location=map_location, weights_only=False)
         hp = dict(ck.get('hyper_parameters', {}))
         hp.update(overrides)
         # every parameter and buffer comes from the checkpoint: build the module on the meta device (shapes only, no random

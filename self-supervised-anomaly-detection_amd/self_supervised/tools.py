@@ -182,29 +182,45 @@ def _fast_mvtec_ok(dataset):
             and os.environ.get("SSAD_FAST_PREDICT", "1") != "0")
 
 
+def _decode_threads():
+    """Decode threads for the streamed predict: the CPUs this process may actually use (the cgroup quota where one is set: a 1-GPU job
+    on a 256-thread host is given 16), at most 16 -- Pillow's PNG inflate runs outside the GIL, so the threads scale until the quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(16, n, int(os.environ.get("SSAD_DECODE_THREADS", "16"))))
+
+
 class _MVTecPrefetch:
     """The host half of the streamed predict, startable before the model exists: a thread pool decodes the test files (Pillow decodes
     outside the GIL) at their native size and reads the ground-truth masks exactly as ``MVTecDataset.__getitem__`` does
     (``get_ground_truth``: resize + dither to mode '1' stay Pillow's).  tools.inference starts it before it loads the checkpoint."""
 
-    def __init__(self, dataset, indices, threads: int = None):
+    def __init__(self, dataset, indices, threads: int = None, extra_files=()):
         from concurrent.futures import ThreadPoolExecutor
         from . import gpu_io
         from .functional import get_ground_truth, get_ground_truth_filename
         self.dataset, self.indices = dataset, list(indices)
-        n = len(self.indices)
+        # extra_files: images decoded and scored IN FRONT of the dataset's own (tools.inference: the training image whose embeddings
+        # become the normality bank rides in the first group instead of a DataLoader pass of its own); 'good' images: all-zero masks
+        self.extra = list(extra_files)
+        n = len(self.extra) + len(self.indices)
         w_img, h_img = dataset.imsize
-        names = [dataset.images_filenames[i] for i in self.indices]
+        names = self.extra + [dataset.images_filenames[i] for i in self.indices]
         self.gt8 = np.zeros((n, h_img, w_img), np.uint8)
         self.native = [None] * n
         gt_dir = dataset.dataset_dir + 'ground_truth/'
 
         def load(j):
             self.native[j] = gpu_io.read_native(names[j])   # decoded at its native size; the resize runs on the device (gpu_io)
-            gfile = get_ground_truth_filename(names[j], gt_dir)
+            gfile = get_ground_truth_filename(names[j], gt_dir) if j >= len(self.extra) else None
             if gfile:                                        # 'good' images: Image.new(mode='1') = all zeros
                 self.gt8[j] = np.asarray(get_ground_truth(gfile, dataset.imsize).convert('L'))
-        self.pool = ThreadPoolExecutor(threads or min(8, os.cpu_count() or 1))
+        self.pool = ThreadPoolExecutor(threads or _decode_threads())
         self._load, self.futs, self._next = load, [None] * n, 0
         # a sliding window of decodes ahead of the consumer (a real MVTec category is 100-170 test images of 1024 x 1024: decoding them
         # all at once would hold 0.3-0.5 GB of native-size arrays with no back-pressure from the GPU side)
@@ -243,8 +259,10 @@ def _predict_mvtec_streamed(model: PeraNet, dataset, device, indices, group: int
     from .datasets import IMAGENET_MEAN, IMAGENET_STD
     from .functional import get_prediction_class
     from .converters import gt2label
-    n = len(indices)
     out = ModelOutputsContainer()
+    pre = prefetch
+    ne = len(pre.extra) if pre is not None else 0      # images in front of the dataset's own (their embeddings: third return value)
+    n = ne + len(indices)
     if n == 0:
         if prefetch is not None:
             prefetch.close()
@@ -273,10 +291,14 @@ def _predict_mvtec_streamed(model: PeraNet, dataset, device, indices, group: int
             logits_host[a * p:b * p].copy_(logits_dev[a * p:b * p])
         for t in (o_dev, x_dev):
             t.record_stream(side)
+    # groups of equal size, about `group` images each (97 images = 96 + the bank image: three forwards of 33 / 32 / 32, not 32 / 32 / 32
+    # and a fourth one of a single image)
+    ngroups = max(1, (n + group // 2) // group)
+    per = -(-n // ngroups)
     try:
         with torch.no_grad():
-            for a in range(0, n, group):
-                b = min(n, a + group)
+            for a in range(0, n, per):
+                b = min(n, a + per)
                 pre.wait(a, b)
                 img_dev = gpu_io.to_rgb_batch(native[a:b], dataset.imsize, device)
                 native[a:b] = [None] * (b - a)
@@ -304,33 +326,73 @@ def _predict_mvtec_streamed(model: PeraNet, dataset, device, indices, group: int
         raise
     pre.close()
     side.synchronize()
+    p = emb_dev.shape[0] // n
+    if ne:
+        # the images in front are not part of the dataset's output: their embeddings stay on the device for the caller
+        out.extra_embeddings = emb_dev[:ne * p]
+        orig, xnorm, gt8 = orig[ne:], xnorm[ne:], gt8[ne:]
+        emb_host, logits_host, emb_dev = emb_host[ne * p:], logits_host[ne * p:], emb_dev[ne * p:]
     gts = torch.from_numpy(gt8).float().div_(255.0).unsqueeze(1)
     out.original_data, out.tensor_data, out.ground_truths = orig, xnorm, gts
     out.raw_predictions, out.embedding_vectors = logits_host, emb_host
-    out.y_hat = get_prediction_class(logits_host)
+    # (first maximum per row, as torch.max(x, 1).indices returns it -- functional.get_prediction_class -- through numpy: 1 ms
+    # instead of 14 for 80 736 rows of four)
+    out.y_hat = torch.from_numpy(logits_host.numpy().argmax(1))
     # predict_step labels every BATCH (of one image) from its ground truth (models.py:314-318)
     out.y_true_binary_labels = torch.tensor(gt2label(gts))
     out.y_true_multiclass_labels = torch.tensor(gt2label(gts, negative=-1, positive=model.num_classes))
     return out, emb_dev
 
 
+TIMELINE = []       # SSAD_TIMELINE=1: (phase, perf_counter) marks of the last tools.inference call (tools/time_inference.py)
+
+
+def _mark(name):
+    if os.environ.get("SSAD_TIMELINE") == "1":
+        import time
+        TIMELINE.append((name, time.perf_counter()))
+
+
 def inference(model_input_dir: str, dataset_dir: str, subject: str, mvtec_inference: bool = True,
               patch_localization: bool = False) -> ModelOutputsContainer:
     """tools.py:310-390."""
+    del TIMELINE[:]
     print('>>> initializing inference')
     # MVTec test data: file lists and decode threads start BEFORE the checkpoint is read, so that the first group of images is
     # decoded by the time the model is on the device (the datamodule draws nothing from the global generators)
     rank, world = world_info()
     datamodule = prefetch = mine = None
+    bank_file = None
     if mvtec_inference:
         datamodule = MVTecDatamodule(dataset_dir, batch_size=1)
         datamodule.setup('predict')
         if _fast_mvtec_ok(datamodule.test_dataset):
             mine = list(range(rank, len(datamodule.test_dataset), world)) if world > 1 else list(range(len(datamodule.test_dataset)))
-            prefetch = _MVTecPrefetch(datamodule.test_dataset, mine)
+            # Which training image becomes the normality bank (tools.py:374-381: element [0] of a prediction over the SHUFFLED training
+            # loader) is decided by two draws from torch's global generator -- the test loader's base seed, then the training loader's
+            # base seed and its sampler's seed.  Nothing between here and there draws from it (the model is built on the meta device, the
+            # forward pass uses no host generator), so the draws are made NOW, in the reference's order, and the image is decoded with
+            # the test images and scored in their first group -- not by a DataLoader pass of its own after them (round 6: 95 ms of
+            # host time per call).  Only the index is taken from the loader; the generator ends in the same state.
+            try:
+                state = torch.get_rng_state()
+                torch.empty((), dtype=torch.int64).random_()                    # (the test loader's iterator, tools.py:336-347)
+                ndm = MVTecDatamodule(dataset_dir, batch_size=1)
+                ndm.num_workers = 0
+                ndm.setup()
+                it = iter(ndm.train_dataloader())
+                first = it._next_index()                                         # the sampler's draw; no image is read
+                bank_file = ndm.train_dataset.images_filenames[int(first[0])]
+                del it
+            except Exception:                                                    # noqa: BLE001  (a DataLoader without these internals:
+                torch.set_rng_state(state)                                       #  the draws are made later, by the loader itself)
+                bank_file = None
+            prefetch = _MVTecPrefetch(datamodule.test_dataset, mine, extra_files=[bank_file] if bank_file else ())
     print('>>> preparing model')
+    _mark("prefetch-started")
     try:
         model = PeraNet.load_from_checkpoint(model_input_dir)
+        _mark("checkpoint")
         model.eval()
         if patch_localization:
             model.enable_patch_level_mode()
@@ -353,9 +415,12 @@ def inference(model_input_dir: str, dataset_dir: str, subject: str, mvtec_infere
         # size 1 (same values; _predict_mvtec_streamed).  The DataLoader iterator the reference creates here draws its base
         # seed from torch's global generator: the draw is kept, so that what follows (the shuffled loader of the normality
         # image) sees the same generator state
-        torch.empty((), dtype=torch.int64).random_()
+        if bank_file is None:
+            torch.empty((), dtype=torch.int64).random_()
         model.to(tester.device).eval()
+        _mark("model-on-device")
         output, emb_dev = _predict_mvtec_streamed(model, datamodule.test_dataset, tester.device, mine, prefetch=prefetch)
+        _mark("predicted")
         n_pred = len(mine)
     else:
         predictions = tester.predict(model, datamodule=datamodule, shard=world > 1)
@@ -369,6 +434,10 @@ def inference(model_input_dir: str, dataset_dir: str, subject: str, mvtec_infere
         detector = AnomalyDetector()
     if model.memory_bank.shape[0] > 1000:            # quirk Q3: the bank is capped at 1000 rows, so this never holds
         normality = model.memory_bank
+    elif bank_file is not None and getattr(output, "extra_embeddings", None) is not None:
+        print(' not enough data in memory bank, sampling new data trom train set')
+        normality = output.extra_embeddings.cpu()       # the training image scored in front of the test images (see above)
+        del output.extra_embeddings
     else:
         print(' not enough data in memory bank, sampling new data trom train set')
         if mvtec_inference:
@@ -396,8 +465,10 @@ def inference(model_input_dir: str, dataset_dir: str, subject: str, mvtec_infere
             detector.bank, detector.threshold = AnomalyDetector._dev(state[0]), state[1]
     else:
         detector.fit(normality)
+    _mark("bank-fitted")
     print(' computing anomaly scores')
     output.anomaly_maps = detector.predict(emb_dev if emb_dev is not None else output.embedding_vectors).cpu()
+    _mark("maps")
     if world > 1:
         n_total = len(datamodule.test_dataset)
         per_image = gather_in_order(_split_container(output, n_pred), n_total)

@@ -145,6 +145,39 @@ def test_inference_maps_match_the_oracle_end_to_end(tmp_path, seeded_sd):
     assert (res.anomaly_maps - want).abs().max().item() < 1e-4
 
 
+def test_inference_bank_image_rides_with_the_test_images(tmp_path, seeded_sd, monkeypatch):
+    """Round 6: tools.inference decides which training image becomes the normality bank BEFORE it predicts (the reference's two draws
+    from torch's global generator, made early and in its order) and scores that image in front of the test images.  With DISTINCT
+    training images the result must be the one of the DataLoader route (SSAD_FAST_PREDICT=0: Trainer.predict over the shuffled
+    training loader, tools.py:374-381): same bank image -> same maps, and the global generator ends in the same state."""
+    from self_supervised import tools, datasets
+    datasets._DataModule.num_workers = 0
+    root = make_tree(str(tmp_path / "data"), categories=("bottle",), n_train=7, n_test_good=2, n_test_bad=2, size=96)
+    ck = str(tmp_path / "seeded.ckpt")
+    torch.save({"state_dict": seeded_sd, "hyper_parameters": {}, "memory_bank": torch.tensor([])}, ck)
+    outs = []
+    for fast in ("1", "0"):
+        monkeypatch.setenv("SSAD_FAST_PREDICT", fast)
+        np.random.seed(3)
+        torch.manual_seed(1234)
+        res = tools.inference(ck, root + "bottle/", "bottle", mvtec_inference=True, patch_localization=True)
+        outs.append((res, torch.get_rng_state().clone()))
+    (a, sa), (b, sb) = outs
+    assert torch.equal(sa, sb)
+    assert torch.equal(a.anomaly_maps, b.anomaly_maps) and torch.equal(a.embedding_vectors, b.embedding_vectors)
+    assert torch.equal(a.y_hat, b.y_hat) and torch.equal(a.ground_truths, b.ground_truths)
+    # a different seed picks (with seven images: almost surely) another bank image: the maps move
+    monkeypatch.setenv("SSAD_FAST_PREDICT", "1")
+    np.random.seed(3)
+    torch.manual_seed(99)
+    c = tools.inference(ck, root + "bottle/", "bottle", mvtec_inference=True, patch_localization=True)
+    np.random.seed(3)
+    torch.manual_seed(1234)
+    d = tools.inference(ck, root + "bottle/", "bottle", mvtec_inference=True, patch_localization=True)
+    assert torch.equal(d.anomaly_maps, a.anomaly_maps)
+    assert tuple(c.anomaly_maps.shape) == tuple(a.anomaly_maps.shape)
+
+
 def test_category_sweep_all_fifteen(tmp_path):
     """BASELINE configs[4]'s shape of work on one GPU: tools.sweep over all fifteen MVTec-AD category names (objects with a fixed
     mask, non-fixed objects with per-image object masks, textures cutting defects from other images, the SLIC pre-segmented
