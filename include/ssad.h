@@ -316,6 +316,14 @@ int ssad_bn_bwd_reduce_mask(const float* dy, const uint8_t* mask4, const float* 
                             float* dbeta, float* dgamma, int64_t R, int C, double* workspace, void* stream);
 int ssad_bn_apply_bwd_mask(const float* dy, const uint8_t* mask4, const float* z, const float* mean, const float* invstd,
                            const float* gamma, const float* dbeta, const float* dgamma, float* dz, int64_t R, int C, void* stream);
+/* The same three over half tensors (the precision-16 step, round 6): a lane's 8 channels take two mask bytes; the mask is that of the
+ * STORED half activation.  Same autograd nodes under pl.Trainer(precision=16) (tools.py:263). */
+int ssad_bn_apply_fwd_mask_h(const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                             const void* residual, void* y, uint8_t* mask4, int64_t R, int C, int relu, void* stream);
+int ssad_bn_bwd_reduce_mask_h(const void* dy, const uint8_t* mask4, const void* z, const float* mean, const float* invstd,
+                              float* dbeta, float* dgamma, int64_t R, int C, double* workspace, void* stream);
+int ssad_bn_apply_bwd_mask_h(const void* dy, const uint8_t* mask4, const void* z, const float* mean, const float* invstd,
+                             const float* gamma, const float* dbeta, const float* dgamma, void* dz, int64_t R, int C, void* stream);
 int ssad_conv_igemm_dgrad_masked(const float* dy, const float* w_flipT, float* dx, const float* residual, const uint8_t* res_mask,
                                  int64_t N, int Hy, int Wy, int Cout, int Hx, int Wx, int Cin, int KH, int KW, int stride, int pad,
                                  void* stream);
@@ -544,14 +552,17 @@ int ssad_conv3x3_h(const void* in, const void* w_ohwi, void* out, const void* re
  * the filter is packed once per step in fragment order [Cout/32][tap][Cin/16][2][32][8] halves (ssad_conv3x3_hw_pack_batch, from the
  * fp32 master weights: desc[5 k ..] = source offset in floats, destination offset in halves, Cout, Cin of the conv that runs on it,
  * flip = 1 when the source is the OHWI filter [Cin][3][3][Cout] of the forward conv whose input gradient this is), the halo is staged
- * by four extra waves of the workgroup.  Arguments of ssad_conv3x3_hw as ssad_conv3x3_h, w_packed in place of w_ohwi. */
+ * by four extra waves of the workgroup.  Arguments of ssad_conv3x3_hw as ssad_conv3x3_h, w_packed in place of w_ohwi, plus res_mask
+ * (optional, with a residual; round 6): the residual is the identity-branch gradient (dy, nibble mask) of ssad_bn_apply_fwd_mask_h --
+ * two mask bytes per 8-half piece -- applied while the residual is staged. */
 int ssad_conv3x3_hw_ok(int64_t N, int H, int W, int Cin, int Cout);
 int64_t ssad_conv3x3_hw_packed_size(int Cin, int Cout);
 int64_t ssad_conv3x3_hw_stats_rows(int64_t N, int H, int W, int Cout);
 int ssad_conv3x3_hw_pack_batch(const float* src, void* dst, const int64_t* desc, int n, void* stream);
-int ssad_conv3x3_hw(const void* in, const void* w_packed, void* out, const void* residual, const float* tr_mean, const float* tr_invstd,
-                    const float* tr_gamma, const float* tr_beta, void* emit, int64_t N, int H, int W, int Cin, int Cout, double* stats_ws,
-                    float eps, float momentum, float* mean, float* invstd, float* running_mean, float* running_var, void* stream);
+int ssad_conv3x3_hw(const void* in, const void* w_packed, void* out, const void* residual, const uint8_t* res_mask, const float* tr_mean,
+                    const float* tr_invstd, const float* tr_gamma, const float* tr_beta, void* emit, int64_t N, int H, int W, int Cin, int Cout,
+                    double* stats_ws, float eps, float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
+                    void* stream);
 /* The exact-fp32 instantiation of the same kernel (csrc/conv16w.hip, T = float: v_mfma_f32_32x32x2_f32, statistics in double per value):
  * the 3 x 3 / stride 1 convs of the fp32 training step (models.py:224) forward and -- with the flipped pack -- their input gradients,
  * whenever the launch fills the chip (ssad_conv3x3_fw_ok; other launches stay on ssad_conv3x3_c64 / ssad_conv_igemm_*).  The filter pack

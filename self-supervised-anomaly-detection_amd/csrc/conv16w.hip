@@ -44,7 +44,7 @@ struct HWParams {
     const T* wp;             // packed filters (ssad_conv3x3_hw_pack_batch / ssad_conv3x3_fw_pack_batch)
     T* out;                  // [N][H][W][Cout]
     const T* residual;       // optional [N][H][W][Cout], added before the rounding
-    const uint8_t* res_mask; // optional (float): one byte per channel quad of the residual, bit k = "pass channel 4 q + k"
+    const uint8_t* res_mask; // optional: one byte per channel quad of the residual, bit k = "pass channel 4 q + k"
     const float* tr_mean;    // optional input transform x <- relu((x - mean) * invstd * gamma + beta), per input channel
     const float* tr_invstd;
     const float* tr_gamma;
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
         unsigned goffr[NR];                                 // the same in the residual tensor (Cout channels per pixel)
         unsigned hyx[NR];                                   // hy << 8 | hx (TW8: image within the tile)
         unsigned inner = 0, valid = 0, inm[2] = {0u, 0u};
-        unsigned rmask[2][F32 ? NR : 1];                    // (float) the residual's pass bits of each piece, 4 bits
+        unsigned rmask[2][NR];                              // the residual's pass bits of each piece: 4 bits (float), 2 x 4 in two bytes (half)
 #pragma unroll
         for (int q = 0; q < NR; ++q) {
             const int hp = (q * SL + sl) / PPR;             // TW8: hp = 64 image + 8 y + x (interior pixels only)
@@ -221,12 +221,15 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
                 u32x4 v = {0u, 0u, 0u, 0u};
                 if (ok && !(CONV16W_ABL & 2)) v = *(const u32x4*)(src + (res ? goffr[q] : goff[q]));
                 reg[SET][q] = v;
-                if (F32) {
-                    // the identity-branch gradient is (dy, nibble mask), never materialised: one mask byte per 16-byte piece, at the
-                    // piece's element index / 4
-                    unsigned mk = 0xfu;
-                    if (res && p.res_mask && ok) mk = p.res_mask[(base * (int64_t)sizeof(T) + goffr[q]) >> 4];
-                    rmask[SET][F32 ? q : 0] = mk;
+                {
+                    // the identity-branch gradient is (dy, nibble mask), never materialised: one mask byte per channel quad, i.e. per
+                    // 16-byte piece one byte (float) or two (half: 8 channels), at the piece's element index / 4
+                    unsigned mk = 0xffffu;
+                    if (res && p.res_mask && ok) {
+                        if (F32) mk = p.res_mask[(base * (int64_t)sizeof(T) + goffr[q]) >> 4];
+                        else mk = *(const uint16_t*)(p.res_mask + ((base * (int64_t)sizeof(T) + goffr[q]) >> 3));
+                    }
+                    rmask[SET][q] = mk;
                 }
                 im |= (ok ? 1u : 0u) << q;
             }
@@ -270,12 +273,22 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
                     if (em && ((inner >> q) & 1u)) *(u32x4*)(em + goff[q]) = w;
                 }
             }
-            if (F32 && p.res_mask && chunk >= p.nchunks) {
+            if (p.res_mask && chunk >= p.nchunks) {
 #pragma unroll
                 for (int q = 0; q < NR; ++q) {
                     u32x4 w = reg[SET][q];
-                    const unsigned mk = rmask[SET][F32 ? q : 0];
-                    w[0] = (mk & 1u) ? w[0] : 0u; w[1] = (mk & 2u) ? w[1] : 0u; w[2] = (mk & 4u) ? w[2] : 0u; w[3] = (mk & 8u) ? w[3] : 0u;
+                    const unsigned mk = rmask[SET][q];
+                    if (F32) {
+                        w[0] = (mk & 1u) ? w[0] : 0u; w[1] = (mk & 2u) ? w[1] : 0u; w[2] = (mk & 4u) ? w[2] : 0u; w[3] = (mk & 8u) ? w[3] : 0u;
+                    } else {
+                        // dword j holds channels 2 j (low half) and 2 j + 1: bits 0-3 of the first byte, bits 0-3 of the second
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const unsigned b0 = j < 2 ? 2 * j : 8 + 2 * (j - 2);
+                            const unsigned keep = ((mk >> b0) & 1u ? 0x0000ffffu : 0u) | ((mk >> (b0 + 1)) & 1u ? 0xffff0000u : 0u);
+                            w[j] &= keep;
+                        }
+                    }
                     reg[SET][q] = w;
                 }
             }
@@ -771,11 +784,11 @@ extern "C" int ssad_conv3x3_fw_pack_batch(const float* src, float* dst, const in
 // NHWC; T = identity or relu((x - tr_mean) * tr_invstd * tr_gamma + tr_beta) per input channel; emit receives T(in); stats_ws != NULL:
 // train-mode BatchNorm statistics of the stored output (ssad_conv3x3_hw_stats_rows(...) * 2 * Cout doubles), finalised as
 // ssad_conv_igemm_fwd_stats does.  The launch must satisfy ssad_conv3x3_hw_ok.
-extern "C" int ssad_conv3x3_hw(const void* in, const void* w_packed, void* out, const void* residual, const float* tr_mean,
-                               const float* tr_invstd, const float* tr_gamma, const float* tr_beta, void* emit, int64_t N, int H, int W,
-                               int Cin, int Cout, double* stats_ws, float eps, float momentum, float* mean, float* invstd,
-                               float* running_mean, float* running_var, void* stream) {
-    return conv_impl<hf>((const hf*)in, (const hf*)w_packed, (hf*)out, (const hf*)residual, nullptr, tr_mean, tr_invstd, tr_gamma, tr_beta,
+extern "C" int ssad_conv3x3_hw(const void* in, const void* w_packed, void* out, const void* residual, const uint8_t* res_mask,
+                               const float* tr_mean, const float* tr_invstd, const float* tr_gamma, const float* tr_beta, void* emit,
+                               int64_t N, int H, int W, int Cin, int Cout, double* stats_ws, float eps, float momentum, float* mean,
+                               float* invstd, float* running_mean, float* running_var, void* stream) {
+    return conv_impl<hf>((const hf*)in, (const hf*)w_packed, (hf*)out, (const hf*)residual, res_mask, tr_mean, tr_invstd, tr_gamma, tr_beta,
                          (hf*)emit, N, H, W, Cin, Cout, stats_ws, eps, momentum, mean, invstd, running_mean, running_var, stream);
 }
 

@@ -28,6 +28,14 @@ static inline ColReduce col_geom(int C, int E = 4) {
     return {TC, 256 / TC};
 }
 
+// Nibble masks: one byte per channel quad, bit k = "the ReLU output of channel 4 q + k was positive".  A lane owns E = 4 (float: one
+// byte) or 8 (half: two bytes, read / written as one uint16) consecutive channels; pass bit of the lane's channel k:
+template <int E> __device__ __forceinline__ unsigned mask_word(const uint8_t* __restrict__ m, int64_t i) {
+    if (E == 4) return m[i];
+    return ((const uint16_t*)m)[i];
+}
+template <int E> __device__ __forceinline__ bool mask_bit(unsigned w, int k) { return (w >> (E == 4 || k < 4 ? k : k + 4)) & 1u; }
+
 // mode 0: s0 = sum z, s1 = sum z^2
 // mode 1: g = dy * (yact > 0 if yact) ; s0 = sum g ; s1 = sum g * (z - mean) * invstd   (z may be null -> s1 = 0)
 //         mask source: yact (the saved activation) or, when zmask_gamma is given (no residual fed the ReLU), the
@@ -70,7 +78,7 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const T* __restrict__ a
                 const int64_t o = (rw < re ? rw : rb + ty) * CE + cq;       // clamp: tail rows re-read a valid row ...
                 v[u] = ldv(a + E * o);
                 if (MODE == 1 && yact) ya[u] = ldv(yact + E * o);
-                if (MODE == 1 && E == 4 && mask4) mk[u] = mask4[o];
+                if (MODE == 1 && mask4) mk[u] = mask_word<E>(mask4, o);
                 if (MODE == 1 && z) zz[u] = ldv(z + E * o);
             }
 #pragma unroll
@@ -83,9 +91,9 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const T* __restrict__ a
                     if (yact) {
 #pragma unroll
                         for (int k = 0; k < E; ++k) v[u][k] = ya[u][k] > 0.f ? v[u][k] : 0.f;
-                    } else if (E == 4 && mask4) {
+                    } else if (mask4) {
 #pragma unroll
-                        for (int k = 0; k < E; ++k) v[u][k] = (mk[u] >> k) & 1u ? v[u][k] : 0.f;
+                        for (int k = 0; k < E; ++k) v[u][k] = mask_bit<E>(mk[u], k) ? v[u][k] : 0.f;
                     } else if (zmask_gamma) {
 #pragma unroll
                         for (int k = 0; k < E; ++k) v[u][k] = (zz[u][k] - mu[k]) * is[k] * mg[k] + mb[k] > 0.f ? v[u][k] : 0.f;
@@ -201,7 +209,15 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const T* __restrict__
 #pragma unroll
             for (int k = 0; k < E; ++k) v[k] += rr[k];
         }
-        if (E == 4 && mask4) mask4[i] = (uint8_t)((v[0] > 0.f) | ((v[1] > 0.f) << 1) | ((v[2] > 0.f) << 2) | ((v[3] > 0.f) << 3));
+        if (mask4) {
+            // (halves: the mask is that of the STORED activation -- a positive value that rounds to zero as a half would pass a
+            // gradient the stored tensor's ReLU does not; rounding to nearest keeps the sign, so only underflow to +0 differs)
+            unsigned mw = 0;
+#pragma unroll
+            for (int k = 0; k < E; ++k) mw |= (unsigned)(stored<T>(v[k]) > 0.f) << (E == 4 || k < 4 ? k : k + 4);
+            if (E == 4) mask4[i] = (uint8_t)mw;
+            else ((uint16_t*)mask4)[i] = (uint16_t)mw;
+        }
         if (relu) {
 #pragma unroll
             for (int k = 0; k < E; ++k) v[k] = fmaxf(v[k], 0.f);
@@ -229,10 +245,10 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const T* __restrict__
             const V ya = ldv(yact + E * i);
 #pragma unroll
             for (int k = 0; k < E; ++k) g[k] = ya[k] > 0.f ? g[k] : 0.f;
-        } else if (E == 4 && mask4) {
-            const unsigned mk = mask4[i];
+        } else if (mask4) {
+            const unsigned mk = mask_word<E>(mask4, i);
 #pragma unroll
-            for (int k = 0; k < E; ++k) g[k] = (mk >> k) & 1u ? g[k] : 0.f;
+            for (int k = 0; k < E; ++k) g[k] = mask_bit<E>(mk, k) ? g[k] : 0.f;
         } else if (zmask_beta) {                 // ReLU mask recomputed from z (layer without residual)
             const V zb = ldpar<V>(zmask_beta, cq);
             const V zm = ldv(z + E * i);
@@ -782,6 +798,18 @@ extern "C" int ssad_bn_apply_fwd_mask(const float* z, const float* mean, const f
     return 0;
 }
 
+// ... over half tensors (round 6: the precision-16 step's residual blocks keep the mask as the fp32 step does: 1/8 of the bytes of the
+// half activation the backward passes would otherwise read twice, and no materialised identity-branch gradient)
+extern "C" int ssad_bn_apply_fwd_mask_h(const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                        const void* residual, void* y, uint8_t* mask4, int64_t R, int C, int relu, void* stream) {
+    SSAD_CHECK_ARG(z && mean && invstd && gamma && beta && y && mask4 && R > 0 && C > 0 && C % 8 == 0, "bad argument");
+    const int64_t total8 = R * (C / 8);
+    hipLaunchKernelGGL(bn_apply_fwd_kernel<hf>, dim3(ew_grid(total8)), dim3(256), 0, (hipStream_t)stream, (const hf*)z, mean, invstd, gamma,
+                       beta, (const hf*)residual, (hf*)y, total8, C / 8, relu, mask4);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
 // Column sums of a tiny matrix (the bias gradient of the 512 -> 4 classifier over a training batch: 32 x 4 values) in ONE launch:
 // the general two-stage reduction gives such a matrix one workgroup whose thread 0 adds 256 LDS values one after the other, then
 // a finalize launch -- 13 + 4 us for 128 numbers.  Lane l of column c adds rows l, l + L, ...; eight lane groups are added in
@@ -816,7 +844,6 @@ static int bn_bwd_reduce_impl(const T* dy, const T* yact, const T* z, const floa
                               float* dbeta, float* dgamma, int64_t R, int C, double* workspace, void* stream,
                               const float* zg, const float* zb, const uint8_t* mask4 = nullptr) {
     SSAD_CHECK_ARG(dy && workspace && R > 0 && C > 0 && C % Lane<T>::E == 0, "bad argument");
-    SSAD_CHECK_ARG(!mask4 || Lane<T>::E == 4, "nibble masks: fp32 tensors only");
     SSAD_CHECK_ARG(!z || (mean && invstd), "z needs mean/invstd");
     SSAD_CHECK_ARG(!zg || (z && zb && !yact), "mask-from-z needs z, gamma, beta and no yact");
     if constexpr (std::is_same<T, float>::value) {
@@ -868,7 +895,6 @@ static int bn_apply_bwd_impl(const T* dy, const T* yact, const T* z, const float
                                  const uint8_t* mask4 = nullptr) {
     constexpr int E = Lane<T>::E;
     SSAD_CHECK_ARG(dy && mean && invstd && gamma && dz && R > 0 && C > 0 && C % E == 0, "bad argument");
-    SSAD_CHECK_ARG(!mask4 || E == 4, "nibble masks: fp32 tensors only");
     SSAD_CHECK_ARG(eval_mode || (z && dbeta && dgamma), "train-mode backward needs z, dbeta, dgamma");
     const int64_t totalE = R * (C / E);
     hipLaunchKernelGGL(bn_apply_bwd_kernel<T>, dim3(ew_grid(totalE)), dim3(256), 0, (hipStream_t)stream, dy, yact, z, mean, invstd,
@@ -1262,6 +1288,19 @@ extern "C" int ssad_bn_apply_bwd_mask(const float* dy, const uint8_t* mask4, con
     return bn_apply_bwd_impl<float>(dy, nullptr, z, mean, invstd, gamma, dbeta, dgamma, dz, nullptr, R, C, 0, stream, nullptr, mask4);
 }
 
+extern "C" int ssad_bn_bwd_reduce_mask_h(const void* dy, const uint8_t* mask4, const void* z, const float* mean,
+                                         const float* invstd, float* dbeta, float* dgamma, int64_t R, int C, double* workspace,
+                                         void* stream) {
+    SSAD_CHECK_ARG(z, "z required");
+    return bn_bwd_reduce_impl<hf>((const hf*)dy, nullptr, (const hf*)z, mean, invstd, dbeta, dgamma, R, C, workspace, stream, nullptr, nullptr, mask4);
+}
+
+extern "C" int ssad_bn_apply_bwd_mask_h(const void* dy, const uint8_t* mask4, const void* z, const float* mean, const float* invstd,
+                                        const float* gamma, const float* dbeta, const float* dgamma, void* dz, int64_t R, int C,
+                                        void* stream) {
+    return bn_apply_bwd_impl<hf>((const hf*)dy, nullptr, (const hf*)z, mean, invstd, gamma, dbeta, dgamma, (hf*)dz, nullptr, R, C, 0, stream, nullptr,
+                                 mask4);
+}
 
 // ssad_flip_transpose_weight for n filters at once: desc[k] = {src offset, dst offset, O, I, KH, KW} (floats, host
 // memory), sources inside `src`, results inside `dst`.  One launch per 32 filters (the kernel's table travels as a launch

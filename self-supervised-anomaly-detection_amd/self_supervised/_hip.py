@@ -160,8 +160,11 @@ SIGNATURES = {
     "ssad_conv3x3_hw_packed_size": [_c_i, _c_i],
     "ssad_conv3x3_hw_stats_rows": [_c_l, _c_i, _c_i, _c_i],
     "ssad_conv3x3_hw_pack_batch": [_c_fp, _c_fp, _c_fp, _c_i, _c_fp],
-    "ssad_conv3x3_hw": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_f, _c_f,
+    "ssad_conv3x3_hw": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_f, _c_f,
                         _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
+    "ssad_bn_apply_fwd_mask_h": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_fp],
+    "ssad_bn_bwd_reduce_mask_h": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_fp, _c_fp],
+    "ssad_bn_apply_bwd_mask_h": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_fp],
     "ssad_conv3x3_fw_ok": [_c_l, _c_i, _c_i, _c_i, _c_i],
     "ssad_conv3x3_fw_pack_batch": [_c_fp, _c_fp, _c_fp, _c_i, _c_fp],
     "ssad_conv3x3_fw": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_f,

@@ -450,7 +450,7 @@ def conv3x3_hw(x, w_packed, cout, residual=None, transform=None, emit=False, sta
     assert x.is_contiguous() and conv3x3_hw_ok(n, h, w, cin, cout, f32), "shape outside ssad_conv3x3_hw_ok"
     assert residual is None or (residual.dtype == x.dtype and tuple(residual.shape) == (n, h, w, cout) and residual.is_contiguous()), \
         "residual must have the output's shape"
-    assert res_mask is None or (f32 and residual is not None and res_mask.numel() == n * h * w * cout // 4 and res_mask.dtype == torch.uint8)
+    assert res_mask is None or (residual is not None and res_mask.numel() == n * h * w * cout // 4 and res_mask.dtype == torch.uint8)
     lib = _hip.lib()
     out = torch.empty((n, h, w, cout), device=x.device, dtype=x.dtype)
     em = torch.empty_like(x) if emit else None
@@ -472,7 +472,8 @@ def conv3x3_hw(x, w_packed, cout, residual=None, transform=None, emit=False, sta
                                          _hip.ptr(mean, True), _hip.ptr(invstd, True), _hip.ptr(rm, True), _hip.ptr(rv, True), _hip.stream()))
     else:
         _run("conv3x3_hw16", 2.0 * out.numel() * 9 * cin, float(nb),
-             lambda: lib.ssad_conv3x3_hw(x.data_ptr(), w_packed.data_ptr(), out.data_ptr(), _p(residual, True), _hip.ptr(tr[0], True),
+             lambda: lib.ssad_conv3x3_hw(x.data_ptr(), w_packed.data_ptr(), out.data_ptr(), _p(residual, True),
+                                         res_mask.data_ptr() if res_mask is not None else None, _hip.ptr(tr[0], True),
                                          _hip.ptr(tr[1], True), _hip.ptr(tr[2], True), _hip.ptr(tr[3], True), _p(em, True), n, h, w, cin, cout,
                                          wsp, eps, mom, _hip.ptr(mean, True), _hip.ptr(invstd, True), _hip.ptr(rm, True), _hip.ptr(rv, True),
                                          _hip.stream()))
@@ -1092,6 +1093,13 @@ def bn_apply_fwd_mask(z, mean, invstd, gamma, beta, residual, relu):
     c = mean.numel()
     y = torch.empty_like(z)
     mask = torch.empty(z.numel() // 4, device=z.device, dtype=torch.uint8)
+    if _is_h(z):                  # half tensors: two mask bytes per lane (8 channels)
+        assert residual is None or _is_h(residual)
+        _run("bn_apply_fwd_h16", 0.0, 2.0 * z.numel() * (3 if residual is not None else 2) + mask.numel(),
+             lambda: _hip.lib().ssad_bn_apply_fwd_mask_h(z.data_ptr(), _hip.ptr(mean), _hip.ptr(invstd), _hip.ptr(gamma), _hip.ptr(beta),
+                                                         _p(residual, True), y.data_ptr(), mask.data_ptr(), z.numel() // c, c,
+                                                         int(relu), _hip.stream()))
+        return y, mask
     _run("bn_apply_fwd", 0.0, 4.0 * z.numel() * (3 if residual is not None else 2) + mask.numel(),
          lambda: _hip.lib().ssad_bn_apply_fwd_mask(_hip.ptr(z), _hip.ptr(mean), _hip.ptr(invstd), _hip.ptr(gamma), _hip.ptr(beta),
                                                    _hip.ptr(residual, True), _hip.ptr(y), mask.data_ptr(), z.numel() // c, c,
@@ -1107,6 +1115,16 @@ def bn_bwd_mask(dy, mask, z, mean, invstd, gamma, dbeta, dgamma):
     ws = _colreduce_ws(r, c, dy)
     lib = _hip.lib()
     mp = mask.data_ptr() if mask is not None else None
+    if _is_h(dy):
+        assert _is_h(z)
+        _run("bn_bwd_reduce_h16", 0.0, 4.0 * dy.numel() + (mask.numel() if mask is not None else 0),
+             lambda: lib.ssad_bn_bwd_reduce_mask_h(dy.data_ptr(), mp, z.data_ptr(), _hip.ptr(mean), _hip.ptr(invstd), _hip.ptr(dbeta),
+                                                   _hip.ptr(dgamma), r, c, ws.data_ptr(), _hip.stream()))
+        dz = torch.empty_like(dy)
+        _run("bn_apply_bwd_h16", 0.0, 6.0 * dy.numel() + (mask.numel() if mask is not None else 0),
+             lambda: lib.ssad_bn_apply_bwd_mask_h(dy.data_ptr(), mp, z.data_ptr(), _hip.ptr(mean), _hip.ptr(invstd), _hip.ptr(gamma),
+                                                  _hip.ptr(dbeta), _hip.ptr(dgamma), dz.data_ptr(), r, c, _hip.stream()))
+        return dz
     _run("bn_bwd_reduce", 0.0, 8.0 * dy.numel() + (mask.numel() if mask is not None else 0),
          lambda: lib.ssad_bn_bwd_reduce_mask(_hip.ptr(dy), mp, _hip.ptr(z), _hip.ptr(mean), _hip.ptr(invstd), _hip.ptr(dbeta),
                                              _hip.ptr(dgamma), r, c, ws.data_ptr(), _hip.stream()))

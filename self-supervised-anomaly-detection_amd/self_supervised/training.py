@@ -318,10 +318,10 @@ class _Affine:
         self.z, self.y, self.res_used, self.mask = z, None, False, None
         return z
 
-    def apply_bn(self, residual=None):
+    def apply_bn(self, residual=None, use_mask=None):
         """The BatchNorm (+ residual) (+ ReLU) of a layer whose raw output fwd_raw_c64 left in self.z."""
         a, bn = self.eng.arena, self.bn
-        if residual is not None and self.relu and self.eng.use_relu_mask():
+        if residual is not None and self.relu and (self.eng.use_relu_mask() if use_mask is None else use_mask):
             # the block's final ReLU leaves its active set as a nibble mask: backward never re-reads the activation
             y, self.mask = ops.bn_apply_fwd_mask(self.z, self.mean, self.invstd, a.w(bn.weight), a.w(bn.bias), residual, True)
             self.res_used, self.y = True, None
@@ -487,8 +487,10 @@ class _Affine:
             if half and dz.dim() == 4 and self.conv16_ok():
                 n_, h_, w_, _ = dzz.shape
                 if self.eng.sw_conv16w and ops.conv3x3_hw_ok(n_, h_, w_, cout, self.lin.in_channels):
-                    dx = ops.conv3x3_hw(dzz, self.eng.packed_hw(self.lin, True), self.lin.in_channels, residual=dx_residual)
+                    dx = ops.conv3x3_hw(dzz, self.eng.packed_hw(self.lin, True), self.lin.in_channels, residual=dx_residual,
+                                        res_mask=dx_res_mask)
                 else:
+                    assert dx_res_mask is None, "use_relu_mask16 keeps the mask away from launches csrc/conv16.hip runs"
                     dx = ops.conv3x3_h(dzz, self.eng.flipped(self.lin, wt, half=True), residual=dx_residual)
             elif (dz.dtype == torch.float32 and dz.dim() == 4 and wt is w and self.is_conv
                   and self.eng.conv32w_ok(self, dz.shape[0], dz.shape[1], dz.shape[2], cout, self.lin.in_channels)):
@@ -497,6 +499,7 @@ class _Affine:
             elif self.c64_ok() and dz.dim() == 4:
                 dx = ops.conv3x3_c64(dzz, self.eng.flipped(self.lin, wt), residual=dx_residual, res_mask=dx_res_mask, bf16=bf)
             elif half:
+                assert dx_res_mask is None
                 dx = ops.conv_dgrad(dzz, self.eng.flipped(self.lin, wt, half=True), self.x_shape, self.stride, self.pad, dx_residual, bf)
             else:
                 wf = self.eng.flipped(self.lin, wt) if wt is w else ops.flip_transpose_weight(wt)
@@ -593,6 +596,7 @@ class TrainEngine:
         self.sw_poolwin = os.environ.get("SSAD_POOLWIN", "1") != "0"     # stem: BatchNorm backward reduction over the pooled tensors
         # off-critical-path launches (slab reductions, head weight gradients, pooling rows, the filter tables of the backward pass)
         # as parallel branches of the step (ops.ASIDE; DataParallelStep switches it on for its steps)
+        self.sw_mask16 = os.environ.get("SSAD_MASK16", "1") != "0"       # precision 16, half tensors: nibble masks for the residual blocks
         self.sw_aside = int(os.environ.get("SSAD_ASIDE", "0"))        # 0 off, 1 every such launch, 2 only the filter tables beside the stem
         self.aside = _Aside()
         self._tables_used = set()     # filter tables the last backward asked for: requested ahead, beside the stem, by the next forward
@@ -603,7 +607,7 @@ class TrainEngine:
 
     def switches(self):
         """Everything besides shapes that decides which launches a step consists of (hipGraph plan key)."""
-        return (self.bf16, self.param_grads, self.sw_c64, self.sw_relu_mask, self.sw_wgrad_halo, self.sw_stem16, self.sw_c64_16, self.sw_act16, self.sw_conv16, self.sw_conv16w, self.sw_conv32w, self.sw_raw32, self.sw_poolwin, self._side_on, self.sw_aside,
+        return (self.bf16, self.param_grads, self.sw_c64, self.sw_relu_mask, self.sw_wgrad_halo, self.sw_stem16, self.sw_c64_16, self.sw_act16, self.sw_conv16, self.sw_conv16w, self.sw_conv32w, self.sw_raw32, self.sw_poolwin, self._side_on, self.sw_aside, self.sw_mask16,
                 os.environ.get("SSAD_WGRAD_HALO", "1") != "0", torch.is_grad_enabled())
 
     # ---- second stream for the weight gradients ----
@@ -725,6 +729,15 @@ class TrainEngine:
         """Residual blocks keep their final ReLU's active set as a nibble mask (exact fp32 path, gradients wanted)."""
         return not self.bf16 and self.trunk_grad and torch.is_grad_enabled() and self.sw_relu_mask
 
+    def use_relu_mask16(self, block_in, has_ds):
+        """The same for a block of the precision-16 step with half tensors (round 6): whoever consumes the identity-branch gradient
+        (dy, mask) must apply the mask itself -- the downsample layer's BatchNorm kernels do, and so does the register-fed conv
+        (csrc/conv16w.hip) as the first conv's input gradient; launches too small for it (csrc/conv16.hip) keep the activation."""
+        if not (self.h16 and self.sw_mask16 and self.trunk_grad and torch.is_grad_enabled() and self.sw_relu_mask):
+            return False
+        n, h, w, c = block_in.shape
+        return bool(has_ds or (self.sw_conv16w and ops.conv3x3_hw_ok(n, h, w, c, c)))
+
     def wgrad_stream(self, *operands):
         return TrainEngine._Side(self, operands)
 
@@ -781,7 +794,7 @@ class TrainEngine:
                 # half tensors: conv2 (and conv1 where it has stride 1) on the halo-tile kernel; bn1 + ReLU inside conv2's input staging
                 z1 = d["c1"].fwd_raw16(a) if d["c1"].conv16_ok() else d["c1"].fwd(a, raw=True)
                 d["c2"].fwd_raw16(z1, producer=d["c1"])
-                a = d["c2"].apply_bn(residual=idt)
+                a = d["c2"].apply_bn(residual=idt, use_mask=self.use_relu_mask16(a, d["ds"] is not None))
             elif d["ds"] is None and d["c1"].c64_ok() and d["c2"].c64_ok():
                 z1 = d["c1"].fwd_raw_c64(a)                       # bn1 + ReLU happen inside conv2's input staging
                 d["c2"].fwd_raw_c64(z1, producer=d["c1"])

@@ -438,3 +438,63 @@ def test_wrong_extents_raise(dev):
     with pytest.raises(AssertionError):
         ops.conv_dgrad(f(2, 8, 8, 64), f(64, 3, 3, 64), (2, 8, 8, 64), 1, 1, residual=f(2, 4, 4, 64))
     torch.cuda.synchronize()
+
+
+# ---------------------------------------------------------------------------------------------
+# round 6: nibble masks of the residual blocks over half tensors
+# ---------------------------------------------------------------------------------------------
+def test_half_nibble_masks(dev):
+    """ssad_bn_apply_fwd_mask_h / _bwd_reduce_mask_h / _apply_bwd_mask_h and the residual mask of ssad_conv3x3_hw: the mask is the sign
+    pattern of the STORED half activation (two bytes per 8 channels, nibble k = channel quad k as in the fp32 form), and every consumer
+    gives bit for bit what it gives when the activation / the pre-masked gradient is handed to it instead."""
+    from self_supervised import ops
+    g = torch.Generator().manual_seed(21)
+    n, h, w, c = 208, 16, 32, 64                      # 208 tiles of 16 x 32 x 64: inside ssad_conv3x3_hw_ok
+    mean, invstd, gamma, beta = _bn_params(c, g, dev)
+    z = torch.randn(n, h, w, c, generator=g).half().to(dev)
+    res = torch.randn(n, h, w, c, generator=g).half().to(dev)
+    y_ref = ops.bn_apply_fwd(z, mean, invstd, gamma, beta, res, True)
+    y, mask = ops.bn_apply_fwd_mask(z, mean, invstd, gamma, beta, res, True)
+    assert y.dtype == torch.float16 and torch.equal(y, y_ref)
+    bits = mask.view(n, h, w, c // 4)
+    want = (y > 0).view(n, h, w, c // 4, 4).to(torch.uint8)
+    want = want[..., 0] | (want[..., 1] << 1) | (want[..., 2] << 2) | (want[..., 3] << 3)
+    assert torch.equal(bits, want)
+    # backward through the BatchNorm: mask == the saved activation
+    dy = torch.randn(n, h, w, c, generator=g).half().to(dev)
+    db0, dg0 = torch.empty(c, device=dev), torch.empty(c, device=dev)
+    ops.bn_bwd_reduce(dy, y, z, mean, invstd, db0, dg0, c)
+    dz0, dres0 = ops.bn_apply_bwd(dy, y, z, mean, invstd, gamma, db0, dg0, True)
+    db1, dg1 = torch.empty(c, device=dev), torch.empty(c, device=dev)
+    dz1 = ops.bn_bwd_mask(dy, mask, z, mean, invstd, gamma, db1, dg1)
+    assert torch.equal(db0, db1) and torch.equal(dg0, dg1) and torch.equal(dz0, dz1)
+    # the identity-branch gradient as (dy, mask) into the register-fed conv == the materialised one
+    assert ops.conv3x3_hw_ok(n, h, w, c, c)
+    wt = (torch.randn(c, 3, 3, c, generator=g) / 24).to(dev)
+    packed, _ = ops.conv3x3_hw_pack(wt.flatten(), [(0, c, c, False)])
+    x = torch.randn(n, h, w, c, generator=g).half().to(dev)
+    a = ops.conv3x3_hw(x, packed, c, residual=dres0)
+    b = ops.conv3x3_hw(x, packed, c, residual=dy, res_mask=mask)
+    assert torch.equal(a, b)
+
+
+def test_half_masks_leave_the_step_bit_identical(dev):
+    """A precision-16 step at 32 x 256 x 256 (layer1 on the register-fed conv with masks, the smaller layers on csrc/conv16.hip without:
+    both branches of TrainEngine.use_relu_mask16) with SSAD_MASK16 on and off: same g everywhere, hence the same bits in every
+    parameter, momentum and running statistic after three steps."""
+    from oracle import weights as ow
+    from self_supervised import training
+    from self_supervised.models import PeraNet
+    sd = ow.seeded_state_dict(0)
+    x, y = ow.synthetic_images(32, 256, seed=31).to(dev), ow.synthetic_labels(32, seed=32).to(dev)
+    states = []
+    for on in (False, True):
+        m = PeraNet(); m.load_state_dict(sd); m.to(dev).train(); m.unfreeze()
+        step = training.DataParallelStep(m, lr=0.01, world_size=1, precision=16, graph=False)
+        step.eng.sw_mask16 = on
+        for _ in range(3):
+            step.step(x, y)
+        torch.cuda.synchronize()
+        assert step.eng.h16
+        states.append(torch.cat([step.eng.arena.p, step.eng.arena.m] + [b.detach().flatten().float() for b in m.buffers()]).clone())
+    assert torch.equal(states[0], states[1])

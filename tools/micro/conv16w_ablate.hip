@@ -14,7 +14,7 @@ static void run(int64_t N, int H, int W, int C) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     auto go = [&]() {
-        return ssad_conv3x3_hw(x, w, y, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, C, C, nullptr, 0.f, 0.f, nullptr, nullptr,
+        return ssad_conv3x3_hw(x, w, y, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, C, C, nullptr, 0.f, 0.f, nullptr, nullptr,
                               nullptr, nullptr, nullptr);
     };
     for (int i = 0; i < 3; ++i) go();
