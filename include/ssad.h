@@ -198,6 +198,12 @@ int ssad_conv_wgrad_x6(const float* dy, const float* x, float* slab, int splits,
                        int KH, int KW, int stride, int pad, int64_t dy_elems, void* stream);   /* three-way split, see ssad_conv_igemm_fwd_x6 */
 int ssad_wgrad_reduce(const float* slab, float* dw, int splits, int Cout, int Kpad, int KH, int KW, int Cin, int to_oihw,
                       int accumulate, void* stream);
+/* Several such reductions in ONE launch (round 6): desc[6 k ..] = slab pointer, output pointer (as integers), splits, Cout, Kpad,
+ * Kreal = KH * KW * Cin.  Nothing on the backward pass's critical path reads a weight gradient, so the training step collects the
+ * reductions of its weight-gradient kernels and runs them where the gradients are first needed (optimizer / a gradient bucket).
+ * Same order of additions per output as ssad_wgrad_reduce: bit-identical.  OHWI outputs, no accumulation; Kreal % 4 == 0, Kpad % 4 == 0,
+ * 16-byte aligned pointers.  Same autograd nodes as ssad_conv_wgrad (Conv2d weight gradients under trainer.fit, models.py:256-277). */
+int ssad_wgrad_reduce_batch(const int64_t* desc, int n, void* stream);
 /* bf16-operand forms of the three MFMA entry points above (fp32 tensors in HBM; operands rounded to bf16 while staging,
  * fp32 accumulate; v_mfma_f32_32x32x16_bf16).  This is what torch.autocast does to the same Conv2d / Linear call sites
  * under the reference's pl.Trainer(precision=16) (src/self_supervised/tools.py:263, :296). */

@@ -98,6 +98,7 @@ SIGNATURES = {
     "ssad_loss_scaler_update": [_c_fp, _c_f, _c_f, _c_i, _c_fp],
     "ssad_conv_wgrad_x3": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_l, _c_fp],
     "ssad_conv_wgrad_x6": [_c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_l, _c_fp],
+    "ssad_wgrad_reduce_batch": [ctypes.POINTER(ctypes.c_int64), _c_i, _c_fp],
     "ssad_wgrad_reduce": [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
     "ssad_stem_im2col": [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_fp],
     "ssad_pack_stem_weight_2d": [_c_fp, _c_fp, _c_fp],

@@ -56,6 +56,36 @@ def _run_aside(kernel, flops, nbytes, rc_fn, keep=()):
     ASIDE.launch(lambda: _hip.check(rc_fn()), keep)
 
 
+# Slab reductions of the weight-gradient kernels, collected while PENDING_REDUCE is a list (TrainEngine sets it for a training step)
+# and run together by flush_reductions() where the gradients are first needed: one launch (ssad_wgrad_reduce_batch) instead of one
+# per layer.  Entries keep their slabs alive until the flush.
+PENDING_REDUCE = None
+
+
+def _wgrad_reduce(slab, dw_out, splits, cout, kpad, kh, kw, cin, to_oihw, accumulate):
+    kreal = kh * kw * cin
+    if (PENDING_REDUCE is not None and PROFILE is None and not to_oihw and not accumulate and kreal % 4 == 0 and kpad % 4 == 0
+            and slab.data_ptr() % 16 == 0 and dw_out.data_ptr() % 16 == 0):
+        PENDING_REDUCE.append((slab, dw_out, int(splits), int(cout), int(kpad), int(kreal)))
+        return
+    _run_aside("wgrad_reduce", 0.0, 4.0 * slab.numel(),
+               lambda: _hip.lib().ssad_wgrad_reduce(_hip.ptr(slab), _hip.ptr(dw_out), splits, cout, kpad, kh, kw, cin, int(to_oihw),
+                                                    int(accumulate), _hip.stream()), keep=(slab,))
+
+
+def flush_reductions():
+    """Run the collected slab reductions (one launch per 24) and release their slabs."""
+    if not PENDING_REDUCE:
+        return
+    import ctypes
+    desc = []
+    for slab, out, splits, cout, kpad, kreal in PENDING_REDUCE:
+        desc += [slab.data_ptr(), out.data_ptr(), splits, cout, kpad, kreal]
+    arr = (ctypes.c_int64 * len(desc))(*desc)
+    _hip.check(_hip.lib().ssad_wgrad_reduce_batch(arr, len(PENDING_REDUCE), _hip.stream()))
+    del PENDING_REDUCE[:]
+
+
 def drain_profile():
     """-> [{kernel, flops, exec_flops, bytes, ms}] for every launch recorded since PROFILE was set."""
     global PROFILE
@@ -756,9 +786,7 @@ def conv_wgrad(dy, x, dw_out, kh, kw, stride, pad, kreal=None, to_oihw=False, ac
             _run("wgrad_h16", 2.0 * m * cout * kh * kw * cin, 2.0 * (dy.numel() + x.numel()) * kh * kw + 4.0 * slab.numel(),
                  lambda: lib.ssad_conv_wgrad_f16_h(dy.data_ptr(), x.data_ptr(), _hip.ptr(slab), splits, n, h, w, cin, cout, kh, kw,
                                                    stride, pad, dy.numel(), _hip.stream()))
-        _run_aside("wgrad_reduce", 0.0, 4.0 * slab.numel(),
-                   lambda: lib.ssad_wgrad_reduce(_hip.ptr(slab), _hip.ptr(dw_out), splits, cout, kh * kw * cin, kh, kw, cin, int(to_oihw),
-                                                 int(accumulate), _hip.stream()), keep=(slab,))
+        _wgrad_reduce(slab, dw_out, splits, cout, kh * kw * cin, kh, kw, cin, to_oihw, accumulate)
         return dw_out
     if (int(bf16) in (0, 1, 2) and not _is_h(dy) and kreal is None and kh == 1 and kw == 1 and h == 1 and w == 1
             and m <= lib.ssad_linear_small_max_rows()):
@@ -783,9 +811,7 @@ def conv_wgrad(dy, x, dw_out, kh, kw, stride, pad, kreal=None, to_oihw=False, ac
             fn = lambda: lib.ssad_conv_wgrad3x3s2_halo(_hip.ptr(dy), _hip.ptr(x), _hip.ptr(slab), splits, n, ho, wo, h, w, cin,
                                                        cout, dy.numel(), _hip.stream())
         _run("wgrad_f32", 2.0 * m * cout * 9 * cin, 4.0 * (dy.numel() + x.numel() + slab.numel()), fn)
-        _run_aside("wgrad_reduce", 0.0, 4.0 * slab.numel(),
-                   lambda: lib.ssad_wgrad_reduce(_hip.ptr(slab), _hip.ptr(dw_out), splits, cout, 9 * cin, 3, 3, cin, int(to_oihw),
-                                                 int(accumulate), _hip.stream()), keep=(slab,))
+        _wgrad_reduce(slab, dw_out, splits, cout, 9 * cin, 3, 3, cin, to_oihw, accumulate)
         return dw_out
     if bf16 in (1, 2, True) and kreal is None and lib.ssad_wgrad3x3_halo16_ok(cin, cout, kh, kw, stride, pad):
         # 16-bit operands, 3x3 / stride 1 / pad 1: halo-tile kernel (dZ and X fetched, converted and transposed once per pixel tile
@@ -795,9 +821,7 @@ def conv_wgrad(dy, x, dw_out, kh, kw, stride, pad, kreal=None, to_oihw=False, ac
         _run(_kname("wgrad", bf16), 2.0 * m * cout * 9 * cin, 4.0 * (dy.numel() + x.numel() + slab.numel()),
              lambda: lib.ssad_conv_wgrad3x3_halo16(_hip.ptr(dy), _hip.ptr(x), _hip.ptr(slab), splits, n, h, w, cin, cout,
                                                    int(bf16 == 2), dy.numel(), _hip.stream()))
-        _run_aside("wgrad_reduce", 0.0, 4.0 * slab.numel(),
-                   lambda: lib.ssad_wgrad_reduce(_hip.ptr(slab), _hip.ptr(dw_out), splits, cout, 9 * cin, 3, 3, cin, int(to_oihw),
-                                                 int(accumulate), _hip.stream()), keep=(slab,))
+        _wgrad_reduce(slab, dw_out, splits, cout, 9 * cin, 3, 3, cin, to_oihw, accumulate)
         return dw_out
     if bf16 == 6 and not force_x6:
         # bf16x6 training keeps weight gradients on the exact fp32 kernel: the wave-specialised fp32 wgrad (110 TFLOP/s) is
@@ -813,9 +837,7 @@ def conv_wgrad(dy, x, dw_out, kh, kw, stride, pad, kreal=None, to_oihw=False, ac
          lambda: fn(_hip.ptr(dy), _hip.ptr(x), _hip.ptr(slab), splits, n, h, w, cin, cout, kh, kw, stride, pad, dy.numel(),
                     _hip.stream()))
     rkh, rkw, rcin = kreal if kreal else (kh, kw, cin)
-    _run_aside("wgrad_reduce", 0.0, 4.0 * slab.numel(),
-               lambda: _hip.lib().ssad_wgrad_reduce(_hip.ptr(slab), _hip.ptr(dw_out), splits, cout, kh * kw * cin, rkh, rkw, rcin,
-                                                    int(to_oihw), int(accumulate), _hip.stream()), keep=(slab,))
+    _wgrad_reduce(slab, dw_out, splits, cout, kh * kw * cin, rkh, rkw, rcin, to_oihw, accumulate)
     return dw_out
 
 

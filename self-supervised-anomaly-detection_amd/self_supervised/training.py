@@ -596,6 +596,11 @@ class TrainEngine:
         self.sw_poolwin = os.environ.get("SSAD_POOLWIN", "1") != "0"     # stem: BatchNorm backward reduction over the pooled tensors
         # off-critical-path launches (slab reductions, head weight gradients, pooling rows, the filter tables of the backward pass)
         # as parallel branches of the step (ops.ASIDE; DataParallelStep switches it on for its steps)
+        # the slab reductions of a step's weight gradients in ONE launch at the end of backward (ssad_wgrad_reduce_batch).  OFF: measured
+        # (round 6, same box, two alternating runs) fp32 32.34 -> 32.38 ms, batch 32 5.424 -> 5.432, precision 16 8.76 -> 8.80: the 19 per-layer
+        # reductions are not launch-bound but byte-bound (40 MB each at ~5 TB/s, read while the slabs are still in the Infinity Cache;
+        # deferred, they come from HBM).  Kept as a switch: it takes 18 dispatches off the step at equal time.
+        self.sw_batch_reduce = os.environ.get("SSAD_BATCH_REDUCE", "0") != "0"
         self.sw_mask16 = os.environ.get("SSAD_MASK16", "1") != "0"       # precision 16, half tensors: nibble masks for the residual blocks
         self.sw_aside = int(os.environ.get("SSAD_ASIDE", "0"))        # 0 off, 1 every such launch, 2 only the filter tables beside the stem
         self.aside = _Aside()
@@ -607,7 +612,7 @@ class TrainEngine:
 
     def switches(self):
         """Everything besides shapes that decides which launches a step consists of (hipGraph plan key)."""
-        return (self.bf16, self.param_grads, self.sw_c64, self.sw_relu_mask, self.sw_wgrad_halo, self.sw_stem16, self.sw_c64_16, self.sw_act16, self.sw_conv16, self.sw_conv16w, self.sw_conv32w, self.sw_raw32, self.sw_poolwin, self._side_on, self.sw_aside, self.sw_mask16,
+        return (self.bf16, self.param_grads, self.sw_c64, self.sw_relu_mask, self.sw_wgrad_halo, self.sw_stem16, self.sw_c64_16, self.sw_act16, self.sw_conv16, self.sw_conv16w, self.sw_conv32w, self.sw_raw32, self.sw_poolwin, self._side_on, self.sw_aside, self.sw_mask16, self.sw_batch_reduce,
                 os.environ.get("SSAD_WGRAD_HALO", "1") != "0", torch.is_grad_enabled())
 
     # ---- second stream for the weight gradients ----
@@ -747,6 +752,7 @@ class TrainEngine:
         if self.side is not None and self._side_keep:
             torch.cuda.current_stream().wait_stream(self.side)
         self._side_keep = []
+        ops.flush_reductions()        # the slab reductions collected since the last join: one launch
         self.aside.join()
 
     # ---- forward (models.py:210-253, train mode) ----
@@ -1286,6 +1292,7 @@ class DataParallelStep:
         eng = self.eng
         a = eng.arena
         ops.ASIDE = eng.aside if eng.sw_aside else None
+        ops.PENDING_REDUCE = [] if eng.sw_batch_reduce else None
         try:
             if eng.sw_aside == 2:
                 eng.prefetch_only = True
@@ -1299,6 +1306,7 @@ class DataParallelStep:
         finally:
             eng.aside.join()                  # (also on an exception: a capture must not end with an un-joined branch)
             ops.ASIDE = None
+            ops.PENDING_REDUCE = None
         if self.bucketer.recorder is None and self.bucketer.works:      # eager launches: the same (optionally timed) wait as a replay
             self._wait_works(self.bucketer.works)
             self.bucketer.works = []
