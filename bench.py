@@ -875,8 +875,13 @@ def main():
     if "score" in prof and "score_s" in res:
         xf = sum(r["exec_flops"] for r in prof["score"]) / args.steps
         wp["score"] = round(xf / (res["score_s"] / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+    if "score_s" in res:
+        # the same pass by SURVEY 8d's ALGORITHMIC count (252.06 GFLOP per map: every tap of every patch), whatever was executed: padding
+        # taps are skipped and, since round 6, layer1 arithmetic shared by overlapping patches is done once per image -- this can exceed 1
+        wp["score_alg"] = round(out["anomaly_maps_per_sec"] / world * U_MAP_GFLOP / 1e3 / PEAK_F32_MFMA_TFLOPS, 4)
     if wp:
-        out["whole_pass_frac"] = dict(wp, note="executed MFMA FLOPs of ALL kernels of the pass / its wall time / the dense fp32-MFMA peak")
+        out["whole_pass_frac"] = dict(wp, note="train / score: executed MFMA FLOPs of ALL kernels of the pass / its wall time / the dense fp32-MFMA "
+                                               "peak; score_alg: SURVEY 8d's algorithmic FLOPs per map x maps/s / the same peak")
     if prof:
         # HBM-bound kernels: algorithmic bytes (each operand read once, each result written once) over their event time
         hbm = {}

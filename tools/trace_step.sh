@@ -4,7 +4,7 @@
 # -> gpurun_out/<TAG, default r04>_b<batch>_trace_step.csv
 B=${1:-32}
 R=$PWD; OUT=$R/gpurun_out; cd /tmp; export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/t_b$B -o s -- python3 $R/bench.py --batch $B --scaling weak --phase train --no-cpu-baseline --no-e2e --no-wrn50 --no-faithful --no-precision16 --no-partition-extra --steps 6 --warmup 3 $BENCH_ARGS > $OUT/${TAG:-r05}_b${B}_trace_line.json 2>/tmp/t_b$B.err && B=$B python3 - <<'PY'
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/t_b$B -o s -- python3 $R/bench.py --batch $B --scaling weak --phase train --no-cpu-baseline --no-e2e --no-wrn50 --no-faithful --no-precision16 --no-partition-extra --steps 6 --warmup 3 $BENCH_ARGS > $OUT/${TAG:-r06}_b${B}_trace_line.json 2>/tmp/t_b$B.err && B=$B python3 - <<'PY'
 import csv, glob, os
 f = glob.glob('/tmp/t_b%s/**/*kernel_trace.csv' % os.environ['B'], recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
