@@ -1007,11 +1007,24 @@ class FusedSGD:
         self.model._plan = None       # the raw-pointer update does not bump tensor versions: drop folded eval weights
 
     def state_dict(self):
-        return {"param_groups": self.param_groups, "momentum": get_engine(self.model).arena.m.cpu()}
+        """Momentum as ONE flat tensor in backward order, WITHOUT the arena's alignment pads (the layout rounds 1-5 wrote)."""
+        a = get_engine(self.model).arena
+        return {"param_groups": self.param_groups,
+                "momentum": torch.cat([a.m[off:off + n] for off, n in (a.offset[id(p)] for p in a.params)]).cpu()}
 
     def load_state_dict(self, sd):
         self.param_groups = sd["param_groups"]
-        get_engine(self.model).arena.m.copy_(sd["momentum"])
+        a = get_engine(self.model).arena
+        mom = sd["momentum"].to(a.m.device)
+        if mom.numel() == a.total:                      # a padded arena image
+            a.m.copy_(mom)
+            return
+        assert mom.numel() == sum(n for _, n in (a.offset[id(p)] for p in a.params)), "momentum does not match this model's parameters"
+        o = 0
+        for p in a.params:
+            off, n = a.offset[id(p)]
+            a.m[off:off + n].copy_(mom[o:o + n])
+            o += n
 
 
 class CosineWarmRestarts:

@@ -532,6 +532,31 @@ def test_batched_slab_reductions_leave_the_step_bit_identical(dev, seeded_sd):
         assert torch.equal(a, b)
 
 
+def test_fused_sgd_state_roundtrip_is_layout_independent(dev, seeded_sd):
+    """FusedSGD.state_dict() holds the momentum WITHOUT the arena's alignment pads (round 6 pads every parameter to 32 bytes; the
+    classifier's 4-element bias leaves a gap): what rounds 1-5 wrote still loads, a padded arena image loads too, and a reloaded
+    optimizer continues bit-identically."""
+    from self_supervised import training
+    from oracle import weights as ow
+    x, y = ow.synthetic_images(4, 64, seed=91).to(dev), ow.synthetic_labels(4, seed=92).to(dev)
+    _, m = _pair(seeded_sd, dev)
+    m.unfreeze()
+    step = training.DataParallelStep(m, lr=0.01, world_size=1, graph=False)
+    step.step(x, y); step.step(x, y)
+    a = step.eng.arena
+    assert a.total > sum(p.numel() for p in m.parameters()) and a.total % 8 == 0
+    assert all(off % 8 == 0 for off, _ in a.offset.values())
+    sd = step.opt.state_dict()
+    assert sd["momentum"].numel() == sum(p.numel() for p in m.parameters())
+    keep = a.m.clone()
+    a.m.zero_()
+    step.opt.load_state_dict(sd)
+    assert torch.equal(a.m, keep)
+    a.m.zero_()
+    step.opt.load_state_dict({"param_groups": sd["param_groups"], "momentum": keep.cpu()})
+    assert torch.equal(a.m, keep)
+
+
 def test_bound_step_inputs(dev, seeded_sd):
     """DataParallelStep.bind_inputs: a producer fills the recorded step's own input buffers in place; replays from them equal replays
     that copy the batch in, bit for bit."""
