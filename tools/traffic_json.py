@@ -4,6 +4,15 @@ usage: traffic_json.py <dir_fetch> <dir_write> <out.json> <patches per launch> [
 (MI355X_MICROARCH.md, HBM: FETCH_SIZE is doubled on gfx950).  The algorithmic bytes per launch are read from the bench line the pass
 itself printed (roofline.alg_MB_per_launch: the same launches, ring launches of the layer1 convs included since round 6)."""
 import csv, glob, json, sys
+def is_pos(name):
+    """conv_igemm_f32_kernel<BM, BN, TM, TN, BK, TS, POS, DB, BF, IO>: the position-major instantiations (7th argument).  (Rounds 1-5
+    matched ", true, " anywhere, which also counted the NHWC launches of the head -- DB = true -- 12 of the 72 launches of r05_traffic.json.)"""
+    if "conv_igemm_f32_kernel<" not in name:
+        return False
+    args = [a.strip() for a in name.split("<", 1)[1].split(">", 1)[0].split(",")]
+    return len(args) > 6 and args[6] == "true"
+
+
 def total(d, counter):
     names = {}
     for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
@@ -12,7 +21,7 @@ def total(d, counter):
     s, disp = 0.0, set()
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            if row["Counter_Name"] == counter and "conv_igemm_f32_kernel" in names.get(row["Dispatch_Id"], "") and ", true, " in names[row["Dispatch_Id"]]:
+            if row["Counter_Name"] == counter and is_pos(names.get(row["Dispatch_Id"], "")):
                 s += float(row["Counter_Value"]); disp.add(row["Dispatch_Id"])
     return s, len(disp)
 fetch, nf = total(sys.argv[1], "FETCH_SIZE")
@@ -29,7 +38,7 @@ alg = 5764.4
 if len(sys.argv) > 5:
     line = json.loads(open(sys.argv[5]).read().strip().splitlines()[-1])
     alg = float(line["roofline"]["alg_MB_per_launch"])
-    assert line["roofline"]["launches"] % max(nf, 1) == 0 or nf % line["roofline"]["launches"] == 0, (nf, line["roofline"]["launches"])
+    assert nf % line["roofline"]["launches"] == 0, (nf, line["roofline"]["launches"])
 out["algorithmic_MB_per_launch"] = alg
 out["ratio_to_algorithmic"] = round(out["traffic_MB_per_launch"] / alg, 3)
 out["note"] = "fabric-side counters: Infinity-Cache hits are included, so this is an upper bound on HBM bytes"
