@@ -860,6 +860,18 @@ def main():
             tms[r["kernel"]] = tms.get(r["kernel"], 0.0) + r["ms"]
     train_tag = max(tms, key=tms.get) if tms else "conv_igemm_f32"
     rf_score, rf_train = roofline_of("score", "conv_igemm_pos_f32"), roofline_of("train", train_tag)
+    if rf_score:
+        # the same kernel template runs two kinds of launches since round 6: the convs of layers 2-4 (every position of 8 x 8 .. 2 x 2
+        # maps: the launches of rounds 1-5) and the RING launches of layer1 (border positions of 16 x 16 maps, 64 channels, 8-18 K-steps
+        # per workgroup).  `frac` covers all of them; the split is given so that rounds stay comparable
+        ring = [r for r in prof.get("score", []) if r["kernel"] == "conv_igemm_pos_f32" and (r.get("tile") or "").startswith("<128,64,")]
+        rest = [r for r in prof.get("score", []) if r["kernel"] == "conv_igemm_pos_f32" and r not in ring]
+        for name, recs in (("layers2_4", rest), ("layer1_ring", ring)):
+            if recs:
+                t = sum(r["ms"] for r in recs) * 1e-3
+                rf_score[name] = {"launches": len(recs), "ms_per_step": round(1e3 * t / args.steps, 3),
+                                  "TFLOPs": round(sum(r["exec_flops"] for r in recs) / t / 1e12, 2),
+                                  "frac": round(sum(r["exec_flops"] for r in recs) / t / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
     if rf_score or rf_train:
         out["roofline"] = dict(rf_score or rf_train)
         out["roofline"]["note"] = ("achieved / frac = MFMA FLOPs issued per second of kernel time (HIP events on the launch stream) "
