@@ -438,3 +438,17 @@ def test_layer1_dedup_equals_patchwise(dev, seeded_sd, monkeypatch):
             engine.trunk_eval(plan, x, 32, 4, m.layer_outputs, pooled)
             outs.append(pooled)
         assert (outs[0] - outs[1]).abs().max().item() <= 2e-6 * max(1.0, outs[0].abs().max().item())
+        # small and odd geometries through the engine: eight 64 x 64 images (5 x 5 windows each, dense maps of 32 x 32), a 96 x 64
+        # batch, windows that barely overlap (stride 16: pooled shift 8), windows one pooled position apart (stride 2)
+        for (bsz, hh, ww, ps) in ((8, 64, 64, 8), (4, 96, 64, 8), (6, 112, 80, 16), (1, 72, 66, 2)):
+            xx = ow.synthetic_images(bsz, 256, seed=14 + ps)[:, :, :hh, :ww].contiguous().to(dev)
+            npat = ((hh - 32) // ps + 1) * ((ww - 32) // ps + 1)
+            assert bsz * npat >= 128
+            outs = []
+            for flag in ("0", "1"):
+                monkeypatch.setenv("SSAD_DEDUP", flag)
+                pooled = torch.empty((bsz * npat, m.concatenator[0].in_features), device=dev)
+                engine.trunk_eval(plan, xx, 32, ps, m.layer_outputs, pooled)
+                outs.append(pooled)
+            err = (outs[0] - outs[1]).abs().max().item()
+            assert err <= 2e-6 * max(1.0, outs[0].abs().max().item()), (bsz, hh, ww, ps, err)
