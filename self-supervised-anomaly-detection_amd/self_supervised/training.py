@@ -784,7 +784,7 @@ class TrainEngine:
         a, self.pool_idx = self.stem.fwd_pool(x.contiguous())
         if aside is not None:
             aside.join()                      # layer1 reads the packs / the rounded weights
-            if getattr(self, "prefetch_only", False):
+            if self.sw_aside == 2:            # only the filter tables run beside the stem: everything else stays on the chain
                 ops.ASIDE = None
         if not self.trunk_grad:
             self.stem.x = None
@@ -1307,8 +1307,6 @@ class DataParallelStep:
         ops.ASIDE = eng.aside if eng.sw_aside else None
         ops.PENDING_REDUCE = [] if eng.sw_batch_reduce else None
         try:
-            if eng.sw_aside == 2:
-                eng.prefetch_only = True
             logits, emb = eng.forward(x)
             dlogits = torch.empty_like(logits)
             la = ops.softmax_ce(logits, y, dlogits, 1.0 / x.shape[0])
