@@ -81,6 +81,14 @@ template <> __device__ __forceinline__ f32x8 ldv<hf>(const hf* p) { return __bui
 template <typename T> __device__ __forceinline__ void stv(T* p, typename Lane<T>::vec v);
 template <> __device__ __forceinline__ void stv<float>(float* p, f32x4 v) { *(f32x4*)p = v; }
 template <> __device__ __forceinline__ void stv<hf>(hf* p, f32x8 v) { *(f16x8*)p = __builtin_convertvector(v, f16x8); }
+// The same 16 bytes WITHOUT the conversion: a kernel that requests several tensors under run-time conditions loads raw pieces first and
+// converts afterwards -- with ldv inside an `if (ptr)` hipcc puts the wait for that load (its convert) into the branch and the
+// requests of one iteration go out one after the other (round 6: the half column reductions ran at 3.0-3.8 TB/s for that reason).
+template <typename T> struct RawLane { using t = f32x4; };
+template <> struct RawLane<hf> { using t = f16x8; };
+template <typename T> __device__ __forceinline__ typename RawLane<T>::t ldrawv(const T* p) { return *(const typename RawLane<T>::t*)p; }
+__device__ __forceinline__ f32x4 cvtraw(f32x4 v) { return v; }
+__device__ __forceinline__ f32x8 cvtraw(f16x8 v) { return __builtin_convertvector(v, f32x8); }
 // E consecutive per-channel parameters (fp32 either way), E = 4 or 8, index in units of E
 template <typename V> __device__ __forceinline__ V ldpar(const float* p, int i);
 template <> __device__ __forceinline__ f32x4 ldpar<f32x4>(const float* p, int i) { return ((const f32x4*)p)[i]; }

@@ -615,12 +615,16 @@ __global__ __launch_bounds__(256) void pack_hw_kernel(const float* __restrict__ 
     const int o = ct * 32 + n, i0 = kb * KST + kh * E;
     const float* w = src + t.e[k][0];
     frag_t v;
+    const float osc = oscale ? oscale[o] : 1.f;
 #pragma unroll
     for (int j = 0; j < E; ++j) {
         // plain: this conv's OHWI filter [O][9][I].  flip: this conv is the input gradient of a conv whose filter is [I][9][O]:
         // its weight (o, tap, i) is that filter's (i, 8 - tap, o)
-        const float x = flip ? w[((int64_t)(i0 + j) * 9 + (8 - tap)) * O + o] : w[((int64_t)o * 9 + tap) * I + i0 + j];
-        v[j] = (T)(oscale ? x * oscale[o] : x);          // inference: the folded BatchNorm's scale of output channel o
+        // (one load per element at a selected INDEX, not a load in each arm of the select: hipcc waited for every such load before the
+        // next one -- eight L2 round trips in a row per thread, round 6)
+        const int64_t src_i = flip ? ((int64_t)(i0 + j) * 9 + (8 - tap)) * O + o : ((int64_t)o * 9 + tap) * I + i0 + j;
+        const float x = w[src_i];
+        v[j] = (T)(x * osc);                             // inference: the folded BatchNorm's scale of output channel o (else 1: exact)
     }
     *(frag_t*)(dst + t.e[k][1] + piece * E) = v;
 }

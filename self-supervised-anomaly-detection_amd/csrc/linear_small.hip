@@ -133,10 +133,17 @@ __global__ __launch_bounds__(256) void small_wgrad_kernel(const float* __restric
         float av[U], bv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            // branch-free: every lane loads from a valid (clamped) address and the value is selected afterwards.  With the loads inside
+            // `ok ? load : 0` branches hipcc sank the 16-bit rounding of the RND != 0 instantiations INTO each branch -- load, s_waitcnt
+            // vmcnt(0), two converts, sixteen times in a row: 17-22 us per launch where the exact-fp32 instantiation takes 6-8
+            // (round 6, found in profiles/r06_p16_b256_trace_step.csv)
             const int m = 2 * (q + 4 * u) + h;
             const bool ok = m < M;
-            av[u] = ok && aok ? dz[(size_t)m * O + o0 + r] : 0.f;
-            bv[u] = ok && bok ? x[(size_t)m * K + k0 + r] : 0.f;
+            const int mc = ok ? m : 0;
+            const float ta = dz[(size_t)mc * O + (aok ? o0 + r : 0)];
+            const float tb = x[(size_t)mc * K + (bok ? k0 + r : 0)];
+            av[u] = ok && aok ? ta : 0.f;
+            bv[u] = ok && bok ? tb : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) acc = mfma32(rnd16<RND>(av[u]), rnd16<RND>(bv[u]), acc);

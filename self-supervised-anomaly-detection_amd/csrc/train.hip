@@ -71,15 +71,22 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const T* __restrict__ a
         constexpr int U = 16 / E;
         for (int64_t row = rb + ty; row < re; row += (int64_t)U * RL) {
             V v[U], ya[U], zz[U];
+            typename RawLane<T>::t rv[U], rya[U], rzz[U];
             unsigned mk[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t rw = row + (int64_t)u * RL;
                 const int64_t o = (rw < re ? rw : rb + ty) * CE + cq;       // clamp: tail rows re-read a valid row ...
-                v[u] = ldv(a + E * o);
-                if (MODE == 1 && yact) ya[u] = ldv(yact + E * o);
+                rv[u] = ldrawv(a + E * o);                                  // raw pieces: the conversions follow all the requests
+                if (MODE == 1 && yact) rya[u] = ldrawv(yact + E * o);
                 if (MODE == 1 && mask4) mk[u] = mask_word<E>(mask4, o);
-                if (MODE == 1 && z) zz[u] = ldv(z + E * o);
+                if (MODE == 1 && z) rzz[u] = ldrawv(z + E * o);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                v[u] = cvtraw(rv[u]);
+                if (MODE == 1 && yact) ya[u] = cvtraw(rya[u]);
+                if (MODE == 1 && z) zz[u] = cvtraw(rzz[u]);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -201,11 +208,15 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const T* __restrict__
         const int cq = (int)(i % CE);
         const V mu = ldpar<V>(mean, cq), is = ldpar<V>(invstd, cq);
         const V g = ldpar<V>(gamma, cq), b = ldpar<V>(beta, cq);
-        V v = ldv(z + E * i);
+        // (both requests before either conversion: see ldrawv in common.h)
+        const typename RawLane<T>::t rz = ldrawv(z + E * i);
+        typename RawLane<T>::t rres = rz;
+        if (res) rres = ldrawv(res + E * i);
+        V v = cvtraw(rz);
 #pragma unroll
         for (int k = 0; k < E; ++k) v[k] = (v[k] - mu[k]) * is[k] * g[k] + b[k];
         if (res) {
-            const V rr = ldv(res + E * i);
+            const V rr = cvtraw(rres);
 #pragma unroll
             for (int k = 0; k < E; ++k) v[k] += rr[k];
         }
@@ -240,18 +251,28 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const T* __restrict__
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < totalE; i += (int64_t)gridDim.x * blockDim.x) {
         const int cq = (int)(i % CE);
         const V mu = ldpar<V>(mean, cq), is = ldpar<V>(invstd, cq), ga = ldpar<V>(gamma, cq);
-        V g = ldv(dy + E * i);
-        if (yact) {
-            const V ya = ldv(yact + E * i);
+        // every tensor this element needs is requested before anything is converted or used (ldrawv, common.h): dy, then the saved
+        // activation or the mask, then z (mask from z and / or the train-mode apply)
+        const typename RawLane<T>::t rg = ldrawv(dy + E * i);
+        typename RawLane<T>::t rya = rg, rzr = rg;
+        unsigned mkw = 0;
+        const bool use_ya = yact != nullptr, use_mk = !use_ya && mask4 != nullptr, use_zm = !use_ya && !use_mk && zmask_beta != nullptr;
+        if (use_ya) rya = ldrawv(yact + E * i);
+        if (use_mk) mkw = mask_word<E>(mask4, i);
+        if (use_zm || !eval_mode) rzr = ldrawv(z + E * i);
+        V g = cvtraw(rg);
+        const V zall = cvtraw(rzr);
+        if (use_ya) {
+            const V ya = cvtraw(rya);
 #pragma unroll
             for (int k = 0; k < E; ++k) g[k] = ya[k] > 0.f ? g[k] : 0.f;
-        } else if (mask4) {
-            const unsigned mk = mask_word<E>(mask4, i);
+        } else if (use_mk) {
+            const unsigned mk = mkw;
 #pragma unroll
             for (int k = 0; k < E; ++k) g[k] = mask_bit<E>(mk, k) ? g[k] : 0.f;
-        } else if (zmask_beta) {                 // ReLU mask recomputed from z (layer without residual)
+        } else if (use_zm) {                     // ReLU mask recomputed from z (layer without residual)
             const V zb = ldpar<V>(zmask_beta, cq);
-            const V zm = ldv(z + E * i);
+            const V zm = zall;
 #pragma unroll
             for (int k = 0; k < E; ++k) g[k] = (zm[k] - mu[k]) * is[k] * ga[k] + zb[k] > 0.f ? g[k] : 0.f;
         }
@@ -262,7 +283,7 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const T* __restrict__
             for (int k = 0; k < E; ++k) o[k] = g[k] * ga[k] * is[k];
         } else {
             const V db = ldpar<V>(dbeta, cq), dg = ldpar<V>(dgamma, cq);
-            const V zz = ldv(z + E * i);
+            const V zz = zall;
 #pragma unroll
             for (int k = 0; k < E; ++k) {
                 const float xh = (zz[k] - mu[k]) * is[k];
@@ -423,6 +444,18 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_kernel(const uint8_t* __restr
                 for (int q = 0; q < E / 4; ++q) pk[dy][dx][q] = ok ? ((const uint32_t*)idx)[o * (E / 4) + q] : 0xffffffffu;   // slot 255 never matches
                 gq[dy][dx] = ldv(dpool + E * o);
             }
+        // ... and the block's four z values, requested with them (branch-free: a pixel outside the map reads the block's first pixel
+        // and is skipped below) -- inside the per-pixel bounds branch each load was waited for on its own (round 6, ISA inspection)
+        V zq[2][2];
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+                const int y = 2 * a + py, x = 2 * b + px;
+                const bool ok = y < H && x < W;
+                const int64_t rowc = (n * H + (ok ? y : 2 * a)) * W + (ok ? x : 2 * b);
+                zq[py][px] = ldv(z + E * (rowc * CE + cq));
+            }
 #pragma unroll
         for (int py = 0; py < 2; ++py)
 #pragma unroll
@@ -442,7 +475,7 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_kernel(const uint8_t* __restr
                         for (int k = 0; k < E; ++k) g[k] += ((pk[dy][dx][k >> 2] >> (8 * (k & 3))) & 0xffu) == slot ? gq[dy][dx][k] : 0.f;
                     }
                 const int64_t row = (n * H + y) * W + x;
-                const V zz = ldv(z + E * (row * CE + cq));
+                const V zz = zq[py][px];
                 V xh;
 #pragma unroll
                 for (int k = 0; k < E; ++k) {
@@ -962,10 +995,24 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restri
     __shared__ double sh[2][8][32];
     const int j = threadIdx.x & 31, ig = threadIdx.x >> 5, c = blockIdx.x * 32 + j;
     double part[2] = {0, 0}, tot[2];
-    for (int r = ig; r < R; r += 8) {
-        const double v = (double)z[(size_t)r * C + c];
-        part[0] += v;
-        part[1] += v * v;
+    // SU rows in flight per thread (branch-free clamped loads, consumed in row order: the sums are bit-identical to the one-row loop).
+    // One row per iteration was one L2 round trip per row -- 32 of them in a row at 256 rows: 15 us per launch for 512 KB (round 6).
+    constexpr int SU = 8;
+    for (int r0 = ig; r0 < R; r0 += 8 * SU) {
+        float v[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int r = r0 + 8 * u;
+            v[u] = z[(size_t)(r < R ? r : ig) * C + c];
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            if (r0 + 8 * u < R) {
+                const double d = (double)v[u];
+                part[0] += d;
+                part[1] += d * d;
+            }
+        }
     }
     small_col_totals(sh, 2, part, ig, j, tot);
     const double m = tot[0] / (double)R;
@@ -982,10 +1029,22 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restri
         }
     }
     const float g = gamma[c], b = beta[c];
-    for (int r = ig; r < R; r += 8) {
-        float v = (z[(size_t)r * C + c] - mu) * is * g + b;
-        if (relu) v = fmaxf(v, 0.f);
-        y[(size_t)r * C + c] = v;
+    for (int r0 = ig; r0 < R; r0 += 8 * SU) {
+        float v[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int r = r0 + 8 * u;
+            v[u] = z[(size_t)(r < R ? r : ig) * C + c];
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int r = r0 + 8 * u;
+            if (r < R) {
+                float o = (v[u] - mu) * is * g + b;
+                if (relu) o = fmaxf(o, 0.f);
+                y[(size_t)r * C + c] = o;
+            }
+        }
     }
 }
 
@@ -1001,12 +1060,26 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
     const float mu = mean[c], is = invstd[c], ga = gamma[c];
     const float zb = zmask_beta ? zmask_beta[c] : 0.f;
     double part[2] = {0, 0}, tot[2];
-    for (int r = ig; r < R; r += 8) {
-        const float zz = z[(size_t)r * C + c];
-        float g = dy[(size_t)r * C + c];
-        if (zmask_beta) g = (zz - mu) * is * ga + zb > 0.f ? g : 0.f;
-        part[0] += (double)g;
-        part[1] += (double)g * (double)((zz - mu) * is);
+    constexpr int SU = 8;                     // rows in flight per thread, consumed in row order (see bn_small_fwd_kernel)
+    for (int r0 = ig; r0 < R; r0 += 8 * SU) {
+        float zv[SU], gv[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int r = r0 + 8 * u;
+            const size_t o = (size_t)(r < R ? r : ig) * C + c;
+            zv[u] = z[o];
+            gv[u] = dy[o];
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            if (r0 + 8 * u < R) {
+                const float zz = zv[u];
+                float g = gv[u];
+                if (zmask_beta) g = (zz - mu) * is * ga + zb > 0.f ? g : 0.f;
+                part[0] += (double)g;
+                part[1] += (double)g * (double)((zz - mu) * is);
+            }
+        }
     }
     small_col_totals(sh, 2, part, ig, j, tot);
     const float db = (float)tot[0], dg = (float)tot[1];
@@ -1016,14 +1089,28 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
     }
     const float invR = 1.f / (float)R;
     double sdz[1] = {0};
-    for (int r = ig; r < R; r += 8) {
-        const float zz = z[(size_t)r * C + c];
-        float g = dy[(size_t)r * C + c];
-        if (zmask_beta) g = (zz - mu) * is * ga + zb > 0.f ? g : 0.f;
-        const float xh = (zz - mu) * is;
-        const float o = ga * is * (g - db * invR - xh * dg * invR);
-        dz[(size_t)r * C + c] = o;
-        sdz[0] += (double)o;
+    for (int r0 = ig; r0 < R; r0 += 8 * SU) {
+        float zv[SU], gv[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int r = r0 + 8 * u;
+            const size_t o = (size_t)(r < R ? r : ig) * C + c;
+            zv[u] = z[o];
+            gv[u] = dy[o];
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int r = r0 + 8 * u;
+            if (r < R) {
+                const float zz = zv[u];
+                float g = gv[u];
+                if (zmask_beta) g = (zz - mu) * is * ga + zb > 0.f ? g : 0.f;
+                const float xh = (zz - mu) * is;
+                const float o = ga * is * (g - db * invR - xh * dg * invR);
+                dz[(size_t)r * C + c] = o;
+                sdz[0] += (double)o;
+            }
+        }
     }
     if (dbias) {
         double t[1];
