@@ -679,9 +679,18 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
 // halved when a gradient is not finite, the scale doubled after `interval` clean steps.
 __global__ void check_finite_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ scaler) {
     bool bad = false;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    // 16 bytes per lane, two pieces in flight (the arena ranges start at multiples of 32 bytes; the tail element-wise)
+    const int64_t n4 = (((uintptr_t)g & 15) == 0) ? n / 4 : 0;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += 2 * step) {
+        const f32x4 a = ((const f32x4*)g)[i];
+        const f32x4 b = ((const f32x4*)g)[i + step < n4 ? i + step : i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bad = bad || !(fabsf(a[k]) <= 3.402823466e38f) || !(fabsf(b[k]) <= 3.402823466e38f);       // inf or nan
+    }
+    for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
         const float v = g[i];
-        bad = bad || !(fabsf(v) <= 3.402823466e38f);       // inf or nan
+        bad = bad || !(fabsf(v) <= 3.402823466e38f);
     }
     if (__any(bad) && (threadIdx.x & 63) == 0) scaler[2] = 1.f;   // benign race: every writer stores the same value
 }
