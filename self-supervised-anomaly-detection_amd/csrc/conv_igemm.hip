@@ -803,13 +803,15 @@ void conv_igemm_f32_kernel(ConvParams p) {
 #pragma unroll
                         for (int j = 0; j < TN; ++j) res[e][j] = p.residual[off[e] + 32 * j];
                     if (p.res_mask) {
+                        unsigned mk[16][TN];             // all mask bytes requested before the first select (see the LDS epilogue below)
 #pragma unroll
                         for (int e = 0; e < 16; ++e)
 #pragma unroll
-                            for (int j = 0; j < TN; ++j) {
-                                const unsigned mk = p.res_mask[(off[e] + 32 * j) >> 2];
-                                res[e][j] = (mk >> (r & 3)) & 1u ? res[e][j] : 0.f;
-                            }
+                            for (int j = 0; j < TN; ++j) mk[e][j] = p.res_mask[(off[e] + 32 * j) >> 2];
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) res[e][j] = (mk[e][j] >> (r & 3)) & 1u ? res[e][j] : 0.f;
                     }
                 } else {
 #pragma unroll
@@ -863,6 +865,8 @@ void conv_igemm_f32_kernel(ConvParams p) {
         }
         int64_t o[NPASS];
         f32x4 res[NPASS];
+        f16x4 rraw[NPASS];
+        unsigned mkq[NPASS];
 #pragma unroll
         for (int q = 0; q < NPASS; ++q) {
             const int lr = rr + q * RP;                                      // row inside the pass tile
@@ -880,12 +884,20 @@ void conv_igemm_f32_kernel(ConvParams p) {
                 ok = ok && row < p.M;
             }
             o[q] = ok ? row * p.Cout + col : -1;
-            if (IO) res[q] = (aligned && ok && p.residual) ? ld4((const hf*)p.residual + o[q]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            // every pass's residual piece (and mask byte) is REQUESTED here; conversions and masking follow the loop.  With the half
+            // conversion / the mask select inside this loop hipcc waited for each piece before asking for the next (round 6: NPASS L2
+            // round trips in a row in the epilogue of the masked and the half-tensor input gradients)
+            if (IO) rraw[q] = *(const f16x4*)((aligned && ok && p.residual) ? (const void*)((const hf*)p.residual + o[q]) : (const void*)g_zero_page);
             else res[q] = *(const f32x4*)((aligned && ok && p.residual) ? p.residual + o[q] : g_zero_page);
-            if (aligned && ok && p.res_mask) {
-                const unsigned mk = p.res_mask[o[q] >> 2];
+            mkq[q] = 0xfu;
+            if (aligned && ok && p.res_mask) mkq[q] = p.res_mask[o[q] >> 2];
+        }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) res[q][k] = (mk >> k) & 1u ? res[q][k] : 0.f;
+        for (int q = 0; q < NPASS; ++q) {
+            if (IO) res[q] = __builtin_convertvector(rraw[q], f32x4);
+            if (p.res_mask) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) res[q][k] = (mkq[q] >> k) & 1u ? res[q][k] : 0.f;
             }
         }
 #pragma unroll
