@@ -37,6 +37,9 @@ int ssad_repack_oihw_to_ohwi(const float* w_oihw, float* w_ohwi, int O, int I, i
 int ssad_repack_ohwi_to_oihw(const float* w_ohwi, float* w_oihw, int O, int I, int KH, int KW, void* stream);
 /* conv1 7x7 OIHW [64][3][7][7] -> MFMA K-order [168][64] (kx padded 7->8 with zeros). */
 int ssad_pack_stem_weight(const float* w_oihw, float* wk, void* stream);
+/* The same pack from an OHWI filter [64][7][7][3]: how the training step's parameter arena holds conv1 (models.py:224 under trainer.fit);
+ * spares the step an OIHW copy of the weight per iteration (round 6). */
+int ssad_pack_stem_weight_ohwi(const float* w_ohwi, float* wk, void* stream);
 
 /* ---- forward kernels ---- */
 /* Replaces: extract_patches (src/self_supervised/functional.py:77-82) + reshape
@@ -257,6 +260,7 @@ int ssad_conv_wgrad3x3s2_halo(const float* dz, const float* x, float* slab, int 
  * (pl.Trainer(precision=16), src/self_supervised/tools.py:263; models.py:224).  wk16: 14 * 64 * 16 halves from ssad_pack_stem_weight16;
  * workspace: ssad_stem_stats_rows() * 128 doubles. */
 int ssad_pack_stem_weight16(const float* w_oihw, void* wk16, int f16, void* stream);
+int ssad_pack_stem_weight16_ohwi(const float* w_ohwi, void* wk16, int f16, void* stream);   /* OHWI source, as ssad_pack_stem_weight_ohwi */
 int ssad_stem_fwd_stats16(const float* img, int B, int H, int W, const void* wk16, float* out, float eps, float momentum, float* mean,
                           float* invstd, float* running_mean, float* running_var, double* workspace, int f16, void* stream);
 /* The same halo-tile weight gradient with 16-bit OPERANDS (fp32 tensors in memory, rounded to fp16 -- f16 != 0 -- or bf16 while

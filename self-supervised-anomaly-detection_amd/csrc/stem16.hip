@@ -164,25 +164,30 @@ __global__ __launch_bounds__(256, 2) void stem_conv7x7_16_kernel(Stem16Params p)
 
 // OIHW [64][3][7][7] fp32 -> [ky][kk][co][16] halves, k = 16 kk + j <-> (kx = (16 kk + j) / 4, c = j % 4); kx = 7 and c = 3 are zeros
 template <bool F16>
-__global__ void pack_stem_weight16_kernel(const float* __restrict__ w, typename Op16<F16>::t* __restrict__ wk) {
+__global__ void pack_stem_weight16_kernel(const float* __restrict__ w, typename Op16<F16>::t* __restrict__ wk, int ohwi = 0) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= W_H) return;
     const int j = i & 15, co = (i >> 4) & 63, kk = (i >> 10) & 1, ky = i >> 11;
     const int k = 16 * kk + j, kx = k >> 2, c = k & 3;
-    const float v = (kx < 7 && c < 3) ? w[((co * 3 + c) * 7 + ky) * 7 + kx] : 0.f;
-    wk[i] = (typename Op16<F16>::t)v;
+    const bool real = kx < 7 && c < 3;
+    const int kxc = real ? kx : 0, cc = real ? c : 0;
+    const float t = w[ohwi ? ((co * 7 + ky) * 7 + kxc) * 3 + cc : ((co * 3 + cc) * 7 + ky) * 7 + kxc];      // ohwi: [64][7][7][3]
+    wk[i] = (typename Op16<F16>::t)(real ? t : 0.f);
 }
 
 }  // namespace
 
 // wk16: 14 * 64 * 16 halves (28 672 bytes); f16 != 0: fp16, else bf16
-extern "C" int ssad_pack_stem_weight16(const float* w_oihw, void* wk16, int f16, void* stream) {
-    SSAD_CHECK_ARG(w_oihw && wk16, "null pointer");
-    if (f16) hipLaunchKernelGGL(pack_stem_weight16_kernel<true>, dim3((W_H + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_oihw, (_Float16*)wk16);
-    else hipLaunchKernelGGL(pack_stem_weight16_kernel<false>, dim3((W_H + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_oihw, (__bf16*)wk16);
+static int pack16(const float* w, void* wk16, int f16, int ohwi, void* stream) {
+    SSAD_CHECK_ARG(w && wk16, "null pointer");
+    if (f16) hipLaunchKernelGGL(pack_stem_weight16_kernel<true>, dim3((W_H + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, (_Float16*)wk16, ohwi);
+    else hipLaunchKernelGGL(pack_stem_weight16_kernel<false>, dim3((W_H + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)wk16, ohwi);
     SSAD_CHECK_LAUNCH();
     return 0;
 }
+extern "C" int ssad_pack_stem_weight16(const float* w_oihw, void* wk16, int f16, void* stream) { return pack16(w_oihw, wk16, f16, 0, stream); }
+// ... from an OHWI filter [64][7][7][3] (the parameter arena's layout; see ssad_pack_stem_weight_ohwi)
+extern "C" int ssad_pack_stem_weight16_ohwi(const float* w_ohwi, void* wk16, int f16, void* stream) { return pack16(w_ohwi, wk16, f16, 1, stream); }
 
 // The 16-bit-operand form of ssad_stem_fwd_stats (whole images, no patch windows): z [B][Ho][Wo][64] fp32, mean / invstd / running
 // statistics of bn1; workspace: ssad_stem_stats_rows() * 128 doubles.

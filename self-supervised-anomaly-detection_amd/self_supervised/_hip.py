@@ -22,6 +22,8 @@ SIGNATURES = {
     "ssad_repack_oihw_to_ohwi": [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp],
     "ssad_repack_ohwi_to_oihw": [_c_fp, _c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp],
     "ssad_pack_stem_weight": [_c_fp, _c_fp, _c_fp],
+    "ssad_pack_stem_weight_ohwi": [_c_fp, _c_fp, _c_fp],
+    "ssad_pack_stem_weight16_ohwi": [_c_fp, _c_fp, _c_i, _c_fp],
     "ssad_stem_fwd": [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_fp, _c_fp],
     "ssad_stem_stats_rows": [],
     "ssad_stem_fwd_stats": [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_f, _c_f, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],

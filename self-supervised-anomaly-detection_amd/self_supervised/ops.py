@@ -136,8 +136,12 @@ def repack_ohwi_to_oihw(w):
 
 
 def pack_stem_weight(w):
-    assert tuple(w.shape) == (64, 3, 7, 7)
+    """conv1's filter in the stem kernel's K order; w OIHW [64][3][7][7], or OHWI [64][7][7][3] (the parameter arena's layout)."""
     out = _new((168, 64), w)
+    if tuple(w.shape) == (64, 7, 7, 3):
+        _hip.check(_hip.lib().ssad_pack_stem_weight_ohwi(_hip.ptr(w), _hip.ptr(out), _hip.stream()))
+        return out
+    assert tuple(w.shape) == (64, 3, 7, 7)
     _hip.check(_hip.lib().ssad_pack_stem_weight(_hip.ptr(w), _hip.ptr(out), _hip.stream()))
     return out
 
@@ -193,11 +197,13 @@ def stem_fwd_stats16(img, w_oihw, eps, momentum, running_mean, running_var, mode
     -> (z [B][Ho][Wo][64] fp32, mean, invstd), statistics from the accumulators as in stem_fwd_stats.
     out_half (mode 2): z is stored as halves and the statistics are those of the stored halves."""
     b, c, h, w = img.shape
-    assert c == 3 and tuple(w_oihw.shape) == (64, 3, 7, 7) and int(mode) in (1, 2)
+    ohwi = tuple(w_oihw.shape) == (64, 7, 7, 3)           # the parameter arena's layout: packed without an OIHW copy
+    assert c == 3 and (ohwi or tuple(w_oihw.shape) == (64, 3, 7, 7)) and int(mode) in (1, 2)
     assert h >= 64 and w >= 64, "images below 64 x 64 are resized first (models.py:217-219): that is the fp32 stem's loader"
     lib = _hip.lib()
     wk = torch.empty(14 * 64 * 16, device=img.device, dtype=torch.float16 if int(mode) == 2 else torch.bfloat16)
-    _hip.check(lib.ssad_pack_stem_weight16(_hip.ptr(w_oihw), wk.data_ptr(), int(int(mode) == 2), _hip.stream()))
+    _hip.check((lib.ssad_pack_stem_weight16_ohwi if ohwi else lib.ssad_pack_stem_weight16)(_hip.ptr(w_oihw), wk.data_ptr(), int(int(mode) == 2),
+                                                                                             _hip.stream()))
     ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
     mean, invstd = _new((64,), img), _new((64,), img)
     ws = torch.empty(lib.ssad_stem_stats_rows() * 128, device=img.device, dtype=torch.float64)

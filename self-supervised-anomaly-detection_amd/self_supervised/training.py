@@ -152,7 +152,7 @@ class _Affine:
     def weight(self):
         a = self.eng.arena
         if self.stem:
-            return ops.pack_stem_weight(self.lin.weight.detach().contiguous())
+            return ops.pack_stem_weight(a.w(self.lin.weight))        # straight from the arena's OHWI view (no OIHW copy per step)
         w = a.w(self.lin.weight)
         return w if self.is_conv else w.view(w.shape[0], 1, 1, w.shape[1])
 
@@ -205,7 +205,7 @@ class _Affine:
         if self.eng.bf16 in (1, 2) and self.eng.sw_stem16 and img.shape[2] >= 64 and img.shape[3] >= 64:
             # (smaller images are first resized to 64 x 64, models.py:217-219: the fp32 stem's loader does that, this kernel does not)
             # precision 16 / 'bf16': conv1 on the 16-bit matrix instructions (csrc/stem16.hip), as autocast runs it
-            z, self.mean, self.invstd = ops.stem_fwd_stats16(img, self.lin.weight.detach().contiguous(), bn.eps, mom, bn.running_mean,
+            z, self.mean, self.invstd = ops.stem_fwd_stats16(img, self.eng.arena.w(self.lin.weight), bn.eps, mom, bn.running_mean,
                                                              bn.running_var, self.eng.bf16, out_half=self.eng.h16)
         else:
             z, self.mean, self.invstd = ops.stem_fwd_stats(img, self.weight(), bn.eps, mom, bn.running_mean, bn.running_var)
