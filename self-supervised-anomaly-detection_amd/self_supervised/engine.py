@@ -51,6 +51,8 @@ class ResNet18Params(nn.Module):
         self.bn1 = nn.BatchNorm2d(64)
         for name, cin, cout, stride in BLOCKS:
             setattr(self, name, nn.Sequential(_Block(cin, cout, stride), _Block(cout, cout, 1)))
+        if self.conv1.weight.is_meta:          # shapes only (PeraNet.load_from_checkpoint): the checkpoint supplies every tensor
+            return
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
