@@ -261,7 +261,7 @@ def _predict_mvtec_streamed(model: PeraNet, dataset, device, indices, group: int
     from .converters import gt2label
     out = ModelOutputsContainer()
     pre = prefetch
-    ne = len(pre.extra) if pre is not None else 0      # images in front of the dataset's own (their embeddings: third return value)
+    ne = len(pre.extra) if pre is not None else 0      # images in front of the dataset's own (their embeddings: out.extra_embeddings)
     n = ne + len(indices)
     if n == 0:
         if prefetch is not None:
@@ -362,7 +362,7 @@ def inference(model_input_dir: str, dataset_dir: str, subject: str, mvtec_infere
     # decoded by the time the model is on the device (the datamodule draws nothing from the global generators)
     rank, world = world_info()
     datamodule = prefetch = mine = None
-    bank_file = None
+    bank_file = bank_item = None
     if mvtec_inference:
         datamodule = MVTecDatamodule(dataset_dir, batch_size=1)
         datamodule.setup('predict')
@@ -383,11 +383,13 @@ def inference(model_input_dir: str, dataset_dir: str, subject: str, mvtec_infere
                 it = iter(ndm.train_dataloader())
                 first = it._next_index()                                         # the sampler's draw; no image is read
                 bank_file = ndm.train_dataset.images_filenames[int(first[0])]
+                bank_item = (ndm.train_dataset, int(first[0]))
                 del it
             except Exception:                                                    # noqa: BLE001  (a DataLoader without these internals:
                 torch.set_rng_state(state)                                       #  the draws are made later, by the loader itself)
                 bank_file = None
-            prefetch = _MVTecPrefetch(datamodule.test_dataset, mine, extra_files=[bank_file] if bank_file else ())
+            # (a rank without test images of its own -- more ranks than images -- scores nothing, the bank image included)
+            prefetch = _MVTecPrefetch(datamodule.test_dataset, mine, extra_files=[bank_file] if (bank_file and mine) else ())
     print('>>> preparing model')
     _mark("prefetch-started")
     try:
@@ -438,6 +440,16 @@ def inference(model_input_dir: str, dataset_dir: str, subject: str, mvtec_infere
         print(' not enough data in memory bank, sampling new data trom train set')
         normality = output.extra_embeddings.cpu()       # the training image scored in front of the test images (see above)
         del output.extra_embeddings
+    elif bank_item is not None:
+        # the draws are made and the image is known, but it did not ride with test images (a rank that has none): score that very
+        # image -- drawing again would pick another one
+        print(' not enough data in memory bank, sampling new data trom train set')
+        ds_, i_ = bank_item
+        model.to(tester.device).eval()
+        with torch.no_grad():
+            one = model.predict_step(tuple(t.unsqueeze(0).to(tester.device) for t in ds_[i_]), 0)
+        one.to_cpu()
+        normality = one.embedding_vectors
     else:
         print(' not enough data in memory bank, sampling new data trom train set')
         if mvtec_inference:
