@@ -33,6 +33,10 @@
 #define CONV16W_ABL 0
 #endif
 
+#ifdef CONV16W_TRACE
+static long long* conv16w_trace_buf = nullptr;
+#endif
+
 namespace {
 
 // T = hf: the precision-16 step's half tensors (v_mfma_f32_32x32x16_f16).  T = float: the exact-fp32 step (v_mfma_f32_32x32x2_f32, four
@@ -59,6 +63,9 @@ struct HWParams {
     int N, H, W, Cin, Cout;
     int tiles_y, tiles_x, nchunks;
     int64_t ntiles;          // TW16: N * tiles_y * tiles_x;  TW8: ceil(N / 4)
+#ifdef CONV16W_TRACE        // tools/micro: 10 ns time stamps of workgroup CONV16W_TRACE's eight waves, 1 024 (tag, time) pairs each
+    long long* trace;
+#endif
 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -81,7 +88,10 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
     constexpr bool F32 = std::is_same<T, float>::value;
     constexpr int E = 16 / (int)sizeof(T);             // elements per 16-byte piece (8 halves / 4 floats)
     constexpr int KST = 2 * E;                         // input channels per step (one fragment deep)
-    constexpr int DB = F32 ? 3 : 6;                    // filter fragments are requested DB steps ahead (an fp32 step is 32 MFMAs of 64 cycles)
+    // filter fragments are requested DB steps ahead (an fp32 step is 32 MFMAs of 64 cycles).  Float, 64-channel form: six -- its 228
+    // registers leave room, and with three the matrix waves waited ~110 cycles per step for fragments (614 -> 602 us on zeros, round 6;
+    // four steps on the 128-channel form, 241 + 8 registers: nothing)
+    constexpr int DB = F32 ? (WN == 1 ? 6 : 3) : 6;
     using frag_t = typename std::conditional<F32, f32x4, f16x8>::type;
     constexpr int WM = 4 / WN;
     constexpr int TWX = (WN == 1 && !TWP) ? 32 : 16;   // tile width in pixels (not TW8)
@@ -106,6 +116,14 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
     float* trp = (float*)(halo + 2 * HALO_H);          // [4][Cin]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef CONV16W_TRACE
+    int tr_i = 0;
+    const bool tr_on = (int)blockIdx.x == CONV16W_TRACE && blockIdx.y == 0 && lane == 0 && p.trace;
+    long long* const tr_p = p.trace + wave * 2048;         // 1 024 (tag, time) pairs per wave
+#define TR(tag) do { if (tr_on && tr_i < 1020) { tr_p[2 * tr_i] = (long long)(tag) | (long long)clock64() << 8; tr_p[2 * tr_i + 1] = wall_clock64(); ++tr_i; } } while (0)
+#else
+#define TR(tag) do { } while (0)
+#endif
     const int64_t my_tiles = p.ntiles > (int64_t)blockIdx.x ? (p.ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
     // fills of a tile: its nchunks input chunks, then -- with a residual -- the RF chunks of the residual's channel slab: the residual is
     // ADDED BY THE MATRIX CORES (a centre-tap step against a one-hot fragment: fp16 x 1.0 into the fp32 accumulator, exact), so it rides
@@ -129,9 +147,11 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
     // issue slot, and a fill's worth of them (1-2 us of stager work per fill with everything else ablated) showed up in full in the
     // matrix stream.  (The guard must be provably wave-uniform: s_setprio ignores EXEC.)  Measured: zero-operand launches 83 / 64 / 58 / 55 ->
     // 79 / 61 / 56 / 53 us (halves), 611 -> 600 us (float, 64-channel layer); the steps themselves: unchanged within noise.
-#ifndef CONV16W_NO_PRIO
-    if (__builtin_amdgcn_readfirstlane(tid) < NMW * 64) __builtin_amdgcn_s_setprio(3);
+#ifndef CONV16W_PRIO_MODE
+#define CONV16W_PRIO_MODE 1
 #endif
+    if (CONV16W_PRIO_MODE == 1 && __builtin_amdgcn_readfirstlane(tid) < NMW * 64) __builtin_amdgcn_s_setprio(3);
+    if (CONV16W_PRIO_MODE == 2 && __builtin_amdgcn_readfirstlane(tid) >= NMW * 64) __builtin_amdgcn_s_setprio(3);
 
     if (wave >= NMW) {
         // =====================================================================================================================
@@ -142,15 +162,31 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
         // pace at the barrier (first form: ~1 500 instructions of index arithmetic per fill = 1.3 us per fill on every layer).
         // Everything that depends only on (lane, piece) is computed ONCE: byte offset from the halo's first pixel, LDS byte offset,
         // halo coordinates, interior flag; per fill there remain the in-image tests and the uniform base address.
+        // Instruction budget (round 6, time stamps inside the kernel -- tools/micro/conv32w_trace.hip): a VALU instruction of a stager
+        // cannot issue while an MFMA of the matrix wave on its SIMD is in the pipe -- every one of them waits for the running MFMA (64
+        // cycles in the float form) and then takes the pipe's next slot.  With ~520 VALU instructions per fill (per-piece in-image tests,
+        // 64-bit address arithmetic, selects around conditional loads, two 64-bit divisions) the stagers needed a whole fill of matrix
+        // work (17-33 us) for 1.7 us of their own, arrived ~1 us AFTER the matrix waves at every barrier, and their instructions showed up
+        // one for one in the matrix stream.  So: loads and the emitted activation go through BUFFER instructions (uniform base in SGPRs,
+        // one precomputed 32-bit offset per piece; an offset beyond the buffer reads zeros / drops the store: padding and missing images
+        // cost no instruction), the per-piece offsets are rebuilt once per TILE, and the tile walk is two scalar cursors (one for the
+        // loads, one for the LDS writes) instead of divisions per fill.  A plain fill is now NR loads + NR LDS writes.
+        constexpr unsigned OOB = 0x80000000u;               // buffer size: offsets from here on are out of range
+        constexpr int SRD3 = 0x00020000;                    // raw buffer, 32-bit data format
+#ifndef CONV16W_NT                                          // experiment: 1 = halo loads non-temporal, 2 = output stores, 3 = both
+#define CONV16W_NT 0
+#endif
+        constexpr int LDAUX = (CONV16W_NT & 1) ? 2 : 0;     // aux bit 1 = nt
         const int sl = (wave - NMW) * 64 + lane;
         const int piece = sl % PPR;                         // SL is a multiple of PPR: a lane stages the same piece of every pixel
         u32x4 reg[2][NR];                                   // two sets: a fill's loads are requested TWO fills before they are written
         unsigned goff[NR];                                  // bytes from the halo's pixel (-1, -1) (TW8: from image 4 tile, pixel (0, 0))
         unsigned loff[NR];                                  // bytes from the start of a halo stage
         unsigned goffr[NR];                                 // the same in the residual tensor (Cout channels per pixel)
-        unsigned hyx[NR];                                   // hy << 8 | hx (TW8: image within the tile)
-        unsigned inner = 0, valid = 0, inm[2] = {0u, 0u};
+        unsigned voff_i[NR], voff_r[NR], voff_m[NR];        // per TILE of the load cursor: input / residual / mask-byte offsets (or OOB)
+        unsigned voff_e[NR];                                // emitted activation: interior pixels only
         unsigned rmask[2][NR];                              // the residual's pass bits of each piece: 4 bits (float), 2 x 4 in two bytes (half)
+        unsigned valid = 0, inner = 0, m_top = 0, m_bot = 0, m_left = 0, m_right = 0, m_i1 = 0, m_i2 = 0, m_i3 = 0;
 #pragma unroll
         for (int q = 0; q < NR; ++q) {
             const int hp = (q * SL + sl) / PPR;             // TW8: hp = 64 image + 8 y + x (interior pixels only)
@@ -159,92 +195,128 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
                 goff[q] = (unsigned)((hp * p.Cin + piece * E) * sizeof(T));
                 goffr[q] = (unsigned)((hp * p.Cout + piece * E) * sizeof(T));
                 loff[q] = (unsigned)((((hp >> 6) * 100 + (((hp >> 3) & 7) + 1) * 10 + (hp & 7) + 1) * LDP + piece * E) * sizeof(T));
-                hyx[q] = (unsigned)(hp >> 6);
                 inner |= 1u << q;
+                if ((hp >> 6) >= 1) m_i1 |= 1u << q;        // pieces of images >= 1 / 2 / 3 of the tile's four
+                if ((hp >> 6) >= 2) m_i2 |= 1u << q;
+                if ((hp >> 6) >= 3) m_i3 |= 1u << q;
             } else {
                 const int img = TWP ? hp / (18 * HW_) : 0, hq = hp - img * 18 * HW_;
                 const int hy = hq / HW_, hx = hq - HW_ * hy;
                 goff[q] = (unsigned)((((img * p.H + hy) * p.W + hx) * p.Cin + piece * E) * sizeof(T));
                 goffr[q] = (unsigned)((((img * p.H + hy) * p.W + hx) * p.Cout + piece * E) * sizeof(T));
                 loff[q] = (unsigned)((hp * LDP + piece * E) * sizeof(T));
-                hyx[q] = (unsigned)(img << 16 | hy << 8 | hx);
                 if (hy >= 1 && hy <= 16 && hx >= 1 && hx <= TWX) inner |= 1u << q;
+                if (hy == 0) m_top |= 1u << q;              // halo rows / columns that fall outside the image when the tile touches
+                if (hy == 17) m_bot |= 1u << q;             // that edge (maps are whole numbers of tiles)
+                if (hx == 0) m_left |= 1u << q;
+                if (hx == TWX + 1) m_right |= 1u << q;
+                if (img == 1) m_i1 |= 1u << q;
             }
         }
-        // uniform per fill: element index of the halo's pixel (-1, -1) at channel chunk * CK (may lie before the tensor: only
-        // in-image pixels are dereferenced), and the tile's position
-        // chunk >= nchunks: a residual fill (chunk - nchunks of the workgroup's channel slab), base then indexes the residual tensor
-        auto origin = [&](int64_t f, int64_t& base, int& chunk, int& y0, int& x0, int& nimg) {
-            const int64_t ti = f / fpt;
-            const int k = (int)(f - ti * fpt);
-            // order of a tile's fills: input chunk 0, residual chunk 0, input 1, residual 1, ... -- a residual fill is four steps of matrix
-            // work, and behind a long input fill its loads (requested two fills ahead) have time to arrive; whatever one kind has more of
-            // follows (first form: all residual fills after the last input chunk, +59 us on the fp32 layer2 shape)
-            const int mpair = p.residual ? (p.nchunks < RF ? p.nchunks : RF) : 0;
-            if (k < 2 * mpair) chunk = (k & 1) ? p.nchunks + (k >> 1) : (k >> 1);
-            else chunk = (p.nchunks > mpair ? 0 : p.nchunks) + (k - mpair);
-            const int64_t tile = (int64_t)blockIdx.x + ti * gridDim.x;
+        inner &= valid;
+#pragma unroll
+        for (int q = 0; q < NR; ++q) voff_e[q] = ((inner >> q) & 1u) ? goff[q] : OOB;
+        const bool lastvalid = (valid >> (NR - 1)) & 1u;    // pieces 0 .. NR - 2 exist in every lane
+
+        // a cursor: fill k of this workgroup's tile number ti, with the tile's geometry
+        struct Cur { int ti, k, y0, x0, nimg, pix; };       // pix: pixel index of the halo's (-1, -1) (TW8: of image 4 tile's first pixel);
+                                                            // may be negative -- only in-image pixels are dereferenced
+        auto enter = [&](Cur& c) {
+            const unsigned tile = blockIdx.x + (unsigned)c.ti * gridDim.x;
+            if (TW8) {
+                c.y0 = c.x0 = 0;
+                c.nimg = p.N - (int)(4 * tile);             // images of this tile that exist
+                c.pix = (int)(4 * tile) * 64;
+            } else if (TWP) {
+                c.y0 = c.x0 = 0;
+                c.nimg = p.N - (int)(2 * tile);
+                c.pix = ((int)(2 * tile) * p.H - 1) * p.W - 1;
+            } else {
+                const unsigned n0 = tile / (unsigned)tpi, rem = tile - n0 * (unsigned)tpi;
+                const unsigned ty = rem / (unsigned)p.tiles_x;
+                c.y0 = (int)ty * 16;
+                c.x0 = (int)(rem - ty * (unsigned)p.tiles_x) * TWX;
+                c.nimg = 1;
+                c.pix = ((int)n0 * p.H + c.y0 - 1) * p.W + c.x0 - 1;
+            }
+        };
+        auto ok_mask = [&](const Cur& c) -> unsigned {      // pieces of the tile's halo that lie inside an existing image
+            unsigned bad = 0;
+            if (TW8) {
+                if (c.nimg < 4) bad = c.nimg <= 1 ? m_i1 : c.nimg == 2 ? m_i2 : m_i3;
+            } else {
+                if (c.y0 == 0) bad |= m_top;
+                if (c.y0 + 16 == p.H) bad |= m_bot;
+                if (c.x0 == 0) bad |= m_left;
+                if (c.x0 + TWX == p.W) bad |= m_right;
+                if (TWP && c.nimg < 2) bad |= m_i1;
+            }
+            return valid & ~bad;
+        };
+        // order of a tile's fills: input chunk 0, residual chunk 0, input 1, residual 1, ... -- a residual fill is four steps of matrix
+        // work, and behind a long input fill its loads (requested two fills ahead) have time to arrive; whatever one kind has more of
+        // follows (first form: all residual fills after the last input chunk, +59 us on the fp32 layer2 shape).
+        // chunk >= nchunks: a residual fill (chunk - nchunks of the workgroup's channel slab)
+        const int mpair = p.residual ? (p.nchunks < RF ? p.nchunks : RF) : 0;
+        auto chunk_of = [&](int k) -> int {
+            if (k < 2 * mpair) return (k & 1) ? p.nchunks + (k >> 1) : (k >> 1);
+            return (p.nchunks > mpair ? 0 : p.nchunks) + (k - mpair);
+        };
+        Cur L = {0, 0, 0, 0, 0, 0}, Wr = {0, 0, 0, 0, 0, 0};
+        unsigned wmask = 0;                                 // in-image pieces of the WRITE cursor's tile (the transform skips the others)
+        auto retarget = [&]() {                             // the load cursor entered a tile: offsets of its in-image pieces
+            const unsigned ok = ok_mask(L);
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                const bool in = (ok >> q) & 1u, rs = in && ((inner >> q) & 1u);     // only the centre tap reads a residual fill
+                voff_i[q] = in ? goff[q] : OOB;
+                voff_r[q] = rs ? goffr[q] : OOB;
+                // the identity-branch gradient is (dy, nibble mask), never materialised: one mask byte per channel quad, i.e. per
+                // 16-byte piece one byte (float) or two (half: 8 channels), at the piece's byte offset / 16 (/ 8)
+                voff_m[q] = rs ? goffr[q] >> (F32 ? 4 : 3) : OOB;
+            }
+        };
+        enter(L); retarget();
+        enter(Wr); wmask = ok_mask(Wr);
+        auto load_fill = [&](auto set_tag) {
+            constexpr int SET = decltype(set_tag)::value;
+            const int chunk = chunk_of(L.k);
             const bool res = chunk >= p.nchunks;
             const int C = res ? p.Cout : p.Cin;
             const int c0 = res ? (int)blockIdx.y * (64 * WN) + (chunk - p.nchunks) * CK : chunk * CK;
-            if (TW8) {
-                y0 = x0 = 0;
-                nimg = p.N - (int)(4 * tile);               // images of this tile that exist
-                base = (int64_t)(4 * tile) * 64 * C + c0;
-            } else if (TWP) {
-                y0 = x0 = 0;
-                nimg = p.N - (int)(2 * tile);
-                base = (((int64_t)(2 * tile) * p.H - 1) * p.W - 1) * C + c0;
-            } else {
-                const int n0 = (int)(tile / tpi);
-                const int rem = (int)(tile - (int64_t)n0 * tpi);
-                y0 = (rem / p.tiles_x) * 16;
-                x0 = (rem % p.tiles_x) * TWX;
-                nimg = 1;
-                base = (((int64_t)n0 * p.H + y0 - 1) * p.W + x0 - 1) * C + c0;
-            }
-        };
-        auto load_fill = [&](int64_t f, auto set_tag) {
-            constexpr int SET = decltype(set_tag)::value;
-            int64_t base; int chunk, y0, x0, nimg;
-            origin(f, base, chunk, y0, x0, nimg);
-            const bool res = chunk >= p.nchunks;
-            const char* src = (const char*)((res ? p.residual : p.in) + base);
-            unsigned im = 0;
+            const int64_t boff = ((int64_t)L.pix * C + c0) * (int64_t)sizeof(T);          // bytes; a multiple of 16
+            const __amdgpu_buffer_rsrc_t rs =
+                __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)(res ? p.residual : p.in) + boff), 0, (int)OOB, SRD3);
+            if (CONV16W_ABL & 2) {
 #pragma unroll
-            for (int q = 0; q < NR; ++q) {
-                bool ok = (valid >> q) & 1u;
-                if (res) ok = ok && ((inner >> q) & 1u);   // only the centre tap reads a residual fill
-                if (TW8) ok = ok && (int)hyx[q] < nimg;
-                else ok = ok && (unsigned)(y0 - 1 + (int)((hyx[q] >> 8) & 255u)) < (unsigned)p.H && (unsigned)(x0 - 1 + (int)(hyx[q] & 255u)) < (unsigned)p.W
-                          && (int)(hyx[q] >> 16) < nimg;
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if (ok && !(CONV16W_ABL & 2)) v = *(const u32x4*)(src + (res ? goffr[q] : goff[q]));
-                reg[SET][q] = v;
-                {
-                    // the identity-branch gradient is (dy, nibble mask), never materialised: one mask byte per channel quad, i.e. per
-                    // 16-byte piece one byte (float) or two (half: 8 channels), at the piece's element index / 4
-                    unsigned mk = 0xffffu;
-                    if (res && p.res_mask && ok) {
-                        if (F32) mk = p.res_mask[(base * (int64_t)sizeof(T) + goffr[q]) >> 4];
-                        else mk = *(const uint16_t*)(p.res_mask + ((base * (int64_t)sizeof(T) + goffr[q]) >> 3));
+                for (int q = 0; q < NR; ++q) reg[SET][q] = u32x4{0u, 0u, 0u, 0u};
+            } else if (res) {
+#pragma unroll
+                for (int q = 0; q < NR; ++q) reg[SET][q] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_r[q], 0, LDAUX);
+                if (p.res_mask) {
+                    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
+                        (void*)(p.res_mask + (boff >> (F32 ? 4 : 3))), 0, (int)(OOB >> (F32 ? 4 : 3)), SRD3);
+#pragma unroll
+                    for (int q = 0; q < NR; ++q) {
+                        if (F32) rmask[SET][q] = __builtin_amdgcn_raw_buffer_load_b8(rm, voff_m[q], 0, 0);
+                        else rmask[SET][q] = __builtin_amdgcn_raw_buffer_load_b16(rm, voff_m[q], 0, 0);
                     }
-                    rmask[SET][q] = mk;
                 }
-                im |= (ok ? 1u : 0u) << q;
+            } else {
+#pragma unroll
+                for (int q = 0; q < NR; ++q) reg[SET][q] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_i[q], 0, LDAUX);
             }
-            inm[SET] = im;
+            if (++L.k == fpt) { L.k = 0; ++L.ti; enter(L); retarget(); }
         };
         typedef float f32x2 __attribute__((ext_vector_type(2)));
-        auto write_fill = [&](int64_t f, auto set_tag) {
+        auto write_fill = [&](auto set_tag) {               // halo stage = set (fill f goes to stage f & 1 and was loaded into set f & 1)
             constexpr int SET = decltype(set_tag)::value;
-            int64_t base; int chunk, y0, x0, nimg;
-            origin(f, base, chunk, y0, x0, nimg);
-            char* dst = (char*)(halo + (int)(f & 1) * HALO_H);
+            const int chunk = chunk_of(Wr.k);
+            char* dst = (char*)halo + SET * HALO_H * (int)sizeof(T);
             if (p.tr_mean && chunk < p.nchunks) {
                 // producer's train-mode BatchNorm + ReLU on load: bn_apply_fwd's expression in fp32 (two channels per packed
-                // instruction); halves: rounded once.  Zero padding pads the TRANSFORMED activation: out-of-image pieces stay zero.
-                // The E channels of this lane's piece: read once per fill.
+                // instruction); halves: rounded once.  Zero padding pads the TRANSFORMED activation: out-of-image pieces stay zero
+                // (they were read as zeros).  The E channels of this lane's piece: read once per fill.
                 const int c = chunk * CK + piece * E;
                 f32x2 mu[E / 2], sc[E / 2], ga[E / 2], be[E / 2];
 #pragma unroll
@@ -252,10 +324,15 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
                     mu[k] = *(const f32x2*)(trp + c + 2 * k); sc[k] = *(const f32x2*)(trp + p.Cin + c + 2 * k);
                     ga[k] = *(const f32x2*)(trp + 2 * p.Cin + c + 2 * k); be[k] = *(const f32x2*)(trp + 3 * p.Cin + c + 2 * k);
                 }
-                char* em = (p.emit && blockIdx.y == 0) ? (char*)(p.emit + base) : nullptr;
+                // interior pixels of the halo: the activation this layer's weight gradient reads (written by channel slab 0; a buffer
+                // of size zero drops every store otherwise)
+                const bool emit = p.emit && blockIdx.y == 0;
+                const int64_t boff = ((int64_t)Wr.pix * p.Cin + chunk * CK) * (int64_t)sizeof(T);
+                const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)((char*)(emit ? p.emit : p.out) + (emit ? boff : 0)), 0, emit ? (int)OOB : 0, SRD3);
 #pragma unroll
                 for (int q = 0; q < NR; ++q) {
-                    if (!((inm[SET] >> q) & 1u)) continue;
+                    if (!((wmask >> q) & 1u)) continue;
                     // (written over an element vector: with the piece held as four dwords and the pairs bit-cast out of / into its
                     // elements, hipcc fed pair 0's RESULT to pairs 1-3 -- found by the emitted activation, tests/test_hip_half.py)
                     const frag_t v = __builtin_bit_cast(frag_t, reg[SET][q]);
@@ -269,8 +346,7 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
                     }
                     const u32x4 w = __builtin_bit_cast(u32x4, o);
                     reg[SET][q] = w;
-                    // interior pixels of the halo: the activation this layer's weight gradient reads
-                    if (em && ((inner >> q) & 1u)) *(u32x4*)(em + goff[q]) = w;
+                    __builtin_amdgcn_raw_buffer_store_b128(w, re, voff_e[q], 0, 0);
                 }
             }
             if (p.res_mask && chunk >= p.nchunks) {
@@ -294,23 +370,31 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
             }
 #pragma unroll
             for (int q = 0; q < NR; ++q)
-                if ((valid >> q) & 1u) *(u32x4*)(dst + loff[q]) = reg[SET][q];
+                if (q < NR - 1 || lastvalid) *(u32x4*)(dst + loff[q]) = reg[SET][q];
+            if (++Wr.k == fpt) { Wr.k = 0; ++Wr.ti; enter(Wr); wmask = ok_mask(Wr); }
         };
         // fill g is loaded into set g & 1 while fill g - 2 (same set, already written) is being consumed: HBM has two fills of matrix
         // work to answer (one was not enough on the 64-channel layer: 18 steps per fill)
         const std::integral_constant<int, 0> S0;
         const std::integral_constant<int, 1> S1;
-        if (nfill > 0) { load_fill(0, S0); write_fill(0, S0); }
-        if (nfill > 1) load_fill(1, S1);
-        if (nfill > 2) load_fill(2, S0);
+        if (nfill > 0) { load_fill(S0); write_fill(S0); }
+        if (nfill > 1) load_fill(S1);
+        if (nfill > 2) load_fill(S0);
+        TR(100);
         __syncthreads();
         for (int64_t f = 0; f < nfill; f += 2) {
-            if (f + 1 < nfill) write_fill(f + 1, S1);
-            if (f + 3 < nfill) load_fill(f + 3, S1);
+            TR(101);
+            if (f + 1 < nfill) write_fill(S1);
+            TR(102);
+            if (f + 3 < nfill) load_fill(S1);
+            TR(103);
             __syncthreads();
             if (f + 1 >= nfill) break;
-            if (f + 2 < nfill) write_fill(f + 2, S0);
-            if (f + 4 < nfill) load_fill(f + 4, S0);
+            TR(101);
+            if (f + 2 < nfill) write_fill(S0);
+            TR(102);
+            if (f + 4 < nfill) load_fill(S0);
+            TR(103);
             __syncthreads();
         }
         if (p.stats) __syncthreads();
@@ -358,13 +442,17 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
     double st0[2] = {0.0, 0.0}, st1[2] = {0.0, 0.0};
 
     frag_t breg[DB][2];
+    frag_t bdummy[DB][2];                                  // ablation 32: the fragment loads are issued, nobody waits for them within a fill
     auto load_b = [&](int chunk, int s, int set) {        // s: step within a chunk (compile-time after unrolling)
         if (CONV16W_ABL & 1) return;
         const int off = tapB[s / KS] + (chunk * KS + (s % KS)) * (64 * E);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) breg[set][j] = *(const frag_t*)(bptr[j] + off);
+        for (int j = 0; j < 2; ++j) {
+            if (CONV16W_ABL & 32) bdummy[set][j] = *(const frag_t*)(bptr[j] + off);
+            else breg[set][j] = *(const frag_t*)(bptr[j] + off);
+        }
     };
-    if (CONV16W_ABL & 1) {
+    if (CONV16W_ABL & 33) {
 #pragma unroll
         for (int d = 0; d < DB; ++d)
 #pragma unroll
@@ -380,7 +468,9 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
     const unsigned lane_off = F32 ? (unsigned)((wrow * p.os_y + (wcol + 4 * h) * p.os_x + wn * 64 + r) * sizeof(T))
                                   : (unsigned)(((wrow * p.W + wcol + 4 * h) * p.Cout + wn * 64 + r) * sizeof(T));
     typedef hf h2 __attribute__((ext_vector_type(2)));
+    TR(0);
     __syncthreads();                                       // fill 0 is staged
+    TR(1);
 
     int chunk = 0;
     int64_t tile_i = 0;
@@ -425,7 +515,15 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
             // live registers) and the matrix stream then waits for the L2 each step -- the software pipeline IS the kernel
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (CONV16W_ABL & 32) {
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(bdummy[d][j]));
+        }
+        TR(2);
         __syncthreads();                                   // everyone is done with halo[f & 1]; fill f + 1 is staged
+        TR(3);
         ++f;
         // ---- a residual fill: acc += residual x one-hot.  Step kk of fill rc covers the slab's channels rc CK + KST kk .. + KST - 1; a wave
         // takes the steps inside its own 64 channels: fragment element j of lane (r, h) of accumulator tile jt is 1 where
@@ -469,6 +567,7 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
         // statistics of the stored halves are two v_dot2_f32_f16 per pair (products of halves are exact in fp32) ----
         const int64_t tile = (int64_t)blockIdx.x + tile_i * gridDim.x;
         ++tile_i;
+        TR(4);
         if (CONV16W_ABL & 128) continue;                   // ablation 128: a tile ends without a single instruction reading its accumulators
         if (CONV16W_ABL & 4) {
             float sum = 0.f;
@@ -540,7 +639,8 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
                             st0[j] += (double)v;
                             st1[j] += (double)v * (double)v;
                         }
-                        *(float*)(ob + o0 + 128 * j) = v;
+                        if (CONV16W_NT & 2) __builtin_nontemporal_store(v, (float*)(ob + o0 + 128 * j));
+                        else *(float*)(ob + o0 + 128 * j) = v;
                     }
                 }
             } else {
@@ -564,6 +664,7 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
         // (unconditional: under `if (p.stats)` the compiler sinks the dot products into the conditional block and keeps every pair alive)
 #pragma unroll
         for (int j = 0; j < 2; ++j) { st0[j] += (double)fs[j]; st1[j] += (double)fq[j]; }
+        TR(5);
     }
 
     if (p.stats) {
@@ -714,6 +815,9 @@ static int conv_impl(const T* in, const T* w_packed, T* out, const T* residual, 
     p.shift = shift; p.relu = relu;
     p.os_n = out_hwnc ? Cout : (int64_t)H * W * Cout; p.os_y = out_hwnc ? (int)(W * N * Cout) : W * Cout; p.os_x = out_hwnc ? (int)(N * Cout) : Cout;
     SSAD_CHECK_ARG(!out_hwnc || (int64_t)H * W * N * Cout < (int64_t)1 << 31, "position-major output too large for 32-bit strides");
+#ifdef CONV16W_TRACE
+    p.trace = conv16w_trace_buf;
+#endif
     p.N = (int)N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
     p.tiles_y = g.tiles_y; p.tiles_x = g.tiles_x; p.nchunks = Cin / (g.ck32 ? CKN : CKW); p.ntiles = g.ntiles;
     const dim3 grid((unsigned)g.gx, (unsigned)g.gy);
