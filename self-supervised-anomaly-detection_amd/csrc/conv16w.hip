@@ -70,6 +70,15 @@ struct HWParams {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// The barrier between fills orders LDS traffic only (the halo stages): __syncthreads() also drains every wave's vector-memory queue -- the
+// stagers' halo loads of two fills ahead and the matrix waves' filter fragments in flight -- at each of the 16-32 barriers.  (Measured
+// neutral on both steps, round 6: the waits it removes were hidden behind the partner waves.)
+__device__ __forceinline__ void fill_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // one fragment deep: a 16-channel MFMA over halves, or four 2-channel MFMAs over floats (element q of both fragments = sub-step q)
 __device__ __forceinline__ f32x16 mma_frag(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 mma_frag(f32x4 a, f32x4 b, f32x16 c) {
@@ -381,21 +390,21 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
         if (nfill > 1) load_fill(S1);
         if (nfill > 2) load_fill(S0);
         TR(100);
-        __syncthreads();
+        fill_barrier();
         for (int64_t f = 0; f < nfill; f += 2) {
             TR(101);
             if (f + 1 < nfill) write_fill(S1);
             TR(102);
             if (f + 3 < nfill) load_fill(S1);
             TR(103);
-            __syncthreads();
+            fill_barrier();
             if (f + 1 >= nfill) break;
             TR(101);
             if (f + 2 < nfill) write_fill(S0);
             TR(102);
             if (f + 4 < nfill) load_fill(S0);
             TR(103);
-            __syncthreads();
+            fill_barrier();
         }
         if (p.stats) __syncthreads();
         return;
@@ -469,7 +478,7 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
                                   : (unsigned)(((wrow * p.W + wcol + 4 * h) * p.Cout + wn * 64 + r) * sizeof(T));
     typedef hf h2 __attribute__((ext_vector_type(2)));
     TR(0);
-    __syncthreads();                                       // fill 0 is staged
+    fill_barrier();                                       // fill 0 is staged
     TR(1);
 
     int chunk = 0;
@@ -522,7 +531,7 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
                 for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(bdummy[d][j]));
         }
         TR(2);
-        __syncthreads();                                   // everyone is done with halo[f & 1]; fill f + 1 is staged
+        fill_barrier();                                   // everyone is done with halo[f & 1]; fill f + 1 is staged
         TR(3);
         ++f;
         // ---- a residual fill: acc += residual x one-hot.  Step kk of fill rc covers the slab's channels rc CK + KST kk .. + KST - 1; a wave
@@ -550,7 +559,7 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
                     }
                 }
             }
-            __syncthreads();
+            fill_barrier();
             ++f;
         };
         if (p.residual && chunk < RF) residual_fill(chunk);
@@ -597,6 +606,8 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
         }
         torg += blockIdx.y * (64 * WN);
         float fs[2] = {0.f, 0.f}, fq[2] = {0.f, 0.f};
+        typedef float f32x2v __attribute__((ext_vector_type(2)));
+        f32x2v ps[2] = {{0.f, 0.f}, {0.f, 0.f}}, pq[2] = {{0.f, 0.f}, {0.f, 0.f}};
         const h2 ones = {(hf)1.f, (hf)1.f};
         // laundered per tile: the 128 per-register offsets below are loop invariants, and hoisted out of the tile loop they are kept
         // alive (in scratch: 119 spilled registers) through the matrix loop
@@ -620,29 +631,41 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
             if (!ok) continue;
             char* const ob = (char*)(p.out + moff);
             if constexpr (F32) {
-                // exact-fp32 step: values stored as they are, statistics in double per value (as the other fp32 kernels take them;
-                // an fp32 tile is ~300 k cycles of matrix work, its 128 conversions do not show).  Inference (p.shift): the folded
-                // BatchNorm's shift and the ReLU instead, no statistics.
-                float sh[2] = {0.f, 0.f};
-                if (p.shift) { sh[0] = p.shift[co0 + r]; sh[1] = p.shift[co0 + 32 + r]; }
+                // exact-fp32 step: values stored as they are.  Statistics: two packed fp32 accumulators per column and tile (32 values
+                // each: v_pk_add_f32 / v_pk_fma_f32, one instruction per value instead of three -- in this kernel every VALU instruction
+                // is time the matrix pipe stands still, ~14 cycles each by the time stamps), added in double across tiles; the rounding
+                // of a 32-value fp32 partial sum is ~1e-8 of the final mean / variance.  Inference (p.shift): the folded BatchNorm's
+                // shift and the ReLU instead, no statistics.
+                // (one uniform branch per accumulator row, not per register pair: with `if (p.shift)` inside, hipcc emitted a branch and
+                // its register shuffles for each of the 64 pairs)
+                auto rows = [&](auto infer_tag) __attribute__((always_inline)) {
+                    constexpr bool INFER = decltype(infer_tag)::value;
+                    float sh[2] = {0.f, 0.f};
+                    if (INFER) { sh[0] = p.shift[co0 + r]; sh[1] = p.shift[co0 + 32 + r]; }
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int eo = TW8 ? (e >> 2) * rowst + (e & 3) * pixst : (e >> 3) * rowst + ((e & 3) + 8 * ((e >> 2) & 1)) * pixst;
-                    const unsigned o0 = lo + 4u * (unsigned)eo;
+                    for (int e = 0; e < 16; e += 2) {
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        float v = acc[m][j][e];
-                        if (p.shift) {
-                            v += sh[j];
-                            if (p.relu) v = fmaxf(v, 0.f);
-                        } else {
-                            st0[j] += (double)v;
-                            st1[j] += (double)v * (double)v;
+                        for (int j = 0; j < 2; ++j) {
+                            f32x2v v = {acc[m][j][e], acc[m][j][e + 1]};
+                            if (INFER) {
+                                v += f32x2v{sh[j], sh[j]};
+                                if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); }
+                            } else {
+                                ps[j] += v;
+                                pq[j] = v * v + pq[j];
+                            }
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) {
+                                const int ee = e + k;
+                                const int eo = TW8 ? (ee >> 2) * rowst + (ee & 3) * pixst : (ee >> 3) * rowst + ((ee & 3) + 8 * ((ee >> 2) & 1)) * pixst;
+                                // uniform base (scalar registers) + this lane's constant 32-bit offset
+                                *(float*)(ob + (int64_t)eo * 4 + 128 * j + lo) = v[k];
+                            }
                         }
-                        if (CONV16W_NT & 2) __builtin_nontemporal_store(v, (float*)(ob + o0 + 128 * j));
-                        else *(float*)(ob + o0 + 128 * j) = v;
                     }
-                }
+                };
+                if (p.shift) rows(std::true_type());
+                else rows(std::false_type());
             } else {
 #pragma unroll
             for (int e = 0; e < 16; e += 2) {
@@ -663,7 +686,10 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
         }
         // (unconditional: under `if (p.stats)` the compiler sinks the dot products into the conditional block and keeps every pair alive)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { st0[j] += (double)fs[j]; st1[j] += (double)fq[j]; }
+        for (int j = 0; j < 2; ++j) {
+            if (F32) { st0[j] += (double)ps[j][0] + (double)ps[j][1]; st1[j] += (double)pq[j][0] + (double)pq[j][1]; }
+            else { st0[j] += (double)fs[j]; st1[j] += (double)fq[j]; }
+        }
         TR(5);
     }
 
