@@ -39,6 +39,14 @@
 #endif
 
 
+// 1 = the staging loads are BUFFER loads: a uniform base in scalar registers (tap / channel-chunk offsets folded into it per K-step) plus
+// one precomputed 32-bit offset per staged row; rows beyond the tensor carry an offset beyond the buffer and read zeros.  In the K loop
+// every VALU instruction is matrix-pipe time (the co-resident wave does not fill the gap: ~15-25 cycles each, tools/micro/conv32w_trace):
+// the pointer form spent ~3.7 of them per 16-byte piece (select against the zero page, 64-bit add).  0 = the pointer form.
+#ifndef IGEMM_BUFLD
+#define IGEMM_BUFLD 1
+#endif
+
 // Phase time stamps per workgroup for tools/micro/igemm_var.hip (-DIGEMM_TRACE=1); never set in the library build.
 #ifndef IGEMM_TRACE
 #define IGEMM_TRACE 0
@@ -242,6 +250,16 @@ void conv_igemm_f32_kernel(ConvParams p) {
     };
 
     // ---- per-thread staging rows (fixed across the K loop): base pointer at tap (0,0) + in-bounds tap mask ----
+    // BUFA: a row's piece is a_org (uniform) + a_voff (this thread's row and 16-byte column, or out of range for rows that do not exist).
+    // Position-major: a_org = the workgroup's first sample at the position's tap (0, 0), and the taps a workgroup walks are in bounds
+    // for every row.  Pixel-major (NHWC): a_org = the first row's image, one padding row and column before its first pixel, so that
+    // every row's offset is non-negative; a row's tap in the padding selects the out-of-range offset instead (one bit test per
+    // piece).  The entry points check that the rows of a tile span less than 2 GB.  BUFB: the same for the weight rows.
+    constexpr bool BUFA = IGEMM_BUFLD && TS == 1, BUFB = IGEMM_BUFLD != 0;
+    constexpr unsigned OOB = 0x80000000u;   // size given to the buffers: offsets from here on read zeros
+    constexpr int SRD3 = 0x00020000;        // raw buffer, 32-bit data format
+    int64_t a_org = 0;                      // elements from p.in
+    unsigned a_voff[AR], b_voff[BR];        // bytes
     const io_t* a_ptr[AR];
     unsigned a_mask[AR];
     int a_iy[AR], a_ix[AR];                 // only live in the TS == 2 instantiation
@@ -281,13 +299,26 @@ void conv_igemm_f32_kernel(ConvParams p) {
         }
         a_mask[i] = (IGEMM_ABL & 2) ? 0u : mk;      // ablation 2: every activation piece comes from the zero page (no HBM latency)
         a_ptr[i] = TS > 1 ? tin + n * in_sn + sc * PE : tin + n * in_sn + ((int64_t)iy0 * p.W + ix0) * in_sp + sc * PE;
+        if (BUFA) {
+            if (POS) {
+                a_org = m0 * in_sn + ((int64_t)iy0 * p.W + ix0) * in_sp;
+                a_voff[i] = (ok && !(IGEMM_ABL & 2)) ? (unsigned)(((int64_t)(sr + RPP * i) * in_sn + sc * PE) * (int64_t)sizeof(io_t)) : OOB;
+            } else {
+                const int64_t nf = (m0 < p.M ? m0 : 0) / HoWo;                      // image of the workgroup's first row (uniform)
+                a_org = nf * in_sn - ((int64_t)p.pad * p.W + p.pad) * in_sp;
+                const int64_t R = (n - nf) * in_sn + ((int64_t)(iy0 + p.pad) * p.W + ix0 + p.pad) * in_sp + sc * PE;
+                a_voff[i] = ok ? (unsigned)(R * (int64_t)sizeof(io_t)) : OOB;
+            }
+        }
     }
     const io_t* b_ptr[BR];
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
         const int co = n0 + sr + RPP * i;
         b_ptr[i] = co < p.Cout ? twt + (int64_t)co * p.K + sc * PE : nullptr;
+        b_voff[i] = co < p.Cout ? (unsigned)(((int64_t)(sr + RPP * i) * p.K + sc * PE) * (int64_t)sizeof(io_t)) : OOB;
     }
+    const io_t* const b_org = twt + (int64_t)n0 * p.K;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -316,6 +347,9 @@ void conv_igemm_f32_kernel(ConvParams p) {
         if (++ld_cc == cpt) {
             ld_cc = 0;
             ld_mask &= ld_mask - 1;
+            // past the last K-step the loader wraps (its pieces land in a stage nobody reads): with buffer loads to the first tap the
+            // workgroup WALKS -- tap 0 may lie in the padding, and nothing but the per-row offset guards a buffer load
+            if (BUFA && POS && !ld_mask) ld_mask = tapmask;
             ld_tap = ld_mask ? __builtin_ctz(ld_mask) : 0;
             ld_ky = ld_tap / p.KW;
             ld_kx = ld_tap - ld_ky * p.KW;
@@ -338,12 +372,23 @@ void conv_igemm_f32_kernel(ConvParams p) {
         }
 #endif
         if (q < AR) {
-            const bool ok = (a_mask[q] >> ld_ptap) & 1u;
-            const io_t* src = a_ptr[q] + ld_koff;
-            if (TS > 1) src += ((int64_t)((a_iy[q] + ld_pky) / TS) * p.W + (a_ix[q] + ld_pkx) / TS) * in_sp;
-            ra2[set][q] = *(const f32x4*)(const void*)(ok ? src : zero);
+            if constexpr (BUFA) {
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(tin + a_org + ld_koff), 0, (int)OOB, SRD3);
+                const unsigned vo = POS ? a_voff[q] : (((a_mask[q] >> ld_ptap) & 1u) ? a_voff[q] : OOB);
+                ra2[set][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0));
+            } else {
+                const bool ok = (a_mask[q] >> ld_ptap) & 1u;
+                const io_t* src = a_ptr[q] + ld_koff;
+                if (TS > 1) src += ((int64_t)((a_iy[q] + ld_pky) / TS) * p.W + (a_ix[q] + ld_pkx) / TS) * in_sp;
+                ra2[set][q] = *(const f32x4*)(const void*)(ok ? src : zero);
+            }
         } else {
-            rb2[set][q - AR] = *(const f32x4*)(const void*)(b_ptr[q - AR] ? b_ptr[q - AR] + ld_woff : zero);
+            if constexpr (BUFB) {
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(b_org + ld_woff), 0, (int)OOB, SRD3);
+                rb2[set][q - AR] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, b_voff[q - AR], 0, 0));
+            } else {
+                rb2[set][q - AR] = *(const f32x4*)(const void*)(b_ptr[q - AR] ? b_ptr[q - AR] + ld_woff : zero);
+            }
         }
     };
     auto load_step = [&]() {
@@ -1116,6 +1161,14 @@ int dispatch(const ConvParams& p, hipStream_t st) {
     }
 }
 
+// buffer-load staging (IGEMM_BUFLD): the rows of a tile -- up to 256 consecutive output pixels, i.e. 256 / (Ho Wo) + 2 input images, or
+// 256 samples of a position-major launch -- are addressed by 32-bit byte offsets from the tile's first image
+static bool tile_span_ok(const ConvParams& p, bool posmajor, int elt_bytes) {
+    const int64_t image = (int64_t)p.H * p.W * p.Cin * elt_bytes;
+    if (posmajor) return p.hwnc || 256 * image < ((int64_t)1 << 31);
+    return (256 / ((int64_t)p.Ho * p.Wo) + 2) * image < ((int64_t)1 << 31);
+}
+
 int conv_fwd_impl(const float* in, const float* w_ohwi, float* out, const float* scale, const float* shift,
                   const float* residual, int relu, int64_t N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
                   int pad, int hwnc, void* stream, int bf16 = 0, double* stats = nullptr, int* stat_rows = nullptr, int io16 = 0,
@@ -1147,6 +1200,7 @@ int conv_fwd_impl(const float* in, const float* w_ohwi, float* out, const float*
     // [H][W][N][C] layout they are also what makes a workgroup's rows contiguous
     const bool posmajor = hwnc || (!stats && pad > 0 && N >= 128 && p.Ho * p.Wo <= 4);
     SSAD_CHECK_ARG(cdiv64(p.M, 128) + 32 * p.Ho * p.Wo < (int64_t)2147483647, "M too large for one launch");
+    SSAD_CHECK_ARG(tile_span_ok(p, posmajor, io16 ? 2 : 4), "input images too large: the rows of a tile must span less than 2 GB");
     hipStream_t st = (hipStream_t)stream;
     int rows;
     SSAD_CHECK_ARG(bf16 == 0 || bf16 == 1 || bf16 == 2 || bf16 == 3 || bf16 == 6,
@@ -1295,6 +1349,7 @@ static int dgrad_impl(const float* dy, const float* w_flipT, float* dx, const fl
     p.M = N * Hx * Wx;
     p.K = KH * KW * Cout;
     SSAD_CHECK_ARG(cdiv64(p.M, 128) < (int64_t)2147483647, "M too large for one launch");
+    SSAD_CHECK_ARG(tile_span_ok(p, false, io16 ? 2 : 4), "gradient images too large: the rows of a tile must span less than 2 GB");
     hipStream_t st = (hipStream_t)stream;
     if (bf16 == 6) {
         if (stride == 1) dispatch_x6<1, false>(p, st);
