@@ -73,8 +73,32 @@ __global__ __launch_bounds__(256, (S == 1 || TH * TW <= 32) ? 2 : 1) void wgrad3
     // NOTHING meanwhile), so address arithmetic placed before or after the matrix loop is paid in full; placed BETWEEN the
     // wave's own MFMAs it is free (the pipe is busy 64 cycles per instruction).  The pieces of the next tile are therefore
     // issued one per MFMA group inside the loop below.
+    // (round 6) The pieces are BUFFER loads: base = the tile's image (scalar registers), size = that image, offset = the tile's origin
+    // (uniform, possibly negative) + this thread's constant offset inside the tile / halo.  Rows above or below the image then fall
+    // outside the buffer by themselves and read zeros; only the columns left and right of the image need a test (one unsigned compare
+    // against the tile's valid column range).  3-4 VALU instructions per piece where the pointer form took ~11 (bounds tests, zero
+    // initialisation of the predicated-off lanes, 64-bit multiply-add, branch) -- each of them ~15-25 cycles of this wave's matrix pipe.
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int SRD3 = 0x00020000;
     int y0n = 0, x0n = 0;                       // origin of the tile being fetched (workgroup-uniform)
     const float *dzn = p.dz, *xn = p.x;         // its image (workgroup-uniform base pointers)
+    unsigned dorg = 0, xorg = 0;                // byte offsets of the tile's first pixel / the halo's pixel (-1, -1) in their images
+    unsigned dcols = 0, xlo = 0, xspan = 0;     // valid tile columns: tx < dcols;  valid halo columns: hx - xlo <= xspan
+    unsigned doff[NDZ], dtx[NDZ], xoff[NX], xhx[NX];
+#pragma unroll
+    for (int g = 0; g < NDZ; ++g) {
+        const int tp = g * 16 + p0;
+        dtx[g] = (unsigned)(tp % TW);
+        doff[g] = (unsigned)((((tp / TW) * p.W + tp % TW) * p.Cout + c4 * 4) * 4);
+    }
+#pragma unroll
+    for (int q = 0; q < NX; ++q) {
+        const int hp = q * 16 + p0;
+        const int hy = hp / HWp, hx = hp - hy * HWp;
+        xhx[q] = hp < NH ? (unsigned)hx : 0x7fffffffu;          // pieces beyond the halo: never inside the column range
+        xoff[q] = (unsigned)(((hy * p.Wx + hx) * p.Cin + c4 * 4) * 4);
+    }
+    const int dz_bytes = (p.H * p.W * p.Cout - co0) * 4, x_bytes = (p.Hx * p.Wx * p.Cin - ci0) * 4;      // from the base to the image's end
     auto set_tile = [&](int tile) {
         const int n = tile / tpi;
         const int rem = tile - n * tpi;
@@ -83,23 +107,22 @@ __global__ __launch_bounds__(256, (S == 1 || TH * TW <= 32) ? 2 : 1) void wgrad3
         x0n = tx * TW;
         dzn = p.dz + (int64_t)n * p.H * p.W * p.Cout + co0;
         xn = p.x + (int64_t)n * p.Hx * p.Wx * p.Cin + ci0;
+        dorg = (unsigned)((y0n * p.W + x0n) * p.Cout * 4);
+        xorg = (unsigned)(((S * y0n - 1) * p.Wx + S * x0n - 1) * p.Cin * 4);
+        dcols = (unsigned)(p.W - x0n);
+        xlo = S * x0n == 0 ? 1u : 0u;                            // halo column 0 is x = -1 at the image's left edge
+        xspan = (unsigned)(p.Wx - S * x0n) - xlo;                // last valid halo column: x = Wx - 1, i.e. hx = Wx - S x0n
     };
     auto load_piece = [&](int g) {              // g is a compile-time constant wherever this is called
         if (g < NDZ) {
-            const int tp = g * 16 + p0;
-            const int y = y0n + tp / TW, x = x0n + tp % TW;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (y < p.H && x < p.W) v = *(const f32x4*)(dzn + (unsigned)((y * p.W + x) * p.Cout + c4 * 4));
-            dv[g] = v;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)dzn, 0, dz_bytes, SRD3);
+            const unsigned vo = dtx[g] < dcols ? doff[g] + dorg : OOB;
+            dv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0));
         } else if (g < NDZ + NX) {
             const int q = g - NDZ;
-            const int hp = q * 16 + p0;
-            const int hy = hp / HWp, hx = hp - hy * HWp;
-            const int y = S * y0n - 1 + hy, x = S * x0n - 1 + hx;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (hp < NH && (unsigned)y < (unsigned)p.Hx && (unsigned)x < (unsigned)p.Wx)
-                v = *(const f32x4*)(xn + (unsigned)((y * p.Wx + x) * p.Cin + c4 * 4));
-            xv[q] = v;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, x_bytes, SRD3);
+            const unsigned vo = xhx[q] - xlo <= xspan ? xoff[q] + xorg : OOB;
+            xv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0));
         }
     };
     const int t_begin_i = (int)t_begin, t_end_i = (int)t_end;
@@ -200,8 +223,8 @@ static int halo_launch(const float* dz, const float* x, float* slab, int splits,
     SSAD_CHECK_ARG(dz && x && slab && N > 0 && H > 0 && W > 0, "bad argument");
     SSAD_CHECK_ARG(dz_elems == N * H * W * Cout, "dz does not hold N x H x W x Cout elements");
     SSAD_CHECK_ARG(Cin % 64 == 0 && Cout % 64 == 0, "channel counts must be multiples of 64");
-    SSAD_CHECK_ARG((int64_t)Hx * Wx * Cin < (int64_t)1 << 32 && (int64_t)H * W * Cout < (int64_t)1 << 32 &&
-                   N * (int64_t)((H + 3) / 4) * ((W + 7) / 8) < (int64_t)1 << 31, "offsets inside an image are 32-bit, tile numbers int");
+    SSAD_CHECK_ARG((int64_t)Hx * Wx * Cin < (int64_t)1 << 28 && (int64_t)H * W * Cout < (int64_t)1 << 28 &&
+                   N * (int64_t)((H + 3) / 4) * ((W + 7) / 8) < (int64_t)1 << 31, "an image must stay below 1 GB (32-bit buffer offsets), tile numbers int");
     static const int s2_tile = getenv("SSAD_WGRAD_HALO_S2_TILE") ? atoi(getenv("SSAD_WGRAD_HALO_S2_TILE")) : 32;
     const bool half = S == 2 && s2_tile == 32;             // stride 2: 4 x 8 output pixels, so that two workgroups fit a CU
     const int TW = half ? 8 : W > 8 ? 16 : 8, TH = half ? 4 : W > 8 ? 4 : 8;     // 64-pixel tiles: 144 accumulator + 44 staging registers fit
