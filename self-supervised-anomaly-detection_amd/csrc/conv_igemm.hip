@@ -254,8 +254,10 @@ void conv_igemm_f32_kernel(ConvParams p) {
     // Position-major: a_org = the workgroup's first sample at the position's tap (0, 0), and the taps a workgroup walks are in bounds
     // for every row.  Pixel-major (NHWC): a_org = the first row's image, one padding row and column before its first pixel, so that
     // every row's offset is non-negative; a row's tap in the padding selects the out-of-range offset instead (one bit test per
-    // piece).  The entry points check that the rows of a tile span less than 2 GB.  BUFB: the same for the weight rows.
-    constexpr bool BUFA = IGEMM_BUFLD && TS == 1, BUFB = IGEMM_BUFLD != 0;
+    // piece).  Transposed gather (TS == 2): inside a parity class a walked tap reads input pixel (a + dky, b + dkx) for the output pixel
+    // (2 a + cpy, 2 b + cpx), with (dky, dkx) the same for every row -- the same uniform-base / per-row-offset split, rows counted in
+    // (a, b).  The entry points check that the rows of a tile span less than 2 GB.  BUFB: the same for the weight rows.
+    constexpr bool BUFA = IGEMM_BUFLD != 0, BUFB = IGEMM_BUFLD != 0;
     constexpr unsigned OOB = 0x80000000u;   // size given to the buffers: offsets from here on read zeros
     constexpr int SRD3 = 0x00020000;        // raw buffer, 32-bit data format
     int64_t a_org = 0;                      // elements from p.in
@@ -303,6 +305,12 @@ void conv_igemm_f32_kernel(ConvParams p) {
             if (POS) {
                 a_org = m0 * in_sn + ((int64_t)iy0 * p.W + ix0) * in_sp;
                 a_voff[i] = (ok && !(IGEMM_ABL & 2)) ? (unsigned)(((int64_t)(sr + RPP * i) * in_sn + sc * PE) * (int64_t)sizeof(io_t)) : OOB;
+            } else if (TS > 1) {
+                const int64_t nf = (m0 < Mc ? m0 : 0) / (Hc * Wc);                  // image of the workgroup's first row (uniform)
+                const int mg = (p.pad + 1) / 2;                                     // dky, dkx >= -mg
+                a_org = nf * in_sn - ((int64_t)mg * p.W + mg) * in_sp;
+                const int64_t R = (n - nf) * in_sn + ((int64_t)((oy - cpy) / 2 + mg) * p.W + (ox - cpx) / 2 + mg) * in_sp + sc * PE;
+                a_voff[i] = ok ? (unsigned)(R * (int64_t)sizeof(io_t)) : OOB;
             } else {
                 const int64_t nf = (m0 < p.M ? m0 : 0) / HoWo;                      // image of the workgroup's first row (uniform)
                 a_org = nf * in_sn - ((int64_t)p.pad * p.W + p.pad) * in_sp;
@@ -341,7 +349,10 @@ void conv_igemm_f32_kernel(ConvParams p) {
     int64_t ld_koff = 0;
     int ld_woff = 0, ld_ptap = 0, ld_pky = 0, ld_pkx = 0;
     auto load_begin = [&]() {              // scalar offsets of the K-step about to be loaded, then the tap / chunk state moves on
-        ld_koff = TS > 1 ? (int64_t)ld_cc * BK : ((int64_t)ld_ky * p.W + ld_kx) * in_sp + ld_cc * BK;
+        if (BUFA && TS > 1)     // (numerators of walked taps are even; the shift floors the others, whose pieces are masked off anyway)
+            ld_koff = ((int64_t)((cpy - p.pad + ld_ky) >> 1) * p.W + ((cpx - p.pad + ld_kx) >> 1)) * in_sp + ld_cc * BK;
+        else
+            ld_koff = TS > 1 ? (int64_t)ld_cc * BK : ((int64_t)ld_ky * p.W + ld_kx) * in_sp + ld_cc * BK;
         ld_woff = (ld_tap * cpt + ld_cc) * BK;
         ld_ptap = ld_tap; ld_pky = ld_ky; ld_pkx = ld_kx;
         if (++ld_cc == cpt) {
@@ -1163,10 +1174,11 @@ int dispatch(const ConvParams& p, hipStream_t st) {
 
 // buffer-load staging (IGEMM_BUFLD): the rows of a tile -- up to 256 consecutive output pixels, i.e. 256 / (Ho Wo) + 2 input images, or
 // 256 samples of a position-major launch -- are addressed by 32-bit byte offsets from the tile's first image
-static bool tile_span_ok(const ConvParams& p, bool posmajor, int elt_bytes) {
+static bool tile_span_ok(const ConvParams& p, bool posmajor, int elt_bytes, int ts = 1) {
     const int64_t image = (int64_t)p.H * p.W * p.Cin * elt_bytes;
     if (posmajor) return p.hwnc || 256 * image < ((int64_t)1 << 31);
-    return (256 / ((int64_t)p.Ho * p.Wo) + 2) * image < ((int64_t)1 << 31);
+    const int64_t rows_per_image = ts > 1 ? (int64_t)(p.Ho / 2) * (p.Wo / 2) : (int64_t)p.Ho * p.Wo;      // (a parity class of the transposed gather)
+    return (256 / (rows_per_image > 0 ? rows_per_image : 1) + 2) * image < ((int64_t)1 << 31);
 }
 
 int conv_fwd_impl(const float* in, const float* w_ohwi, float* out, const float* scale, const float* shift,
@@ -1349,7 +1361,7 @@ static int dgrad_impl(const float* dy, const float* w_flipT, float* dx, const fl
     p.M = N * Hx * Wx;
     p.K = KH * KW * Cout;
     SSAD_CHECK_ARG(cdiv64(p.M, 128) < (int64_t)2147483647, "M too large for one launch");
-    SSAD_CHECK_ARG(tile_span_ok(p, false, io16 ? 2 : 4), "gradient images too large: the rows of a tile must span less than 2 GB");
+    SSAD_CHECK_ARG(tile_span_ok(p, false, io16 ? 2 : 4, stride), "gradient images too large: the rows of a tile must span less than 2 GB");
     hipStream_t st = (hipStream_t)stream;
     if (bf16 == 6) {
         if (stride == 1) dispatch_x6<1, false>(p, st);
