@@ -430,13 +430,23 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
     const T* bptr[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) bptr[j] = p.wp + (int64_t)(co0 / 32 + j) * 9 * KB * (64 * E) + lane * E;
+    // the fragments as BUFFER loads: the wave's first fragment in scalar registers, the lane's 16 bytes a constant offset, the step's
+    // fragment a scalar offset -- no address arithmetic in the matrix stream (the pointer form: one 64-bit add per fragment and tap)
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.wp + (int64_t)__builtin_amdgcn_readfirstlane(co0 / 32) * 9 * KB * (64 * E)), 0, (int)0x80000000u, 0x00020000);
+    const unsigned blane = (unsigned)(lane * 16);
+    const int bcol = 9 * KB * (64 * E) * (int)sizeof(T);          // bytes between the two 32-channel fragments of a wave
 
     // Every workgroup walks the nine taps in its own rotation (conv16.hip: persistent workgroups run in lockstep, with one common order
     // all of them ask the L2 for the same lines at the same moment).  fp32 accumulation order differs between workgroups by the
     // rotation only: deterministic for a given launch geometry.
     // (fp32: no rotation -- a fragment is requested every 2 048 cycles, and one common tap order keeps every output value's summation
     // order independent of the launch geometry)
+#ifdef CONV16W_NO_ROT
+    const int rot = 0;
+#else
     const int rot = F32 ? 0 : (int)((blockIdx.x + blockIdx.y) % 9);
+#endif
     int toffA[9], tapB[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -458,7 +468,7 @@ __global__ __launch_bounds__(512) void conv3x3_hw_kernel(HWParams<T> p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             if (CONV16W_ABL & 32) bdummy[set][j] = *(const frag_t*)(bptr[j] + off);
-            else breg[set][j] = *(const frag_t*)(bptr[j] + off);
+            else breg[set][j] = __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(brs, blane, off * (int)sizeof(T) + j * bcol, 0));
         }
     };
     if (CONV16W_ABL & 33) {
