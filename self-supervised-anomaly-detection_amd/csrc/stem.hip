@@ -10,6 +10,7 @@
 // (kx = 2q+h padded 7 -> 8 with a zero weight row) so that the two lane halves of v_mfma_f32_32x32x2_f32
 // read LDS addresses a constant 3 floats apart and every K-step offset is an immediate.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -132,6 +133,47 @@ __global__ __launch_bounds__(256, 2) void stem_conv7x7_kernel(StemParams p) {
                 }
 
         // ---- epilogue ----
+        // Whole tiles (all 32 columns exist): straight-line code -- a uniform base per output row, a constant per-lane byte offset, the
+        // register's pixel as a scalar offset; statistics as packed fp32 pairs (one instruction per two values).  Every VALU
+        // instruction here is time the wave's matrix pipe stands still (tools/micro/conv32w_trace.hip, round 6); the general form
+        // below spent ~10 per value on bounds tests, 64-bit pixel arithmetic and flag branches.
+        if (tx0 + 32 <= p.Wo) {
+            const int64_t pst = p.hwnc ? p.Nsamp * 256 : 256;                      // bytes between neighbouring pixels of a row
+            const unsigned lane_off = (unsigned)((int64_t)(4 * h) * pst + r * 4);
+            typedef float f32x2v __attribute__((ext_vector_type(2)));
+            auto rows = [&](auto stats_tag) __attribute__((always_inline)) {
+                constexpr bool ST = decltype(stats_tag)::value;
+                const float lowb = p.relu ? 0.f : -__builtin_huge_valf();
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int oy = ty0 + 2 * wave + i;
+                    if (oy >= p.Ho) continue;
+                    const int64_t pix0 = p.hwnc ? ((int64_t)oy * p.Wo + tx0) * p.Nsamp + n : (n * p.Ho + oy) * p.Wo + tx0;
+                    char* const ob = (char*)(p.out + pix0 * 64);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        f32x2v ps = {0.f, 0.f}, pq = {0.f, 0.f};
+#pragma unroll
+                        for (int e = 0; e < 16; e += 2) {
+                            f32x2v v = {acc[i][j][e], acc[i][j][e + 1]};
+                            if (ST) {
+                                ps += v;
+                                pq = v * v + pq;
+                            } else {
+                                v = v * f32x2v{sc[j], sc[j]} + f32x2v{sh[j], sh[j]};
+                                v[0] = fmaxf(v[0], lowb); v[1] = fmaxf(v[1], lowb);
+                            }
+#pragma unroll
+                            for (int k = 0; k < 2; ++k)
+                                *(float*)(ob + (int64_t)(((e + k) & 3) + 8 * ((e + k) >> 2)) * pst + j * 128 + lane_off) = v[k];
+                        }
+                        if (ST) { st0[j] += (double)ps[0] + (double)ps[1]; st1[j] += (double)pq[0] + (double)pq[1]; }
+                    }
+                }
+            };
+            if (p.stats && !p.scale && !p.shift && !p.relu) { rows(std::true_type()); continue; }
+            if (!p.stats) { rows(std::false_type()); continue; }
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int oy = ty0 + 2 * wave + i;
