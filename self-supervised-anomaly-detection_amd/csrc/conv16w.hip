@@ -904,7 +904,8 @@ extern "C" int ssad_conv3x3_fw_ok(int64_t N, int H, int W, int Cin, int Cout) {
     static const int on = getenv("SSAD_CONV32W") ? atoi(getenv("SSAD_CONV32W")) : 1;
     if (!on || !shape_ok(N, H, W, Cin, Cout)) return 0;
     const GeoW g = geometry_w(N, H, W, Cout);
-    return g.ntiles * g.gy >= 512 || Cin >= 256;
+    static const int min_pairs = getenv("SSAD_CONV32W_MIN") ? atoi(getenv("SSAD_CONV32W_MIN")) : 512;
+    return g.ntiles * g.gy >= min_pairs || Cin >= 256;
 }
 
 // elements of one packed filter of Cout x 3 x 3 x Cin (halves / floats)

@@ -1116,17 +1116,23 @@ int dispatch_x3(const ConvParams& p, hipStream_t st) {
 
 // Tile of the exact-fp32 instantiation a problem is given (also reported by ssad_conv_igemm_tile: bench.py names the
 // instantiations its roofline sums over)
-enum IgemmTile { T_256x64_K16 = 0, T_256x64_SB, T_128x64, T_256x128, T_256x128_W4, T_128x256, T_64x64, T_128x128, T_256x256 };
+enum IgemmTile { T_256x64_K16 = 0, T_256x64_SB, T_128x64, T_256x128, T_256x128_W4, T_128x256, T_64x64, T_128x128, T_256x256, T_128x64_SB, T_128x64_K16, T_128x128_K16 };
 
 template <bool POS>
 IgemmTile pick_tile(const ConvParams& p) {
     static const int variant = getenv("SSAD_CONV64_VARIANT") ? atoi(getenv("SSAD_CONV64_VARIANT")) : 1;
     // ring launches (a skipped square of positions: the patch-scoring pass's layer1, round 6): what is left are the border positions,
     // 8-18 K-steps per workgroup -- the 128-row tile (twice the workgroups, half the prologue each) measured 314 against 320 ms per
-    // 256 images for the pass's position-major convs
-    if (p.Cout <= 64 && POS && p.skip_lo <= p.skip_hi && !getenv("SSAD_CONV64_VARIANT")) return T_128x64;
+    // 256 images for the pass's position-major convs.  With 16-float K-steps its two LDS stages take 30 KB instead of 55: FOUR workgroups
+    // per CU instead of two, so that a prologue / epilogue (10-25 k + 7-16 k cycles beside 24-55 k of K loop, tools/micro/igemm_var.hip
+    // with -DIGEMM_TRACE) finds other workgroups' matrix loops to hide behind: 2.58 -> 2.47 ms per launch (SSAD_CONV_RING_VARIANT=3: the
+    // 32-float form, 1: one stage)
+    static const int ring = getenv("SSAD_CONV_RING_VARIANT") ? atoi(getenv("SSAD_CONV_RING_VARIANT")) : 0;
+    if (p.Cout <= 64 && POS && p.skip_lo <= p.skip_hi && !getenv("SSAD_CONV64_VARIANT"))
+        return ring == 1 ? T_128x64_SB : ring == 3 ? T_128x64 : T_128x64_K16;
     if (p.Cout <= 64) return variant == 2 ? T_256x64_SB : variant == 1 ? T_256x64_K16 : T_128x64;
     static const int big = getenv("SSAD_CONV128_VARIANT") ? atoi(getenv("SSAD_CONV128_VARIANT")) : 0;
+    if (big == 7) return T_128x128_K16;                                  // 16-float K-steps: 41 KB of LDS, three workgroups per CU
     if (big == 1) return T_256x128;
     if (big == 2) return T_256x128_W4;                                    // one workgroup per CU, four waves of 128 x 64
     // 256 x 256 tile, four waves of 128 x 128 (16 accumulator tiles each): 16 staged pieces per 256 MFMAs (SSAD_CONV128_VARIANT=6,
@@ -1152,6 +1158,10 @@ IgemmTile pick_tile(const ConvParams& p) {
         if (cdiv64(p.M, 128) * ((p.Cout + 63) / 64) < tiny_min && p.M > 128) return T_64x64;
         if (g128 < small_min) return T_128x64;
     }
+    // position-major launches: 16-float K-steps (41 KB of LDS: three workgroups per CU instead of two), 11.70 -> 11.53 ms on the
+    // layer2 shape of the scoring pass; the pixel-major training launches measured the same either way
+    static const int k16 = getenv("SSAD_CONV128_K16") ? atoi(getenv("SSAD_CONV128_K16")) : 1;
+    if (POS && k16) return T_128x128_K16;
     return T_128x128;
 }
 
@@ -1161,6 +1171,9 @@ int dispatch(const ConvParams& p, hipStream_t st) {
         case T_256x64_SB: return launch<256, 64, 2, 2, 32, TS, POS, false>(p, st);
         case T_256x64_K16: return launch<256, 64, 2, 2, 16, TS, POS>(p, st);
         case T_128x64: return launch<128, 64, 1, 2, 32, TS, POS>(p, st);
+        case T_128x64_SB: return launch<128, 64, 1, 2, 32, TS, POS, false>(p, st);      // one LDS stage: 27 KB, up to five workgroups per CU
+        case T_128x64_K16: return launch<128, 64, 1, 2, 16, TS, POS>(p, st);            // 16-float K-steps: 30 KB, two stages
+        case T_128x128_K16: return launch<128, 128, 2, 2, 16, TS, POS>(p, st);
         case T_256x128: return launch<256, 128, 2, 2, 32, TS, POS>(p, st);
         case T_256x128_W4: return launch<256, 128, 4, 2, 32, TS, POS>(p, st);
         case T_128x256: return launch<128, 256, 2, 4, 32, TS, POS>(p, st);
@@ -1326,8 +1339,8 @@ extern "C" int ssad_conv_igemm_tile(int64_t N, int H, int W, int Cin, int Cout, 
     p.Wo = (W + 2 * pad - KW) / stride + 1;
     p.M = N * p.Ho * p.Wo;
     const bool posmajor = hwnc || (pad > 0 && N >= 128 && p.Ho * p.Wo <= 4);
-    static const int dims[9][3] = {{256, 64, 16}, {256, 64, 32}, {128, 64, 32}, {256, 128, 32}, {256, 128, 32}, {128, 256, 32},
-                                   {64, 64, 32}, {128, 128, 32}, {256, 256, 32}};
+    static const int dims[12][3] = {{256, 64, 16}, {256, 64, 32}, {128, 64, 32}, {256, 128, 32}, {256, 128, 32}, {128, 256, 32},
+                                    {64, 64, 32}, {128, 128, 32}, {256, 256, 32}, {128, 64, 32}, {128, 64, 16}, {128, 128, 16}};
     const int t = posmajor ? (int)pick_tile<true>(p) : (int)pick_tile<false>(p);
     const int code = dims[t][0] * 100000 + dims[t][1] * 100 + dims[t][2];
     return posmajor ? -code : code;

@@ -165,9 +165,9 @@ __global__ __launch_bounds__(256, (S == 1 || TH * TW <= 32) ? 2 : 1) void wgrad3
         read_group(0, 0);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            if (g + 1 < NG) read_group(g + 1, (g + 1) & 1);
+            if (g + 1 < NG && !(WGH_ABL & 4)) read_group(g + 1, (g + 1) & 1);      // ablation 4: every group multiplies group 0's fragments
 #pragma unroll
-            for (int t = 0; t < 9; ++t) acc[t] = mfma32(a[g & 1], b[g & 1][t], acc[t]);
+            for (int t = 0; t < 9; ++t) acc[t] = mfma32(a[(WGH_ABL & 4) ? 0 : (g & 1)], b[(WGH_ABL & 4) ? 0 : (g & 1)][t], acc[t]);
             if (!(WGH_ABL & 1)) load_piece(g);       // one piece of the next tile in this group's shadow
             static_assert(NDZ + NX <= NG, "more staged pieces than MFMA groups to hide them in");
             __builtin_amdgcn_sched_barrier(0);

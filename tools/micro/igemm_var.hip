@@ -30,7 +30,10 @@ static void run(const char* name, int64_t N, int H, int W, int Cin, int Cout, in
     float* x = dev_rand(nx, 1, true); float* w = dev_rand(nw, 7, false); float* y; float* dyv = nullptr;
     hipMalloc(&y, (mode == 2 ? nx : ny) * 4);
     if (mode == 2) dyv = dev_rand(ny, 3, false);
+    float* aff = dev_rand(2 * (size_t)Cout, 11, false);       // mode 3: a ring launch of the shared layer1 (folded BatchNorm, residual, ReLU)
+    float* resid = mode == 3 ? dev_rand(ny, 5, false) : nullptr;
     auto go = [&]() {
+        if (mode == 3) return ssad_conv_igemm_fwd_hwnc_ring(x, w, y, aff, aff + Cout, resid, 1, N, H, W, Cin, Cout, k, k, s, p, 4, 12, nullptr);
         if (mode == 2) return ssad_conv_igemm_dgrad(dyv, w, y, nullptr, N, Ho, Wo, Cout, H, W, Cin, k, k, s, p, nullptr);
         return mode ? ssad_conv_igemm_fwd_hwnc(x, w, y, nullptr, nullptr, nullptr, 1, N, H, W, Cin, Cout, k, k, s, p, nullptr)
                     : ssad_conv_igemm_fwd(x, w, y, nullptr, nullptr, nullptr, 1, N, H, W, Cin, Cout, k, k, s, p, nullptr); };
@@ -43,7 +46,7 @@ static void run(const char* name, int64_t N, int H, int W, int Cin, int Cout, in
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= it;
     const double alg = 2.0 * N * Ho * Wo * Cin * Cout * k * k;
-    const double exe = mode == 1 ? 2.0 * N * Cin * Cout * inb(H, k, s, p) * inb(W, k, s, p) : alg;
+    const double exe = mode == 3 ? alg * (256 - 81) / 256.0 * 0.9 : mode == 1 ? 2.0 * N * Cin * Cout * inb(H, k, s, p) * inb(W, k, s, p) : alg;
 #if IGEMM_TRACE
     {   // phase time line of the workgroups that ran on the CU of workgroup 0 (one extra launch)
         const size_t nwg = 1 << 20;
@@ -81,6 +84,8 @@ static void run(const char* name, int64_t N, int H, int W, int Cin, int Cout, in
     hipFree(x); hipFree(y); hipFree(w); if (dyv) hipFree(dyv);
 }
 int main() {
+    if (getenv("L2_ONLY")) { run("score l2 107648x8x8 128>128", 107648, 8, 8, 128, 128, 3, 1, 1, 1); run("train l2 256x32x32 128>128", 256, 32, 32, 128, 128, 3, 1, 1, 0); return 0; }
+    if (getenv("RING_ONLY")) { run("score l1 ring 26912x16x16 64>64", 26912, 16, 16, 64, 64, 3, 1, 1, 3); return 0; }
     run("train l2 256x32x32 128>128", 256, 32, 32, 128, 128, 3, 1, 1, 0);
     run("train l3 256x16x16 256>256", 256, 16, 16, 256, 256, 3, 1, 1, 0);
     run("train l4 256x8x8 512>512", 256, 8, 8, 512, 512, 3, 1, 1, 0);
@@ -95,5 +100,6 @@ int main() {
     run("score l3 15979x4x4 256>256", 15979, 4, 4, 256, 256, 3, 1, 1, 1);
     run("score l4 15979x2x2 512>512", 15979, 2, 2, 512, 512, 3, 1, 1, 1);
     run("score l2 107648x8x8 128>128", 107648, 8, 8, 128, 128, 3, 1, 1, 1);
+    run("score l1 ring 26912x16x16 64>64", 26912, 16, 16, 64, 64, 3, 1, 1, 3);
     return 0;
 }

@@ -1,5 +1,5 @@
 // Where does the halo-tile weight-gradient kernel's time go?  Builds csrc/wgrad_halo.hip with -DWGH_ABL=<bits>.
-//   bits: 1 = no next-tile global loads (address math + 15 loads per tile)   2 = no per-tile LDS restaging / barriers
+//   bits: 1 = no next-tile global loads   2 = no per-tile LDS restaging / barriers   4 = no LDS fragment reads in the matrix loop
 #include <stdarg.h>
 #include <stdlib.h>
 #include <vector>
