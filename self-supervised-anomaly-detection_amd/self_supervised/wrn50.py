@@ -11,6 +11,7 @@ from torch import nn
 from . import engine, ops
 
 LAYERS = (("layer1", 64, 3, 1), ("layer2", 128, 4, 2), ("layer3", 256, 6, 2))
+FW_EVAL = __import__("os").environ.get("SSAD_WRN_FW", "1") != "0"      # 0: every conv on the implicit GEMM (rounds 3-5)
 
 
 class _Bottleneck(nn.Module):
@@ -53,6 +54,11 @@ class WideResNet50Features(nn.Module):
                     for k in (1, 2, 3):
                         d[f"w{k}"] = ops.repack_oihw_to_ohwi(getattr(blk, f"conv{k}").weight.contiguous())
                         d[f"s{k}"], d[f"t{k}"] = engine._fold_bn(getattr(blk, f"bn{k}"))
+                    if blk.stride == 1 and FW_EVAL:
+                        # the 3 x 3 / stride 1 convs on the register-fed kernel (csrc/conv16w.hip, float form: 0.86-0.9 of the fp32-MFMA
+                        # peak where the implicit GEMM reaches 0.81): BatchNorm scale folded into the packed filter, shift + ReLU in
+                        # its epilogue
+                        d["p2"] = ops.conv3x3_fw_pack_scaled(d["w2"], d["s2"])
                     if blk.downsample is not None:
                         d["wd"] = ops.repack_oihw_to_ohwi(blk.downsample[0].weight.contiguous())
                         d["sd"], d["td"] = engine._fold_bn(blk.downsample[1])
@@ -76,7 +82,10 @@ class WideResNet50Features(nn.Module):
             last = d["name"]
             idt = a if "wd" not in d else ops.conv_fwd(a, d["wd"], d["sd"], d["td"], None, False, d["stride"], 0)
             t = ops.conv_fwd(a, d["w1"], d["s1"], d["t1"], None, True, 1, 0)
-            t = ops.conv_fwd(t, d["w2"], d["s2"], d["t2"], None, True, d["stride"], 1)
+            if "p2" in d and ops.conv3x3_fw_eval_ok(t.shape[0], t.shape[1], t.shape[2], t.shape[3], t.shape[3]):
+                t = ops.conv3x3_fw_eval(t, d["p2"], t.shape[3], d["t2"], None, True)
+            else:
+                t = ops.conv_fwd(t, d["w2"], d["s2"], d["t2"], None, True, d["stride"], 1)
             a = ops.conv_fwd(t, d["w3"], d["s3"], d["t3"], idt, True, 1, 0)
         feats.append(a)
         return feats
