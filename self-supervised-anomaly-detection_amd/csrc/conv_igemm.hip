@@ -112,7 +112,7 @@ struct ConvParams {
 //        precision-16 training step with its tensors as torch.autocast keeps them.  A 16-byte piece is then 8 consecutive k, staged
 //        without conversion; outputs are rounded once, in the epilogue; BatchNorm statistics are those of the stored halves.
 template <int BM, int BN, int TM, int TN, int BK, int TS, bool POS, bool DB = true, int BF = 0, bool IO = false>
-__global__ __launch_bounds__((BM / (32 * TM)) * (BN / (32 * TN)) * 64, TM * TN >= 8 ? 1 : 2)
+__global__ __launch_bounds__((BM / (32 * TM)) * (BN / (32 * TN)) * 64, (TM * TN > 8 || (TM * TN == 8 && BK >= 32)) ? 1 : 2)
 void conv_igemm_f32_kernel(ConvParams p) {
     static_assert(!IO || BF == 2, "half tensors go with fp16 operands");
     using io_t = std::conditional_t<IO, hf, float>;
@@ -1116,7 +1116,7 @@ int dispatch_x3(const ConvParams& p, hipStream_t st) {
 
 // Tile of the exact-fp32 instantiation a problem is given (also reported by ssad_conv_igemm_tile: bench.py names the
 // instantiations its roofline sums over)
-enum IgemmTile { T_256x64_K16 = 0, T_256x64_SB, T_128x64, T_256x128, T_256x128_W4, T_128x256, T_64x64, T_128x128, T_256x256, T_128x64_SB, T_128x64_K16, T_128x128_K16 };
+enum IgemmTile { T_256x64_K16 = 0, T_256x64_SB, T_128x64, T_256x128, T_256x128_W4, T_128x256, T_64x64, T_128x128, T_256x256, T_128x64_SB, T_128x64_K16, T_128x128_K16, T_128x256_K16 };
 
 template <bool POS>
 IgemmTile pick_tile(const ConvParams& p) {
@@ -1145,7 +1145,11 @@ IgemmTile pick_tile(const ConvParams& p) {
     static const int wide_min = getenv("SSAD_CONV_WIDE_GRID") ? atoi(getenv("SSAD_CONV_WIDE_GRID")) : 256;
     if (big != 5 && p.Cout % 256 == 0 && wide_min > 0) {
         const int64_t rows = POS ? cdiv64(p.N, 128) * p.Ho * p.Wo : cdiv64(p.M, 128);
-        if (rows * (p.Cout / 256) >= wide_min) return T_128x256;
+        // ... with 16-float K-steps (61 KB of LDS, 256 registers: the staging sets halve) TWO such workgroups fit a CU and one's prologue
+        // and epilogue hide behind the other's K loop: 9.79 -> 9.51 / 6.29 -> 6.15 ms on the layer3 / layer4 shapes of the scoring pass
+        // (SSAD_CONV256_K16: 0 off, 1 position-major launches only, 2 all -- the WideResNet-50 1 x 1 convs gain 0.5 %, the training step nothing)
+        static const int wide_k16 = getenv("SSAD_CONV256_K16") ? atoi(getenv("SSAD_CONV256_K16")) : 2;
+        if (rows * (p.Cout / 256) >= wide_min) return (wide_k16 == 2 || (POS && wide_k16)) ? T_128x256_K16 : T_128x256;
     }
     // small problems (batch 32-96 on the 8x8 / 16x16 maps of layer3 / layer4): 128x128 tiles leave CUs idle -- fewer than
     // ~1.5 workgroups per CU -- so the 128x64 tile doubles the grid (measured at batch 96 / 32: see DESIGN.md)
@@ -1174,6 +1178,7 @@ int dispatch(const ConvParams& p, hipStream_t st) {
         case T_128x64_SB: return launch<128, 64, 1, 2, 32, TS, POS, false>(p, st);      // one LDS stage: 27 KB, up to five workgroups per CU
         case T_128x64_K16: return launch<128, 64, 1, 2, 16, TS, POS>(p, st);            // 16-float K-steps: 30 KB, two stages
         case T_128x128_K16: return launch<128, 128, 2, 2, 16, TS, POS>(p, st);
+        case T_128x256_K16: return launch<128, 256, 2, 4, 16, TS, POS>(p, st);          // 61 KB, 256 registers: two workgroups per CU
         case T_256x128: return launch<256, 128, 2, 2, 32, TS, POS>(p, st);
         case T_256x128_W4: return launch<256, 128, 4, 2, 32, TS, POS>(p, st);
         case T_128x256: return launch<128, 256, 2, 4, 32, TS, POS>(p, st);
@@ -1339,8 +1344,8 @@ extern "C" int ssad_conv_igemm_tile(int64_t N, int H, int W, int Cin, int Cout, 
     p.Wo = (W + 2 * pad - KW) / stride + 1;
     p.M = N * p.Ho * p.Wo;
     const bool posmajor = hwnc || (pad > 0 && N >= 128 && p.Ho * p.Wo <= 4);
-    static const int dims[12][3] = {{256, 64, 16}, {256, 64, 32}, {128, 64, 32}, {256, 128, 32}, {256, 128, 32}, {128, 256, 32},
-                                    {64, 64, 32}, {128, 128, 32}, {256, 256, 32}, {128, 64, 32}, {128, 64, 16}, {128, 128, 16}};
+    static const int dims[13][3] = {{256, 64, 16}, {256, 64, 32}, {128, 64, 32}, {256, 128, 32}, {256, 128, 32}, {128, 256, 32},
+                                    {64, 64, 32}, {128, 128, 32}, {256, 256, 32}, {128, 64, 32}, {128, 64, 16}, {128, 128, 16}, {128, 256, 16}};
     const int t = posmajor ? (int)pick_tile<true>(p) : (int)pick_tile<false>(p);
     const int code = dims[t][0] * 100000 + dims[t][1] * 100 + dims[t][2];
     return posmajor ? -code : code;

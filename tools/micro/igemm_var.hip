@@ -85,6 +85,7 @@ static void run(const char* name, int64_t N, int H, int W, int Cin, int Cout, in
 }
 int main() {
     if (getenv("L2_ONLY")) { run("score l2 107648x8x8 128>128", 107648, 8, 8, 128, 128, 3, 1, 1, 1); run("train l2 256x32x32 128>128", 256, 32, 32, 128, 128, 3, 1, 1, 0); return 0; }
+    if (getenv("L34_ONLY")) { run("score l3 107648x4x4 256>256", 107648, 4, 4, 256, 256, 3, 1, 1, 1); run("score l4 107648x2x2 512>512", 107648, 2, 2, 512, 512, 3, 1, 1, 1); return 0; }
     if (getenv("RING_ONLY")) { run("score l1 ring 26912x16x16 64>64", 26912, 16, 16, 64, 64, 3, 1, 1, 3); return 0; }
     run("train l2 256x32x32 128>128", 256, 32, 32, 128, 128, 3, 1, 1, 0);
     run("train l3 256x16x16 256>256", 256, 16, 16, 256, 256, 3, 1, 1, 0);
