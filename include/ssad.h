@@ -573,7 +573,8 @@ int ssad_conv3x3_hw(const void* in, const void* w_packed, void* out, const void*
                     const float* tr_invstd, const float* tr_gamma, const float* tr_beta, void* emit, int64_t N, int H, int W, int Cin, int Cout,
                     double* stats_ws, float eps, float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
                     void* stream);
-/* The exact-fp32 instantiation of the same kernel (csrc/conv16w.hip, T = float: v_mfma_f32_32x32x2_f32, statistics in double per value):
+/* The exact-fp32 instantiation of the same kernel (csrc/conv16w.hip, T = float: v_mfma_f32_32x32x2_f32; statistics: packed fp32 sums of 32 values per tile and column, added in
+ * double across tiles):
  * the 3 x 3 / stride 1 convs of the fp32 training step (models.py:224) forward and -- with the flipped pack -- their input gradients,
  * whenever the launch fills the chip (ssad_conv3x3_fw_ok; other launches stay on ssad_conv3x3_c64 / ssad_conv_igemm_*).  The filter pack
  * holds floats in fragment order [Cout/32][tap][Cin/8][2][32][4]; res_mask: the residual is the identity-branch gradient (dy, nibble mask)

@@ -21,9 +21,12 @@
 //     would hold back every filter fragment behind it -- the stagers keep their own queue, apply the producer's BatchNorm + ReLU on load
 //     (fp32, rounded once) and emit the normalised activation for the weight gradient; all their per-lane index arithmetic is done once;
 //   * a residual is ADDED BY THE MATRIX CORES (centre-tap steps against a one-hot fragment: exact), its tiles riding the same staging;
-//   * one barrier per (tile, chunk) = per 36 steps.
+//   * one barrier per (tile, chunk) = per 36 steps;
+//   * (round 6) halo pieces and filter fragments are BUFFER loads -- scalar base, per-lane 32-bit offset, out-of-range offsets read zeros:
+//     a VALU instruction costs the matrix pipe ~15-25 cycles whichever wave issues it, and the stagers only advance in the matrix waves'
+//     stalls (time stamps: tools/micro/conv32w_trace.hip, -DCONV16W_TRACE).
 // Workgroups are persistent over tiles of ONE channel slab (blockIdx.y), so the BatchNorm statistics of the stored output stay in
-// registers (per tile in fp32, across tiles in double; the float form: double per value) and leave as one partial row per workgroup.
+// registers (per tile in fp32, across tiles in double) and leave as one partial row per workgroup.
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -937,7 +940,7 @@ extern "C" int ssad_conv3x3_hw(const void* in, const void* w_packed, void* out, 
                          (hf*)emit, N, H, W, Cin, Cout, stats_ws, eps, momentum, mean, invstd, running_mean, running_var, stream);
 }
 
-// The exact-fp32 form of the same kernel (fp32 tensors, v_mfma_f32_32x32x2_f32, statistics in double per value): the 3 x 3 / stride 1
+// The exact-fp32 form of the same kernel (fp32 tensors, v_mfma_f32_32x32x2_f32, statistics per tile in packed fp32, across tiles in double): the 3 x 3 / stride 1
 // convs of the fp32 training step forward and -- with the flipped pack -- their input gradients.  res_mask (optional): the residual is the
 // identity-branch gradient (dy, nibble mask) of a residual block, one byte per channel quad as ssad_bn_apply_fwd_mask writes them.
 extern "C" int ssad_conv3x3_fw(const float* in, const float* w_packed, float* out, const float* residual, const uint8_t* res_mask,
