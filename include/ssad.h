@@ -106,6 +106,10 @@ int ssad_conv_igemm_fwd_hwnc_ring(const float* in, const float* w_ohwi, float* o
                                   int stride, int pad, int skip_lo, int skip_hi, void* stream);
 int ssad_patch_gather_hwnc(const float* dense, float* out, int64_t B, int prow, int pcol, int shift, int Hd, int Wd, int C,
                            int H, int W, int lo, int hi, void* stream);
+/* The same copy without the inner square ilo <= u, v <= ihi (ilo > ihi: none): the ring conv that follows reads its input within one
+ * position of the outputs it computes, the deep interior of an intermediate layer1 map is read by nobody. */
+int ssad_patch_gather_hwnc_band(const float* dense, float* out, int64_t B, int prow, int pcol, int shift, int Hd, int Wd, int C,
+                                int H, int W, int lo, int hi, int ilo, int ihi, void* stream);
 
 /* Which exact-fp32 instantiation ssad_conv_igemm_fwd (hwnc = 0) / ssad_conv_igemm_fwd_hwnc (hwnc = 1) gives a problem:
  * BM * 100000 + BN * 100 + BK of the workgroup tile, negated when its rows are position-major (hwnc = 2: the tile of a

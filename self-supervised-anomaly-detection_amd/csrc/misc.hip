@@ -323,7 +323,8 @@ extern "C" int ssad_gap_fwd_h(const void* in, float* out, int64_t N, int HW, int
 // zero-padded border of the patch is within reach of that position (ssad_conv_igemm_fwd_hwnc_ring computes the others).
 namespace {
 __global__ __launch_bounds__(256) void patch_gather_hwnc_kernel(const f32x4* __restrict__ dense, f32x4* __restrict__ out, int64_t N, int prow,
-                                                               int pcol, int shift, int Hd, int Wd, int C4, int W, int lo, int side) {
+                                                               int pcol, int shift, int Hd, int Wd, int C4, int W, int lo, int side,
+                                                               int ilo, int iside) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= N * C4) return;
     const int c4 = (int)(i % C4);
@@ -332,24 +333,45 @@ __global__ __launch_bounds__(256) void patch_gather_hwnc_kernel(const f32x4* __r
     const int64_t b = n / pp;
     const int rem = (int)(n - b * pp);
     const int pr = rem / pcol, pc = rem - pr * pcol;
-    const int u = lo + (int)blockIdx.y / side, v = lo + (int)blockIdx.y % side;
+    // blockIdx.y counts the positions of the square [lo, lo + side) that lie OUTSIDE the inner square [ilo, ilo + iside) (iside = 0:
+    // none), row by row: full rows above, two flanks per row beside, full rows below
+    int u, v;
+    {
+        const int k = (int)blockIdx.y, top = (ilo - lo) * side, w2 = side - iside, mid = iside * w2;
+        if (iside == 0 || k < top) { u = lo + k / side; v = lo + k % side; }
+        else if (k < top + mid) {
+            const int kk = k - top, j = kk % w2;
+            u = ilo + kk / w2;
+            v = j < ilo - lo ? lo + j : ilo + iside + (j - (ilo - lo));
+        } else { const int kk = k - top - mid; u = ilo + iside + kk / side; v = lo + kk % side; }
+    }
     const f32x4 val = dense[((b * Hd + shift * pr + u) * Wd + shift * pc + v) * C4 + c4];
     out[(((int64_t)u * W + v) * N + n) * C4 + c4] = val;
 }
 }  // namespace
 
-extern "C" int ssad_patch_gather_hwnc(const float* dense, float* out, int64_t B, int prow, int pcol, int shift, int Hd, int Wd, int C,
-                                      int H, int W, int lo, int hi, void* stream) {
+// ... of the square lo <= u, v <= hi only the positions outside the inner square ilo <= u, v <= ihi (ilo > ihi: the whole square): the
+// next ring conv reads its input within one position of the outputs it computes, so the deep interior of an intermediate map is never
+// read by anyone (round 6: 83 of the 276 positions copied per image pass).
+extern "C" int ssad_patch_gather_hwnc_band(const float* dense, float* out, int64_t B, int prow, int pcol, int shift, int Hd, int Wd, int C,
+                                           int H, int W, int lo, int hi, int ilo, int ihi, void* stream) {
     SSAD_CHECK_ARG(dense && out && B > 0 && prow > 0 && pcol > 0 && shift > 0 && C > 0 && C % 4 == 0, "bad argument");
     SSAD_CHECK_ARG(lo >= 0 && hi >= lo && hi < H && hi < W, "the copied square must lie inside the map");
+    SSAD_CHECK_ARG(ilo > ihi || (ilo > lo && ihi < hi), "the inner square must lie strictly inside the copied one");
     SSAD_CHECK_ARG(shift * (prow - 1) + hi < Hd && shift * (pcol - 1) + hi < Wd, "the dense map does not cover the last patch");
     const int64_t N = B * prow * pcol;
     const int side = hi - lo + 1;
+    const int iside = ilo > ihi ? 0 : ihi - ilo + 1;
     SSAD_CHECK_ARG(cdiv64(N * (C / 4), 256) < (int64_t)2147483647 && side * side <= 65535, "too large for one launch");
-    hipLaunchKernelGGL(patch_gather_hwnc_kernel, dim3((unsigned)cdiv64(N * (C / 4), 256), side * side), dim3(256), 0, (hipStream_t)stream,
-                       (const f32x4*)dense, (f32x4*)out, N, prow, pcol, shift, Hd, Wd, C / 4, W, lo, side);
+    hipLaunchKernelGGL(patch_gather_hwnc_kernel, dim3((unsigned)cdiv64(N * (C / 4), 256), side * side - iside * iside), dim3(256), 0,
+                       (hipStream_t)stream, (const f32x4*)dense, (f32x4*)out, N, prow, pcol, shift, Hd, Wd, C / 4, W, lo, side, ilo, iside);
     SSAD_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int ssad_patch_gather_hwnc(const float* dense, float* out, int64_t B, int prow, int pcol, int shift, int Hd, int Wd, int C,
+                                      int H, int W, int lo, int hi, void* stream) {
+    return ssad_patch_gather_hwnc_band(dense, out, B, prow, pcol, shift, Hd, Wd, C, H, W, lo, hi, 1, 0, stream);
 }
 
 extern "C" int ssad_gradcam_map(const float* act, const float* alpha, float* out, int64_t B, int HW, int C, int alpha_stride,

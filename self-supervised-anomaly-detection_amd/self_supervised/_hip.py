@@ -37,6 +37,7 @@ SIGNATURES = {
     "ssad_conv_igemm_fwd_hwnc_ring": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
                                       _c_i, _c_i, _c_i, _c_i, _c_fp],
     "ssad_patch_gather_hwnc": [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
+    "ssad_patch_gather_hwnc_band": [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
     "ssad_conv_igemm_tile": [_c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i],
     "ssad_gap_fwd": [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fp],
     "ssad_l2_normalize_rows": [_c_fp, _c_fp, _c_l, _c_i, _c_fp],

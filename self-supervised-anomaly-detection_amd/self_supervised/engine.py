@@ -191,6 +191,7 @@ def _trunk_eval_dedup(plan, x, patch_stride, layer_outputs, pooled, conv):
     b, _, h, w = x.shape
     prow, pcol = (h - 32) // patch_stride + 1, (w - 32) // patch_stride + 1
     shift = patch_stride // 2
+    band = _os.environ.get("SSAD_GATHER_BAND", "1") != "0"
     a = ops.stem_patch_pool_fwd(x, plan.stem_wf, plan.stem_s, plan.stem_t, patch_stride, True)          # [16][16][N][64]
     dn = ops.stem_fwd(x, plan.stem_w, plan.stem_s, plan.stem_t, True, resize_to=(2 * h, 2 * w))         # [B][h][w][64]
     dn = ops.maxpool3x3s2_fwd(dn)                                                                       # [B][h/2][w/2][64]
@@ -206,10 +207,13 @@ def _trunk_eval_dedup(plan, x, patch_stride, layer_outputs, pooled, conv):
             lo, hi = 3 + 2 * i, 13 - 2 * i                       # interior after this block's first conv; one less per side after its second
             dt = ops.conv3x3_c64_eval(dn, d["w1"], d["s1"], d["t1"], None, True)
             dn2 = ops.conv3x3_c64_eval(dt, d["w2"], d["s2"], d["t2"], dn, True)
+            # (the copies leave out what nobody reads: a ring conv reads its input within one position of the outputs it computes, so
+            # of t only the positions outside [lo + 2, hi - 2] are read, of block 0's output only those outside [lo + 3, hi - 3] -- by
+            # block 1's first conv and as the residual of its second; block 1's output feeds layer2 whole)
             t = ops.conv_fwd_hwnc_ring(a, d["w1"], d["s1"], d["t1"], None, True, lo, hi)
-            ops.patch_gather_hwnc(dt, t, prow, pcol, shift, lo, hi)
+            ops.patch_gather_hwnc(dt, t, prow, pcol, shift, lo, hi, *((lo + 2, hi - 2) if band else (1, 0)))
             a2 = ops.conv_fwd_hwnc_ring(t, d["w2"], d["s2"], d["t2"], a, True, lo + 1, hi - 1)
-            ops.patch_gather_hwnc(dn2, a2, prow, pcol, shift, lo + 1, hi - 1)
+            ops.patch_gather_hwnc(dn2, a2, prow, pcol, shift, lo + 1, hi - 1, *((lo + 3, hi - 3) if band and i == 0 else (1, 0)))
             a, dn = a2, dn2
         else:
             idt = a

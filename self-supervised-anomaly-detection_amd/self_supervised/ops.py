@@ -301,16 +301,17 @@ def conv_fwd_hwnc_ring(x, w_ohwi, scale, shift, residual, relu, skip_lo, skip_hi
     return out
 
 
-def patch_gather_hwnc(dense, out, prow, pcol, shift, lo, hi):
+def patch_gather_hwnc(dense, out, prow, pcol, shift, lo, hi, ilo=1, ihi=0):
     """out[u][v][n][:] = dense[b][shift * pr + u][shift * pc + v][:] for lo <= u, v <= hi (n = (b * prow + pr) * pcol + pc): the
-    positions of every patch's map that equal the per-image dense map.  dense NHWC [B][Hd][Wd][C], out [H][W][N][C], in place."""
+    positions of every patch's map that equal the per-image dense map.  dense NHWC [B][Hd][Wd][C], out [H][W][N][C], in place.
+    ilo <= ihi: the inner square ilo <= u, v <= ihi is left untouched (nobody reads it)."""
     b, hd, wd, c = dense.shape
     h, w, n, c2 = out.shape
     assert c == c2 and n == b * prow * pcol
-    side = hi - lo + 1
-    _run("patch_gather", 0.0, 8.0 * n * side * side * c,
-         lambda: _hip.lib().ssad_patch_gather_hwnc(_hip.ptr(dense), _hip.ptr(out), b, prow, pcol, shift, hd, wd, c, h, w, lo, hi,
-                                                   _hip.stream()))
+    side, iside = hi - lo + 1, max(ihi - ilo + 1, 0)
+    _run("patch_gather", 0.0, 8.0 * n * (side * side - iside * iside) * c,
+         lambda: _hip.lib().ssad_patch_gather_hwnc_band(_hip.ptr(dense), _hip.ptr(out), b, prow, pcol, shift, hd, wd, c, h, w, lo, hi,
+                                                        ilo, ihi, _hip.stream()))
     return out
 
 

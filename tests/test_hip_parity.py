@@ -405,6 +405,18 @@ def test_ring_conv_and_patch_gather_kernels(dev):
                     nn_ = (bi * prow + pr) * pcol + pc
                     want[lo:hi + 1, lo:hi + 1, nn_] = dense[bi, shift * pr + lo:shift * pr + hi + 1, shift * pc + lo:shift * pc + hi + 1]
         assert torch.equal(out, want)
+    # the band form: the inner square stays as it was (poisoned), everything else of the copied square as above
+    for lo, hi, ilo, ihi in ((3, 13, 5, 11), (4, 12, 6, 10), (5, 11, 7, 9), (2, 14, 8, 8)):
+        out = torch.full((16, 16, b * prow * pcol, 64), 7.5, device=dev)
+        ops.patch_gather_hwnc(dense, out, prow, pcol, shift, lo, hi, ilo, ihi)
+        want = torch.full_like(out, 7.5)
+        for bi in range(b):
+            for pr in range(prow):
+                for pc in range(pcol):
+                    nn_ = (bi * prow + pr) * pcol + pc
+                    want[lo:hi + 1, lo:hi + 1, nn_] = dense[bi, shift * pr + lo:shift * pr + hi + 1, shift * pc + lo:shift * pc + hi + 1]
+        want[ilo:ihi + 1, ilo:ihi + 1] = 7.5
+        assert torch.equal(out, want), (lo, hi, ilo, ihi)
     with pytest.raises(RuntimeError):
         ops.patch_gather_hwnc(dense[:, :20], torch.zeros(16, 16, b * prow * pcol, 64, device=dev), prow, pcol, shift, 3, 13)
 
