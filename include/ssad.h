@@ -71,6 +71,11 @@ int ssad_stem_fwd_stats(const float* img, int B, int H, int W, int Hv, int Wv, c
 int ssad_pack_stem_weight_folded(const float* w_oihw, float* wf, void* stream);
 int ssad_stem_patch_pool_fwd(const float* img, int B, int H, int W, int patch_stride, const float* wf, const float* scale,
                              const float* shift, int hwnc, float* out, void* stream);
+/* The same without the pooled positions skip_lo <= py, px <= skip_hi of every patch (neither pooled nor stored): with layer1 shared between
+ * overlapping patches the first ring conv (ssad_conv_igemm_fwd_hwnc_ring) reads the pooled map within one position of the outputs it
+ * computes -- the interior is read by nobody. */
+int ssad_stem_patch_pool_fwd_ring(const float* img, int B, int H, int W, int patch_stride, const float* wf, const float* scale,
+                                  const float* shift, int hwnc, int skip_lo, int skip_hi, float* out, void* stream);
 
 /* Replaces nn.MaxPool2d(3, 2, 1) of the torchvision stem (models.py:224).  NHWC, or [H][W][N][C] when hwnc. */
 int ssad_maxpool3x3s2_fwd(const float* in, float* out, int64_t N, int H, int W, int C, int hwnc, void* stream);

@@ -242,6 +242,7 @@ struct StemPatchParams {
     const float* shift;
     float* out;
     int B, H, W, ps, prow, pcol, hwnc;
+    int skip_lo, skip_hi;        // pooled positions skip_lo <= py, px <= skip_hi are neither pooled nor stored (skip_lo > skip_hi: none)
     int64_t Nsamp;
 };
 
@@ -326,6 +327,7 @@ __global__ __launch_bounds__(256, 2) void stem_patch_fused_kernel(StemPatchParam
                 for (int k = 0; k < 2; ++k) {
                     const int item = tid + 256 * k;
                     const int c4 = item & 7, px = (item >> 3) & 15, j = item >> 7;
+                    if (4 * t + j >= p.skip_lo && 4 * t + j <= p.skip_hi && px >= p.skip_lo && px <= p.skip_hi) continue;
                     f32x4 m = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int dy = 0; dy < 3; ++dy)
@@ -546,13 +548,24 @@ extern "C" int ssad_pack_stem_weight_folded(const float* w_oihw, float* wf, void
     return 0;
 }
 
+// ... leaving out the pooled positions skip_lo <= py, px <= skip_hi of every patch (the patch-scoring pass with layer1 shared between
+// overlapping patches: its first ring conv reads the pooled map within one position of the outputs it computes)
+extern "C" int ssad_stem_patch_pool_fwd_ring(const float* img, int B, int H, int W, int patch_stride, const float* wf,
+                                             const float* scale, const float* shift, int hwnc, int skip_lo, int skip_hi, float* out,
+                                             void* stream);
 extern "C" int ssad_stem_patch_pool_fwd(const float* img, int B, int H, int W, int patch_stride, const float* wf,
                                         const float* scale, const float* shift, int hwnc, float* out, void* stream) {
+    return ssad_stem_patch_pool_fwd_ring(img, B, H, W, patch_stride, wf, scale, shift, hwnc, 1, 0, out, stream);
+}
+extern "C" int ssad_stem_patch_pool_fwd_ring(const float* img, int B, int H, int W, int patch_stride, const float* wf,
+                                             const float* scale, const float* shift, int hwnc, int skip_lo, int skip_hi, float* out,
+                                             void* stream) {
     SSAD_CHECK_ARG(img && wf && out, "null pointer");
+    SSAD_CHECK_ARG(skip_lo > skip_hi || (skip_lo >= 0 && skip_hi < 16), "skipped square outside the 16 x 16 map");
     SSAD_CHECK_ARG(B > 0 && H >= 32 && W >= 32 && patch_stride > 0, "bad shape (32x32 windows)");
     StemPatchParams p;
     p.img = img; p.wf = wf; p.scale = scale; p.shift = shift; p.out = out;
-    p.B = B; p.H = H; p.W = W; p.ps = patch_stride; p.hwnc = hwnc;
+    p.B = B; p.H = H; p.W = W; p.ps = patch_stride; p.hwnc = hwnc; p.skip_lo = skip_lo; p.skip_hi = skip_hi;
     p.prow = (H - 32) / patch_stride + 1;
     p.pcol = (W - 32) / patch_stride + 1;
     p.Nsamp = (int64_t)B * p.prow * p.pcol;

@@ -192,7 +192,9 @@ def _trunk_eval_dedup(plan, x, patch_stride, layer_outputs, pooled, conv):
     prow, pcol = (h - 32) // patch_stride + 1, (w - 32) // patch_stride + 1
     shift = patch_stride // 2
     band = _os.environ.get("SSAD_GATHER_BAND", "1") != "0"
-    a = ops.stem_patch_pool_fwd(x, plan.stem_wf, plan.stem_s, plan.stem_t, patch_stride, True)          # [16][16][N][64]
+    # (the pooled map's interior [4, 12]^2 is read by nobody: the first ring conv computes the outputs outside [3, 13] and reads within
+    # one position of them, block 0's second conv takes its residual at the positions outside [4, 12])
+    a = ops.stem_patch_pool_fwd(x, plan.stem_wf, plan.stem_s, plan.stem_t, patch_stride, True, (4, 12) if band else None)   # [16][16][N][64]
     dn = ops.stem_fwd(x, plan.stem_w, plan.stem_s, plan.stem_t, True, resize_to=(2 * h, 2 * w))         # [B][h][w][64]
     dn = ops.maxpool3x3s2_fwd(dn)                                                                       # [B][h/2][w/2][64]
     offs, off = {}, 0

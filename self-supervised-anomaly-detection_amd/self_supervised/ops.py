@@ -230,15 +230,17 @@ def pack_stem_weight_folded(w):
     return out
 
 
-def stem_patch_pool_fwd(img, wf, scale, shift, patch_stride=8, hwnc=False):
+def stem_patch_pool_fwd(img, wf, scale, shift, patch_stride=8, hwnc=False, skip=None):
     """32x32 windows (stride patch_stride) of img [B][3][H][W] -> pooled stem output [N][16][16][64] / [16][16][N][64]:
-    window + 2x nearest upsample + conv7x7/2 + affine + ReLU + max-pool in one kernel."""
+    window + 2x nearest upsample + conv7x7/2 + affine + ReLU + max-pool in one kernel.  skip = (lo, hi): the pooled positions
+    lo <= py, px <= hi of every patch are left unwritten (nobody reads them when layer1 is shared between overlapping patches)."""
     b, c, h, w = img.shape
     n = b * ((h - 32) // patch_stride + 1) * ((w - 32) // patch_stride + 1)
     out = _new((16, 16, n, 64) if hwnc else (n, 16, 16, 64), img)
+    lo, hi = skip if skip is not None else (1, 0)
     _run("stem_patch_pool", 2.0 * n * 32 * 32 * 64 * 147, 4.0 * (img.numel() + out.numel()),
-         lambda: _hip.lib().ssad_stem_patch_pool_fwd(_hip.ptr(img), b, h, w, patch_stride, _hip.ptr(wf), _hip.ptr(scale, True),
-                                                     _hip.ptr(shift, True), int(hwnc), _hip.ptr(out), _hip.stream()))
+         lambda: _hip.lib().ssad_stem_patch_pool_fwd_ring(_hip.ptr(img), b, h, w, patch_stride, _hip.ptr(wf), _hip.ptr(scale, True),
+                                                          _hip.ptr(shift, True), int(hwnc), lo, hi, _hip.ptr(out), _hip.stream()))
     return out
 
 

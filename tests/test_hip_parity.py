@@ -151,8 +151,16 @@ def test_fused_patch_stem(dev, seeded_sd, hwnc):
     want = F.max_pool2d((F.conv2d(F.interpolate(p, 64, mode="nearest"), w, None, 2, 3) * sc.view(1, -1, 1, 1)
                          + sh.view(1, -1, 1, 1)).relu(), 3, 2, 1)
     got = ops.stem_patch_pool_fwd(x.to(dev), ops.pack_stem_weight_folded(w.to(dev)), sc.to(dev), sh.to(dev), 8, hwnc)
+    full = got
     got = got.permute(2, 3, 0, 1) if hwnc else got.permute(0, 3, 1, 2)
     assert_close(got, want, 2e-5)
+    # the ring form (layer1 shared between overlapping patches): everything outside the skipped square, bit for bit
+    for lo, hi in ((4, 12), (0, 15), (7, 7)):
+        ring = ops.stem_patch_pool_fwd(x.to(dev), ops.pack_stem_weight_folded(w.to(dev)), sc.to(dev), sh.to(dev), 8, hwnc, (lo, hi))
+        keep = torch.ones(16, 16, dtype=torch.bool)
+        keep[lo:hi + 1, lo:hi + 1] = False
+        a, b = (ring[keep.to(dev)], full[keep.to(dev)]) if hwnc else (ring[:, keep.to(dev)], full[:, keep.to(dev)])
+        assert torch.equal(a, b), (lo, hi)
     # image-level 32x32 inputs take the same kernel (one window per image)
     xi = ow.synthetic_images(3, 32, seed=12)
     want = F.max_pool2d((F.conv2d(F.interpolate(xi, 64, mode="nearest"), w, None, 2, 3) * sc.view(1, -1, 1, 1)
