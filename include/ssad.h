@@ -76,6 +76,12 @@ int ssad_stem_patch_pool_fwd(const float* img, int B, int H, int W, int patch_st
  * computes -- the interior is read by nobody. */
 int ssad_stem_patch_pool_fwd_ring(const float* img, int B, int H, int W, int patch_stride, const float* wf, const float* scale,
                                   const float* shift, int hwnc, int skip_lo, int skip_hi, float* out, void* stream);
+/* Only the BORDER of that pooled map -- rows / columns 0, 1 and 15 of every patch, the positions where the patch's own zero padding makes
+ * it differ from the per-image pooled map -- written position-major [16][16][Nsamp][64]; the other positions are left untouched
+ * (ssad_patch_gather_hwnc_band copies rows / columns 2-3 and 13-14 from the per-image map; nobody reads the rest).  Values bit-identical
+ * to ssad_stem_patch_pool_fwd at the positions written. */
+int ssad_stem_patch_border_fwd(const float* img, int B, int H, int W, int patch_stride, const float* wf, const float* scale,
+                               const float* shift, float* out, void* stream);
 
 /* Replaces nn.MaxPool2d(3, 2, 1) of the torchvision stem (models.py:224).  NHWC, or [H][W][N][C] when hwnc. */
 int ssad_maxpool3x3s2_fwd(const float* in, float* out, int64_t N, int H, int W, int C, int hwnc, void* stream);

@@ -350,6 +350,146 @@ __global__ __launch_bounds__(256, 2) void stem_patch_fused_kernel(StemPatchParam
     }
 }
 
+// The BORDER of the same pooled map only (round 6, layer1 shared between overlapping patches): pooled rows / columns 0, 1 and 15 of
+// every patch -- the positions that differ from the per-image pooled map because the patch's own zero padding is within reach (stem rows
+// 0, 1, 31) -- 87 of the 256 positions.  Everything else the first ring conv reads (rows / columns 2, 3, 13, 14) is copied from the dense
+// map (ssad_patch_gather_hwnc_band).  The conv values needed are rows 0-3 and 29-31 (7 tiles of 32 pixels) and columns 0-3 and 29-31 of
+// rows 3-29 (189 pixels = 6 tiles): 13 tiles instead of 32, each the same 24 MFMAs in the same order as the fused kernel above -- the
+// values are bit-identical to its output at these positions.  Output position-major [16][16][Nsamp][64] only.
+constexpr int SB_CB = 7 * 32 * 32;                    // conv buffer: 7 rows x 32 pixels (rows phase) / 189 pixels (columns phase) x 32 channels
+
+__global__ __launch_bounds__(256, 2) void stem_patch_border_kernel(StemPatchParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wl = lds;
+    float* src = lds + SP_WF;
+    float* cb = src + SP_SRC;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    for (int i = tid; i < SP_WF / 4; i += 256) ((f32x4*)wl)[i] = ((const f32x4*)p.wf)[i];
+    const int P = p.prow * p.pcol;
+    const int64_t plane = (int64_t)p.H * p.W;
+    constexpr int NSRC = (SP_SH * SP_SW + 255) / 256;
+    float pv[NSRC][3];
+    auto fetch_patch = [&](int64_t n) {
+        const int b = (int)(n / P);
+        const int pi = (int)(n - (int64_t)b * P);
+        const int y0 = (pi / p.pcol) * p.ps, x0 = (pi % p.pcol) * p.ps;
+        const float* im = p.img + (int64_t)b * 3 * plane;
+#pragma unroll
+        for (int q = 0; q < NSRC; ++q) {
+            const int i = tid + 256 * q;
+            const int ty = i / SP_SW, tx = i - ty * SP_SW;
+            const int sy = ty - 2, sx = tx - 2;
+            float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+            if (i < SP_SH * SP_SW && (unsigned)sy < 32u && (unsigned)sx < 32u) {
+                const float* s = im + (int64_t)(y0 + sy) * p.W + x0 + sx;
+                v0 = s[0]; v1 = s[plane]; v2 = s[2 * plane];
+            }
+            pv[q][0] = v0; pv[q][1] = v1; pv[q][2] = v2;
+        }
+    };
+    // this lane's pixels (A rows) of the wave's two tiles in each phase: rows phase tiles 2 wave, 2 wave + 1 of the row list
+    // {0, 1, 2, 3, 29, 30, 31}; columns phase tiles 2 wave, 2 wave + 1 of the pixel list q = (oy - 3) * 7 + ci, ci -> ox {0, 1, 2, 3, 29, 30, 31}
+    auto row_of = [](int t) { return t < 4 ? t : 25 + t; };                    // t = 4, 5, 6 -> 29, 30, 31
+    const int ta0 = 2 * wave, ta1 = 2 * wave + 1 < 7 ? 2 * wave + 1 : 2 * wave;  // (wave 3: one tile, computed twice, stored once)
+    const float* pa0 = src + (row_of(ta0) * SP_SW + r + h) * 3;
+    const float* pa1 = src + (row_of(ta1) * SP_SW + r + h) * 3;
+    const float *pb0, *pb1;
+    {
+        int q0 = (2 * wave) * 32 + r, q1 = (2 * wave + 1) * 32 + r;
+        q0 = q0 < 189 ? q0 : 188; q1 = q1 < 189 ? q1 : 188;
+        const int c0 = q0 % 7, c1 = q1 % 7;
+        pb0 = src + ((3 + q0 / 7) * SP_SW + (c0 < 4 ? c0 : 25 + c0) + h) * 3;
+        pb1 = src + ((3 + q1 / 7) * SP_SW + (c1 < 4 ? c1 : 25 + c1) + h) * 3;
+    }
+    auto two_tiles = [&](const float* a0, const float* a1, int pass, f32x16& acc0, f32x16& acc1) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+        const float* bw = wl + h * 64 + pass * 32 + r;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int ko = (a * SP_SW + 2 * q) * 3 + c;
+                    const float w = bw[((a * 2 + q) * 3 + c) * 128];
+                    acc0 = mfma32(a0[ko], w, acc0);
+                    acc1 = mfma32(a1[ko], w, acc1);
+                }
+    };
+    if ((int64_t)blockIdx.x < p.Nsamp) fetch_patch(blockIdx.x);
+    for (int64_t n = blockIdx.x; n < p.Nsamp; n += gridDim.x) {
+        __syncthreads();                                    // previous patch fully consumed
+#pragma unroll
+        for (int q = 0; q < NSRC; ++q) {
+            const int i = tid + 256 * q;
+            if (i < SP_SH * SP_SW) {
+                float* d = src + i * 3;
+                d[0] = pv[q][0]; d[1] = pv[q][1]; d[2] = pv[q][2];
+            }
+        }
+        if (n + gridDim.x < p.Nsamp) fetch_patch(n + gridDim.x);
+        __syncthreads();
+        for (int pass = 0; pass < 2; ++pass) {
+            const float sc = p.scale ? p.scale[pass * 32 + r] : 1.f;
+            const float sh = p.shift ? p.shift[pass * 32 + r] : 0.f;
+            f32x16 acc0, acc1;
+            // ---- rows phase: conv rows 0-3, 29-31 -> cb[t][ox][ch] ----
+            two_tiles(pa0, pa1, pass, acc0, acc1);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ox = (e & 3) + 8 * (e >> 2) + 4 * h;
+                cb[((2 * wave) * 32 + ox) * 32 + r] = fmaxf(acc0[e] * sc + sh, 0.f);
+                if (2 * wave + 1 < 7) cb[((2 * wave + 1) * 32 + ox) * 32 + r] = fmaxf(acc1[e] * sc + sh, 0.f);
+            }
+            __syncthreads();
+            for (int item = tid; item < 3 * 16 * 8; item += 256) {      // pooled rows 0, 1, 15: all 16 columns
+                const int c4 = item & 7, px = (item >> 3) & 15, pr = item >> 7;
+                const int t_lo = pr == 0 ? 0 : pr == 1 ? 1 : 4, t_hi = pr == 0 ? 1 : pr == 1 ? 3 : 6;
+                f32x4 m = {0.f, 0.f, 0.f, 0.f};
+                for (int t = t_lo; t <= t_hi; ++t)
+#pragma unroll
+                    for (int dx = -1; dx < 2; ++dx) {
+                        const int cx = 2 * px + dx;
+                        if (cx < 0) continue;
+                        const f32x4 v = *(const f32x4*)(cb + (t * 32 + cx) * 32 + c4 * 4);
+                        m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+                    }
+                const int py = pr < 2 ? pr : 15;
+                *(f32x4*)(p.out + (((int64_t)py * 16 + px) * p.Nsamp + n) * 64 + pass * 32 + c4 * 4) = m;
+            }
+            __syncthreads();
+            // ---- columns phase: conv columns 0-3, 29-31 of rows 3-29 -> cb[q][ch] ----
+            if (wave < 3) {
+                two_tiles(pb0, pb1, pass, acc0, acc1);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int i = (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const int q0 = (2 * wave) * 32 + i, q1 = q0 + 32;
+                    if (q0 < 189) cb[q0 * 32 + r] = fmaxf(acc0[e] * sc + sh, 0.f);
+                    if (q1 < 189) cb[q1 * 32 + r] = fmaxf(acc1[e] * sc + sh, 0.f);
+                }
+            }
+            __syncthreads();
+            for (int item = tid; item < 13 * 3 * 8; item += 256) {      // pooled rows 2-14, columns 0, 1, 15
+                const int c4 = item & 7, k = item >> 3, pk = k % 3, py = 2 + k / 3;
+                const int ci_lo = pk == 0 ? 0 : pk == 1 ? 1 : 4, ci_hi = pk == 0 ? 1 : pk == 1 ? 3 : 6;
+                f32x4 m = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int dy = -1; dy < 2; ++dy)
+                    for (int ci = ci_lo; ci <= ci_hi; ++ci) {
+                        const f32x4 v = *(const f32x4*)(cb + ((2 * py + dy - 3) * 7 + ci) * 32 + c4 * 4);
+                        m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+                    }
+                const int px = pk < 2 ? pk : 15;
+                *(f32x4*)(p.out + (((int64_t)py * 16 + px) * p.Nsamp + n) * 64 + pass * 32 + c4 * 4) = m;
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // OIHW [64][3][7][7] -> folded [ (a*2+q)*3 + c ][h][co], b = 2q+h, a/b tap groups {0},{1,2},{3,4},{5,6}
 __global__ void pack_stem_weight_folded_kernel(const float* __restrict__ w, float* __restrict__ wf) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -577,6 +717,30 @@ extern "C" int ssad_stem_patch_pool_fwd_ring(const float* img, int B, int H, int
     }
     const int64_t grid = p.Nsamp < 2048 ? p.Nsamp : 2048;
     hipLaunchKernelGGL(stem_patch_fused_kernel, dim3((unsigned)grid), dim3(256), lds_bytes, (hipStream_t)stream, p);
+    SSAD_CHECK_LAUNCH();
+    return 0;
+}
+
+// Pooled rows / columns 0, 1 and 15 of every patch's stem map, position-major [16][16][Nsamp][64]; the other positions are not written
+// (ssad_patch_gather_hwnc_band fills rows / columns 2-3 and 13-14 from the per-image map, the interior is read by nobody).
+extern "C" int ssad_stem_patch_border_fwd(const float* img, int B, int H, int W, int patch_stride, const float* wf, const float* scale,
+                                          const float* shift, float* out, void* stream) {
+    SSAD_CHECK_ARG(img && wf && out, "null pointer");
+    SSAD_CHECK_ARG(B > 0 && H >= 32 && W >= 32 && patch_stride > 0, "bad shape (32x32 windows)");
+    StemPatchParams p;
+    p.img = img; p.wf = wf; p.scale = scale; p.shift = shift; p.out = out;
+    p.B = B; p.H = H; p.W = W; p.ps = patch_stride; p.hwnc = 1; p.skip_lo = 1; p.skip_hi = 0;
+    p.prow = (H - 32) / patch_stride + 1;
+    p.pcol = (W - 32) / patch_stride + 1;
+    p.Nsamp = (int64_t)B * p.prow * p.pcol;
+    constexpr int lds_bytes = (SP_WF + SP_SRC + SB_CB) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SSAD_SET_DYN_LDS(stem_patch_border_kernel, lds_bytes);
+        attr_set = true;
+    }
+    const int64_t grid = p.Nsamp < 2048 ? p.Nsamp : 2048;
+    hipLaunchKernelGGL(stem_patch_border_kernel, dim3((unsigned)grid), dim3(256), lds_bytes, (hipStream_t)stream, p);
     SSAD_CHECK_LAUNCH();
     return 0;
 }

@@ -30,6 +30,7 @@ SIGNATURES = {
     "ssad_pack_stem_weight_folded": [_c_fp, _c_fp, _c_fp],
     "ssad_stem_patch_pool_fwd": [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_i, _c_fp, _c_fp],
     "ssad_stem_patch_pool_fwd_ring": [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_fp, _c_fp],
+    "ssad_stem_patch_border_fwd": [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
     "ssad_maxpool3x3s2_fwd": [_c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_i, _c_fp],
     "ssad_conv_igemm_fwd": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
                             _c_i, _c_i, _c_fp],

@@ -194,9 +194,15 @@ def _trunk_eval_dedup(plan, x, patch_stride, layer_outputs, pooled, conv):
     band = _os.environ.get("SSAD_GATHER_BAND", "1") != "0"
     # (the pooled map's interior [4, 12]^2 is read by nobody: the first ring conv computes the outputs outside [3, 13] and reads within
     # one position of them, block 0's second conv takes its residual at the positions outside [4, 12])
-    a = ops.stem_patch_pool_fwd(x, plan.stem_wf, plan.stem_s, plan.stem_t, patch_stride, True, (4, 12) if band else None)   # [16][16][N][64]
     dn = ops.stem_fwd(x, plan.stem_w, plan.stem_s, plan.stem_t, True, resize_to=(2 * h, 2 * w))         # [B][h][w][64]
     dn = ops.maxpool3x3s2_fwd(dn)                                                                       # [B][h/2][w/2][64]
+    if band and _os.environ.get("SSAD_STEM_BORDER", "1") != "0":
+        # the pooled map itself: only rows / columns 0, 1, 15 are the patch's own (13 of the stem's 32 tiles of matrix work); rows /
+        # columns 2-3 and 13-14 are the per-image pooled map's
+        a = ops.stem_patch_border_fwd(x, plan.stem_wf, plan.stem_s, plan.stem_t, patch_stride)          # [16][16][N][64]
+        ops.patch_gather_hwnc(dn, a, prow, pcol, shift, 2, 14, 4, 12)
+    else:
+        a = ops.stem_patch_pool_fwd(x, plan.stem_wf, plan.stem_s, plan.stem_t, patch_stride, True, (4, 12) if band else None)
     offs, off = {}, 0
     for k in ("layer1", "layer2", "layer3"):
         if k in layer_outputs:

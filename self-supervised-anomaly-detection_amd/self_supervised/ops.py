@@ -244,6 +244,18 @@ def stem_patch_pool_fwd(img, wf, scale, shift, patch_stride=8, hwnc=False, skip=
     return out
 
 
+def stem_patch_border_fwd(img, wf, scale, shift, patch_stride=8):
+    """Pooled rows / columns 0, 1 and 15 of every 32x32 window's stem map (the positions its own zero padding reaches), written into a
+    position-major [16][16][N][64] buffer whose other positions stay unwritten: see patch_gather_hwnc for rows / columns 2-3, 13-14."""
+    b, c, h, w = img.shape
+    n = b * ((h - 32) // patch_stride + 1) * ((w - 32) // patch_stride + 1)
+    out = _new((16, 16, n, 64), img)
+    _run("stem_patch_pool", 2.0 * n * 13 * 32 * 64 * 147, 4.0 * (img.numel() + out.numel() * 87 // 256),
+         lambda: _hip.lib().ssad_stem_patch_border_fwd(_hip.ptr(img), b, h, w, patch_stride, _hip.ptr(wf), _hip.ptr(scale, True),
+                                                       _hip.ptr(shift, True), _hip.ptr(out), _hip.stream()))
+    return out
+
+
 def maxpool3x3s2_fwd(x, hwnc=False):
     if hwnc:
         h, w, n, c = x.shape

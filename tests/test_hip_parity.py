@@ -161,6 +161,19 @@ def test_fused_patch_stem(dev, seeded_sd, hwnc):
         keep[lo:hi + 1, lo:hi + 1] = False
         a, b = (ring[keep.to(dev)], full[keep.to(dev)]) if hwnc else (ring[:, keep.to(dev)], full[:, keep.to(dev)])
         assert torch.equal(a, b), (lo, hi)
+    if hwnc:
+        # the border form: rows / columns 0, 1, 15, bit for bit; nothing else written
+        border = ops.stem_patch_border_fwd(x.to(dev), ops.pack_stem_weight_folded(w.to(dev)), sc.to(dev), sh.to(dev), 8)
+        edge = torch.zeros(16, 16, dtype=torch.bool)
+        edge[[0, 1, 15], :] = True
+        edge[:, [0, 1, 15]] = True
+        assert torch.equal(border[edge.to(dev)], full[edge.to(dev)])
+        from self_supervised import _hip
+        poisoned = torch.full_like(full, 3.25)
+        xd, wfd, scd, shd = x.to(dev), ops.pack_stem_weight_folded(w.to(dev)), sc.to(dev), sh.to(dev)      # (kept alive across the launch)
+        _hip.check(_hip.lib().ssad_stem_patch_border_fwd(_hip.ptr(xd), 2, 64, 56, 8, _hip.ptr(wfd), _hip.ptr(scd), _hip.ptr(shd),
+                                                         _hip.ptr(poisoned), _hip.stream()))
+        assert (poisoned[(~edge).to(dev)] == 3.25).all() and torch.equal(poisoned[edge.to(dev)], full[edge.to(dev)])
     # image-level 32x32 inputs take the same kernel (one window per image)
     xi = ow.synthetic_images(3, 32, seed=12)
     want = F.max_pool2d((F.conv2d(F.interpolate(xi, 64, mode="nearest"), w, None, 2, 3) * sc.view(1, -1, 1, 1)
