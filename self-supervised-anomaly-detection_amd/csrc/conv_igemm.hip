@@ -1156,7 +1156,9 @@ IgemmTile pick_tile(const ConvParams& p) {
     static const int small_min = getenv("SSAD_CONV_SMALL_GRID") ? atoi(getenv("SSAD_CONV_SMALL_GRID")) : 500;
     // ... and when even that leaves most CUs without a workgroup (batch 32 on the 8x8 maps of layer4: 128 workgroups of
     // 144 K-steps each) the 64x64 tile doubles the grid again (measured at batch 32: layer4 3x3 0.204 -> see DESIGN.md)
-    static const int tiny_min = getenv("SSAD_CONV_TINY_GRID") ? atoi(getenv("SSAD_CONV_TINY_GRID")) : 200;
+    // (round 6, with the buffer-load K loop: 520 instead of 200 -- layer3 at batch 32 and layer4 at batch 96 take the 64 x 64 tile too:
+    // batch 32 5.265 -> 5.20 ms, batch 96 13.29 -> 12.86 ms, batch 256 untouched)
+    static const int tiny_min = getenv("SSAD_CONV_TINY_GRID") ? atoi(getenv("SSAD_CONV_TINY_GRID")) : 520;
     if (!POS) {
         const int64_t g128 = cdiv64(p.M, 128) * ((p.Cout + 127) / 128);
         if (cdiv64(p.M, 128) * ((p.Cout + 63) / 64) < tiny_min && p.M > 128) return T_64x64;
